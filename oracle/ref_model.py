@@ -1,0 +1,197 @@
+"""ORACLE — test infrastructure only, never the product path.
+
+CPU (PyTorch fp32, autograd) restatement of the reference's DCNv2 pretraining hot path,
+written functionally over a flat {state_dict key: tensor} parameter dict.  Only `tests/`,
+`__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this package.
+
+Parity pin: every function here is checked against golden vectors produced by running
+the real reference modules (tests/golden/gen_golden.py -> tests/golden/*.npz) in
+tests/test_oracle_golden.py.  The optimizer (third-party transformers==4.26.1 AdamW,
+absent from /root/reference and from this image) is pinned by a hand-computed
+known-answer test instead: "parity unpinned upstream" for that one function.
+
+Reference sites restated (paths under /root/reference/code):
+  embed            layers.py:97-102     (nn.Embedding gather, flatten in models.py:308)
+  cross            layers.py:197-201    Xi+1 = Xi + X0 * (W_i Xi + b_i)
+  dnn              layers.py:173-188    [Linear, ReLU, Dropout(p=0)] x NL
+  trunk            models.py:306-314    cat(cross, dnn)
+  mfp head         models.py:71-78, nce/nce_loss.py:79-144,158-173,201-230,
+                   nce/index_linear.py:68-106
+  rfd head         models.py:79-85,119-124
+  ctr head         models.py:88-93,304,319
+  nce buffers      nce/nce_loss.py:55-71, nce/index_linear.py:41-48
+  alias table      nce/alias_multinomial.py:39-72 ; draw :81-97
+  dynamic_mask     trainer.py:217-240
+  optimizer        trainer.py:60-85 + transformers 4.26.1 optimization.py AdamW.step
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as Fn
+
+BACKOFF_PROB = 1e-10   # nce_loss.py:10
+MASK_ID = 3            # trainer.py:229
+
+
+# ----------------------------------------------------------------------------- trunk
+def embed(params, ids):
+    return params["embed.embedding.weight"][ids].flatten(1)
+
+
+def cross(params, x0, num_cross):
+    xi = x0
+    for i in range(num_cross):
+        w = params[f"cross_net.cross_layers.{i}.weight"]
+        b = params[f"cross_net.cross_layers.{i}.bias"]
+        xi = xi + x0 * (xi @ w.t() + b)
+    return xi
+
+
+def dnn(params, x, num_hidden):
+    for i in range(num_hidden):
+        w = params[f"parallel_dnn.dnn.{3 * i}.weight"]
+        b = params[f"parallel_dnn.dnn.{3 * i}.bias"]
+        x = torch.relu(x @ w.t() + b)
+    return x
+
+
+def trunk(params, ids, num_cross, num_hidden):
+    x0 = embed(params, ids)
+    c = cross(params, x0, num_cross)
+    if num_hidden > 0:
+        return torch.cat([c, dnn(params, x0, num_hidden)], dim=-1)
+    return c
+
+
+# ----------------------------------------------------------------------------- heads
+def nce_buffers(feat_count):
+    """-> (logprob_noise [V] f32, norm_term = ln V, renormalised noise probs [V] f32)."""
+    fc = torch.as_tensor(feat_count, dtype=torch.float32)
+    probs = (fc / fc.sum()).clamp(min=BACKOFF_PROB)
+    probs = probs / probs.sum()
+    return probs.log(), math.log(fc.numel()), probs
+
+
+def softplus(x):
+    return torch.clamp(x, min=0) + torch.log1p(torch.exp(-x.abs()))
+
+
+def mfp_head(params, final, labels, masked_index, noise, logq, num_fields, proj, neg_num):
+    """-> (loss scalar, logits [B,L,K+1] (= s, not noise-corrected), total_acc int)."""
+    B = final.shape[0]
+    enc = (final @ params["feat_encoder.weight"].t() + params["feat_encoder.bias"])
+    enc = enc.view(B, num_fields, proj)
+    h = torch.gather(enc, 1, masked_index.unsqueeze(-1).expand(-1, -1, proj))       # [B,L,P]
+    idx = torch.cat([labels.unsqueeze(-1), noise], dim=-1)                          # [B,L,K+1]
+    rows = params["mfp_criterion.emb.weight"][idx]                                  # [B,L,K+1,P]
+    bias = params["mfp_criterion.bias.weight"][idx].squeeze(-1)
+    s = (h.unsqueeze(2) * rows).sum(-1) + bias - math.log(logq.numel())
+    lt = s - logq[idx] - math.log(neg_num)
+    per_target = softplus(-lt[..., 0]) + softplus(lt[..., 1:]).sum(-1)
+    loss = per_target.mean()
+    total_acc = int((s[..., :1] >= s).all(dim=-1).sum())     # argmax==0, ties -> first index
+    return loss, s, total_acc
+
+
+def rfd_head(params, final, labels):
+    """-> (loss, count, acc tensor, pos_ratio tensor, logits [B,F])."""
+    z = torch.relu(final @ params["pred_rfd.0.weight"].t() + params["pred_rfd.0.bias"])
+    logits = z @ params["pred_rfd.2.weight"].t() + params["pred_rfd.2.bias"]
+    loss = Fn.binary_cross_entropy_with_logits(logits, labels)
+    count = labels.numel()
+    acc = ((torch.sigmoid(logits) > 0.5).float() == labels).sum() / count
+    return loss, count, acc, labels.mean(), logits
+
+
+def ctr_head(params, final, y=None):
+    logits = final @ params["fc_out.weight"].t() + params["fc_out.bias"]
+    if y is None:
+        return (logits,)
+    return Fn.binary_cross_entropy_with_logits(logits.view(-1), y.float()), logits
+
+
+# ----------------------------------------------------------------------------- masking
+def dynamic_mask_mfp(ids, masked_index):
+    labels = torch.gather(ids, 1, masked_index)
+    masked = torch.scatter(ids, 1, masked_index, torch.full_like(masked_index, MASK_ID))
+    return masked, labels
+
+
+def dynamic_mask_rfd(ids, masked_index, replace_feat):
+    """Duplicate positions in masked_index: the LAST one written wins (CPU scatter order)."""
+    out = ids.clone()
+    B, L = masked_index.shape
+    for b in range(B):
+        for l in range(L):
+            out[b, masked_index[b, l]] = replace_feat[b, l]
+    return out, (ids != out).float()
+
+
+# ----------------------------------------------------------------------------- alias
+def alias_build(probs):
+    """Walker table in the reference's exact visiting order, float32 arithmetic.
+    -> (prob f32 [V], alias i64 [V])."""
+    p = np.asarray(probs, dtype=np.float32)
+    K = p.shape[0]
+    q = np.zeros(K, dtype=np.float32)
+    alias = np.zeros(K, dtype=np.int64)
+    small, large = [], []
+    kf = np.float32(K)
+    for i in range(K):
+        q[i] = kf * p[i]
+        (small if q[i] < 1.0 else large).append(i)
+    one = np.float32(1.0)
+    while small and large:
+        s, l = small.pop(), large.pop()
+        alias[s] = l
+        q[l] = (q[l] - one) + q[s]
+        (small if q[l] < 1.0 else large).append(l)
+    for i in small + large:
+        q[i] = 1.0
+    return q, alias
+
+
+def alias_draw(prob, alias, kk, u):
+    """Injected randomness: kk ~ U{0..V-1} i64, u ~ U[0,1).  b = u < prob[kk]."""
+    b = (u < prob[kk])
+    return torch.where(b, kk, alias[kk])
+
+
+def alias_distribution(prob, alias):
+    """The distribution a (prob, alias) table encodes (float64)."""
+    prob = np.asarray(prob, dtype=np.float64)
+    V = prob.shape[0]
+    out = prob / V
+    np.add.at(out, np.asarray(alias), (1.0 - prob) / V)
+    return out
+
+
+# ----------------------------------------------------------------------------- optimizer
+def lr_lambda(kind, step, total, warmup):
+    """transformers get_{cosine,constant}_schedule_with_warmup multipliers."""
+    if step < warmup:
+        return float(step) / float(max(1, warmup))
+    if kind == "const":
+        return 1.0
+    prog = float(step - warmup) / float(max(1, total - warmup))
+    return max(0.0, 0.5 * (1.0 + math.cos(math.pi * 0.5 * 2.0 * prog)))
+
+
+def hf_adamw_step(p, g, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.0):
+    """One transformers-4.26 AdamW update, in place; t = 1-based step count.
+    Differences from torch.optim.AdamW: eps added to sqrt(v) un-scaled; bias correction
+    folded into the step size; decoupled decay applied AFTER the Adam update."""
+    m.mul_(beta1).add_(g, alpha=1.0 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1.0 - beta2)
+    denom = v.sqrt().add_(eps)
+    step_size = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+    p.addcdiv_(m, denom, value=-step_size)
+    if wd > 0.0:
+        p.add_(p, alpha=-lr * wd)
+
+
+def decays(name):
+    """trainer.py:61-63: no decay iff the parameter NAME contains 'bias' or
+    'LayerNorm.weight' (so mfp_criterion.bias.weight is not decayed; tables are)."""
+    return not any(nd in name for nd in ("bias", "LayerNorm.weight"))

@@ -1,0 +1,114 @@
+"""Deterministic inputs / parameters shared by the fixture generator and the tests.
+
+Pure numpy, no torch RNG: both `gen_golden.py` (which runs the real reference, in the
+build container only) and the parity tests (which run anywhere) rebuild bit-identical
+parameters and inputs from a case description, so fixtures only need to hold OUTPUTS.
+"""
+import zlib
+
+import numpy as np
+
+RESERVED = 10          # ids 0..9 are <pad>,<cls>,<sep>,<mask>=3,<unused0-5>  
+MASK_ID = 3
+FULL_MAX = 20000       # tensors up to this many elements are stored whole in a fixture
+
+# The fixture cases: canonical run-script shapes for A, reduced hidden size for B/C so
+# that fixtures stay small.  F = 23 (paper Avazu), 25 (proc_avazu.py layout), 39 (Criteo).
+CASES = {
+    "A_f23_b7": dict(F=23, B=7, V=1000, E=16, H=1000, NL=3, NC=3, P=32, K=25, mask_ratio=0.3),
+    "B_f25_b64": dict(F=25, B=64, V=1000, E=16, H=64, NL=3, NC=3, P=32, K=25, mask_ratio=0.3),
+    "C_f39_b64": dict(F=39, B=64, V=1000, E=16, H=64, NL=2, NC=2, P=32, K=25, mask_ratio=0.3),
+}
+
+
+def _rng(*key):
+    return np.random.default_rng(zlib.crc32("/".join(str(k) for k in key).encode()))
+
+
+def field_ranges(F, V):
+    """Contiguous per-field id ranges over [RESERVED, V) with a skewed size profile."""
+    w = np.array([1.0 + (i % 5) ** 2 + (7.0 if i % 4 == 0 else 0.0) for i in range(F)])
+    sizes = np.maximum(2, np.floor(w / w.sum() * (V - RESERVED)).astype(np.int64))
+    sizes[-1] += (V - RESERVED) - sizes.sum()
+    assert sizes.min() >= 2 and sizes.sum() == V - RESERVED
+    lo = RESERVED + np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    return lo.astype(np.int64), (lo + sizes).astype(np.int64)
+
+
+def make_inputs(case, cfg):
+    """input_ids [B,F] (global ids, field f inside its range, low ids more frequent),
+    masked_index [B,L] (with replacement -> duplicates, like `randint` masking),
+    noise [B,L,K], ctr labels [B], feat_count [V] (contains zeros -> clamp path)."""
+    F, B, V, K = cfg["F"], cfg["B"], cfg["V"], cfg["K"]
+    L = int(F * cfg["mask_ratio"])
+    r = _rng(case, "inputs")
+    lo, hi = field_ranges(F, V)
+    u = r.random((B, F))
+    ids = (lo[None, :] + np.floor((u ** 2.5) * (hi - lo)[None, :])).astype(np.int64)
+    masked_index = r.integers(0, F, size=(B, L)).astype(np.int64)
+    masked_index[0, 1] = masked_index[0, 0]          # force at least one duplicate
+    noise = r.integers(0, V, size=(B, L, K)).astype(np.int64)
+    noise[0, 0, :3] = ids[0, masked_index[0, 0]]     # noise that collides with the target
+    y = (r.random(B) < 0.3).astype(np.int64)
+    cnt = np.floor(r.pareto(1.2, size=V) * 5.0).astype(np.float32)
+    cnt[:RESERVED] = 0.0
+    cnt[r.integers(RESERVED, V, size=V // 10)] = 0.0  # never-seen ids -> BACKOFF clamp
+    cnt[ids.reshape(-1)] += 1.0
+    # RFD replacement ids: a column drawn from other rows (Unigram flavour)
+    repl = ids[r.integers(0, B, size=(B, L)), masked_index]
+    return dict(input_ids=ids, masked_index=masked_index, noise=noise, y=y,
+                feat_count=cnt, replace_feat=repl.astype(np.int64))
+
+
+def make_param(case, name, shape, scale):
+    return (_rng(case, "param", name).standard_normal(shape) * scale).astype(np.float32)
+
+
+def param_shapes(cfg, mode):
+    """state_dict key -> (shape, init scale) for DCNv2 in `mode` in {MFP, RFD, CTR}.
+    Key layout = SURVEY §8(b) checkpoint manifest."""
+    F, V, E, H, NL, NC, P = (cfg[k] for k in ("F", "V", "E", "H", "NL", "NC", "P"))
+    D = F * E
+    out = {"embed.embedding.weight": ((V, E), (2.0 / (F + E)) ** 0.5)}
+    for i in range(NC):
+        out[f"cross_net.cross_layers.{i}.weight"] = ((D, D), D ** -0.5)
+        out[f"cross_net.cross_layers.{i}.bias"] = ((D,), 0.1)
+    d_in = D
+    for i in range(NL):
+        out[f"parallel_dnn.dnn.{3 * i}.weight"] = ((H, d_in), d_in ** -0.5)
+        out[f"parallel_dnn.dnn.{3 * i}.bias"] = ((H,), 0.1)
+        d_in = H
+    Dfin = D + (H if NL > 0 else 0)
+    if mode == "MFP":
+        out["feat_encoder.weight"] = ((F * P, Dfin), Dfin ** -0.5)
+        out["feat_encoder.bias"] = ((F * P,), 0.1)
+        out["mfp_criterion.emb.weight"] = ((V, P), P ** -0.5)
+        out["mfp_criterion.bias.weight"] = ((V, 1), 0.5)
+    elif mode == "RFD":
+        out["pred_rfd.0.weight"] = ((F * P, Dfin), Dfin ** -0.5)
+        out["pred_rfd.0.bias"] = ((F * P,), 0.1)
+        out["pred_rfd.2.weight"] = ((F, F * P), (F * P) ** -0.5)
+        out["pred_rfd.2.bias"] = ((F,), 0.1)
+    elif mode == "CTR":
+        out["fc_out.weight"] = ((1, Dfin), Dfin ** -0.5)
+        out["fc_out.bias"] = ((1,), 0.1)
+    else:
+        raise ValueError(mode)
+    return out
+
+
+def make_params(case, cfg, mode):
+    return {k: make_param(case, k, shp, sc) for k, (shp, sc) in param_shapes(cfg, mode).items()}
+
+
+def digest(name, g):
+    """What a fixture keeps of a (gradient) tensor: everything when small, else linear
+    functionals (random projections along each axis) + sums, all tolerance-comparable."""
+    g = np.asarray(g, dtype=np.float32)
+    if g.size <= FULL_MAX:
+        return {"full": g}
+    g2 = g.reshape(g.shape[0], -1).astype(np.float64)
+    rr = _rng("proj", name, "r").standard_normal(g2.shape[1])
+    rl = _rng("proj", name, "l").standard_normal(g2.shape[0])
+    return {"sum": np.float64(g2.sum()), "abssum": np.float64(np.abs(g2).sum()),
+            "proj_r": g2 @ rr, "proj_l": rl @ g2}

@@ -1,0 +1,147 @@
+"""Pin the oracle (oracle/ref_model.py) against golden vectors captured from the real
+reference modules (tests/golden/gen_golden.py).  CPU only."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import paramgen as pg
+from oracle import ref_model as R
+from util import assert_digest, load_case, t
+
+CASES = list(pg.CASES)
+
+
+def _params(params, requires_grad=True):
+    return {k: t(v).requires_grad_(requires_grad) for k, v in params.items()}
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_mfp_matches_reference(case):
+    cfg, z, inp, params = load_case(case, "MFP")
+    P = _params(params)
+    ids, mi = t(inp["input_ids"]), t(inp["masked_index"])
+    masked, labels = R.dynamic_mask_mfp(ids, mi)
+    assert torch.equal(masked, t(z["in/input_ids_masked"]))
+    assert torch.equal(labels, t(z["in/labels"]))
+    logq, lnV, _ = R.nce_buffers(inp["feat_count"])
+    np.testing.assert_allclose(logq.numpy(), z["nce/logprob_noise"], rtol=1e-6, atol=1e-6)
+    assert lnV == pytest.approx(float(z["nce/norm_term"]))
+    final = R.trunk(P, masked, cfg["NC"], cfg["NL"])
+    loss, logits, acc = R.mfp_head(P, final, labels, mi, t(inp["noise"]), logq,
+                                   cfg["F"], cfg["P"], cfg["K"])
+    np.testing.assert_allclose(loss.item(), float(z["out/loss"]), rtol=2e-6)
+    np.testing.assert_allclose(logits.detach().numpy(), z["out/logits"], rtol=1e-5, atol=2e-6)
+    assert acc == int(z["out/total_acc"])
+    assert labels.numel() == int(z["out/count"])
+    loss.backward()
+    for k, p in P.items():
+        assert_digest(z, "grad", k, p.grad.numpy())
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_rfd_matches_reference(case):
+    cfg, z, inp, params = load_case(case, "RFD")
+    P = _params(params)
+    ids, mi = t(inp["input_ids"]), t(inp["masked_index"])
+    replaced, labels = R.dynamic_mask_rfd(ids, mi, t(inp["replace_feat"]))
+    assert torch.equal(replaced, t(z["in/input_ids_replaced"]))
+    assert torch.equal(labels, t(z["in/labels"]))
+    final = R.trunk(P, replaced, cfg["NC"], cfg["NL"])
+    loss, count, acc, pos, logits = R.rfd_head(P, final, labels)
+    np.testing.assert_allclose(loss.item(), float(z["out/loss"]), rtol=2e-6)
+    np.testing.assert_allclose(logits.detach().numpy(), z["out/logits"], rtol=1e-5, atol=2e-6)
+    assert count == int(z["out/count"])
+    np.testing.assert_allclose(acc.item(), float(z["out/acc"]), rtol=1e-6)
+    np.testing.assert_allclose(pos.item(), float(z["out/pos_ratio"]), rtol=1e-6)
+    loss.backward()
+    for k, p in P.items():
+        assert_digest(z, "grad", k, p.grad.numpy())
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_ctr_matches_reference(case):
+    cfg, z, inp, params = load_case(case, "CTR")
+    P = _params(params)
+    ids = t(inp["input_ids"])
+    x0 = R.embed(P, ids)
+    np.testing.assert_array_equal(x0.detach().numpy(), z["mid/embed_flat"])
+    np.testing.assert_allclose(R.cross(P, x0, cfg["NC"]).detach().numpy(), z["mid/cross_out"],
+                               rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(R.dnn(P, x0, cfg["NL"]).detach().numpy(), z["mid/dnn_out"],
+                               rtol=1e-5, atol=2e-6)
+    final = R.trunk(P, ids, cfg["NC"], cfg["NL"])
+    loss, logits = R.ctr_head(P, final, t(inp["y"]))
+    np.testing.assert_allclose(loss.item(), float(z["out/loss"]), rtol=2e-6)
+    np.testing.assert_allclose(logits.detach().numpy(), z["out/logits"], rtol=1e-5, atol=2e-6)
+    loss.backward()
+    for k, p in P.items():
+        assert_digest(z, "grad", k, p.grad.numpy())
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_alias_table_and_bias_init(case):
+    cfg, z, inp, _ = load_case(case, "MFP")
+    logq, lnV, q = R.nce_buffers(inp["feat_count"])
+    prob, alias = R.alias_build(q.numpy())
+    np.testing.assert_array_equal(alias, z["nce/alias_alias"])
+    np.testing.assert_allclose(prob, z["nce/alias_prob"], rtol=0, atol=0)
+    # the table encodes the renormalised noise distribution
+    np.testing.assert_allclose(R.alias_distribution(prob, alias), q.double().numpy(),
+                               rtol=0, atol=5e-7)
+    np.testing.assert_allclose((logq + lnV).numpy()[:, None], z["nce/bias_init"], rtol=1e-6,
+                               atol=1e-6)
+    assert float(z["nce/emb_init_absmax"]) <= 1.0 / math.sqrt(cfg["P"]) + 1e-7
+    assert float(z["init/embed_std"]) == pytest.approx(math.sqrt(2.0 / (cfg["F"] + cfg["E"])),
+                                                       rel=0.05)
+
+
+def test_alias_draw_semantics():
+    prob = torch.tensor([1.0, 0.25, 0.5])
+    alias = torch.tensor([0, 0, 1])
+    kk = torch.tensor([0, 1, 1, 2, 2])
+    u = torch.tensor([0.99, 0.1, 0.3, 0.49, 0.5])
+    assert R.alias_draw(prob, alias, kk, u).tolist() == [0, 1, 0, 2, 1]
+
+
+def test_lr_schedules_match_transformers(golden_dir):
+    import os
+    z = np.load(os.path.join(golden_dir, "lr_schedules.npz"))
+    for name in z.files:
+        kind, T, W = name.split("_")
+        T, W = int(T[1:]), int(W[1:])
+        kind = "cosine" if kind == "cos" else "const"
+        got = [R.lr_lambda(kind, s, T, W) for s in range(len(z[name]))]
+        np.testing.assert_allclose(got, z[name], rtol=1e-12, atol=1e-15, err_msg=name)
+
+
+def test_hf_adamw_known_answer():
+    """Hand-computed (float64) two-step trajectory of transformers-4.26 AdamW semantics:
+    m,v EMA; denom = sqrt(v)+eps (eps NOT bias-scaled); step = lr*sqrt(1-b2^t)/(1-b1^t);
+    decay p -= lr*wd*p applied after the update on the already-updated p."""
+    lr, b1, b2, eps, wd = 1e-2, 0.9, 0.999, 1e-8, 0.1
+    p0, g1, g2 = 0.5, 0.2, -0.4
+    m1, v1 = (1 - b1) * g1, (1 - b2) * g1 * g1
+    s1 = lr * math.sqrt(1 - b2) / (1 - b1)
+    p1 = p0 - s1 * m1 / (math.sqrt(v1) + eps)
+    p1 = p1 - lr * wd * p1
+    m2, v2 = b1 * m1 + (1 - b1) * g2, b2 * v1 + (1 - b2) * g2 * g2
+    s2 = lr * math.sqrt(1 - b2 ** 2) / (1 - b1 ** 2)
+    p2 = p1 - s2 * m2 / (math.sqrt(v2) + eps)
+    p2 = p2 - lr * wd * p2
+    p, m, v = torch.tensor([p0]), torch.zeros(1), torch.zeros(1)
+    R.hf_adamw_step(p, torch.tensor([g1]), m, v, 1, lr, b1, b2, eps, wd)
+    assert p.item() == pytest.approx(p1, rel=1e-6)
+    R.hf_adamw_step(p, torch.tensor([g2]), m, v, 2, lr, b1, b2, eps, wd)
+    assert p.item() == pytest.approx(p2, rel=1e-6)
+    assert m.item() == pytest.approx(m2, rel=1e-6) and v.item() == pytest.approx(v2, rel=1e-6)
+    # first step of Adam moves by ~lr regardless of gradient scale
+    assert abs((p0 - p1 / (1 - lr * wd)) - lr) < 1e-6
+
+
+def test_decay_groups():
+    assert R.decays("embed.embedding.weight") and R.decays("mfp_criterion.emb.weight")
+    assert not R.decays("mfp_criterion.bias.weight")       # name contains "bias"
+    assert not R.decays("cross_net.cross_layers.0.bias")
+    assert R.decays("parallel_dnn.dnn.3.weight")
