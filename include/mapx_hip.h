@@ -1,0 +1,187 @@
+/* libmapx_hip.so — C ABI of the MI355X (gfx950) kernels behind the DCNv2 + MFP/RFD
+ * pretraining hot path of CHIANGEL/MAP-CODE.
+ *
+ * The reference has no FFI of its own (it is pure PyTorch); each entry point below names
+ * the reference Python site (file:line under /root/reference/code) whose arithmetic it
+ * replaces.  INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - the caller owns all memory (outputs and workspaces are caller-allocated; the library
+ *     never allocates or frees device memory and never synchronises the stream);
+ *   - kernels are enqueued on `stream`; return value 0 = enqueued, <0 = error
+ *     (MAPX_E*), message via mapx_last_error();
+ *   - ids cross the boundary as int64 (the reference's dtype); inside, table row ids are
+ *     int32 (V < 2^31);
+ *   - row-major, fp32 everywhere unless stated.
+ */
+#ifndef MAPX_HIP_H_
+#define MAPX_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
+#else
+#include <hip/hip_runtime_api.h>
+#endif
+
+#define MAPX_ABI_VERSION 1
+
+#define MAPX_OK 0
+#define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
+#define MAPX_EHIP (-2)       /* HIP runtime / launch error */
+#define MAPX_EWORKSPACE (-3) /* caller workspace too small */
+
+const char* mapx_last_error(void);
+int mapx_abi_version(void);
+
+/* ------------------------------------------------------------------ embedding (a3)
+ * layers.py:97-102 (nn.Embedding forward) + models.py:308 flatten: out[i,:] = table[ids[i],:].
+ * ids [n] (= [B,F] flattened), table [V,E], out [n,E] (= [B, F*E]).  An out-of-range id
+ * sets *err_flag (may be NULL) and yields a zero row (reference: IndexError). */
+int mapx_emb_gather_fwd(const int64_t* ids, int64_t n, const float* table, int64_t V, int E,
+                        float* out, int* err_flag, hipStream_t stream);
+
+/* int64 ids -> int32 row keys, range-checked against V. */
+int mapx_ids_to_i32(const int64_t* ids, int64_t n, int64_t V, int32_t* out, int* err_flag,
+                    hipStream_t stream);
+
+/* ------------------------------------------------------------------ sparse gradients (a3, a10)
+ * Replaces aten::embedding_dense_backward / index_select backward (layers.py:86,
+ * nce/index_linear.py:99-100: dense [V,E] zero-fill + index_add) by a deterministic
+ * reduce-by-key.  mapx_seg_plan sorts n keys and describes the runs of equal keys:
+ *   sorted_keys[n], perm[n] (sorted position -> original position), rank[n] (1-based run
+ *   id), uniq[<=n] (key of each run), seg_start[<=n+1] (first sorted position of each run,
+ *   closed by n), n_uniq[1].  All int32 device arrays of capacity n (seg_start: n+1). */
+size_t mapx_seg_plan_workspace_bytes(int64_t n, int64_t V);
+int mapx_seg_plan(const int32_t* keys, int64_t n, int64_t V, void* ws, size_t ws_bytes,
+                  int32_t* sorted_keys, int32_t* perm, int32_t* rank, int32_t* uniq,
+                  int32_t* seg_start, int32_t* n_uniq, hipStream_t stream);
+
+/* out[u,:] = sum_{j in run u} src[perm[j],:]  (W floats per row, W % 4 == 0).  Embedding
+ * table gradient: src = dL/dX0 viewed [B*F, E], plan over input_ids.flatten(). */
+size_t mapx_seg_reduce_workspace_bytes(int64_t n, int W);
+int mapx_seg_reduce_rows(int64_t n, const int32_t* perm, const int32_t* rank,
+                         const int32_t* seg_start, const float* src, int W, float* out, void* ws,
+                         size_t ws_bytes, hipStream_t stream);
+
+/* ------------------------------------------------------------------ NCE sampler (a7, a8)
+ * nce/alias_multinomial.py:39-72: Walker table from the renormalised noise probabilities,
+ * same visiting order and float32 arithmetic as the reference (HOST memory, one-off). */
+int mapx_alias_build_host(const float* probs_host, int64_t n, float* out_prob_host,
+                          int64_t* out_alias_host);
+/* (prob f32[V], alias i64[V]) -> packed 8-byte records {f32 prob, i32 alias} [V]. */
+int mapx_alias_pack(const float* prob, const int64_t* alias, int64_t V, void* packed,
+                    hipStream_t stream);
+/* nce/alias_multinomial.py:81-97 + nce_loss.py:146-156: idx[t,0] = targets[t],
+ * idx[t,1+k] = k-th negative (Philox4x32-10 keyed by (seed, offset)).  idx int32 [T, K+1]. */
+int mapx_alias_draw(const void* packed, int64_t V, const int64_t* targets, int64_t T, int K,
+                    uint64_t seed, uint64_t offset, int32_t* idx, hipStream_t stream);
+/* Same index matrix from caller-provided negatives noise[T,K] (parity tests). */
+int mapx_nce_pack_idx(const int64_t* targets, const int64_t* noise, int64_t T, int K, int64_t V,
+                      int32_t* idx, int* err_flag, hipStream_t stream);
+
+/* ------------------------------------------------------------------ NCE loss (a6, a9, a10)
+ * models.py:74-77 + nce_loss.py:79-144,201-230 + index_linear.py:68-106, fused.
+ *   enc [B, F*P] (feat_encoder output), masked_index [B,L], idx [B*L, K+1],
+ *   emb [V,P], bias [V], logq [V] (= logprob_noise).
+ * Outputs: h_out [B*L,P] (gathered hidden), dlogit [B*L,K+1] = dLoss/dlogit (mean over
+ * B*L folded in), dh [B*L,P] = dLoss/dh, logits_opt [B*L,K+1] or NULL (the reference's
+ * `logits`, i.e. score - ln V), loss_out[1] (mean), acc_out[1] (# targets ranked first). */
+size_t mapx_nce_fwd_workspace_bytes(void);
+int mapx_nce_fwd(const float* enc, int64_t B, int L, int F, int P, const int64_t* masked_index,
+                 const int32_t* idx, int K, const float* emb, const float* bias,
+                 const float* logq, int64_t V, float* h_out, float* dlogit, float* dh,
+                 float* logits_opt, float* loss_out, int32_t* acc_out, void* ws, size_t ws_bytes,
+                 hipStream_t stream);
+/* Backward of the field gather: denc[b, f*P+p] = g * sum_{l: mi[b,l]==f} dh[b,l,p]; denc
+ * [B, F*P] fully written.  gscale_opt: device scalar (upstream dLoss) or NULL = 1. */
+int mapx_nce_scatter_dh(const float* dh, const int64_t* masked_index, const float* gscale_opt,
+                        int64_t B, int L, int F, int P, float* denc, hipStream_t stream);
+/* Output-table gradient rows for the plan over idx.flatten() (n = B*L*(K+1)):
+ * out_emb[u,:] = sum dlogit*h, out_bias[u] = sum dlogit over run u. */
+size_t mapx_nce_table_grad_workspace_bytes(int64_t n, int P);
+int mapx_nce_table_grad(int64_t n, const int32_t* perm, const int32_t* rank,
+                        const int32_t* seg_start, const float* dlogit, const float* h, int K,
+                        int P, float* out_emb, float* out_bias, void* ws, size_t ws_bytes,
+                        hipStream_t stream);
+int mapx_scale_inplace(float* x, int64_t n, const float* g, hipStream_t stream);
+
+/* ------------------------------------------------------------------ dense trunk (a4, a5, a6, a11, a12)
+ * fp32 MFMA GEMM  C[m,n] = epi( sum_k A(m,k) * B(k,n) ):
+ *   a_kc != 0 : A(m,k) = A[m*lda + k]   else A(m,k) = A[k*lda + m]
+ *   b_kc != 0 : B(k,n) = B[n*ldb + k]   else B(k,n) = B[k*ldb + n]
+ * nn.Linear forward  Y = X W^T + b            : a_kc=1, b_kc=1  (layers.py:178, models.py:74,120-122,304)
+ * dX = dY W                                   : a_kc=1, b_kc=0
+ * dW = dY^T X                                 : a_kc=0, b_kc=0
+ * Epilogues: NONE; BIAS (+bias[n]); BIAS_RELU; BIAS_CROSS: u = acc + bias, out2 = u,
+ * C = aux1 + aux2 * u  (CrossNetV2 layer, layers.py:200: aux1 = Xi, aux2 = X0);
+ * ADD: C = acc + aux1; RELU_MASK: C = aux1 > 0 ? acc : 0 (ReLU backward).
+ * nsplit > 1: deterministic split-K through `ws` (EPI_NONE, ldc == N). */
+#define MAPX_EPI_NONE 0
+#define MAPX_EPI_BIAS 1
+#define MAPX_EPI_BIAS_RELU 2
+#define MAPX_EPI_BIAS_CROSS 3
+#define MAPX_EPI_ADD 4
+#define MAPX_EPI_RELU_MASK 5
+size_t mapx_gemm_splitk_workspace_bytes(int M, int N, int nsplit);
+int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, int64_t lda,
+                  const float* B, int64_t ldb, float* C, int64_t ldc, int epi, const float* bias,
+                  const float* aux1, int64_t ld1, const float* aux2, int64_t ld2, float* out2,
+                  int64_t ldo2, int nsplit, void* ws, size_t ws_bytes, hipStream_t stream);
+/* out[n] = sum_m x[m*ld + n]  (bias gradients), deterministic two-stage. */
+size_t mapx_colsum_workspace_bytes(int N);
+int mapx_colsum(const float* x, int64_t ld, int M, int N, float* out, void* ws, size_t ws_bytes,
+                hipStream_t stream);
+/* CrossNetV2 backward, elementwise part of one layer: t = g*x0; dx0 (+)= g*u  (n % 4 == 0). */
+int mapx_cross_bwd_pre(const float* g, const float* x0, const float* u, int64_t n, float* t,
+                       float* dx0, int accumulate, hipStream_t stream);
+
+/* ReLU backward: out = y > 0 ? dy : 0 (y = activated output of layers.py:178-185). */
+int mapx_relu_mask(const float* dy, const float* y, int64_t n, float* out, hipStream_t stream);
+
+/* ------------------------------------------------------------------ heads + masking (a1, a2, a11, a12)
+ * BCEWithLogits mean (models.py:81,91) + dlogits (= dLoss/dlogits, may be NULL) +
+ * out3 = {loss, accuracy ((sigmoid>0.5)==y mean), mean(y)}. */
+size_t mapx_bce_workspace_bytes(void);
+int mapx_bce_with_logits(const float* logits, const float* labels, int64_t n, float* dlogits_opt,
+                         float* out3, void* ws, size_t ws_bytes, hipStream_t stream);
+/* trainer.py:217-232 (MFP, sampling_method="randint"): masked_index_in NULL -> Philox. */
+int mapx_dynamic_mask_mfp(const int64_t* ids, int64_t B, int F, int L,
+                          const int64_t* masked_index_in, uint64_t seed, uint64_t offset,
+                          int64_t* ids_out, int64_t* labels, int64_t* masked_index_out,
+                          hipStream_t stream);
+/* trainer.py:233-240 (RFD, RFD_replace="Unigram"): x_train [N,F] device-resident; labels f32 [B,F]. */
+int mapx_dynamic_mask_rfd(const int64_t* ids, int64_t B, int F, int L,
+                          const int64_t* masked_index_in, const int64_t* replace_in,
+                          const int64_t* x_train, int64_t N, uint64_t seed, uint64_t offset,
+                          int64_t* ids_out, float* labels, int64_t* masked_index_out,
+                          hipStream_t stream);
+
+/* ------------------------------------------------------------------ optimizer (a13)
+ * transformers-4.26 AdamW semantics (trainer.py:60-85).  sched [sched_len][2] f32 =
+ * {lr_s*sqrt(1-b2^s)/(1-b1^s), lr_s} for update s = index+1; *done = updates applied. */
+int mapx_adamw_dense(float* p, const float* g, float* m, float* v, int64_t n, const float* sched,
+                     int sched_len, const int32_t* done, float beta1, float beta2, float eps,
+                     float weight_decay, hipStream_t stream);
+int mapx_step_advance(int32_t* done, hipStream_t stream);
+/* Lazy exact row-sparse AdamW on a table group {p0 [V,W0] (+ optional p1 [V])} sharing
+ * last[V].  rows NULL: rows row_begin..row_begin+n_rows-1 (flush / sweep); else rows[i],
+ * i < *n_rows_dev (or n_rows if NULL).  grad0 NULL: catch-up to *done only; else catch-up
+ * then update *done+1 with grad0 [*, W0] (grad1 [*]) and last = *done+1. */
+int mapx_table_adam(float* p0, float* m0, float* v0, int W0, float wd0, float* p1, float* m1,
+                    float* v1, float wd1, int32_t* last, const int32_t* rows, int64_t row_begin,
+                    int64_t n_rows, const int32_t* n_rows_dev, const float* grad0,
+                    const float* grad1, const float* sched, int sched_len, const int32_t* done,
+                    float beta1, float beta2, float eps, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAPX_HIP_H_ */

@@ -1,0 +1,77 @@
+// Embedding row gather (reference code/layers.py:97-102 -> nn.Embedding forward, flattened
+// to [B, F*E] in models.py:308) and its helpers.  HBM-bound: 8 B of id + 2*E*4 B per row.
+#include "../../include/mapx_hip.h"
+#include "common.h"
+
+namespace mapx {
+
+// One float4 per thread: E/4 consecutive lanes cover one row (E = 16 -> 4 lanes x 16 B =
+// one 64-B segment), 16 rows per wave-instruction; ids are re-read by the E/4 lanes of a
+// row from the same cache line.  Out-of-range ids set *err and produce zeros (the
+// reference raises IndexError on CPU; the host layer turns *err into the same exception).
+template <int VEC>
+__global__ void __launch_bounds__(256) emb_gather_kernel(const int64_t* __restrict__ ids,
+                                                         int64_t n, const float* __restrict__ table,
+                                                         int64_t V, int E, float* __restrict__ out,
+                                                         int* __restrict__ err) {
+  const int per_row = E / VEC;
+  const int64_t total = n * per_row;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = t / per_row;
+    const int c = (int)(t - row * per_row) * VEC;
+    const int64_t id = ids[row];
+    const bool ok = (id >= 0) & (id < V);
+    if (!ok && err) atomicOr(err, 1);
+    if (VEC == 4) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) v = *reinterpret_cast<const float4*>(table + id * E + c);
+      *reinterpret_cast<float4*>(out + row * E + c) = v;
+    } else {
+      out[row * E + c] = ok ? table[id * E + c] : 0.f;
+    }
+  }
+}
+
+// int64 ids -> int32 keys for the sort / segment machinery (V < 2^31), range-checked.
+__global__ void __launch_bounds__(256) ids_to_i32_kernel(const int64_t* __restrict__ ids, int64_t n,
+                                                         int64_t V, int32_t* __restrict__ out,
+                                                         int* __restrict__ err) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t id = ids[t];
+    const bool ok = (id >= 0) & (id < V);
+    if (!ok && err) atomicOr(err, 1);
+    out[t] = ok ? (int32_t)id : 0;
+  }
+}
+
+}  // namespace mapx
+
+extern "C" int mapx_emb_gather_fwd(const int64_t* ids, int64_t n, const float* table, int64_t V,
+                                   int E, float* out, int* err_flag, hipStream_t stream) {
+  MAPX_REQUIRE(ids && table && out, "emb_gather_fwd: null pointer");
+  MAPX_REQUIRE(n >= 0 && V > 0 && E > 0, "emb_gather_fwd: bad sizes n=%lld V=%lld E=%d",
+               (long long)n, (long long)V, E);
+  if (n == 0) return MAPX_OK;
+  const bool vec = (E % 4 == 0) && ((uintptr_t)table % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  const int64_t total = n * (vec ? E / 4 : E);
+  const int grid = mapx::grid_for(total, 256);
+  if (vec)
+    hipLaunchKernelGGL(mapx::emb_gather_kernel<4>, dim3(grid), dim3(256), 0, stream, ids, n, table,
+                       V, E, out, err_flag);
+  else
+    hipLaunchKernelGGL(mapx::emb_gather_kernel<1>, dim3(grid), dim3(256), 0, stream, ids, n, table,
+                       V, E, out, err_flag);
+  return mapx::check_launch("emb_gather_fwd");
+}
+
+extern "C" int mapx_ids_to_i32(const int64_t* ids, int64_t n, int64_t V, int32_t* out,
+                               int* err_flag, hipStream_t stream) {
+  MAPX_REQUIRE(ids && out, "ids_to_i32: null pointer");
+  MAPX_REQUIRE(n >= 0 && V > 0 && V < (1LL << 31), "ids_to_i32: bad sizes");
+  if (n == 0) return MAPX_OK;
+  hipLaunchKernelGGL(mapx::ids_to_i32_kernel, dim3(mapx::grid_for(n, 256)), dim3(256), 0, stream,
+                     ids, n, V, out, err_flag);
+  return mapx::check_launch("ids_to_i32");
+}

@@ -1,0 +1,191 @@
+// Small per-step kernels around the dense trunk:
+//   * BCE-with-logits loss + gradient + statistics for the RFD head (code/models.py:80-85)
+//     and the CTR head (models.py:88-93);
+//   * dynamic_mask on device (code/trainer.py:217-240): MFP masking and RFD/Unigram
+//     replacement, with Philox-generated or caller-injected field indices.
+#include "../../include/mapx_hip.h"
+#include "common.h"
+
+namespace mapx {
+
+constexpr int kLossBlocks = 256;
+
+// loss_i = max(x,0) - x*y + log1p(exp(-|x|));  dlogit_i = (sigmoid(x) - y) / n
+// stats: [0] = # (sigmoid(x) > 0.5) == y, [1] = sum(y)  (both exact integers in float)
+__global__ void __launch_bounds__(256) bce_fwd_kernel(const float* __restrict__ x,
+                                                      const float* __restrict__ y, int64_t n,
+                                                      float inv_n, float* __restrict__ dx,
+                                                      float* __restrict__ part /*[blocks][3]*/) {
+  float loss = 0.f, hit = 0.f, pos = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float xv = x[i], yv = y[i];
+    loss += fmaxf(xv, 0.f) - xv * yv + log1pf(__expf(-fabsf(xv)));
+    const float sig = 1.f / (1.f + __expf(-xv));
+    if (dx) dx[i] = (sig - yv) * inv_n;
+    hit += ((sig > 0.5f ? 1.f : 0.f) == yv) ? 1.f : 0.f;
+    pos += yv;
+  }
+  __shared__ float s[3][256];
+  s[0][threadIdx.x] = loss; s[1][threadIdx.x] = hit; s[2][threadIdx.x] = pos;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      s[0][threadIdx.x] += s[0][threadIdx.x + o];
+      s[1][threadIdx.x] += s[1][threadIdx.x + o];
+      s[2][threadIdx.x] += s[2][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    part[blockIdx.x * 3 + 0] = s[0][0];
+    part[blockIdx.x * 3 + 1] = s[1][0];
+    part[blockIdx.x * 3 + 2] = s[2][0];
+  }
+}
+
+__global__ void bce_finalize_kernel(const float* __restrict__ part, int nblocks, float inv_n,
+                                    float* __restrict__ out /*[3]: loss mean, acc, pos ratio*/) {
+  float a = 0.f, b = 0.f, c = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += kWave) {
+    a += part[i * 3]; b += part[i * 3 + 1]; c += part[i * 3 + 2];
+  }
+  a = group_sum<kWave>(a); b = group_sum<kWave>(b); c = group_sum<kWave>(c);
+  if (threadIdx.x == 0) { out[0] = a * inv_n; out[1] = b * inv_n; out[2] = c * inv_n; }
+}
+
+// MFP branch of dynamic_mask (trainer.py:224-232): one thread per row.
+//   masked_index[b,l] ~ U{0..F-1} with replacement (sampling_method == "randint")
+//   labels[b,l] = ids[b, masked_index[b,l]];  ids_out = ids with those fields set to 3
+__global__ void __launch_bounds__(256) mask_mfp_kernel(const int64_t* __restrict__ ids, int64_t B,
+                                                       int F, int L,
+                                                       const int64_t* __restrict__ mi_in,
+                                                       uint64_t seed, uint64_t offset,
+                                                       int64_t* __restrict__ ids_out,
+                                                       int64_t* __restrict__ labels,
+                                                       int64_t* __restrict__ mi_out) {
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B;
+       b += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t* row = ids + b * F;
+    int64_t* orow = ids_out + b * F;
+    for (int f = 0; f < F; ++f) orow[f] = row[f];
+    for (int l = 0; l < L; ++l) {
+      int64_t f;
+      if (mi_in) {
+        f = mi_in[b * L + l];
+      } else {
+        const Philox4 r = philox4x32_10(seed, (uint64_t)(b * L + l), offset);
+        f = bounded(r.x, (uint32_t)F);
+      }
+      if (mi_out) mi_out[b * L + l] = f;
+      labels[b * L + l] = row[f];
+      orow[f] = 3;  // '<mask>'
+    }
+  }
+}
+
+// RFD / Unigram branch (trainer.py:234-240): replacement ids are the masked field's column
+// of B*L rows drawn uniformly from the training matrix x_train [N,F] (resident in HBM), or
+// caller-injected replace_in [B,L].  Duplicate fields in masked_index: the LAST l wins (CPU
+// scatter order).  labels[b,f] = (ids[b,f] != ids_out[b,f]).
+__global__ void __launch_bounds__(256) mask_rfd_kernel(const int64_t* __restrict__ ids, int64_t B,
+                                                       int F, int L,
+                                                       const int64_t* __restrict__ mi_in,
+                                                       const int64_t* __restrict__ replace_in,
+                                                       const int64_t* __restrict__ x_train, int64_t N,
+                                                       uint64_t seed, uint64_t offset,
+                                                       int64_t* __restrict__ ids_out,
+                                                       float* __restrict__ labels,
+                                                       int64_t* __restrict__ mi_out) {
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B;
+       b += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t* row = ids + b * F;
+    int64_t* orow = ids_out + b * F;
+    for (int f = 0; f < F; ++f) orow[f] = row[f];
+    for (int l = 0; l < L; ++l) {
+      const Philox4 r = philox4x32_10(seed, (uint64_t)(b * L + l), offset);
+      const int64_t f = mi_in ? mi_in[b * L + l] : (int64_t)bounded(r.x, (uint32_t)F);
+      int64_t rep;
+      if (replace_in) {
+        rep = replace_in[b * L + l];
+      } else {
+        // 64-bit row index from two words (N may exceed 2^32 in principle)
+        const uint64_t w = ((uint64_t)r.y << 32) | r.z;
+        const uint64_t hi = (uint64_t)(((unsigned __int128)w * (unsigned __int128)N) >> 64);
+        rep = x_train[(int64_t)hi * F + f];
+      }
+      if (mi_out) mi_out[b * L + l] = f;
+      orow[f] = rep;
+    }
+    for (int f = 0; f < F; ++f) labels[b * F + f] = (row[f] != orow[f]) ? 1.f : 0.f;
+  }
+}
+
+// ReLU backward: out = y > 0 ? dy : 0  (y = the layer's activated output)
+__global__ void __launch_bounds__(256) relu_mask_kernel(const float* __restrict__ dy,
+                                                        const float* __restrict__ y, int64_t n,
+                                                        float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+}  // namespace mapx
+
+extern "C" int mapx_relu_mask(const float* dy, const float* y, int64_t n, float* out,
+                              hipStream_t stream) {
+  MAPX_REQUIRE(dy && y && out && n >= 0, "relu_mask: bad arguments");
+  if (n == 0) return MAPX_OK;
+  hipLaunchKernelGGL(mapx::relu_mask_kernel, dim3(mapx::grid_for(n, 256)), dim3(256), 0, stream, dy,
+                     y, n, out);
+  return mapx::check_launch("relu_mask");
+}
+
+extern "C" size_t mapx_bce_workspace_bytes(void) { return mapx::kLossBlocks * 3 * sizeof(float); }
+
+extern "C" int mapx_bce_with_logits(const float* logits, const float* labels, int64_t n,
+                                    float* dlogits_opt, float* out3, void* ws, size_t ws_bytes,
+                                    hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(logits && labels && out3 && n > 0, "bce_with_logits: bad arguments");
+  if (!ws || ws_bytes < mapx_bce_workspace_bytes()) {
+    set_error("bce_with_logits: workspace too small");
+    return MAPX_EWORKSPACE;
+  }
+  int grid = grid_for(n, 256, kLossBlocks);
+  float* part = static_cast<float*>(ws);
+  const float inv_n = (float)(1.0 / (double)n);
+  hipLaunchKernelGGL(bce_fwd_kernel, dim3(grid), dim3(256), 0, stream, logits, labels, n, inv_n,
+                     dlogits_opt, part);
+  hipLaunchKernelGGL(bce_finalize_kernel, dim3(1), dim3(64), 0, stream, part, grid, inv_n, out3);
+  return check_launch("bce_with_logits");
+}
+
+extern "C" int mapx_dynamic_mask_mfp(const int64_t* ids, int64_t B, int F, int L,
+                                     const int64_t* masked_index_in, uint64_t seed, uint64_t offset,
+                                     int64_t* ids_out, int64_t* labels, int64_t* masked_index_out,
+                                     hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(ids && ids_out && labels && B >= 0 && F > 0 && L >= 0, "dynamic_mask_mfp: bad arguments");
+  MAPX_REQUIRE(ids != ids_out, "dynamic_mask_mfp: in-place masking is not supported");
+  if (B == 0) return MAPX_OK;
+  hipLaunchKernelGGL(mask_mfp_kernel, dim3(grid_for(B, 256)), dim3(256), 0, stream, ids, B, F, L,
+                     masked_index_in, seed, offset, ids_out, labels, masked_index_out);
+  return check_launch("dynamic_mask_mfp");
+}
+
+extern "C" int mapx_dynamic_mask_rfd(const int64_t* ids, int64_t B, int F, int L,
+                                     const int64_t* masked_index_in, const int64_t* replace_in,
+                                     const int64_t* x_train, int64_t N, uint64_t seed,
+                                     uint64_t offset, int64_t* ids_out, float* labels,
+                                     int64_t* masked_index_out, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(ids && ids_out && labels && B >= 0 && F > 0 && L >= 0, "dynamic_mask_rfd: bad arguments");
+  MAPX_REQUIRE(replace_in || (x_train && N > 0), "dynamic_mask_rfd: need replace_in or x_train");
+  MAPX_REQUIRE(ids != ids_out, "dynamic_mask_rfd: in-place replacement is not supported");
+  if (B == 0) return MAPX_OK;
+  hipLaunchKernelGGL(mask_rfd_kernel, dim3(grid_for(B, 256)), dim3(256), 0, stream, ids, B, F, L,
+                     masked_index_in, replace_in, x_train, N, seed, offset, ids_out, labels,
+                     masked_index_out);
+  return check_launch("dynamic_mask_rfd");
+}

@@ -1,0 +1,310 @@
+// MFP head: alias-method negative sampler + fused NCE gather-dot-loss (+ its backward
+// coefficients) + output-table gradient.  Reference: code/nce/alias_multinomial.py:81-97
+// (draw), code/nce/nce_loss.py:79-144,158-173,201-230 (loss), code/nce/index_linear.py:68-106
+// (the (K+1)-row gather per target), code/models.py:75-77 (field gather, accuracy).
+//
+// HBM-bound.  The reference gathers B*L*(K+1) rows of emb[V,P] into an intermediate, reads
+// it again for the dot, and in backward scatters dense [V,P]+[V,1] gradients.  Here every
+// table row is read ONCE per step: the forward kernel keeps the row in registers for the
+// logit, the loss, and dL/dh; the table gradient is a reduce-by-key over (dlogit, h) that
+// never materialises per-pair rows (segreduce.h: NceContrib).
+#include "../../include/mapx_hip.h"
+#include "common.h"
+#include "segreduce.h"
+
+namespace mapx {
+
+struct AliasRec {  // packed Walker table: one 8-byte record per class
+  float prob;
+  int32_t alias;
+};
+
+__global__ void __launch_bounds__(256) alias_pack_kernel(const float* __restrict__ prob,
+                                                         const int64_t* __restrict__ alias,
+                                                         int64_t V, AliasRec* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < V;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = AliasRec{prob[i], (int32_t)alias[i]};
+}
+
+// idx[t, 0] = target id, idx[t, 1 + k] = k-th negative: kk ~ U{0..V-1}; keep kk with
+// probability prob[kk], else alias[kk].  One Philox block serves two draws.
+__global__ void __launch_bounds__(256) alias_draw_kernel(const AliasRec* __restrict__ table,
+                                                         int64_t V, const int64_t* __restrict__ targets,
+                                                         int64_t T, int K, uint64_t seed,
+                                                         uint64_t offset, int32_t* __restrict__ idx) {
+  const int K1 = K + 1;
+  const int64_t pairs_per_t = (K + 1) / 2;  // pairs of negatives per target (K odd -> exact)
+  const int64_t total = T * pairs_per_t;
+  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total;
+       w += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = w / pairs_per_t;
+    const int k0 = (int)(w - t * pairs_per_t) * 2;
+    const Philox4 r = philox4x32_10(seed, (uint64_t)w, offset);
+    const uint32_t kk0 = bounded(r.x, (uint32_t)V);
+    const AliasRec a0 = table[kk0];
+    idx[t * K1 + 1 + k0] = (unit_float(r.y) < a0.prob) ? (int32_t)kk0 : a0.alias;
+    if (k0 + 1 < K) {
+      const uint32_t kk1 = bounded(r.z, (uint32_t)V);
+      const AliasRec a1 = table[kk1];
+      idx[t * K1 + 2 + k0] = (unit_float(r.w) < a1.prob) ? (int32_t)kk1 : a1.alias;
+    }
+    if (k0 == 0) idx[t * K1] = (int32_t)targets[t];
+  }
+}
+
+// Injected-noise variant (parity tests): copy caller-provided int64 indices.
+__global__ void __launch_bounds__(256) nce_pack_idx_kernel(const int64_t* __restrict__ targets,
+                                                           const int64_t* __restrict__ noise,
+                                                           int64_t T, int K, int64_t V,
+                                                           int32_t* __restrict__ idx,
+                                                           int* __restrict__ err) {
+  const int K1 = K + 1;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < T * K1;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = e / K1;
+    const int j = (int)(e - t * K1);
+    const int64_t id = j == 0 ? targets[t] : noise[t * K + j - 1];
+    const bool ok = (id >= 0) & (id < V);
+    if (!ok && err) atomicOr(err, 1);
+    idx[e] = ok ? (int32_t)id : 0;
+  }
+}
+
+__device__ inline float softplus_f(float x) {
+  return fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x)));
+}
+
+// LG = P/4 lanes per target.  Per target t = b*L + l:
+//   h      = enc[b, masked_index[b,l]*P : +P]                       (models.py:75)
+//   s_j    = <h, emb[idx_j]> + bias[idx_j] - lnV                    (index_linear.py:102, nce_loss.py:171)
+//   lt_j   = s_j - logq[idx_j] - lnK                                (nce_loss.py:215)
+//   loss_t = softplus(-lt_0) + sum_{j>=1} softplus(lt_j)            (nce_loss.py:217-229)
+//   dlogit = (sigmoid(lt_j) - [j==0]) / T,  dh = sum_j dlogit_j * emb[idx_j]
+template <int LG>
+__global__ void __launch_bounds__(256) nce_fwd_kernel(
+    const float* __restrict__ enc, int64_t enc_stride, const int64_t* __restrict__ masked_index,
+    int L, const int32_t* __restrict__ idx, int64_t T, int K1, const float* __restrict__ emb,
+    const float* __restrict__ bias, const float* __restrict__ logq, float lnV, float lnK,
+    float invT, float* __restrict__ h_out, float* __restrict__ dlogit, float* __restrict__ dh,
+    float* __restrict__ logits, float* __restrict__ loss_partial, int* __restrict__ acc_count) {
+  constexpr int P = LG * 4;
+  constexpr int GPB = 256 / LG;  // targets per block pass
+  const int sub = threadIdx.x % LG;
+  const int gib = threadIdx.x / LG;
+  float loss_acc = 0.f;
+  int acc_acc = 0;
+  for (int64_t t = (int64_t)blockIdx.x * GPB + gib; t < T; t += (int64_t)gridDim.x * GPB) {
+    const int64_t b = t / L;
+    const int64_t mi = masked_index[t];
+    const float4 h4 =
+        *reinterpret_cast<const float4*>(enc + b * enc_stride + mi * P + 4 * sub);
+    *reinterpret_cast<float4*>(h_out + t * P + 4 * sub) = h4;
+    float4 dh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float s0 = 0.f, smax = -INFINITY, loss_t = 0.f;
+    const int32_t* ix = idx + t * K1;
+#pragma unroll 2
+    for (int j = 0; j < K1; ++j) {
+      const int32_t id = ix[j];
+      const float4 r4 = *reinterpret_cast<const float4*>(emb + (int64_t)id * P + 4 * sub);
+      const float bq = bias[id];
+      const float lq = logq[id];
+      float part = h4.x * r4.x + h4.y * r4.y + h4.z * r4.z + h4.w * r4.w;
+      part = group_sum<LG>(part);
+      const float s = part + bq - lnV;
+      const float lt = s - lq - lnK;
+      const float sig = 1.f / (1.f + __expf(-lt));
+      float d;
+      if (j == 0) {
+        s0 = s;
+        loss_t += softplus_f(-lt);
+        d = (sig - 1.f) * invT;
+      } else {
+        smax = fmaxf(smax, s);
+        loss_t += softplus_f(lt);
+        d = sig * invT;
+      }
+      dh4.x += d * r4.x; dh4.y += d * r4.y; dh4.z += d * r4.z; dh4.w += d * r4.w;
+      if ((j % LG) == sub) {
+        dlogit[t * K1 + j] = d;
+        if (logits) logits[t * K1 + j] = s;
+      }
+    }
+    *reinterpret_cast<float4*>(dh + t * P + 4 * sub) = dh4;
+    if (sub == 0) {
+      loss_acc += loss_t;
+      acc_acc += (s0 >= smax) ? 1 : 0;  // argmax == 0, ties resolve to the first index
+    }
+  }
+  // block reduction in a fixed order: lane-group leaders -> LDS -> thread 0
+  __shared__ float sl[GPB];
+  __shared__ int sa[GPB];
+  if (sub == 0) { sl[gib] = loss_acc; sa[gib] = acc_acc; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float l = 0.f;
+    int a = 0;
+    for (int i = 0; i < GPB; ++i) { l += sl[i]; a += sa[i]; }
+    loss_partial[blockIdx.x] = l;
+    if (a) atomicAdd(acc_count, a);
+  }
+}
+
+__global__ void nce_loss_finalize_kernel(const float* __restrict__ partial, int n, float invT,
+                                         float* __restrict__ loss) {
+  // single wave, fixed order: lane i sums partial[i], partial[i+64], ...; then butterfly
+  float v = 0.f;
+  for (int i = threadIdx.x; i < n; i += kWave) v += partial[i];
+  v = group_sum<kWave>(v);
+  if (threadIdx.x == 0) *loss = v * invT;
+}
+
+// d enc[b, f*P + p] = g * sum_{l : masked_index[b,l] == f} dh[b,l,p]   (backward of the
+// field gather, models.py:75).  One thread per (b, p) walks l in order: duplicates in
+// masked_index accumulate deterministically, untouched fields are written as zero.
+__global__ void __launch_bounds__(256) nce_scatter_dh_kernel(const float* __restrict__ dh,
+                                                             const int64_t* __restrict__ masked_index,
+                                                             const float* __restrict__ gscale,
+                                                             int64_t B, int L, int F, int P,
+                                                             float* __restrict__ denc) {
+  const float g = gscale ? *gscale : 1.f;
+  const int64_t total = B * P;
+  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total;
+       w += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = w / P;
+    const int p = (int)(w - b * P);
+    float* row = denc + b * (int64_t)F * P;
+    for (int f = 0; f < F; ++f) row[f * P + p] = 0.f;
+    for (int l = 0; l < L; ++l) {
+      const int64_t f = masked_index[b * L + l];
+      row[f * P + p] += g * dh[(b * L + l) * P + p];
+    }
+  }
+}
+
+// scale rows in place by a device scalar (upstream gradient of the loss)
+__global__ void __launch_bounds__(256) scale_kernel(float* __restrict__ x, int64_t n,
+                                                    const float* __restrict__ g) {
+  const float s = *g;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    x[i] *= s;
+}
+
+constexpr int kNceBlocks = 1024;
+
+}  // namespace mapx
+
+extern "C" int mapx_alias_pack(const float* prob, const int64_t* alias, int64_t V, void* packed,
+                               hipStream_t stream) {
+  MAPX_REQUIRE(prob && alias && packed && V > 0 && V < (1LL << 31), "alias_pack: bad arguments");
+  hipLaunchKernelGGL(mapx::alias_pack_kernel, dim3(mapx::grid_for(V, 256)), dim3(256), 0, stream,
+                     prob, alias, V, static_cast<mapx::AliasRec*>(packed));
+  return mapx::check_launch("alias_pack");
+}
+
+extern "C" int mapx_alias_draw(const void* packed, int64_t V, const int64_t* targets, int64_t T,
+                               int K, uint64_t seed, uint64_t offset, int32_t* idx,
+                               hipStream_t stream) {
+  MAPX_REQUIRE(packed && targets && idx, "alias_draw: null pointer");
+  MAPX_REQUIRE(V > 0 && V < (1LL << 31) && T >= 0 && K >= 1, "alias_draw: bad sizes");
+  if (T == 0) return MAPX_OK;
+  const int64_t work = T * ((K + 1) / 2);
+  hipLaunchKernelGGL(mapx::alias_draw_kernel, dim3(mapx::grid_for(work, 256)), dim3(256), 0,
+                     stream, static_cast<const mapx::AliasRec*>(packed), V, targets, T, K, seed,
+                     offset, idx);
+  return mapx::check_launch("alias_draw");
+}
+
+extern "C" int mapx_nce_pack_idx(const int64_t* targets, const int64_t* noise, int64_t T, int K,
+                                 int64_t V, int32_t* idx, int* err_flag, hipStream_t stream) {
+  MAPX_REQUIRE(targets && noise && idx && T >= 0 && K >= 1, "nce_pack_idx: bad arguments");
+  if (T == 0) return MAPX_OK;
+  hipLaunchKernelGGL(mapx::nce_pack_idx_kernel, dim3(mapx::grid_for(T * (K + 1), 256)), dim3(256),
+                     0, stream, targets, noise, T, K, V, idx, err_flag);
+  return mapx::check_launch("nce_pack_idx");
+}
+
+extern "C" size_t mapx_nce_fwd_workspace_bytes(void) { return mapx::kNceBlocks * sizeof(float); }
+
+extern "C" int mapx_nce_fwd(const float* enc, int64_t B, int L, int F, int P,
+                            const int64_t* masked_index, const int32_t* idx, int K,
+                            const float* emb, const float* bias, const float* logq, int64_t V,
+                            float* h_out, float* dlogit, float* dh, float* logits_opt,
+                            float* loss_out, int32_t* acc_out, void* ws, size_t ws_bytes,
+                            hipStream_t stream) {
+  MAPX_REQUIRE(enc && masked_index && idx && emb && bias && logq && h_out && dlogit && dh &&
+                   loss_out && acc_out && ws,
+               "nce_fwd: null pointer");
+  MAPX_REQUIRE(B >= 0 && L >= 1 && F >= 1 && K >= 1 && V > 0, "nce_fwd: bad sizes");
+  MAPX_REQUIRE(P == 8 || P == 16 || P == 32 || P == 64 || P == 128,
+               "nce_fwd: proj_size %d unsupported (8, 16, 32, 64, 128)", P);
+  if (ws_bytes < mapx_nce_fwd_workspace_bytes()) {
+    mapx::set_error("nce_fwd: workspace too small");
+    return MAPX_EWORKSPACE;
+  }
+  const int64_t T = B * L;
+  MAPX_HIP(hipMemsetAsync(acc_out, 0, sizeof(int32_t), stream));
+  if (T == 0) {
+    MAPX_HIP(hipMemsetAsync(loss_out, 0, sizeof(float), stream));
+    return MAPX_OK;
+  }
+  const int LG = P / 4, GPB = 256 / LG;
+  int grid = (int)mapx::ceil_div(T, GPB);
+  if (grid > mapx::kNceBlocks) grid = mapx::kNceBlocks;
+  float* partial = static_cast<float*>(ws);
+  const float lnV = (float)log((double)V), lnK = (float)log((double)K), invT = 1.0f / (float)T;
+  const int64_t enc_stride = (int64_t)F * P;
+#define MAPX_NCE(LG_)                                                                           \
+  hipLaunchKernelGGL(mapx::nce_fwd_kernel<LG_>, dim3(grid), dim3(256), 0, stream, enc,          \
+                     enc_stride, masked_index, L, idx, T, K + 1, emb, bias, logq, lnV, lnK,     \
+                     invT, h_out, dlogit, dh, logits_opt, partial, acc_out)
+  switch (LG) {
+    case 2: MAPX_NCE(2); break;
+    case 4: MAPX_NCE(4); break;
+    case 8: MAPX_NCE(8); break;
+    case 16: MAPX_NCE(16); break;
+    default: MAPX_NCE(32); break;
+  }
+#undef MAPX_NCE
+  hipLaunchKernelGGL(mapx::nce_loss_finalize_kernel, dim3(1), dim3(64), 0, stream, partial, grid,
+                     invT, loss_out);
+  return mapx::check_launch("nce_fwd");
+}
+
+extern "C" int mapx_nce_scatter_dh(const float* dh, const int64_t* masked_index,
+                                   const float* gscale_opt, int64_t B, int L, int F, int P,
+                                   float* denc, hipStream_t stream) {
+  MAPX_REQUIRE(dh && masked_index && denc, "nce_scatter_dh: null pointer");
+  if (B == 0) return MAPX_OK;
+  hipLaunchKernelGGL(mapx::nce_scatter_dh_kernel, dim3(mapx::grid_for(B * P, 256)), dim3(256), 0,
+                     stream, dh, masked_index, gscale_opt, B, L, F, P, denc);
+  return mapx::check_launch("nce_scatter_dh");
+}
+
+extern "C" size_t mapx_nce_table_grad_workspace_bytes(int64_t n, int P) {
+  return mapx::seg_reduce_partial_bytes(n, P, true) + 256;
+}
+
+// out_emb[u, :] / out_bias[u] = gradient rows of the unique table rows uniq[u] of the plan
+// built over idx.flatten() (n = T*(K+1) keys).
+extern "C" int mapx_nce_table_grad(int64_t n, const int32_t* perm, const int32_t* rank,
+                                   const int32_t* seg_start, const float* dlogit, const float* h,
+                                   int K, int P, float* out_emb, float* out_bias, void* ws,
+                                   size_t ws_bytes, hipStream_t stream) {
+  MAPX_REQUIRE(n >= 0, "nce_table_grad: n < 0");
+  if (n == 0) return MAPX_OK;
+  MAPX_REQUIRE(perm && rank && seg_start && dlogit && h && out_emb && out_bias,
+               "nce_table_grad: null pointer");
+  mapx::SegPlanView pl{n, perm, rank, seg_start};
+  mapx::NceContrib c{dlogit, h, K + 1, P};
+  return mapx::seg_reduce_launch<true>(pl, c, P, out_emb, out_bias, ws, ws_bytes, stream,
+                                       "nce_table_grad");
+}
+
+extern "C" int mapx_scale_inplace(float* x, int64_t n, const float* g, hipStream_t stream) {
+  MAPX_REQUIRE(x && g && n >= 0, "scale_inplace: bad arguments");
+  if (n == 0) return MAPX_OK;
+  hipLaunchKernelGGL(mapx::scale_kernel, dim3(mapx::grid_for(n, 256)), dim3(256), 0, stream, x, n, g);
+  return mapx::check_launch("scale_inplace");
+}

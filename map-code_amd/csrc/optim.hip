@@ -1,0 +1,221 @@
+// transformers-4.26 AdamW (the optimizer reference code/trainer.py:60-85 constructs), as
+// (1) one fused dense sweep per flat parameter group and (2) a lazy, EXACT row-sparse form
+// for the [V,*] tables.
+//
+// Update number s (1-based), gradient g, on fp32 state (p, m, v):
+//     m = b1*m + (1-b1)*g ;  v = b2*v + (1-b2)*g*g
+//     p = p - step_s * m / (sqrt(v) + eps)        step_s = lr_s*sqrt(1-b2^s)/(1-b1^s)
+//     p = p - lr_s*wd * p                          (decoupled decay AFTER the Adam update)
+// with lr_s = lr0 * lambda(s-1) (scheduler stepped after the optimizer, trainer.py:328-329).
+// (step_s, lr_s) come from a device table sched[s-1] = {step_s, lr_s} computed once on the
+// host in double, and the update counter lives in device memory, so a captured hipGraph
+// replays the whole step without host-side scalars.
+//
+// The reference never uses sparse gradients, so every table row takes a zero-gradient
+// update on every step it is not touched (m, v decay; p moves by the decaying momentum and
+// shrinks by the weight decay): 49*V parameters * 28 B per step.  The lazy form keeps
+// `last[row]` = number of updates already applied to that row and replays the missing
+// zero-gradient updates IN REGISTERS, with the same fp32 operations in the same order,
+// when the row is next needed (catch-up before the forward gather; again, as a no-op,
+// inside the gradient update) or when the table is flushed (checkpoint / eval).
+#include "../../include/mapx_hip.h"
+#include "common.h"
+
+namespace mapx {
+
+struct AdamHyper {
+  float beta1, beta2, eps;
+  float one_m_b1, one_m_b2;
+};
+
+__device__ inline void adam_elem(float& p, float& m, float& v, float g, float step, float decay,
+                                 const AdamHyper& h) {
+  m = m * h.beta1 + g * h.one_m_b1;
+  v = v * h.beta2 + (h.one_m_b2 * g) * g;
+  const float denom = sqrtf(v) + h.eps;
+  p = p + ((-step) * m) / denom;   // ATen addcdiv: self + (value * t1) / t2
+  if (decay != 0.f) p = p + (-decay) * p;
+}
+
+__device__ inline void adam_elem_zero_grad(float& p, float& m, float& v, float step, float decay,
+                                           const AdamHyper& h) {
+  m = m * h.beta1;
+  v = v * h.beta2;
+  const float denom = sqrtf(v) + h.eps;
+  p = p + ((-step) * m) / denom;
+  if (decay != 0.f) p = p + (-decay) * p;
+}
+
+__global__ void __launch_bounds__(256) adamw_dense_kernel(float* __restrict__ p,
+                                                          const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v,
+                                                          int64_t n, const float2* __restrict__ sched,
+                                                          int sched_len, const int32_t* __restrict__ done,
+                                                          AdamHyper h, float wd) {
+  int s = *done;  // updates applied so far; this is update s+1 -> sched[s]
+  if (s >= sched_len) s = sched_len - 1;
+  const float2 sc = sched[s];
+  const float step = sc.x, decay = sc.y * wd;
+  const int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float4 pv = reinterpret_cast<float4*>(p)[i];
+    float4 mv = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    adam_elem(pv.x, mv.x, vv.x, gv.x, step, decay, h);
+    adam_elem(pv.y, mv.y, vv.y, gv.y, step, decay, h);
+    adam_elem(pv.z, mv.z, vv.z, gv.z, step, decay, h);
+    adam_elem(pv.w, mv.w, vv.w, gv.w, step, decay, h);
+    reinterpret_cast<float4*>(p)[i] = pv;
+    reinterpret_cast<float4*>(m)[i] = mv;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  // tail (n % 4)
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    adam_elem(p[i], m[i], v[i], g[i], step, decay, h);
+}
+
+__global__ void step_advance_kernel(int32_t* done) { *done += 1; }
+
+// ---------------------------------------------------------------------------- lazy tables
+struct TableGroup {
+  float* p0; float* m0; float* v0; int W0; float wd0;   // main table [V, W0], W0 % 4 == 0
+  float* p1; float* m1; float* v1; float wd1;           // optional scalar-per-row table [V] or null
+  int32_t* last;                                        // [V] updates applied to each row
+};
+
+// Replay zero-gradient updates (from+1 .. to) on one float4 of a row.
+__device__ inline void replay4(float4& p, float4& m, float4& v, int from, int to,
+                               const float2* __restrict__ sched, int sched_len, float wd,
+                               const AdamHyper& h) {
+  for (int s = from; s < to; ++s) {  // update s+1 uses sched[s]
+    const float2 sc = sched[s < sched_len ? s : sched_len - 1];
+    const float decay = sc.y * wd;
+    adam_elem_zero_grad(p.x, m.x, v.x, sc.x, decay, h);
+    adam_elem_zero_grad(p.y, m.y, v.y, sc.x, decay, h);
+    adam_elem_zero_grad(p.z, m.z, v.z, sc.x, decay, h);
+    adam_elem_zero_grad(p.w, m.w, v.w, sc.x, decay, h);
+  }
+}
+
+// rows == nullptr: rows are row_begin + i (range sweep / flush), count = n_rows.
+// rows != nullptr: rows[i], count = *n_rows_dev (device, <= capacity n_rows).
+// grad == nullptr: catch-up only, rows become current through `*done` updates.
+// grad != nullptr: catch-up through *done, then apply update *done+1 with grad rows
+//                  grad0[i, :] (and grad1[i]); last = *done + 1.
+template <int LG>
+__global__ void __launch_bounds__(256) table_adam_kernel(TableGroup tg, const int32_t* __restrict__ rows,
+                                                         int64_t row_begin, int64_t n_rows,
+                                                         const int32_t* __restrict__ n_rows_dev,
+                                                         const float* __restrict__ grad0,
+                                                         const float* __restrict__ grad1,
+                                                         const float2* __restrict__ sched,
+                                                         int sched_len, const int32_t* __restrict__ done,
+                                                         AdamHyper h) {
+  const int64_t count = n_rows_dev ? (int64_t)*n_rows_dev : n_rows;
+  const int target = *done;
+  const int lig = threadIdx.x % LG;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LG; i < count;
+       i += ((int64_t)gridDim.x * blockDim.x) / LG) {
+    const int64_t r = rows ? (int64_t)rows[i] : row_begin + i;
+    const int from = tg.last[r];
+    if (from >= target && !grad0) continue;
+    for (int sub = lig; sub * 4 < tg.W0; sub += LG) {
+      float* pp = tg.p0 + r * tg.W0 + 4 * sub;
+      float* pm = tg.m0 + r * tg.W0 + 4 * sub;
+      float* pv = tg.v0 + r * tg.W0 + 4 * sub;
+      float4 p = *reinterpret_cast<float4*>(pp);
+      float4 m = *reinterpret_cast<float4*>(pm);
+      float4 v = *reinterpret_cast<float4*>(pv);
+      replay4(p, m, v, from, target, sched, sched_len, tg.wd0, h);
+      if (grad0) {
+        const float2 sc = sched[target < sched_len ? target : sched_len - 1];
+        const float4 g = *reinterpret_cast<const float4*>(grad0 + i * tg.W0 + 4 * sub);
+        const float decay = sc.y * tg.wd0;
+        adam_elem(p.x, m.x, v.x, g.x, sc.x, decay, h);
+        adam_elem(p.y, m.y, v.y, g.y, sc.x, decay, h);
+        adam_elem(p.z, m.z, v.z, g.z, sc.x, decay, h);
+        adam_elem(p.w, m.w, v.w, g.w, sc.x, decay, h);
+      }
+      *reinterpret_cast<float4*>(pp) = p;
+      *reinterpret_cast<float4*>(pm) = m;
+      *reinterpret_cast<float4*>(pv) = v;
+    }
+    if (tg.p1 && lig == 0) {
+      float p = tg.p1[r], m = tg.m1[r], v = tg.v1[r];
+      for (int s = from; s < target; ++s) {
+        const float2 sc = sched[s < sched_len ? s : sched_len - 1];
+        adam_elem_zero_grad(p, m, v, sc.x, sc.y * tg.wd1, h);
+      }
+      if (grad1) {
+        const float2 sc = sched[target < sched_len ? target : sched_len - 1];
+        adam_elem(p, m, v, grad1[i], sc.x, sc.y * tg.wd1, h);
+      }
+      tg.p1[r] = p; tg.m1[r] = m; tg.v1[r] = v;
+    }
+    // all lanes of the row have read `from`; the row's lanes sit in one wave, so the store
+    // below cannot overtake their reads of tg.last[r] (program order within the wave)
+    if (lig == 0) tg.last[r] = grad0 ? target + 1 : target;
+  }
+}
+
+static AdamHyper make_hyper(float b1, float b2, float eps) {
+  AdamHyper h;
+  h.beta1 = b1; h.beta2 = b2; h.eps = eps;
+  h.one_m_b1 = (float)(1.0 - (double)b1);
+  h.one_m_b2 = (float)(1.0 - (double)b2);
+  return h;
+}
+
+}  // namespace mapx
+
+extern "C" int mapx_adamw_dense(float* p, const float* g, float* m, float* v, int64_t n,
+                                const float* sched, int sched_len, const int32_t* done,
+                                float beta1, float beta2, float eps, float weight_decay,
+                                hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(p && g && m && v && sched && done && n >= 0 && sched_len > 0, "adamw_dense: bad arguments");
+  MAPX_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
+                   ((uintptr_t)v % 16 == 0),
+               "adamw_dense: pointers must be 16-byte aligned");
+  if (n == 0) return MAPX_OK;
+  hipLaunchKernelGGL(adamw_dense_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, stream, p, g, m,
+                     v, n, reinterpret_cast<const float2*>(sched), sched_len, done,
+                     make_hyper(beta1, beta2, eps), weight_decay);
+  return check_launch("adamw_dense");
+}
+
+extern "C" int mapx_step_advance(int32_t* done, hipStream_t stream) {
+  MAPX_REQUIRE(done, "step_advance: null");
+  hipLaunchKernelGGL(mapx::step_advance_kernel, dim3(1), dim3(1), 0, stream, done);
+  return mapx::check_launch("step_advance");
+}
+
+extern "C" int mapx_table_adam(float* p0, float* m0, float* v0, int W0, float wd0, float* p1,
+                               float* m1, float* v1, float wd1, int32_t* last,
+                               const int32_t* rows, int64_t row_begin, int64_t n_rows,
+                               const int32_t* n_rows_dev, const float* grad0, const float* grad1,
+                               const float* sched, int sched_len, const int32_t* done, float beta1,
+                               float beta2, float eps, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(p0 && m0 && v0 && last && sched && done, "table_adam: null pointer");
+  MAPX_REQUIRE(W0 > 0 && W0 % 4 == 0, "table_adam: row width %d must be a multiple of 4", W0);
+  MAPX_REQUIRE(!p1 || (m1 && v1), "table_adam: secondary state missing");
+  MAPX_REQUIRE(!(grad0 && p1) || grad1, "table_adam: secondary gradient missing");
+  if (n_rows <= 0) return MAPX_OK;
+  TableGroup tg{p0, m0, v0, W0, wd0, p1, m1, v1, wd1, last};
+  const int lg = (W0 <= 16) ? 4 : (W0 <= 32 ? 8 : 16);
+  const int grid = grid_for(n_rows * lg, 256, 4096);
+  const AdamHyper h = make_hyper(beta1, beta2, eps);
+  const float2* sc = reinterpret_cast<const float2*>(sched);
+#define MAPX_TA(LG_)                                                                              \
+  hipLaunchKernelGGL(table_adam_kernel<LG_>, dim3(grid), dim3(256), 0, stream, tg, rows, row_begin, \
+                     n_rows, n_rows_dev, grad0, grad1, sc, sched_len, done, h)
+  if (lg == 4) MAPX_TA(4);
+  else if (lg == 8) MAPX_TA(8);
+  else MAPX_TA(16);
+#undef MAPX_TA
+  return check_launch("table_adam");
+}

@@ -1,0 +1,215 @@
+// Deterministic reduce-by-key of gradient rows ("sparse embedding grad"): replaces the
+// dense [V,E] zero-fill + index_add of aten::embedding_dense_backward / index_select
+// backward (reference code/layers.py:86, nce/index_linear.py:99-100).
+//
+// A SegPlan (segplan.hip) gives, for n keys: the sorted order `perm`, the 1-based segment
+// rank of every sorted position, and the segment starts.  Reduction is chunk-aligned so
+// that skewed keys (id 3 = <mask> receives B*L rows, 2-value fields receive ~B/2 each)
+// cost no more than uniform ones:
+//   pass A  a group of W/4 lanes walks CH consecutive SORTED positions, accumulating in
+//           registers and flushing whenever the segment rank changes.  Segments that lie
+//           inside the chunk go straight to out[rank-1]; the piece that continues from
+//           the previous chunk goes to part_head[chunk], the piece that continues into
+//           the next chunk to part_tail[chunk].
+//   pass B  one wave per chunk; the chunk whose tail piece STARTS a spanning segment owns
+//           it and sums tail + the following chunks' head pieces, strided over the wave's
+//           lane groups and combined in a fixed order.
+// No float atomics anywhere: sums are bit-reproducible, so data-parallel replicas that
+// apply the same merged gradient stay bit-identical.
+#pragma once
+#include "common.h"
+
+namespace mapx {
+
+constexpr int kSegChunk = 32;  // sorted positions per lane group in pass A
+
+struct SegPlanView {
+  int64_t n;
+  const int32_t* perm;       // [n]  sorted position -> original position
+  const int32_t* rank;       // [n]  1-based segment id of each sorted position
+  const int32_t* seg_start;  // [U+1] first sorted position of each segment; [U] = n
+};
+
+// Contribution functors: value of row `p` (original position), float4 column `sub`.
+struct RowsContrib {
+  const float* src;  // [n, W]
+  int W;
+  __device__ inline float4 operator()(int32_t p, int sub, float& extra) const {
+    extra = 0.f;
+    return *reinterpret_cast<const float4*>(src + (int64_t)p * W + 4 * sub);
+  }
+};
+
+// NCE output-table gradient, never materialised per (target, sample) pair:
+// d emb[idx[t,j]] += dlogit[t,j] * h[t,:]   d bias[idx[t,j]] += dlogit[t,j]
+// (backward of reference nce/index_linear.py:99-102; p = t*(K+1)+j)
+struct NceContrib {
+  const float* dlogit;  // [T*(K+1)]
+  const float* h;       // [T, P]
+  int K1, P;
+  __device__ inline float4 operator()(int32_t p, int sub, float& extra) const {
+    const float d = dlogit[p];
+    const int t = p / K1;
+    float4 v = *reinterpret_cast<const float4*>(h + (int64_t)t * P + 4 * sub);
+    extra = d;
+    return make_float4(d * v.x, d * v.y, d * v.z, d * v.w);
+  }
+};
+
+__device__ inline void add4(float4& a, const float4& b) {
+  a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+}
+
+// W = row width in floats (multiple of 4, <= 256).  Row layout of out/part_*: WS floats
+// per row where WS = W (+4 if EXTRA: the extra scalar lives at column W).
+template <int LG, bool EXTRA, class Contrib>
+__global__ void __launch_bounds__(256) seg_reduce_pass_a(SegPlanView pl, Contrib contrib, int W,
+                                                         float* __restrict__ out,
+                                                         float* __restrict__ out_extra,
+                                                         float* __restrict__ part_head,
+                                                         float* __restrict__ part_tail) {
+  const int WS = EXTRA ? W + 4 : W;
+  const int lane_in_group = threadIdx.x % LG;
+  const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LG;
+  const int64_t ngroups = ceil_div(pl.n, kSegChunk);
+  if (group >= ngroups) return;
+  // LG lanes cover W/4 float4 columns, possibly in several rounds (W > 4*LG)
+  for (int sub = lane_in_group; sub * 4 < W; sub += LG) {
+    const int64_t j0 = group * kSegChunk;
+    const int64_t j1 = (j0 + kSegChunk < pl.n) ? j0 + kSegChunk : pl.n;
+    int cur = pl.rank[j0];
+    bool started_inside = (j0 == 0) || (pl.rank[j0 - 1] != cur);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float accx = 0.f;
+    for (int64_t j = j0; j < j1; ++j) {
+      const int r = pl.rank[j];
+      if (r != cur) {
+        float* dst = started_inside ? out + (int64_t)(cur - 1) * W : part_head + group * WS;
+        *reinterpret_cast<float4*>(dst + 4 * sub) = acc;
+        if (EXTRA && sub == 0) {
+          if (started_inside) out_extra[cur - 1] = accx;
+          else part_head[group * WS + W] = accx;
+        }
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        accx = 0.f;
+        cur = r;
+        started_inside = true;
+      }
+      float ex;
+      const float4 v = contrib(pl.perm[j], sub, ex);
+      add4(acc, v);
+      if (EXTRA) accx += ex;
+    }
+    const bool ends = (j1 == pl.n) || (pl.rank[j1] != cur);
+    float* dst;
+    float* dstx;
+    if (started_inside && ends) {
+      dst = out + (int64_t)(cur - 1) * W;
+      dstx = out_extra + (cur - 1);
+    } else if (!started_inside) {
+      dst = part_head + group * WS;
+      dstx = part_head + group * WS + W;
+    } else {
+      dst = part_tail + group * WS;
+      dstx = part_tail + group * WS + W;
+    }
+    *reinterpret_cast<float4*>(dst + 4 * sub) = acc;
+    if (EXTRA && sub == 0) *dstx = accx;
+  }
+}
+
+// One wave per chunk.  Owner test: the chunk's last segment started inside the chunk and
+// continues past its end.  Sum = tail[c] + head[c+1] + ... + head[c_last].
+template <int LG, bool EXTRA>
+__global__ void __launch_bounds__(256) seg_reduce_pass_b(SegPlanView pl, int W,
+                                                         float* __restrict__ out,
+                                                         float* __restrict__ out_extra,
+                                                         const float* __restrict__ part_head,
+                                                         const float* __restrict__ part_tail) {
+  const int WS = EXTRA ? W + 4 : W;
+  const int lane = threadIdx.x % kWave;
+  const int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+  const int64_t nchunks = ceil_div(pl.n, kSegChunk);
+  if (c >= nchunks) return;
+  const int64_t j0 = c * kSegChunk, j1 = j0 + kSegChunk;
+  if (j1 >= pl.n) return;                       // last chunk cannot have a continuing tail
+  const int cur = pl.rank[j1 - 1];
+  if (pl.rank[j1] != cur) return;               // tail segment ends with the chunk
+  const int64_t s0 = pl.seg_start[cur - 1];
+  if (s0 < j0) return;                          // it started in an earlier chunk: not the owner
+  const int64_t c_last = (pl.seg_start[cur] - 1) / kSegChunk;
+  constexpr int G = kWave / LG;                 // lane groups per wave
+  const int g = lane / LG, lig = lane % LG;
+  for (int sub0 = 0; sub0 * 4 < W; sub0 += LG) {   // wave-uniform trip count (shuffles inside)
+    const int sub = sub0 + lig;
+    const bool live = sub * 4 < W;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float accx = 0.f;
+    if (live) {
+      for (int64_t cc = c + 1 + g; cc <= c_last; cc += G) {
+        add4(acc, *reinterpret_cast<const float4*>(part_head + cc * WS + 4 * sub));
+        if (EXTRA && sub == 0) accx += part_head[cc * WS + W];
+      }
+    }
+    // combine the G strided partial sums in group order 0..G-1 (fixed -> reproducible)
+    float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+    float totx = 0.f;
+    if (g == 0 && live) {
+      tot = *reinterpret_cast<const float4*>(part_tail + c * WS + 4 * sub);
+      if (EXTRA && sub == 0) totx = part_tail[c * WS + W];
+    }
+#pragma unroll
+    for (int gg = 0; gg < G; ++gg) {
+      const int src = gg * LG + lig;
+      tot.x += __shfl(acc.x, src, kWave);
+      tot.y += __shfl(acc.y, src, kWave);
+      tot.z += __shfl(acc.z, src, kWave);
+      tot.w += __shfl(acc.w, src, kWave);
+      if (EXTRA) totx += __shfl(accx, src, kWave);
+    }
+    if (g == 0 && live) {
+      *reinterpret_cast<float4*>(out + (int64_t)(cur - 1) * W + 4 * sub) = tot;
+      if (EXTRA && sub == 0) out_extra[cur - 1] = totx;
+    }
+  }
+}
+
+// Bytes of partial storage seg_reduce needs for n keys of row width W (+extra).
+inline size_t seg_reduce_partial_bytes(int64_t n, int W, bool extra) {
+  const int WS = extra ? W + 4 : W;
+  return (size_t)ceil_div(n > 0 ? n : 1, kSegChunk) * WS * sizeof(float) * 2;
+}
+
+template <bool EXTRA, class Contrib>
+int seg_reduce_launch(const SegPlanView& pl, const Contrib& contrib, int W, float* out,
+                      float* out_extra, void* ws, size_t ws_bytes, hipStream_t stream,
+                      const char* what) {
+  if (pl.n == 0) return MAPX_OK;
+  MAPX_REQUIRE(W % 4 == 0 && W >= 4 && W <= 256, "%s: row width %d must be a multiple of 4", what, W);
+  const size_t need = seg_reduce_partial_bytes(pl.n, W, EXTRA);
+  if (ws_bytes < need || !ws) {
+    set_error("%s: workspace %zu < %zu bytes", what, ws_bytes, need);
+    return MAPX_EWORKSPACE;
+  }
+  const int WS = EXTRA ? W + 4 : W;
+  const int64_t nchunks = ceil_div(pl.n, kSegChunk);
+  float* part_head = static_cast<float*>(ws);
+  float* part_tail = part_head + nchunks * WS;
+  // lane-group width: 4 lanes for 16-float rows, 8 for 32-float rows, 16 beyond
+  const int lg = (W <= 16) ? 4 : (W <= 32 ? 8 : 16);
+  const int64_t threads_a = nchunks * lg;
+  const int grid_a = (int)ceil_div(threads_a, 256);
+  const int grid_b = (int)ceil_div(nchunks * kWave, 256);
+#define MAPX_SEG_LAUNCH(LG_)                                                                    \
+  hipLaunchKernelGGL((seg_reduce_pass_a<LG_, EXTRA, Contrib>), dim3(grid_a), dim3(256), 0,      \
+                     stream, pl, contrib, W, out, out_extra, part_head, part_tail);             \
+  hipLaunchKernelGGL((seg_reduce_pass_b<LG_, EXTRA>), dim3(grid_b), dim3(256), 0, stream, pl,   \
+                     W, out, out_extra, part_head, part_tail)
+  if (lg == 4) { MAPX_SEG_LAUNCH(4); }
+  else if (lg == 8) { MAPX_SEG_LAUNCH(8); }
+  else { MAPX_SEG_LAUNCH(16); }
+#undef MAPX_SEG_LAUNCH
+  return check_launch(what);
+}
+
+}  // namespace mapx

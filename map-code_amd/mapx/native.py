@@ -1,0 +1,100 @@
+"""ctypes binding of libmapx_hip.so (C ABI: include/mapx_hip.h).
+
+The library is the product: there is no Python/CPU fallback.  Importing this module
+without the built .so raises; calling a kernel without a GPU raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmapx_hip.so")
+
+MAPX_ABI_VERSION = 1
+EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_CROSS, EPI_ADD, EPI_RELU_MASK = range(6)
+
+_p, _i, _i64, _u64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/mapx_hip.h one-to-one
+SIGNATURES = {
+    "mapx_last_error": (C.c_char_p, []),
+    "mapx_abi_version": (_i, []),
+    "mapx_emb_gather_fwd": (_i, [_p, _i64, _p, _i64, _i, _p, _p, _p]),
+    "mapx_ids_to_i32": (_i, [_p, _i64, _i64, _p, _p, _p]),
+    "mapx_seg_plan_workspace_bytes": (_sz, [_i64, _i64]),
+    "mapx_seg_plan": (_i, [_p, _i64, _i64, _p, _sz, _p, _p, _p, _p, _p, _p, _p]),
+    "mapx_seg_reduce_workspace_bytes": (_sz, [_i64, _i]),
+    "mapx_seg_reduce_rows": (_i, [_i64, _p, _p, _p, _p, _i, _p, _p, _sz, _p]),
+    "mapx_alias_build_host": (_i, [_p, _i64, _p, _p]),
+    "mapx_alias_pack": (_i, [_p, _p, _i64, _p, _p]),
+    "mapx_alias_draw": (_i, [_p, _i64, _p, _i64, _i, _u64, _u64, _p, _p]),
+    "mapx_nce_pack_idx": (_i, [_p, _p, _i64, _i, _i64, _p, _p, _p]),
+    "mapx_nce_fwd_workspace_bytes": (_sz, []),
+    "mapx_nce_fwd": (_i, [_p, _i64, _i, _i, _i, _p, _p, _i, _p, _p, _p, _i64, _p, _p, _p, _p, _p,
+                          _p, _p, _sz, _p]),
+    "mapx_nce_scatter_dh": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p, _p]),
+    "mapx_nce_table_grad_workspace_bytes": (_sz, [_i64, _i]),
+    "mapx_nce_table_grad": (_i, [_i64, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _sz, _p]),
+    "mapx_scale_inplace": (_i, [_p, _i64, _p, _p]),
+    "mapx_gemm_splitk_workspace_bytes": (_sz, [_i, _i, _i]),
+    "mapx_gemm_f32": (_i, [_i, _i, _i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _i, _p, _p, _i64, _p,
+                           _i64, _p, _i64, _i, _p, _sz, _p]),
+    "mapx_colsum_workspace_bytes": (_sz, [_i]),
+    "mapx_colsum": (_i, [_p, _i64, _i, _i, _p, _p, _sz, _p]),
+    "mapx_cross_bwd_pre": (_i, [_p, _p, _p, _i64, _p, _p, _i, _p]),
+    "mapx_relu_mask": (_i, [_p, _p, _i64, _p, _p]),
+    "mapx_bce_workspace_bytes": (_sz, []),
+    "mapx_bce_with_logits": (_i, [_p, _p, _i64, _p, _p, _p, _sz, _p]),
+    "mapx_dynamic_mask_mfp": (_i, [_p, _i64, _i, _i, _p, _u64, _u64, _p, _p, _p, _p]),
+    "mapx_dynamic_mask_rfd": (_i, [_p, _i64, _i, _i, _p, _p, _p, _i64, _u64, _u64, _p, _p, _p, _p]),
+    "mapx_adamw_dense": (_i, [_p, _p, _p, _p, _i64, _p, _i, _p, _f, _f, _f, _f, _p]),
+    "mapx_step_advance": (_i, [_p, _p]),
+    "mapx_table_adam": (_i, [_p, _p, _p, _i, _f, _p, _p, _p, _f, _p, _p, _i64, _i64, _p, _p, _p, _p,
+                             _i, _p, _f, _f, _f, _p]),
+}
+
+
+class MapxError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C map-code_amd/csrc` "
+            "(or __graft_entry__.build()).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    got = lib.mapx_abi_version()
+    if got != MAPX_ABI_VERSION:
+        raise ImportError(f"libmapx_hip.so ABI {got} != binding ABI {MAPX_ABI_VERSION}")
+    return lib
+
+
+lib = _load()
+
+
+def check(status):
+    if status != 0:
+        raise MapxError(f"mapx status {status}: {lib.mapx_last_error().decode()}")
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise MapxError("mapx kernels need device (HIP) tensors; there is no CPU path")
+
+
+def ptr(t):
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "mapx kernels take contiguous tensors"
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

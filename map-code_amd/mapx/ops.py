@@ -1,0 +1,355 @@
+"""Functional wrappers over the C ABI: tensors in, tensors out, no autograd.
+
+Every function enqueues HIP kernels on torch's current stream and returns immediately.
+Scratch memory is a per-(device, stream) byte buffer grown on demand; kernels that share it
+run in stream order, so one buffer suffices.
+"""
+import math
+
+import torch
+
+from . import native as N
+from .native import check, lib, ptr, require_gpu, stream
+
+_scratch = {}
+
+
+def scratch(nbytes, device):
+    key = (device.index, stream())
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _scratch[key] = buf
+    return buf
+
+
+def _err_flag(device):
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+# --------------------------------------------------------------------------- embedding
+def emb_gather(ids, table, validate=False):
+    """ids int64 [...], table [V,E] -> [..., E]  (layers.py:97-102)."""
+    require_gpu(ids, table)
+    ids = ids.contiguous()
+    out = torch.empty(*ids.shape, table.shape[1], dtype=torch.float32, device=table.device)
+    err = _err_flag(table.device) if validate else None
+    check(lib.mapx_emb_gather_fwd(ptr(ids), ids.numel(), ptr(table), table.shape[0], table.shape[1],
+                                  ptr(out), ptr(err), stream()))
+    if validate and int(err.item()):
+        raise IndexError("index out of range in self")          # reference CPU behaviour
+    return out
+
+
+def ids_to_i32(ids, V, validate=False):
+    require_gpu(ids)
+    ids = ids.contiguous()
+    out = torch.empty(ids.numel(), dtype=torch.int32, device=ids.device)
+    err = _err_flag(ids.device) if validate else None
+    check(lib.mapx_ids_to_i32(ptr(ids), ids.numel(), V, ptr(out), ptr(err), stream()))
+    if validate and int(err.item()):
+        raise IndexError("index out of range in self")
+    return out
+
+
+class SegPlan:
+    """Sorted-run description of n int32 keys (see include/mapx_hip.h: mapx_seg_plan)."""
+
+    def __init__(self, keys_i32, V):
+        require_gpu(keys_i32)
+        n, dev = keys_i32.numel(), keys_i32.device
+        self.n, self.V = n, V
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.sorted_keys = torch.empty(max(n, 1), **i32)
+        self.perm = torch.empty(max(n, 1), **i32)
+        self.rank = torch.empty(max(n, 1), **i32)
+        self.uniq = torch.empty(max(n, 1), **i32)
+        self.seg_start = torch.empty(n + 1, **i32)
+        self.n_uniq = torch.empty(1, **i32)
+        nb = lib.mapx_seg_plan_workspace_bytes(n, V)
+        ws = scratch(nb, dev)
+        check(lib.mapx_seg_plan(ptr(keys_i32), n, V, ptr(ws), ws.numel(), ptr(self.sorted_keys),
+                                ptr(self.perm), ptr(self.rank), ptr(self.uniq), ptr(self.seg_start),
+                                ptr(self.n_uniq), stream()))
+
+    def count(self):
+        """Number of unique keys (host sync)."""
+        return int(self.n_uniq.item())
+
+
+def seg_reduce_rows(plan, src, W):
+    """out[u,:] = sum of src rows whose key is plan.uniq[u]; out has capacity plan.n rows."""
+    require_gpu(src)
+    out = torch.empty(max(plan.n, 1), W, dtype=torch.float32, device=src.device)
+    nb = lib.mapx_seg_reduce_workspace_bytes(plan.n, W)
+    ws = scratch(nb, src.device)
+    check(lib.mapx_seg_reduce_rows(plan.n, ptr(plan.perm), ptr(plan.rank), ptr(plan.seg_start),
+                                   ptr(src), W, ptr(out), ptr(ws), ws.numel(), stream()))
+    return out
+
+
+# --------------------------------------------------------------------------- NCE
+def alias_build(probs_cpu):
+    """Host Walker table, bit-identical to the reference's (alias_multinomial.py:39-72)."""
+    probs_cpu = probs_cpu.detach().to("cpu", torch.float32).contiguous()
+    V = probs_cpu.numel()
+    prob = torch.empty(V, dtype=torch.float32)
+    alias = torch.empty(V, dtype=torch.int64)
+    check(lib.mapx_alias_build_host(probs_cpu.data_ptr(), V, prob.data_ptr(), alias.data_ptr()))
+    return prob, alias
+
+
+def alias_pack(prob, alias):
+    require_gpu(prob, alias)
+    packed = torch.empty(prob.numel(), 2, dtype=torch.int32, device=prob.device)
+    check(lib.mapx_alias_pack(ptr(prob), ptr(alias), prob.numel(), ptr(packed), stream()))
+    return packed
+
+
+def alias_draw(packed, targets, K, seed, offset):
+    """-> idx int32 [T, K+1]; column 0 = targets."""
+    require_gpu(packed, targets)
+    targets = targets.contiguous()
+    T = targets.numel()
+    idx = torch.empty(T, K + 1, dtype=torch.int32, device=targets.device)
+    check(lib.mapx_alias_draw(ptr(packed), packed.shape[0], ptr(targets), T, K, seed, offset,
+                              ptr(idx), stream()))
+    return idx
+
+
+def nce_pack_idx(targets, noise, V, validate=False):
+    require_gpu(targets, noise)
+    targets, noise = targets.contiguous(), noise.contiguous()
+    T, K = targets.numel(), noise.shape[-1]
+    idx = torch.empty(T, K + 1, dtype=torch.int32, device=targets.device)
+    err = _err_flag(targets.device) if validate else None
+    check(lib.mapx_nce_pack_idx(ptr(targets), ptr(noise), T, K, V, ptr(idx), ptr(err), stream()))
+    if validate and int(err.item()):
+        raise IndexError("index out of range in self")
+    return idx
+
+
+def nce_fwd(enc, masked_index, idx, emb, bias, logq, F, P, want_logits=False):
+    """-> dict(loss [1], acc [1] i32, h [T,P], dlogit [T,K+1], dh [T,P], logits or None)."""
+    require_gpu(enc, masked_index, idx, emb, bias, logq)
+    B, L = masked_index.shape
+    T, K1 = idx.shape
+    assert T == B * L and enc.shape == (B, F * P)
+    dev = enc.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    out = dict(loss=torch.empty(1, **f32), acc=torch.empty(1, dtype=torch.int32, device=dev),
+               h=torch.empty(T, P, **f32), dlogit=torch.empty(T, K1, **f32),
+               dh=torch.empty(T, P, **f32),
+               logits=torch.empty(T, K1, **f32) if want_logits else None)
+    ws = scratch(lib.mapx_nce_fwd_workspace_bytes(), dev)
+    check(lib.mapx_nce_fwd(ptr(enc), B, L, F, P, ptr(masked_index.contiguous()), ptr(idx), K1 - 1,
+                           ptr(emb), ptr(bias), ptr(logq), emb.shape[0], ptr(out["h"]),
+                           ptr(out["dlogit"]), ptr(out["dh"]), ptr(out["logits"]), ptr(out["loss"]),
+                           ptr(out["acc"]), ptr(ws), ws.numel(), stream()))
+    return out
+
+
+def nce_scatter_dh(dh, masked_index, F, P, gscale=None):
+    require_gpu(dh, masked_index)
+    B, L = masked_index.shape
+    denc = torch.empty(B, F * P, dtype=torch.float32, device=dh.device)
+    check(lib.mapx_nce_scatter_dh(ptr(dh), ptr(masked_index.contiguous()), ptr(gscale), B, L, F, P,
+                                  ptr(denc), stream()))
+    return denc
+
+
+def nce_table_grad(plan, dlogit, h, K, P):
+    """-> (emb grad rows [cap,P], bias grad rows [cap]) for plan.uniq."""
+    dev = dlogit.device
+    out_emb = torch.empty(max(plan.n, 1), P, dtype=torch.float32, device=dev)
+    out_bias = torch.empty(max(plan.n, 1), dtype=torch.float32, device=dev)
+    nb = lib.mapx_nce_table_grad_workspace_bytes(plan.n, P)
+    ws = scratch(nb, dev)
+    check(lib.mapx_nce_table_grad(plan.n, ptr(plan.perm), ptr(plan.rank), ptr(plan.seg_start),
+                                  ptr(dlogit), ptr(h), K, P, ptr(out_emb), ptr(out_bias), ptr(ws),
+                                  ws.numel(), stream()))
+    return out_emb, out_bias
+
+
+def scale_(x, g):
+    check(lib.mapx_scale_inplace(ptr(x), x.numel(), ptr(g), stream()))
+    return x
+
+
+# --------------------------------------------------------------------------- dense
+def gemm(a, b, a_kc, b_kc, M, N, K, out=None, ldc=None, epi=N.EPI_NONE, bias=None, aux1=None,
+         aux2=None, out2=None, nsplit=1, lda=None, ldb=None):
+    """C[M,N] = epi(sum_k A(m,k) B(k,n)); see include/mapx_hip.h: mapx_gemm_f32."""
+    require_gpu(a, b)
+    dev = a.device
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=dev)
+    ldc = ldc if ldc is not None else out.stride(0)
+    lda = lda if lda is not None else a.stride(0)
+    ldb = ldb if ldb is not None else b.stride(0)
+    ws, wsn = None, 0
+    if nsplit > 1:
+        wsn = lib.mapx_gemm_splitk_workspace_bytes(M, N, nsplit)
+        ws = scratch(wsn, dev)
+        wsn = ws.numel()
+    ld1 = aux1.stride(0) if aux1 is not None else 0
+    ld2 = aux2.stride(0) if aux2 is not None else 0
+    ldo2 = out2.stride(0) if out2 is not None else 0
+    check(lib.mapx_gemm_f32(int(a_kc), int(b_kc), M, N, K, a.data_ptr(), lda, b.data_ptr(), ldb,
+                            out.data_ptr(), ldc, epi, ptr(bias),
+                            aux1.data_ptr() if aux1 is not None else None, ld1,
+                            aux2.data_ptr() if aux2 is not None else None, ld2,
+                            out2.data_ptr() if out2 is not None else None, ldo2, nsplit,
+                            ws.data_ptr() if ws is not None else None, wsn, stream()))
+    return out
+
+
+def linear_fwd(x, w, b, relu=False, out=None):
+    """nn.Linear (+ReLU): x [M,K], w [N,K], b [N] -> [M,N]; `out` may be a column slice."""
+    M, K = x.shape
+    Nn = w.shape[0]
+    return gemm(x, w, True, True, M, Nn, K, out=out, epi=N.EPI_BIAS_RELU if relu else N.EPI_BIAS,
+                bias=b)
+
+
+def linear_bwd_input(dy, w, out=None, add=None, relu_of=None):
+    """dX = dY W  (+ add)  or masked by relu_of > 0.  dy [M,N], w [N,K] -> [M,K]."""
+    M, Nn = dy.shape
+    K = w.shape[1]
+    epi, aux = N.EPI_NONE, None
+    if add is not None:
+        epi, aux = N.EPI_ADD, add
+    elif relu_of is not None:
+        epi, aux = N.EPI_RELU_MASK, relu_of
+    return gemm(dy, w, True, False, M, K, Nn, out=out, epi=epi, aux1=aux)
+
+
+def _splits_for(M, Nn, Kred):
+    """split-K factor for weight-gradient GEMMs (output [M,Nn] small, reduction Kred long)."""
+    blocks = math.ceil(M / 64) * math.ceil(Nn / 64)
+    if blocks >= 192 or Kred < 1024:
+        return 1
+    return max(1, min(16, 256 // max(blocks, 1), Kred // 256))
+
+
+def linear_bwd_weight(dy, x, out=None):
+    """dW = dY^T X.  dy [B,N], x [B,K] -> [N,K]."""
+    Bn, Nn = dy.shape
+    K = x.shape[1]
+    ns = _splits_for(Nn, K, Bn)
+    if out is not None and out.stride(0) != K:
+        ns = 1
+    return gemm(dy, x, False, False, Nn, K, Bn, out=out, nsplit=ns)
+
+
+def colsum(x, out=None):
+    require_gpu(x)
+    M, Nn = x.shape
+    if out is None:
+        out = torch.empty(Nn, dtype=torch.float32, device=x.device)
+    ws = scratch(lib.mapx_colsum_workspace_bytes(Nn), x.device)
+    check(lib.mapx_colsum(x.data_ptr(), x.stride(0), M, Nn, ptr(out), ptr(ws), ws.numel(), stream()))
+    return out
+
+
+def cross_layer_fwd(x0, xi, w, b, out=None):
+    """-> (X_{i+1} = Xi + X0 * (Xi W^T + b), u = Xi W^T + b)   (layers.py:200)."""
+    M, D = xi.shape
+    u = torch.empty(M, D, dtype=torch.float32, device=xi.device)
+    y = gemm(xi, w, True, True, M, D, D, out=out, epi=N.EPI_BIAS_CROSS, bias=b, aux1=xi, aux2=x0,
+             out2=u)
+    return y, u
+
+
+def cross_bwd_pre(g, x0, u, dx0=None):
+    """t = g*x0; dx0 (+)= g*u.  Returns (t, dx0)."""
+    t = torch.empty_like(g)
+    acc = dx0 is not None
+    if dx0 is None:
+        dx0 = torch.empty_like(g)
+    check(lib.mapx_cross_bwd_pre(ptr(g), ptr(x0), ptr(u), g.numel(), ptr(t), ptr(dx0), int(acc),
+                                 stream()))
+    return t, dx0
+
+
+def relu_mask(dy, y):
+    out = torch.empty_like(dy)
+    check(lib.mapx_relu_mask(ptr(dy), ptr(y), dy.numel(), ptr(out), stream()))
+    return out
+
+
+# --------------------------------------------------------------------------- heads / masks
+def bce_with_logits(logits, labels, want_grad=True):
+    """-> (out3 = [loss, acc, pos_ratio] f32 device, dlogits or None)."""
+    require_gpu(logits, labels)
+    logits, labels = logits.contiguous(), labels.contiguous()
+    n = logits.numel()
+    out3 = torch.empty(3, dtype=torch.float32, device=logits.device)
+    dl = torch.empty_like(logits) if want_grad else None
+    ws = scratch(lib.mapx_bce_workspace_bytes(), logits.device)
+    check(lib.mapx_bce_with_logits(ptr(logits), ptr(labels), n, ptr(dl), ptr(out3), ptr(ws),
+                                   ws.numel(), stream()))
+    return out3, dl
+
+
+def dynamic_mask_mfp(ids, L, masked_index=None, seed=0, offset=0):
+    """-> (masked ids [B,F], labels [B,L], masked_index [B,L])  (trainer.py:217-232)."""
+    require_gpu(ids)
+    ids = ids.contiguous()
+    B, F = ids.shape
+    out = torch.empty_like(ids)
+    labels = torch.empty(B, L, dtype=torch.int64, device=ids.device)
+    mi_out = torch.empty(B, L, dtype=torch.int64, device=ids.device)
+    mi_in = masked_index.contiguous() if masked_index is not None else None
+    check(lib.mapx_dynamic_mask_mfp(ptr(ids), B, F, L, ptr(mi_in), seed, offset, ptr(out), ptr(labels),
+                                    ptr(mi_out), stream()))
+    return out, labels, mi_out
+
+
+def dynamic_mask_rfd(ids, L, masked_index=None, replace_feat=None, x_train=None, seed=0, offset=0):
+    """-> (replaced ids [B,F], labels f32 [B,F], masked_index [B,L])  (trainer.py:233-240)."""
+    require_gpu(ids)
+    ids = ids.contiguous()
+    B, F = ids.shape
+    out = torch.empty_like(ids)
+    labels = torch.empty(B, F, dtype=torch.float32, device=ids.device)
+    mi_out = torch.empty(B, L, dtype=torch.int64, device=ids.device)
+    mi_in = masked_index.contiguous() if masked_index is not None else None
+    rep = replace_feat.contiguous() if replace_feat is not None else None
+    nrows = x_train.shape[0] if x_train is not None else 0
+    check(lib.mapx_dynamic_mask_rfd(ptr(ids), B, F, L, ptr(mi_in), ptr(rep), ptr(x_train), nrows,
+                                    seed, offset, ptr(out), ptr(labels), ptr(mi_out), stream()))
+    return out, labels, mi_out
+
+
+# --------------------------------------------------------------------------- optimizer
+def make_sched(lr0, lambdas, beta1, beta2):
+    """Host (float64) -> device table [T,2] f32 of {step_size_s, lr_s}, s = 1..T."""
+    rows = []
+    for i, lam in enumerate(lambdas):
+        s = i + 1
+        lr = lr0 * lam
+        rows.append((lr * math.sqrt(1.0 - beta2 ** s) / (1.0 - beta1 ** s), lr))
+    return torch.tensor(rows, dtype=torch.float64).to(torch.float32)
+
+
+def adamw_dense(p, g, m, v, sched, done, beta1, beta2, eps, wd):
+    require_gpu(p, g, m, v, sched, done)
+    check(lib.mapx_adamw_dense(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(sched), sched.shape[0],
+                               ptr(done), beta1, beta2, eps, wd, stream()))
+
+
+def step_advance(done):
+    check(lib.mapx_step_advance(ptr(done), stream()))
+
+
+def table_adam(p0, m0, v0, wd0, last, sched, done, beta1, beta2, eps, p1=None, m1=None, v1=None,
+               wd1=0.0, rows=None, n_rows_dev=None, row_begin=0, n_rows=None, grad0=None, grad1=None):
+    require_gpu(p0, m0, v0, last, sched, done)
+    W0 = p0.shape[1]
+    if n_rows is None:
+        n_rows = rows.numel() if rows is not None else p0.shape[0] - row_begin
+    check(lib.mapx_table_adam(ptr(p0), ptr(m0), ptr(v0), W0, wd0, ptr(p1), ptr(m1), ptr(v1), wd1,
+                              ptr(last), ptr(rows), row_begin, n_rows, ptr(n_rows_dev), ptr(grad0),
+                              ptr(grad1), ptr(sched), sched.shape[0], ptr(done), beta1, beta2, eps,
+                              stream()))

@@ -1,0 +1,402 @@
+"""Kernel-level parity: every C-ABI entry point against the oracle / plain torch-CPU fp32
+on the same seeded inputs.  Bit-exact for index work; fp32 tolerance written per test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mapx import ops as _ops
+    return _ops
+
+
+def _cpu(x):
+    return x.detach().cpu()
+
+
+# --------------------------------------------------------------------------- gather
+@pytest.mark.parametrize("n,E", [(0, 16), (1, 16), (7 * 23, 16), (4096 * 23, 16), (33, 8), (5, 6)])
+def test_emb_gather_bit_exact(ops, n, E):
+    g = torch.Generator().manual_seed(n + E)
+    V = 1000
+    table = torch.randn(V, E, generator=g)
+    ids = torch.randint(0, V, (n,), generator=g)
+    out = ops.emb_gather(ids.to(DEV), table.to(DEV), validate=True)
+    assert torch.equal(_cpu(out), table[ids])
+
+
+def test_emb_gather_out_of_range_raises(ops):
+    table = torch.randn(10, 16, device=DEV)
+    with pytest.raises(IndexError):
+        ops.emb_gather(torch.tensor([1, 10], device=DEV), table, validate=True)
+    with pytest.raises(IndexError):
+        ops.emb_gather(torch.tensor([-1], device=DEV), table, validate=True)
+
+
+# --------------------------------------------------------------------------- seg plan / reduce
+def _skewed_keys(n, V, seed):
+    g = torch.Generator().manual_seed(seed)
+    k = (torch.rand(n, generator=g) ** 6 * V).long().clamp_(0, V - 1)
+    k[: n // 4] = 3                       # a '<mask>'-like hot key spanning many chunks
+    return k[torch.randperm(n, generator=g)]
+
+
+@pytest.mark.parametrize("n,V,W", [(1, 50, 16), (31, 50, 16), (32, 50, 16), (33, 7, 16),
+                                   (5000, 1000, 16), (94208, 9449445, 16), (70001, 300, 32),
+                                   (4097, 5, 64), (2000, 100, 4)])
+def test_seg_plan_and_reduce_rows(ops, n, V, W):
+    keys = _skewed_keys(n, V, n)
+    src = torch.randn(n, W, generator=torch.Generator().manual_seed(1))
+    plan = ops.SegPlan(keys.to(torch.int32).to(DEV), V)
+    U = plan.count()
+    uniq_ref, inv = torch.unique(keys, return_inverse=True)
+    assert U == uniq_ref.numel()
+    assert torch.equal(_cpu(plan.uniq[:U]).long(), uniq_ref)
+    sk = _cpu(plan.sorted_keys[:n]).long()
+    assert torch.equal(sk, keys[_cpu(plan.perm[:n]).long()]) and bool((sk[1:] >= sk[:-1]).all())
+    out = ops.seg_reduce_rows(plan, src.to(DEV), W)
+    ref = torch.zeros(U, W, dtype=torch.float64).index_add_(0, inv, src.double())
+    scale = torch.zeros(U, W, dtype=torch.float64).index_add_(0, inv, src.double().abs())
+    err = (_cpu(out[:U]).double() - ref).abs()
+    assert bool((err <= 1e-6 * scale + 1e-6).all()), float(err.max())
+    # bit-reproducible: same inputs -> same bits
+    out2 = ops.seg_reduce_rows(plan, src.to(DEV), W)
+    assert torch.equal(out[:U], out2[:U])
+
+
+def test_seg_plan_empty(ops):
+    plan = ops.SegPlan(torch.empty(0, dtype=torch.int32, device=DEV), 10)
+    assert plan.count() == 0
+
+
+# --------------------------------------------------------------------------- alias
+def test_alias_build_matches_oracle(ops):
+    from oracle import ref_model as R
+    g = np.random.default_rng(0)
+    cnt = np.floor(g.pareto(1.2, 5000) * 5).astype(np.float32)
+    cnt[:10] = 0
+    _, _, q = R.nce_buffers(cnt)
+    prob, alias = ops.alias_build(q)
+    p_ref, a_ref = R.alias_build(q.numpy())
+    assert np.array_equal(alias.numpy(), a_ref) and np.array_equal(prob.numpy(), p_ref)
+
+
+def test_alias_draw_distribution(ops):
+    """chi-square of 2.5 M draws against the renormalised noise distribution."""
+    from oracle import ref_model as R
+    g = np.random.default_rng(1)
+    V, T, K = 200, 100000, 25
+    cnt = np.floor(g.pareto(1.0, V) * 20).astype(np.float32) + (g.random(V) < 0.8)
+    _, _, q = R.nce_buffers(cnt)
+    prob, alias = ops.alias_build(q)
+    packed = ops.alias_pack(prob.to(DEV), alias.to(DEV))
+    targets = torch.randint(0, V, (T,), device=DEV)
+    idx = ops.alias_draw(packed, targets, K, seed=1234, offset=7)
+    assert torch.equal(idx[:, 0].long(), targets)
+    noise = _cpu(idx[:, 1:]).reshape(-1).long()
+    assert int(noise.min()) >= 0 and int(noise.max()) < V
+    obs = torch.bincount(noise, minlength=V).double().numpy()
+    exp = R.alias_distribution(prob.numpy(), alias.numpy()) * noise.numel()
+    big = exp > 20
+    chi2 = float((((obs - exp) ** 2) / np.maximum(exp, 1e-9))[big].sum())
+    dof = int(big.sum()) - 1
+    assert chi2 < dof + 6 * math.sqrt(2 * dof), (chi2, dof)
+    assert obs[~big].sum() <= exp[~big].sum() + 6 * math.sqrt(exp[~big].sum() + 1) + 5
+    # a different offset gives a different stream; the same (seed, offset) repeats exactly
+    idx2 = ops.alias_draw(packed, targets, K, seed=1234, offset=8)
+    idx3 = ops.alias_draw(packed, targets, K, seed=1234, offset=7)
+    assert not torch.equal(idx, idx2) and torch.equal(idx, idx3)
+
+
+# --------------------------------------------------------------------------- NCE
+@pytest.mark.parametrize("B,F,P,K,V", [(7, 23, 32, 25, 1000), (64, 39, 32, 25, 1000),
+                                       (33, 25, 16, 4, 300), (256, 23, 32, 25, 50000)])
+def test_nce_fwd_and_grads_vs_oracle(ops, B, F, P, K, V):
+    from oracle import ref_model as R
+    g = torch.Generator().manual_seed(B * F)
+    L = int(F * 0.3)
+    enc = torch.randn(B, F * P, generator=g).requires_grad_(True)
+    mi = torch.randint(0, F, (B, L), generator=g)
+    mi[0, 1] = mi[0, 0]
+    labels = torch.randint(0, V, (B, L), generator=g)
+    noise = (torch.rand(B, L, K, generator=g) ** 3 * V).long().clamp_(0, V - 1)
+    noise[0, 0, :2] = labels[0, 0]
+    emb = (torch.rand(V, P, generator=g) * 2 - 1) / math.sqrt(P)
+    emb.requires_grad_(True)
+    cnt = torch.floor(torch.rand(V, generator=g) ** 4 * 100)
+    logq, lnV, _ = R.nce_buffers(cnt)
+    bias = (logq + lnV + 0.1 * torch.randn(V, generator=g)).unsqueeze(1).requires_grad_(True)
+    params = {"feat_encoder.weight": torch.eye(F * P), "feat_encoder.bias": torch.zeros(F * P),
+              "mfp_criterion.emb.weight": emb, "mfp_criterion.bias.weight": bias}
+    loss_ref, logits_ref, acc_ref = R.mfp_head(params, enc, labels, mi, noise, logq, F, P, K)
+    loss_ref.backward()
+
+    idx = ops.nce_pack_idx(labels.to(DEV), noise.to(DEV), V, validate=True)
+    o = ops.nce_fwd(enc.detach().to(DEV), mi.to(DEV), idx, emb.detach().to(DEV),
+                    bias.detach().view(-1).to(DEV), logq.to(DEV), F, P, want_logits=True)
+    # tolerance: fp32 1e-5 relative (north star), logits have |s| ~ 1..10
+    np.testing.assert_allclose(_cpu(o["logits"]).view(B, L, K + 1).numpy(),
+                               logits_ref.detach().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(float(o["loss"]), float(loss_ref), rtol=1e-5)
+    assert int(o["acc"]) == acc_ref
+    denc = ops.nce_scatter_dh(o["dh"], mi.to(DEV), F, P)
+    np.testing.assert_allclose(_cpu(denc).numpy(), enc.grad.numpy(), rtol=1e-4, atol=1e-7)
+    plan = ops.SegPlan(idx.view(-1), V)
+    ge, gb = ops.nce_table_grad(plan, o["dlogit"], o["h"], K, P)
+    U = plan.count()
+    uniq = _cpu(plan.uniq[:U]).long()
+    dense_e = torch.zeros(V, P).index_copy_(0, uniq, _cpu(ge[:U]))
+    dense_b = torch.zeros(V).index_copy_(0, uniq, _cpu(gb[:U]))
+    np.testing.assert_allclose(dense_e.numpy(), emb.grad.numpy(), rtol=1e-4, atol=2e-7)
+    np.testing.assert_allclose(dense_b.numpy(), bias.grad.view(-1).numpy(), rtol=1e-4, atol=2e-7)
+    # rows never sampled get no gradient at all (sparse semantics == dense zeros)
+    touched = torch.zeros(V, dtype=torch.bool).index_fill_(0, uniq, True)
+    assert float(emb.grad[~touched].abs().sum()) == 0.0
+
+
+# --------------------------------------------------------------------------- GEMM family
+def _ref_mm(a, b):
+    return (a.double() @ b.double())
+
+
+@pytest.mark.parametrize("M,N,K", [(7, 368, 368), (64, 1000, 400), (4096, 1000, 368), (256, 736, 1368),
+                                   (100, 23, 736), (129, 1, 1368), (4096, 368, 368), (65, 130, 17)])
+def test_gemm_linear_forward(ops, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    ref = _ref_mm(x, w.t()) + b.double()
+    y = ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV))
+    # fp32 k-ordered fma chain: |err| <= ~1e-6 * sum|a*b|
+    bound = 2e-6 * (x.abs().double() @ w.abs().double().t()) + 1e-6
+    assert bool(((_cpu(y).double() - ref).abs() <= bound).all())
+    yr = ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), relu=True)
+    assert bool(((_cpu(yr).double() - ref.clamp(min=0)).abs() <= bound).all())
+
+
+@pytest.mark.parametrize("M,N,K", [(7, 368, 400), (4096, 1000, 368), (64, 23, 736), (300, 1, 1368),
+                                   (4096, 368, 368), (33, 65, 129)])
+def test_gemm_backward_products(ops, M, N, K):
+    """dX = dY W (a_kc, b_nc) and dW = dY^T X (a_mc, b_nc), incl. deterministic split-K."""
+    g = torch.Generator().manual_seed(M * N + K)
+    dy, w, x = torch.randn(M, N, generator=g), torch.randn(N, K, generator=g), torch.randn(M, K, generator=g)
+    dx = ops.linear_bwd_input(dy.to(DEV), w.to(DEV))
+    ref = _ref_mm(dy, w)
+    bound = 2e-6 * (dy.abs().double() @ w.abs().double()) + 1e-6
+    assert bool(((_cpu(dx).double() - ref).abs() <= bound).all())
+    dw = ops.linear_bwd_weight(dy.to(DEV), x.to(DEV))
+    refw = _ref_mm(dy.t(), x)
+    boundw = 4e-6 * (dy.abs().double().t() @ x.abs().double()) + 1e-6
+    assert bool(((_cpu(dw).double() - refw).abs() <= boundw).all())
+    assert torch.equal(dw, ops.linear_bwd_weight(dy.to(DEV), x.to(DEV)))   # reproducible
+    add = torch.randn(M, K, generator=g)
+    dxa = ops.linear_bwd_input(dy.to(DEV), w.to(DEV), add=add.to(DEV))
+    assert bool(((_cpu(dxa).double() - ref - add.double()).abs() <= bound).all())
+    act = torch.randn(M, K, generator=g)
+    dxm = ops.linear_bwd_input(dy.to(DEV), w.to(DEV), relu_of=act.to(DEV))
+    assert bool(((_cpu(dxm).double() - ref * (act > 0)).abs() <= bound).all())
+
+
+def test_gemm_writes_into_column_slice(ops):
+    x, w, b = torch.randn(50, 64, device=DEV), torch.randn(40, 64, device=DEV), torch.randn(40, device=DEV)
+    final = torch.full((50, 100), 7.0, device=DEV)
+    ops.linear_fwd(x, w, b, out=final[:, 60:])
+    assert bool((final[:, :60] == 7.0).all())
+    np.testing.assert_allclose(_cpu(final[:, 60:]).numpy(), (_cpu(x) @ _cpu(w).t() + _cpu(b)).numpy(),
+                               rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,N", [(1, 5), (4096, 1000), (77, 368), (5000, 23)])
+def test_colsum(ops, M, N):
+    x = torch.randn(M, N, generator=torch.Generator().manual_seed(M))
+    out = ops.colsum(x.to(DEV))
+    np.testing.assert_allclose(_cpu(out).double().numpy(), x.double().sum(0).numpy(),
+                               rtol=0, atol=2e-6 * float(x.abs().sum(0).max()) + 1e-6)
+
+
+@pytest.mark.parametrize("B,D,NC", [(7, 368, 3), (64, 400, 3), (4096, 368, 3), (33, 624, 2)])
+def test_cross_network_fwd_bwd_vs_oracle(ops, B, D, NC):
+    """CrossNetV2 forward + hand-written backward chain vs autograd on the oracle."""
+    from oracle import ref_model as R
+    g = torch.Generator().manual_seed(B + D)
+    x0 = (0.3 * torch.randn(B, D, generator=g)).requires_grad_(True)
+    P = {}
+    for i in range(NC):
+        P[f"cross_net.cross_layers.{i}.weight"] = (torch.randn(D, D, generator=g) / math.sqrt(D)).requires_grad_(True)
+        P[f"cross_net.cross_layers.{i}.bias"] = (0.1 * torch.randn(D, generator=g)).requires_grad_(True)
+    y_ref = R.cross(P, x0, NC)
+    gout = torch.randn(B, D, generator=g)
+    y_ref.backward(gout)
+
+    x0d = x0.detach().to(DEV)
+    xs, us = [x0d], []
+    for i in range(NC):
+        y, u = ops.cross_layer_fwd(x0d, xs[-1], P[f"cross_net.cross_layers.{i}.weight"].detach().to(DEV),
+                                   P[f"cross_net.cross_layers.{i}.bias"].detach().to(DEV))
+        xs.append(y)
+        us.append(u)
+    np.testing.assert_allclose(_cpu(xs[-1]).numpy(), y_ref.detach().numpy(), rtol=1e-5, atol=1e-5)
+    gcur, dx0 = gout.to(DEV), None
+    for i in reversed(range(NC)):
+        w = P[f"cross_net.cross_layers.{i}.weight"]
+        t, dx0 = ops.cross_bwd_pre(gcur, x0d, us[i], dx0)
+        dw = ops.linear_bwd_weight(t, xs[i])
+        db = ops.colsum(t)
+        gcur = ops.linear_bwd_input(t, w.detach().to(DEV), add=gcur)
+        np.testing.assert_allclose(_cpu(dw).numpy(), w.grad.numpy(), rtol=2e-4,
+                                   atol=2e-5 * float(w.grad.abs().max()))
+        np.testing.assert_allclose(_cpu(db).numpy(), P[f"cross_net.cross_layers.{i}.bias"].grad.numpy(),
+                                   rtol=2e-4, atol=2e-5 * float(P[f"cross_net.cross_layers.{i}.bias"].grad.abs().max()))
+    dx0_total = _cpu(dx0 + gcur)
+    np.testing.assert_allclose(dx0_total.numpy(), x0.grad.numpy(), rtol=2e-4,
+                               atol=2e-5 * float(x0.grad.abs().max()))
+
+
+# --------------------------------------------------------------------------- heads / masks
+@pytest.mark.parametrize("n", [1, 7 * 23, 4096 * 23, 4096])
+def test_bce_with_logits(ops, n):
+    g = torch.Generator().manual_seed(n)
+    x = 3 * torch.randn(n, generator=g)
+    y = (torch.rand(n, generator=g) < 0.3).float()
+    xr = x.clone().requires_grad_(True)
+    ref = torch.nn.functional.binary_cross_entropy_with_logits(xr, y)
+    ref.backward()
+    out3, dl = ops.bce_with_logits(x.to(DEV), y.to(DEV))
+    out3 = _cpu(out3)
+    np.testing.assert_allclose(float(out3[0]), float(ref), rtol=1e-5)
+    acc = ((torch.sigmoid(x) > 0.5).float() == y).sum() / n
+    np.testing.assert_allclose(float(out3[1]), float(acc), rtol=1e-6)
+    np.testing.assert_allclose(float(out3[2]), float(y.mean()), rtol=1e-6)
+    np.testing.assert_allclose(_cpu(dl).numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-9)
+
+
+def test_dynamic_mask_injected_matches_oracle(ops):
+    from oracle import ref_model as R
+    g = torch.Generator().manual_seed(5)
+    B, F, L = 300, 23, 6
+    ids = torch.randint(10, 1000, (B, F), generator=g)
+    mi = torch.randint(0, F, (B, L), generator=g)
+    mi[:, 1] = mi[:, 0]                                          # duplicates everywhere
+    rep = torch.randint(10, 1000, (B, L), generator=g)
+    m_ref, l_ref = R.dynamic_mask_mfp(ids, mi)
+    m, l, mo = ops.dynamic_mask_mfp(ids.to(DEV), L, masked_index=mi.to(DEV))
+    assert torch.equal(_cpu(m), m_ref) and torch.equal(_cpu(l), l_ref) and torch.equal(_cpu(mo), mi)
+    r_ref, y_ref = R.dynamic_mask_rfd(ids, mi, rep)
+    r, y, _ = ops.dynamic_mask_rfd(ids.to(DEV), L, masked_index=mi.to(DEV), replace_feat=rep.to(DEV))
+    assert torch.equal(_cpu(r), r_ref) and torch.equal(_cpu(y), y_ref)
+
+
+def test_dynamic_mask_generated_properties(ops):
+    B, F, L, Ntrain = 4096, 23, 6, 20000
+    g = torch.Generator().manual_seed(6)
+    lo = torch.arange(F) * 100 + 10
+    x_train = (lo[None, :] + torch.randint(0, 100, (Ntrain, F), generator=g)).to(DEV)
+    ids = x_train[:B].clone()
+    m, labels, mi = ops.dynamic_mask_mfp(ids, L, seed=42, offset=3)
+    mi_c, m_c, ids_c = _cpu(mi), _cpu(m), _cpu(ids)
+    assert int(mi_c.min()) >= 0 and int(mi_c.max()) < F
+    assert torch.equal(_cpu(labels), torch.gather(ids_c, 1, mi_c))
+    expect = torch.scatter(ids_c, 1, mi_c, torch.full_like(mi_c, 3))
+    assert torch.equal(m_c, expect)
+    counts = torch.bincount(mi_c.view(-1), minlength=F).double()
+    chi2 = float(((counts - B * L / F) ** 2 / (B * L / F)).sum())
+    assert chi2 < (F - 1) + 6 * math.sqrt(2 * (F - 1))
+    # RFD/Unigram: replaced fields stay inside their own field's id range
+    r, y, mi2 = ops.dynamic_mask_rfd(ids, L, x_train=x_train, seed=42, offset=4)
+    r_c, y_c = _cpu(r), _cpu(y)
+    fld = (r_c - 10) // 100
+    assert torch.equal(fld, torch.arange(F).expand(B, F))
+    assert torch.equal(y_c, (r_c != ids_c).float())
+    untouched = torch.ones(B, F, dtype=torch.bool).scatter_(1, _cpu(mi2), False)
+    assert bool((r_c[untouched] == ids_c[untouched]).all())
+    assert 0.15 < float(y_c.mean()) < 0.3          # ~ (1-(1-1/F)^L) * P(different value)
+
+
+# --------------------------------------------------------------------------- optimizer
+def _sched(ops, T, lr0=1e-3, kind="cosine", warm=0, b1=0.9, b2=0.999):
+    from oracle import ref_model as R
+    lambdas = [R.lr_lambda(kind, s, T, warm) for s in range(T)]
+    return ops.make_sched(lr0, lambdas, b1, b2).to(DEV), lambdas
+
+
+@pytest.mark.parametrize("wd", [0.0, 0.05])
+def test_adamw_dense_trajectory_vs_oracle(ops, wd):
+    from oracle import ref_model as R
+    T, n = 12, 1003
+    sched, lambdas = _sched(ops, T)
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(n, generator=g)
+    p_ref, m_ref, v_ref = p0.clone(), torch.zeros(n), torch.zeros(n)
+    p = p0.to(DEV).clone()
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    done = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for s in range(1, T + 1):
+        grad = torch.randn(n, generator=g) * (0.1 if s % 3 else 0.0)
+        R.hf_adamw_step(p_ref, grad, m_ref, v_ref, s, 1e-3 * lambdas[s - 1], wd=wd)
+        ops.adamw_dense(p, grad.to(DEV), m, v, sched, done, 0.9, 0.999, 1e-8, wd)
+        ops.step_advance(done)
+    assert int(done) == T
+    np.testing.assert_allclose(_cpu(p).numpy(), p_ref.numpy(), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(_cpu(m).numpy(), m_ref.numpy(), rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(_cpu(v).numpy(), v_ref.numpy(), rtol=2e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("W,with_bias", [(16, False), (32, True)])
+def test_lazy_table_adam_equals_dense_reference(ops, W, with_bias):
+    """Row-sparse lazy AdamW == the reference's dense every-row-every-step AdamW (rows that
+    receive no gradient still decay and move by momentum), after a final flush."""
+    from oracle import ref_model as R
+    T, V = 40, 257
+    sched, lambdas = _sched(ops, T, kind="cosine")
+    g = torch.Generator().manual_seed(W)
+    p0, b0 = torch.randn(V, W, generator=g), torch.randn(V, generator=g)
+    pr, mr, vr = p0.clone(), torch.zeros(V, W), torch.zeros(V, W)
+    br, bmr, bvr = b0.clone(), torch.zeros(V), torch.zeros(V)
+    p, m, v = p0.to(DEV).clone(), torch.zeros(V, W, device=DEV), torch.zeros(V, W, device=DEV)
+    b, bm, bv = b0.to(DEV).clone(), torch.zeros(V, device=DEV), torch.zeros(V, device=DEV)
+    last = torch.zeros(V, dtype=torch.int32, device=DEV)
+    done = torch.zeros(1, dtype=torch.int32, device=DEV)
+    kw = dict(p1=b, m1=bm, v1=bv, wd1=0.0) if with_bias else {}
+    for s in range(1, T + 1):
+        nrow = int(torch.randint(1, 40, (1,), generator=g))
+        rows = torch.randperm(V, generator=g)[:nrow].sort().values
+        grad = 0.1 * torch.randn(nrow, W, generator=g)
+        gb = 0.1 * torch.randn(nrow, generator=g)
+        dense_g = torch.zeros(V, W).index_copy_(0, rows, grad)
+        dense_gb = torch.zeros(V).index_copy_(0, rows, gb)
+        lr = 1e-3 * lambdas[s - 1]
+        R.hf_adamw_step(pr, dense_g, mr, vr, s, lr, wd=0.05)
+        if with_bias:
+            R.hf_adamw_step(br, dense_gb, bmr, bvr, s, lr, wd=0.0)
+        rows_d = rows.to(torch.int32).to(DEV)
+        nrd = torch.tensor([nrow], dtype=torch.int32, device=DEV)
+        # catch-up before "forward": touched rows must already equal the dense reference
+        ops.table_adam(p, m, v, 0.05, last, sched, done, 0.9, 0.999, 1e-8, rows=rows_d,
+                       n_rows_dev=nrd, **kw)
+        ops.table_adam(p, m, v, 0.05, last, sched, done, 0.9, 0.999, 1e-8, rows=rows_d,
+                       n_rows_dev=nrd, grad0=grad.to(DEV), grad1=gb.to(DEV) if with_bias else None, **kw)
+        ops.step_advance(done)
+        np.testing.assert_allclose(_cpu(p)[rows].numpy(), pr[rows].numpy(), rtol=5e-6, atol=1e-7)
+    ops.table_adam(p, m, v, 0.05, last, sched, done, 0.9, 0.999, 1e-8, **kw)       # flush all rows
+    assert bool((_cpu(last) == T).all())
+    np.testing.assert_allclose(_cpu(p).numpy(), pr.numpy(), rtol=5e-6, atol=1e-7)
+    np.testing.assert_allclose(_cpu(m).numpy(), mr.numpy(), rtol=5e-6, atol=1e-10)
+    np.testing.assert_allclose(_cpu(v).numpy(), vr.numpy(), rtol=5e-6, atol=1e-13)
+    if with_bias:
+        np.testing.assert_allclose(_cpu(b).numpy(), br.numpy(), rtol=5e-6, atol=1e-7)
+
+
+def test_errors_are_loud(ops):
+    from mapx.native import MapxError
+    with pytest.raises(MapxError):
+        ops.emb_gather(torch.zeros(3, dtype=torch.int64), torch.zeros(4, 16))      # CPU tensors
+    with pytest.raises(MapxError):
+        ops.nce_fwd(torch.zeros(2, 23 * 12, device=DEV), torch.zeros(2, 6, dtype=torch.int64, device=DEV),
+                    torch.zeros(12, 26, dtype=torch.int32, device=DEV), torch.zeros(10, 12, device=DEV),
+                    torch.zeros(10, device=DEV), torch.zeros(10, device=DEV), 23, 12)   # P = 12 unsupported
