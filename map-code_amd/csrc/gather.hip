@@ -50,10 +50,10 @@ __global__ void __launch_bounds__(256) ids_to_i32_kernel(const int64_t* __restri
 
 extern "C" int mapx_emb_gather_fwd(const int64_t* ids, int64_t n, const float* table, int64_t V,
                                    int E, float* out, int* err_flag, hipStream_t stream) {
-  MAPX_REQUIRE(ids && table && out, "emb_gather_fwd: null pointer");
   MAPX_REQUIRE(n >= 0 && V > 0 && E > 0, "emb_gather_fwd: bad sizes n=%lld V=%lld E=%d",
                (long long)n, (long long)V, E);
   if (n == 0) return MAPX_OK;
+  MAPX_REQUIRE(ids && table && out, "emb_gather_fwd: null pointer");
   const bool vec = (E % 4 == 0) && ((uintptr_t)table % 16 == 0) && ((uintptr_t)out % 16 == 0);
   const int64_t total = n * (vec ? E / 4 : E);
   const int grid = mapx::grid_for(total, 256);
@@ -68,9 +68,9 @@ extern "C" int mapx_emb_gather_fwd(const int64_t* ids, int64_t n, const float* t
 
 extern "C" int mapx_ids_to_i32(const int64_t* ids, int64_t n, int64_t V, int32_t* out,
                                int* err_flag, hipStream_t stream) {
-  MAPX_REQUIRE(ids && out, "ids_to_i32: null pointer");
   MAPX_REQUIRE(n >= 0 && V > 0 && V < (1LL << 31), "ids_to_i32: bad sizes");
   if (n == 0) return MAPX_OK;
+  MAPX_REQUIRE(ids && out, "ids_to_i32: null pointer");
   hipLaunchKernelGGL(mapx::ids_to_i32_kernel, dim3(mapx::grid_for(n, 256)), dim3(256), 0, stream,
                      ids, n, V, out, err_flag);
   return mapx::check_launch("ids_to_i32");
