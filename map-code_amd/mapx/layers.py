@@ -1,0 +1,220 @@
+"""DCNv2 building blocks over the gfx950 kernels (host mirror of reference code/layers.py:
+Embeddings :83-102, MLPBlock :173-188, CrossNetV2 :191-201).  autograd.Function = glue only:
+every forward/backward body is a C-ABI call (mapx.ops)."""
+import math
+
+import torch
+from torch import nn
+from torch.autograd import Function
+
+from . import ops
+
+
+# ----------------------------------------------------------------------------- row tables
+class RowTable:
+    """A [V, W] parameter table read by row id, with row-sparse gradients.
+
+    The reference keeps such tables as nn.Embedding with DENSE gradients and lets AdamW sweep
+    all V rows every step.  Here the gradient of a step is (plan.uniq, rows) — see
+    csrc/segreduce.h — and the optimizer (mapx.optim.TableAdam) updates touched rows only,
+    replaying the zero-gradient updates the reference would have applied to a row when the
+    row is next read (`prepare`) or when the table is flushed."""
+
+    def __init__(self, name, p0, p1=None):
+        self.name, self.p0, self.p1 = name, p0, p1
+        self.sparse_grad = None      # (plan, rows0, rows1|None) after backward
+        self.lazy = None             # TableAdam state once an optimizer is attached
+        self.plan = None
+
+    @property
+    def num_rows(self):
+        return self.p0.shape[0]
+
+    def prepare(self, keys_i32, need_plan):
+        """Sort this step's row ids; bring exactly those rows up to date.  Returns the plan."""
+        stale = self.lazy is not None and self.lazy.stale
+        if not (need_plan or stale):
+            self.plan = None
+            return None
+        self.plan = ops.SegPlan(keys_i32, self.num_rows)
+        if stale:
+            self.lazy.catch_up(self.plan)
+        return self.plan
+
+    def dense_grad(self):
+        """Reference-layout dense gradients [(V,W), (V,1)|None] from the sparse ones (tests)."""
+        plan, r0, r1 = self.sparse_grad
+        U = plan.count()
+        uniq = plan.uniq[:U].long()
+        g0 = torch.zeros_like(self.p0).index_copy_(0, uniq, r0[:U])
+        g1 = None
+        if self.p1 is not None:
+            g1 = torch.zeros_like(self.p1).index_copy_(0, uniq, r1[:U].unsqueeze(1))
+        return g0, g1
+
+
+class TableWeight(nn.Module):
+    """Holds `weight` [V, W] under the attribute name the reference's nn.Embedding has."""
+
+    def __init__(self, num_rows, width):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(num_rows, width))
+
+    @property
+    def embedding_dim(self):
+        return self.weight.shape[1]
+
+
+class _Gather(Function):
+    @staticmethod
+    def forward(ctx, weight, ids, table):
+        ctx.table, ctx.plan, ctx.width = table, table.plan, weight.shape[1]
+        return ops.emb_gather(ids, weight)
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.plan is None:
+            raise RuntimeError("embedding backward without a segment plan")
+        g = g.contiguous().view(-1, ctx.width)
+        ctx.table.sparse_grad = (ctx.plan, ops.seg_reduce_rows(ctx.plan, g, ctx.width), None)
+        return None, None, None
+
+
+class Embeddings(nn.Module):
+    """One shared id space over all fields (reference layers.py:83-102)."""
+
+    def __init__(self, config):
+        super().__init__()
+        if getattr(config, "embed_norm", False):
+            raise NotImplementedError("embed_norm=True (LayerNorm on embeddings) is outside the DCNv2 scripts")
+        if getattr(config, "embed_dropout_rate", 0.0) > 0:
+            raise NotImplementedError("embed_dropout_rate > 0 is outside the DCNv2 scripts")
+        self.embedding = TableWeight(config.input_size, config.embed_size)
+        std = math.sqrt(2.0 / float(config.num_fields + config.embed_size))
+        with torch.no_grad():
+            self.embedding.weight.normal_(0.0, std)
+        self.table = RowTable("embed.embedding", self.embedding.weight)
+        self.validate_ids = False
+
+    def forward(self, input_ids):
+        w = self.embedding.weight
+        need_grad = torch.is_grad_enabled() and w.requires_grad
+        keys = ops.ids_to_i32(input_ids, w.shape[0], validate=self.validate_ids) \
+            if (need_grad or self.table.lazy is not None) else None
+        if keys is not None:
+            self.table.prepare(keys, need_grad)
+        return _Gather.apply(w, input_ids, self.table)
+
+
+# ----------------------------------------------------------------------------- dense layers
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        x = x.contiguous()
+        y = ops.linear_fwd(x, w, b, relu=relu)
+        ctx.relu = relu
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        dz = ops.relu_mask(gy.contiguous(), y) if ctx.relu else gy.contiguous()
+        dx = ops.linear_bwd_input(dz, w) if ctx.needs_input_grad[0] else None
+        dw = ops.linear_bwd_weight(dz, x) if ctx.needs_input_grad[1] else None
+        db = ops.colsum(dz) if ctx.needs_input_grad[2] else None
+        return dx, dw, db, None
+
+
+class HipLinear(nn.Module):
+    """nn.Linear (y = x W^T + b, optional fused ReLU) on the fp32 MFMA GEMM; parameters keep
+    nn.Linear's names, shapes and default initialisation."""
+
+    def __init__(self, in_features, out_features, relu=False):
+        super().__init__()
+        self.in_features, self.out_features, self.relu = in_features, out_features, relu
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features))
+        bound = 1.0 / math.sqrt(in_features)
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+            self.bias.uniform_(-bound, bound)
+
+    def forward(self, x):
+        return _Linear.apply(x, self.weight, self.bias, self.relu)
+
+
+class MLPBlock(nn.Module):
+    """[Linear, ReLU, Dropout(p)] x n; state_dict keys dnn.{0,3,6,...} like the reference's
+    nn.Sequential (layers.py:173-188).  Only relu / p = 0 (the DCNv2 scripts) are built."""
+
+    def __init__(self, input_dim, hidden_size=128, num_hidden_layers=3, hidden_act="relu",
+                 hidden_dropout_rate=0.5, batch_norm=False):
+        super().__init__()
+        if str(hidden_act).lower() != "relu":
+            raise NotImplementedError(f"hidden_act={hidden_act!r}: only relu is built (DCNv2 scripts)")
+        if hidden_dropout_rate > 0:
+            raise NotImplementedError("hidden_dropout_rate > 0 is outside the DCNv2 scripts")
+        self.dnn = nn.ModuleDict()
+        for i in range(num_hidden_layers):
+            self.dnn[str(3 * i)] = HipLinear(input_dim, hidden_size, relu=True)
+            input_dim = hidden_size
+
+    def forward(self, x):
+        for layer in self.dnn.values():
+            x = layer(x)
+        return x
+
+
+class _CrossLayer(Function):
+    @staticmethod
+    def forward(ctx, x0, xi, w, b):
+        x0, xi = x0.contiguous(), xi.contiguous()
+        y, u = ops.cross_layer_fwd(x0, xi, w, b)
+        ctx.save_for_backward(x0, xi, w, u)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x0, xi, w, u = ctx.saved_tensors
+        g = g.contiguous()
+        t, dx0 = ops.cross_bwd_pre(g, x0, u)              # t = g*x0, dx0 = g*u
+        dxi = ops.linear_bwd_input(t, w, add=g)           # g + t W
+        dw = ops.linear_bwd_weight(t, xi)                 # t^T xi
+        db = ops.colsum(t)
+        return dx0, dxi, dw, db
+
+
+class CrossNetV2(nn.Module):
+    """X_{i+1} = X_i + X_0 * (W_i X_i + b_i) with full-rank W_i (reference layers.py:191-201);
+    the Hadamard/residual epilogue is fused into the MFMA GEMM."""
+
+    def __init__(self, input_dim, num_cross_layers):
+        super().__init__()
+        self.num_layers = num_cross_layers
+        self.cross_layers = nn.ModuleList(HipLinear(input_dim, input_dim) for _ in range(num_cross_layers))
+
+    def forward(self, x0):
+        xi = x0
+        for layer in self.cross_layers:
+            xi = _CrossLayer.apply(x0, xi, layer.weight, layer.bias)
+        return xi
+
+
+class _Bce(Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        out3, dl = ops.bce_with_logits(logits, labels, want_grad=True)
+        ctx.save_for_backward(dl)
+        ctx.mark_non_differentiable(out3)
+        return out3[0].clone(), out3
+
+    @staticmethod
+    def backward(ctx, g, _):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None
+
+
+def bce_with_logits(logits, labels):
+    """-> (mean loss, stats = [loss, accuracy, mean(label)])  (BCEWithLogitsLoss, models.py:81,91)."""
+    return _Bce.apply(logits, labels)

@@ -1,0 +1,149 @@
+"""BaseModel + DCNV2 (host mirror of reference code/models.py:21-127, 282-322): same factory,
+same forward signature and output tuples, same state_dict key layout; every arithmetic step
+is a gfx950 kernel."""
+import logging
+
+import torch
+from torch import nn
+
+from .arguments import Config
+from .layers import CrossNetV2, Embeddings, HipLinear, MLPBlock, bce_with_logits
+from .nce import IndexLinear
+
+logger = logging.getLogger(__name__)
+
+_OTHER_BACKBONES = ("dnn", "autoint", "trans", "fignn", "fgcnn", "deepfm", "xdeepfm")
+
+
+class _RfdPredictor(nn.ModuleDict):
+    """Linear -> ReLU -> Linear with the reference nn.Sequential's keys "0" and "2"
+    (models.py:119-123); the ReLU is fused into the first GEMM's epilogue."""
+
+    def __init__(self, input_dim, hidden, out):
+        super().__init__({"0": HipLinear(input_dim, hidden, relu=True), "2": HipLinear(hidden, out)})
+
+    def forward(self, x):
+        return self["2"](self["0"](x))
+
+
+class BaseModel(nn.Module):
+    used_params = []
+
+    def __init__(self, model_name="BaseModel", config: Config = None):
+        super().__init__()
+        self.model_name = model_name
+        self.config = config
+
+    @classmethod
+    def from_config(cls, config: Config):
+        name = config.model_name.lower()
+        if name == "dcnv2":
+            return DCNV2(config)
+        if name in _OTHER_BACKBONES:
+            raise NotImplementedError(
+                f"{config.model_name}: only the DCNv2 backbone is built in mapx (SURVEY §8: the "
+                "other backbones are out of the hot-path scope)")
+        raise NotImplementedError(config.model_name)
+
+    def validate_model_config(self):
+        logger.info(f"  model_name = {self.model_name}")
+        for key in self.used_params:
+            logger.info(f"  {key} = {getattr(self.config, key)}")
+
+    # ------------------------------------------------------------------ heads
+    def get_outputs(self, inputs, labels=None, masked_index=None, is_pretrain=None, noise_samples=None):
+        """MFP -> (loss, #signals, #targets ranked first)            (models.py:71-78)
+        RFD -> (loss, #signals, accuracy, positive ratio)            (models.py:79-85)
+        CTR -> (loss, logits) or (logits,)                           (models.py:88-93)
+        `#targets ranked first` is a device scalar (no host sync per step); the reference
+        returns a Python int after `.item()`."""
+        cfg = self.config
+        if (is_pretrain is None and cfg.pretrain) or is_pretrain:
+            if cfg.pt_type == "MFP":
+                enc = self.feat_encoder(inputs)
+                loss, _logits, _idx = self.mfp_criterion(labels, enc, masked_index=masked_index,
+                                                         noise_samples=noise_samples)
+                return (loss, labels.shape[0] * labels.shape[1], self.mfp_criterion.last_acc)
+            if cfg.pt_type == "RFD":
+                logits = self.pred_rfd(inputs)
+                loss, stats = bce_with_logits(logits, labels)
+                return (loss, labels.shape[0] * labels.shape[1], stats[1], stats[2])
+            raise NotImplementedError(cfg.pt_type)
+        outputs = (inputs,)
+        if labels is not None:
+            loss, _ = bce_with_logits(inputs.view(-1), labels.float())
+            outputs = (loss,) + outputs
+        return outputs
+
+    def create_pretraining_predictor(self, input_dim):
+        cfg = self.config
+        if cfg.pt_type == "MFP":
+            self.feat_encoder = HipLinear(input_dim, cfg.num_fields * cfg.proj_size)
+            self.mfp_criterion = IndexLinear(cfg)
+        elif cfg.pt_type == "RFD":
+            self.pred_rfd = _RfdPredictor(input_dim, cfg.num_fields * cfg.proj_size, cfg.num_fields)
+        else:
+            raise NotImplementedError(cfg.pt_type)
+
+    # ------------------------------------------------------------------ checkpoints
+    def load_from_target_model(self, target_model_dict):
+        """Copy every tensor whose NAME and SHAPE match; report the rest (models.py:97-107)."""
+        own = self.state_dict()
+        skipped = []
+        for k, v in target_model_dict.items():
+            if k in own and own[k].shape == v.shape:
+                own[k] = v
+                logger.info(f"Load tensor: {k}, {tuple(v.shape)}")
+            else:
+                skipped.append(k)
+                logger.info(f"Unmatched tensor in the target model: {k}, {tuple(v.shape)}")
+        self.load_state_dict(own)
+        return skipped
+
+    def load_for_finetune(self, model_path):
+        return self.load_from_target_model(torch.load(model_path, map_location="cpu"))
+
+    def row_tables(self):
+        """The [V,*] tables with row-sparse gradients (optimised by mapx.optim.TableAdam)."""
+        return [m.table for m in self.modules() if hasattr(m, "table")]
+
+    def table_parameter_ids(self):
+        ids = set()
+        for t in self.row_tables():
+            ids.add(id(t.p0))
+            if t.p1 is not None:
+                ids.add(id(t.p1))
+        return ids
+
+
+class DCNV2(BaseModel):
+    used_params = ["embed_size", "hidden_size", "num_hidden_layers", "hidden_dropout_rate", "hidden_act",
+                   "num_cross_layers"]
+
+    def __init__(self, config: Config):
+        super().__init__(model_name="DCNV2", config=config)
+        self.embed = Embeddings(config)
+        input_dim = config.num_fields * config.embed_size
+        self.cross_net = CrossNetV2(input_dim, config.num_cross_layers)
+        final_dim = input_dim
+        if config.num_hidden_layers > 0:
+            self.parallel_dnn = MLPBlock(input_dim=input_dim, hidden_size=config.hidden_size,
+                                         num_hidden_layers=config.num_hidden_layers,
+                                         hidden_dropout_rate=config.hidden_dropout_rate,
+                                         hidden_act=config.hidden_act)
+            final_dim += config.hidden_size
+        if config.pretrain:
+            self.create_pretraining_predictor(final_dim)
+        else:
+            self.fc_out = HipLinear(final_dim, 1)
+
+    def forward(self, input_ids, labels=None, masked_index=None, noise_samples=None):
+        feat_embed = self.embed(input_ids).flatten(start_dim=1)
+        cross_output = self.cross_net(feat_embed)
+        if self.config.num_hidden_layers > 0:
+            final_output = torch.cat([cross_output, self.parallel_dnn(feat_embed)], dim=-1)
+        else:
+            final_output = cross_output
+        if self.config.pretrain:
+            return self.get_outputs(final_output, labels, masked_index, noise_samples=noise_samples)
+        return self.get_outputs(self.fc_out(final_output), labels)

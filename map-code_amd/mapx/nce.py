@@ -1,0 +1,146 @@
+"""MFP criterion: NCE over the whole feature vocabulary (host mirror of reference
+code/nce/nce_loss.py NCELoss, nce/index_linear.py IndexLinear, nce/alias_multinomial.py
+AliasMultinomial — `nce` loss type, per-word noise: the only mode the reference reaches)."""
+import math
+import os
+
+import torch
+from torch import nn
+from torch.autograd import Function
+
+from . import ops
+from .layers import RowTable, TableWeight
+
+BACKOFF_PROB = 1e-10
+
+
+class AliasMultinomial(nn.Module):
+    """Walker alias sampler.  Buffers `prob` [V] f32 and `alias` [V] i64 keep the reference's
+    checkpoint layout; the table is built by the C++ host builder in the reference's visiting
+    order and cached in data_dir/alias_self_{prob,alias}.h5 (torch.save files, as upstream)."""
+
+    def __init__(self, probs, config):
+        super().__init__()
+        data_dir = getattr(config, "data_dir", None)
+        pf = os.path.join(data_dir, "alias_self_prob.h5") if data_dir else None
+        af = os.path.join(data_dir, "alias_self_alias.h5") if data_dir else None
+        if pf and os.path.exists(pf) and os.path.exists(af):
+            prob, alias = torch.load(pf), torch.load(af)
+            if prob.numel() != probs.numel():
+                raise ValueError(f"{pf} holds {prob.numel()} classes, expected {probs.numel()}")
+        else:
+            prob, alias = ops.alias_build(probs)
+            if pf and os.path.isdir(data_dir):
+                torch.save(prob, pf)
+                torch.save(alias, af)
+        self.register_buffer("prob", prob)
+        self.register_buffer("alias", alias)
+        self._packed = None
+
+    def _load_from_state_dict(self, *a, **k):
+        self._packed = None
+        return super()._load_from_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def packed(self):
+        if self._packed is None:
+            self._packed = ops.alias_pack(self.prob, self.alias)
+        return self._packed
+
+    def draw_index_matrix(self, targets, K, seed, offset):
+        """idx int32 [T, K+1]: column 0 = targets, then K negatives."""
+        return ops.alias_draw(self.packed(), targets, K, seed, offset)
+
+
+class _NceLoss(Function):
+    @staticmethod
+    def forward(ctx, enc, emb_w, bias_w, logq, masked_index, idx, crit, F, P, want_logits):
+        o = ops.nce_fwd(enc.contiguous(), masked_index, idx, emb_w, bias_w.view(-1), logq, F, P,
+                        want_logits=want_logits)
+        ctx.crit, ctx.F, ctx.P, ctx.K = crit, F, P, idx.shape[1] - 1
+        ctx.plan = crit.table.plan
+        ctx.save_for_backward(o["dlogit"], o["dh"], o["h"], masked_index)
+        logits = o["logits"] if want_logits else torch.empty(0, device=enc.device)
+        ctx.mark_non_differentiable(o["acc"], logits)
+        return o["loss"].view(()), o["acc"].view(()), logits
+
+    @staticmethod
+    def backward(ctx, gl, _a, _l):
+        dlogit, dh, h, mi = ctx.saved_tensors
+        gl = gl.contiguous().float()
+        denc = ops.nce_scatter_dh(dh, mi, ctx.F, ctx.P, gscale=gl)
+        if ctx.plan is None:
+            raise RuntimeError("NCE backward without a segment plan")
+        ops.scale_(dlogit, gl)
+        ge, gb = ops.nce_table_grad(ctx.plan, dlogit, h, ctx.K, ctx.P)
+        ctx.crit.table.sparse_grad = (ctx.plan, ge, gb)
+        return denc, None, None, None, None, None, None, None, None, None
+
+
+class IndexLinear(nn.Module):
+    """Output embedding emb [V,P] + bias [V,1] scored only at the target and K sampled
+    negatives, with the NCE binary loss.  Buffers/parameters keep the reference names:
+    logprob_noise, alias.{prob,alias}, emb.weight, bias.weight."""
+
+    def __init__(self, config):
+        super().__init__()
+        noise = torch.as_tensor(config.feat_count, dtype=torch.float32).cpu()
+        probs = (noise / noise.sum()).clamp(min=BACKOFF_PROB)
+        renormed = probs / probs.sum()
+        self.register_buffer("logprob_noise", renormed.log())
+        self.alias = AliasMultinomial(renormed, config)
+        self.noise_ratio = config.pt_neg_num
+        self.norm_term = math.log(noise.numel())
+        self.proj_size = config.proj_size
+        self.loss_type = "nce"
+        self.emb = TableWeight(config.input_size, config.proj_size)
+        self.bias = TableWeight(config.input_size, 1)
+        self.reset_parameters()
+        self.table = RowTable("mfp_criterion", self.emb.weight, self.bias.weight)
+        self.seed = int(getattr(config, "seed", 42))
+        self.rank = int(getattr(config, "rank", 0))
+        self._draws = 0
+        self.return_logits = False
+
+    def reset_parameters(self):
+        stdv = 1.0 / math.sqrt(self.proj_size)
+        with torch.no_grad():
+            self.emb.weight.uniform_(-stdv, stdv)
+            # unigram initialisation of the bias (index_linear.py:44-48)
+            self.bias.weight.copy_((self.logprob_noise + self.norm_term).unsqueeze(1))
+
+    def get_noise_index(self, target):
+        self._draws += 1
+        offset = (self.rank << 40) + self._draws
+        return self.alias.draw_index_matrix(target.reshape(-1), self.noise_ratio, self.seed, offset)
+
+    def forward(self, target, input, masked_index=None, noise_samples=None):
+        """target [B,L] i64.  `input` is either the selected hidden [B,L,P] (reference call
+        form, models.py:76) or, with `masked_index` [B,L], the whole encoder output [B,F*P] —
+        then the field gather is fused into the loss kernel.
+        -> (loss, logits [B,L,K+1] or empty, indices int32 [B,L,K+1]); `self.last_acc` holds
+        the number of targets ranked first (device scalar)."""
+        B, L = target.shape
+        P = self.proj_size
+        if masked_index is None:
+            enc = input.reshape(B, L * P)
+            F = L
+            masked_index = torch.arange(L, device=target.device).expand(B, L).contiguous()
+        else:
+            enc, F = input, input.shape[1] // P
+        V = self.emb.weight.shape[0]
+        if noise_samples is not None:
+            idx = ops.nce_pack_idx(target.reshape(-1), noise_samples.reshape(B * L, -1), V)
+        else:
+            idx = self.get_noise_index(target)
+        need_grad = torch.is_grad_enabled() and self.emb.weight.requires_grad
+        self.table.prepare(idx.view(-1), need_grad)
+        loss, acc, logits = _NceLoss.apply(enc, self.emb.weight, self.bias.weight, self.logprob_noise,
+                                           masked_index, idx, self, F, P, self.return_logits)
+        self.last_acc = acc
+        if self.return_logits:
+            logits = logits.view(B, L, -1)
+        return loss, logits, idx.view(B, L, -1)

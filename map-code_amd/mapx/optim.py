@@ -1,0 +1,179 @@
+"""Optimizer of the hot path: transformers-4.26 AdamW + cosine/const schedule, as the
+reference's Trainer.get_optimizer builds it (code/trainer.py:60-85), on device.
+
+* dense parameters live in two flat fp32 buffers (decay / no-decay group, split by the
+  reference's NAME rule) and take one fused kernel per group per step;
+* the [V,*] tables take row-sparse updates with exact lazy replay of the zero-gradient
+  updates the reference applies to untouched rows (csrc/optim.hip);
+* {step size, lr} per update come from a device table and the update counter is a device
+  int, so nothing is synchronised with the host during training.
+"""
+import math
+
+import torch
+
+from . import ops
+
+NO_DECAY = ("bias", "LayerNorm.weight")          # trainer.py:61
+
+
+def decays(name):
+    return not any(nd in name for nd in NO_DECAY)
+
+
+def lr_lambda(kind, step, total, warmup):
+    """get_{cosine,constant}_schedule_with_warmup multiplier at scheduler step `step`."""
+    kind = kind.lower()
+    if kind not in ("cosine", "const"):
+        raise NotImplementedError(kind)                       # trainer.py:82-83
+    if step < warmup:
+        return float(step) / float(max(1, warmup))
+    if kind == "const":
+        return 1.0
+    progress = float(step - warmup) / float(max(1, total - warmup))
+    return max(0.0, 0.5 * (1.0 + math.cos(math.pi * progress)))
+
+
+class TableAdam:
+    """Lazy exact AdamW state of one RowTable."""
+
+    def __init__(self, table, wd0, wd1, hyper, sched, done, max_gap):
+        self.table, self.wd0, self.wd1 = table, wd0, wd1
+        self.b1, self.b2, self.eps = hyper
+        self.sched, self.done = sched, done
+        p0, p1 = table.p0.data, (table.p1.data if table.p1 is not None else None)
+        self.m0, self.v0 = torch.zeros_like(p0), torch.zeros_like(p0)
+        self.m1 = torch.zeros(p1.shape[0], device=p1.device) if p1 is not None else None
+        self.v1 = torch.zeros(p1.shape[0], device=p1.device) if p1 is not None else None
+        self.last = torch.zeros(p0.shape[0], dtype=torch.int32, device=p0.device)
+        self.stale = False
+        self.cursor = 0
+        self.sweep = max(1, math.ceil(p0.shape[0] / max(1, max_gap)))
+        table.lazy = self
+
+    def _call(self, **kw):
+        t = self.table
+        ops.table_adam(t.p0.data, self.m0, self.v0, self.wd0, self.last, self.sched, self.done,
+                       self.b1, self.b2, self.eps,
+                       p1=t.p1.data.view(-1) if t.p1 is not None else None,
+                       m1=self.m1, v1=self.v1, wd1=self.wd1, **kw)
+
+    def catch_up(self, plan):
+        self._call(rows=plan.uniq, n_rows=plan.n, n_rows_dev=plan.n_uniq)
+
+    def update(self):
+        sg = self.table.sparse_grad
+        if sg is None:
+            return
+        plan, r0, r1 = sg
+        self._call(rows=plan.uniq, n_rows=plan.n, n_rows_dev=plan.n_uniq, grad0=r0, grad1=r1)
+        self.table.sparse_grad = None
+        self.stale = True
+
+    def sweep_some(self):
+        """Bound the replay length: every row is brought up to date at least every max_gap steps."""
+        V = self.table.num_rows
+        n = min(self.sweep, V - self.cursor)
+        self._call(row_begin=self.cursor, n_rows=n)
+        self.cursor = (self.cursor + n) % V
+
+    def flush(self):
+        if self.stale:
+            self._call(row_begin=0, n_rows=self.table.num_rows)
+            self.stale = False
+
+
+class MapxOptimizer:
+    """optimizer + scheduler of reference Trainer.get_optimizer, fused.  `step()` = the
+    reference's optimizer.step(); scheduler.step(); model.zero_grad()."""
+
+    def __init__(self, model, args, num_training_steps, num_warmup_steps, max_gap=256):
+        b1, b2 = (float(x) for x in args.adam_betas.split(","))
+        self.hyper = (b1, b2, float(args.adam_epsilon))
+        self.lr0, self.wd = float(args.learning_rate), float(args.weight_decay)
+        self.kind, self.total, self.warmup = args.lr_sched.lower(), int(num_training_steps), int(num_warmup_steps)
+        self.max_grad_norm = float(getattr(args, "max_grad_norm", 0.0))
+        lambdas = [lr_lambda(self.kind, s, self.total, self.warmup) for s in range(max(1, self.total))]
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("MapxOptimizer needs the model on the GPU (call model.to(device) first)")
+        self.sched = ops.make_sched(self.lr0, lambdas, b1, b2).to(dev)
+        self.done = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.steps_done = 0
+        table_ids = model.table_parameter_ids()
+        named = [(n, p) for n, p in model.named_parameters() if id(p) not in table_ids and p.requires_grad]
+        self.groups = []
+        for wd, members in ((self.wd, [(n, p) for n, p in named if decays(n)]),
+                            (0.0, [(n, p) for n, p in named if not decays(n)])):
+            if members:
+                self.groups.append(self._flatten(members, wd, dev))
+        names = {id(p): n for n, p in model.named_parameters()}
+        self.tables = []
+        for t in model.row_tables():
+            wd0 = self.wd if decays(names[id(t.p0)]) else 0.0
+            wd1 = (self.wd if decays(names[id(t.p1)]) else 0.0) if t.p1 is not None else 0.0
+            self.tables.append(TableAdam(t, wd0, wd1, self.hyper, self.sched, self.done, max_gap))
+
+    @staticmethod
+    def _flatten(members, wd, dev):
+        sizes = [(p.numel() + 3) // 4 * 4 for _, p in members]      # keep every view 16-B aligned
+        total = sum(sizes)
+        flat_p = torch.zeros(total, device=dev)
+        flat_g = torch.zeros(total, device=dev)
+        off = 0
+        for (_, p), sz in zip(members, sizes):
+            view = flat_p[off:off + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = flat_g[off:off + p.numel()].view_as(p)
+            off += sz
+        return dict(p=flat_p, g=flat_g, m=torch.zeros_like(flat_p), v=torch.zeros_like(flat_p), wd=wd,
+                    names=[n for n, _ in members])
+
+    # ------------------------------------------------------------------
+    def clip_grad_norm_(self):
+        sq = sum((g["g"] ** 2).sum() for g in self.groups)
+        for t in self.tables:
+            if t.table.sparse_grad is not None:
+                plan, r0, r1 = t.table.sparse_grad
+                live = (torch.arange(r0.shape[0], device=r0.device) < plan.n_uniq).float()
+                sq = sq + ((r0 ** 2).sum(1) * live).sum()
+                if r1 is not None:
+                    sq = sq + ((r1 ** 2) * live).sum()
+        coef = (self.max_grad_norm / (sq.sqrt() + 1e-6)).clamp(max=1.0)
+        for g in self.groups:
+            g["g"].mul_(coef)
+        for t in self.tables:
+            if t.table.sparse_grad is not None:
+                _, r0, r1 = t.table.sparse_grad
+                r0.mul_(coef)
+                if r1 is not None:
+                    r1.mul_(coef)
+
+    def step(self):
+        if self.max_grad_norm > 0:
+            self.clip_grad_norm_()
+        b1, b2, eps = self.hyper
+        for g in self.groups:
+            ops.adamw_dense(g["p"], g["g"], g["m"], g["v"], self.sched, self.done, b1, b2, eps, g["wd"])
+        for t in self.tables:
+            t.update()
+        ops.step_advance(self.done)
+        self.steps_done += 1
+        for t in self.tables:
+            t.sweep_some()
+        self.zero_grad()
+
+    def zero_grad(self):
+        for g in self.groups:
+            g["g"].zero_()
+        for t in self.tables:
+            t.table.sparse_grad = None
+
+    def flush(self):
+        """Materialise reference-equivalent table weights (before eval / checkpoint)."""
+        for t in self.tables:
+            t.flush()
+
+    def get_last_lr(self):
+        return [self.lr0 * lr_lambda(self.kind, self.steps_done, self.total, self.warmup)]

@@ -1,0 +1,340 @@
+"""Step loops of the hot path (host mirror of reference code/trainer.py): Trainer.train /
+MFP_pretrain / RFD_pretrain / eval / test / dynamic_mask / save_model / load_model, with the
+reference's step order  mask -> forward -> backward -> (clip) -> optimizer -> scheduler ->
+zero_grad  and its checkpoint rules.
+
+Differences that are deliberate:
+  * the id matrix of a split is resident in HBM and a batch is a row-gather by a shuffled
+    index on the device (the reference collates 4096 numpy rows per step in Python);
+  * masks / replacements / negatives are drawn on the device from Philox streams;
+  * step metrics stay on the device and are fetched every `logging_steps` steps (the
+    reference synchronises twice per step with .item());
+  * the reference's NameError at trainer.py:341 (`log` undefined) is not reproduced.
+"""
+import logging
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import ops, parallel
+from .optim import MapxOptimizer
+
+logger = logging.getLogger(__name__)
+
+
+class DeviceSplit:
+    """A dataset split resident on the GPU: X int64 [N,F], Y int64 [N]."""
+
+    def __init__(self, dataset, device):
+        self.X = torch.as_tensor(np.ascontiguousarray(dataset.X)).to(device)
+        self.Y = torch.as_tensor(np.ascontiguousarray(dataset.Y)).to(device)
+        self.n = self.X.shape[0]
+
+    def batches(self, batch_size, shuffle, generator=None, shard=(0, 1)):
+        """Yield (X_b, Y_b).  shard = (rank, world): rank r takes batches r, r+world, ..."""
+        order = torch.randperm(self.n, device=self.X.device, generator=generator) if shuffle else None
+        r, w = shard
+        starts = list(range(0, self.n, batch_size))
+        for bi in range(r, len(starts) - (len(starts) % w if w > 1 else 0), w):
+            s = starts[bi]
+            if order is None:
+                yield self.X[s:s + batch_size], self.Y[s:s + batch_size]
+            else:
+                sel = order[s:s + batch_size]
+                yield self.X[sel], self.Y[sel]
+
+    def num_batches(self, batch_size, world=1):
+        nb = (self.n + batch_size - 1) // batch_size
+        return nb // world if world > 1 else nb
+
+
+class Trainer:
+    def __init__(self, model, model_config, training_args, train_dataset, eval_dataset):
+        self.model, self.model_config, self.args = model, model_config, training_args
+        self.device = self.args.device
+        self.train_dataset, self.eval_dataset = train_dataset, eval_dataset
+        self.global_step = 0
+        self.eval_metrics = []
+        self.optimizer = None
+        self.best_eval_auc, self.best_eval_step = 0, -1
+        self.rank, self.world = parallel.rank(), parallel.world()
+        self._splits = {}
+        self._mask_calls = 0
+        self._gen = None
+        logger.info(f"setting device {self.device}")
+
+    # ------------------------------------------------------------------ plumbing
+    def _split(self, dataset):
+        key = id(dataset)
+        if key not in self._splits:
+            self._splits[key] = DeviceSplit(dataset, self.device)
+        return self._splits[key]
+
+    def _generator(self):
+        if self._gen is None:
+            self._gen = torch.Generator(device=self.device)
+            self._gen.manual_seed(int(self.args.seed))     # same permutation on every rank
+        return self._gen
+
+    def get_optimizer(self, num_training_steps, num_warmup_steps):
+        return MapxOptimizer(self.model, self.args, num_training_steps, num_warmup_steps)
+
+    def _begin(self, what):
+        train = self._split(self.train_dataset)
+        steps_per_epoch = train.num_batches(self.args.per_gpu_train_batch_size, self.world)
+        t_total = int(steps_per_epoch * self.args.num_train_epochs)
+        t_warmup = int(t_total * self.args.warmup_ratio)
+        self.model.to(self.device)
+        self.optimizer = self.get_optimizer(t_total, t_warmup)
+        self.scheduler = self.optimizer                      # get_last_lr() lives there
+        logger.info(f"***** running {what} *****")
+        for k, v in (("dataset_name", self.args.dataset_name), ("input_size", self.model_config.input_size),
+                     ("num_fields", self.model_config.num_fields), ("num_examples", len(self.train_dataset)),
+                     ("num_epochs", self.args.num_train_epochs), ("batch_size", self.args.train_batch_size),
+                     ("per_gpu_train_batch_size", self.args.per_gpu_train_batch_size),
+                     ("total_steps", t_total), ("warmup_steps", t_warmup),
+                     ("learning_rate", self.args.learning_rate), ("weight_decay", self.args.weight_decay),
+                     ("lr_sched", self.args.lr_sched)):
+            logger.info(f"  {k} = {v}")
+        self.model.validate_model_config()
+        self.global_step, self.eval_metrics = 0, []
+        return train
+
+    def _optimizer_step(self):
+        parallel.sync_gradients(self.optimizer)
+        self.optimizer.step()                                # + scheduler.step() + zero_grad()
+        self.global_step += 1
+
+    # ------------------------------------------------------------------ masking (a1, a2)
+    def dynamic_mask(self, inputs, sampling_method="normal", masked_index=None, replace_feat=None):
+        ids = inputs["input_ids"]
+        F = self.model_config.num_fields
+        L = int(F * self.args.mask_ratio)
+        self._mask_calls += 1
+        seed, offset = int(self.args.seed), (self.rank << 40) + self._mask_calls
+        if masked_index is None:
+            if sampling_method == "normal":        # L distinct fields per row (trainer.py:222)
+                masked_index = torch.rand(ids.shape[0], F, device=ids.device,
+                                          generator=self._generator()).argsort(1)[:, :L].contiguous()
+            elif sampling_method != "randint":
+                raise NotImplementedError(sampling_method)
+        if self.args.pt_type == "MFP":
+            inputs["input_ids"], inputs["labels"], inputs["masked_index"] = ops.dynamic_mask_mfp(
+                ids, L, masked_index=masked_index, seed=seed, offset=offset)
+        elif self.args.pt_type == "RFD":
+            if self.args.RFD_replace != "Unigram" and replace_feat is None:
+                if self.args.RFD_replace in ("Uniform", "Whole-Uniform", "Whole-Unigram"):
+                    raise NotImplementedError(
+                        f"RFD_replace={self.args.RFD_replace}: only Unigram (the run scripts' generator) is built")
+                raise NotImplementedError
+            x_train = self._split(self.train_dataset).X
+            inputs["input_ids"], inputs["labels"], _ = ops.dynamic_mask_rfd(
+                ids, L, masked_index=masked_index, replace_feat=replace_feat, x_train=x_train,
+                seed=seed, offset=offset)
+        else:
+            raise NotImplementedError(self.args.pt_type)
+        return inputs
+
+    # ------------------------------------------------------------------ MFP (north-star loop)
+    def MFP_pretrain(self):
+        train = self._begin("pretraining")
+        logger.info(f"  mask_ratio = {self.args.mask_ratio}")
+        logger.info(f"  pt_neg_num = {self.model_config.pt_neg_num}")
+        logger.info(f"  pt_type = {self.model_config.pt_type}")
+        B = self.args.per_gpu_train_batch_size
+        win_loss = torch.zeros((), device=self.device)
+        win_acc = torch.zeros((), device=self.device)
+        start_time = time.time()
+        for epoch in range(self.args.num_train_epochs):
+            logger.info(f"-------------------- epoch-{epoch} --------------------")
+            self.model.train()
+            for X, Y in train.batches(B, True, self._generator(), (self.rank, self.world)):
+                inputs = self.dynamic_mask({"input_ids": X, "labels": Y}, self.args.sampling_method)
+                loss, count, acc = self.model(**inputs)
+                loss.backward()
+                self._optimizer_step()
+                win_loss += loss.detach()
+                win_acc += acc.float() / count
+                if self.global_step % self.args.logging_steps == 0:
+                    n = self.args.logging_steps
+                    _log = {"window_loss": float(win_loss) / n, "window_acc": float(win_acc) / n,
+                            "time_cost": time.time() - start_time}
+                    logger.info(f"step = {self.global_step}, {_log}")
+                    win_loss.zero_(); win_acc.zero_()
+                    start_time = time.time()
+            if self.args.local_rank in [-1, 0]:
+                self.MFP_pretrain_eval()
+        if self.args.local_rank in [-1, 0]:
+            self.save_model(self.args.output_dir)
+        logger.info(str(self.eval_metrics))
+
+    def MFP_pretrain_eval(self):
+        ev = self._split(self.eval_dataset)
+        logger.info("***** running eval *****")
+        logger.info(f"  num examples = {ev.n}")
+        self.optimizer.flush()
+        self.model.eval()
+        tot_loss = torch.zeros((), device=self.device)
+        tot_acc = torch.zeros((), device=self.device)
+        count = 0
+        t0 = time.time()
+        with torch.no_grad():
+            for X, Y in ev.batches(self.args.per_gpu_eval_batch_size, False):
+                inputs = self.dynamic_mask({"input_ids": X, "labels": Y}, self.args.sampling_method)
+                loss, n, acc = self.model(**inputs)
+                tot_loss += loss * n
+                tot_acc += acc.float()
+                count += n
+        _log = {"learning_rate": self.scheduler.get_last_lr()[0], "eval_mfp_loss": float(tot_loss) / count,
+                "eval_mfp_acc": float(tot_acc) / count, "eval_time_cost": time.time() - t0}
+        self.eval_metrics.append([_log["eval_mfp_loss"], _log["eval_mfp_acc"]])
+        logger.info(str(_log))
+        return _log
+
+    # ------------------------------------------------------------------ RFD
+    def RFD_pretrain(self):
+        train = self._begin("pretraining")
+        logger.info(f"  pt_type = {self.model_config.pt_type}")
+        logger.info(f"  mask_ratio = {self.args.mask_ratio}")
+        logger.info(f"  RFD_replace = {self.args.RFD_replace}")
+        B = self.args.per_gpu_train_batch_size
+        win = torch.zeros(2, device=self.device)
+        start_time = time.time()
+        for epoch in range(self.args.num_train_epochs):
+            logger.info(f"-------------------- epoch-{epoch} --------------------")
+            self.model.train()
+            for X, Y in train.batches(B, True, self._generator(), (self.rank, self.world)):
+                inputs = self.dynamic_mask({"input_ids": X, "labels": Y}, self.args.sampling_method)
+                loss, count, acc, pos_ratio = self.model(**inputs)
+                loss.backward()
+                self._optimizer_step()
+                win += torch.stack([loss.detach(), acc])
+                if self.global_step % self.args.logging_steps == 0:
+                    n = self.args.logging_steps
+                    w = win.tolist()
+                    _log = {"window_rfd_loss": w[0] / n, "window_rfd_acc": w[1] / n,
+                            "time_cost": time.time() - start_time}
+                    logger.info(f"step = {self.global_step}, {_log}")
+                    win.zero_()
+                    start_time = time.time()
+            if self.args.local_rank in [-1, 0]:
+                self.RFD_pretrain_eval()
+        if self.args.local_rank in [-1, 0]:
+            self.save_model(self.args.output_dir)
+        logger.info(str(self.eval_metrics))
+
+    def RFD_pretrain_eval(self):
+        ev = self._split(self.eval_dataset)
+        logger.info("***** running eval *****")
+        logger.info(f"  num examples = {ev.n}")
+        self.optimizer.flush()
+        self.model.eval()
+        tot = torch.zeros(2, device=self.device)
+        count = 0
+        t0 = time.time()
+        with torch.no_grad():
+            for X, Y in ev.batches(self.args.per_gpu_eval_batch_size, False):
+                inputs = self.dynamic_mask({"input_ids": X, "labels": Y}, self.args.sampling_method)
+                loss, n, acc = self.model(**inputs)[:3]
+                tot += torch.stack([loss, acc]) * n
+                count += n
+        t = tot.tolist()
+        _log = {"learning_rate": self.scheduler.get_last_lr()[0], "eval_rfd_loss": t[0] / count,
+                "eval_rfd_acc": t[1] / count, "eval_time_cost": time.time() - t0}
+        self.eval_metrics.append([_log["eval_rfd_loss"], _log["eval_rfd_acc"]])
+        logger.info(str(_log))
+        return _log
+
+    # ------------------------------------------------------------------ CTR (scratch / finetune)
+    def train(self):
+        from sklearn.metrics import roc_auc_score
+        train = self._begin("training")
+        self._patience, self._stop_training = 0, False
+        B = self.args.per_gpu_train_batch_size
+        win_loss = torch.zeros((), device=self.device)
+        win_logits, win_labels = [], []
+        for epoch in range(self.args.num_train_epochs):
+            logger.info(f"-------------------- epoch-{epoch} --------------------")
+            self.model.train()
+            for X, Y in train.batches(B, True, self._generator(), (self.rank, self.world)):
+                loss, logits = self.model(input_ids=X, labels=Y)
+                loss.backward()
+                self._optimizer_step()
+                win_loss += loss.detach()
+                win_logits.append(logits.detach().view(-1))
+                win_labels.append(Y)
+                if self.global_step % self.args.logging_steps == 0:
+                    probs = torch.sigmoid(torch.cat(win_logits)).cpu().numpy()
+                    labels = torch.cat(win_labels).cpu().numpy()
+                    auc = roc_auc_score(np.int32(labels), probs) if 0 < labels.sum() < len(labels) else float("nan")
+                    _log = {"window_auc": auc, "window_loss": float(win_loss) / self.args.logging_steps}
+                    logger.info(f"step = {self.global_step}, {_log}")
+                    win_loss.zero_()
+                    win_logits, win_labels = [], []
+            self.eval()
+            if self._stop_training:
+                break
+        logger.info(str(self.eval_metrics))
+
+    def eval(self, eval_dataset=None, test_eval=False):
+        from sklearn.metrics import log_loss, roc_auc_score
+        ev = self._split(self.eval_dataset if eval_dataset is None else eval_dataset)
+        logger.info("***** running TEST *****" if test_eval else "***** running eval *****")
+        logger.info(f"  num examples = {ev.n}")
+        if self.optimizer is not None:
+            self.optimizer.flush()
+        self.model.eval()
+        all_logits = []
+        with torch.no_grad():
+            for X, Y in ev.batches(self.args.per_gpu_eval_batch_size, False):
+                all_logits.append(self.model(input_ids=X, labels=Y)[1].view(-1))
+        preds = torch.cat(all_logits).cpu().numpy().astype("float64")
+        probs = 1.0 / (1.0 + np.exp(-preds))
+        label_ids = ev.Y.cpu().numpy()
+        auc = roc_auc_score(y_true=label_ids, y_score=probs)
+        ll = log_loss(y_true=label_ids, y_pred=probs)
+        self.eval_metrics.append([auc, ll])
+        lr = self.scheduler.get_last_lr()[0] if self.optimizer is not None else float("nan")
+        _log = {"learning_rate": lr, "eval_auc": auc, "eval_loss": ll, "avg_logits": preds.mean(),
+                "avg_probs": probs.mean()}
+        logger.info(str(_log))
+        if not test_eval:
+            if auc > self.best_eval_auc:
+                self.best_eval_auc, self.best_eval_step, self._patience = auc, self.global_step, 0
+                if self.args.local_rank in [-1, 0]:
+                    self.save_model(self.args.output_dir)
+            else:
+                self._patience += 1
+            if self._patience > self.args.patience:
+                self._stop_training = True
+        return _log
+
+    # ------------------------------------------------------------------ checkpoints (a15)
+    def save_model(self, model_dir):
+        """{global_step}.model = torch.save(state_dict): weights + buffers only, fp32, reference
+        key layout; lazy table rows are flushed first so the file holds reference-equivalent
+        weights."""
+        if self.optimizer is not None:
+            self.optimizer.flush()
+        sd = {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}
+        torch.save(sd, os.path.join(model_dir, f"{self.global_step}.model"))
+
+    def load_model(self, load_step, model_dir):
+        sd = torch.load(os.path.join(model_dir, f"{load_step}.model"), map_location="cpu")
+        with torch.no_grad():
+            own = self.model.state_dict()
+            missing = set(own) - set(sd)
+            unexpected = set(sd) - set(own)
+            if missing or unexpected:
+                raise RuntimeError(f"Error(s) in loading state_dict: missing {sorted(missing)}, "
+                                   f"unexpected {sorted(unexpected)}")
+            for k, v in sd.items():
+                own[k].copy_(v)          # in place: parameters may be views of the flat buffers
+
+    def test(self, test_dataset, load_step=-1, model_dir=None):
+        if load_step == -1:
+            load_step = self.best_eval_step
+        self.load_model(load_step, self.args.output_dir if model_dir is None else model_dir)
+        return self.eval(test_dataset, test_eval=True)

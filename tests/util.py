@@ -38,3 +38,27 @@ def assert_digest(z, prefix, name, got, rtol=2e-5, atol=1e-6):
             scale = max(scale, float(np.asarray(want.get("abssum", 1.0))) * 1e-3)
         np.testing.assert_allclose(g, w, rtol=rtol, atol=atol * scale,
                                    err_msg=f"{prefix}/{name}/{k}")
+
+
+def make_config(cfg, mode, feat_count=None, data_dir=None, seed=42):
+    """mapx Config for a fixture case (the 11 runtime keys of reference run.py:50-61 + flags)."""
+    from mapx.arguments import Config
+    return Config(model_name="DCNv2", data_dir=data_dir, input_size=cfg["V"], num_fields=cfg["F"],
+                  embed_size=cfg["E"], embed_dropout_rate=0.0, embed_norm=False, layer_norm_eps=1e-12,
+                  hidden_size=cfg["H"], num_hidden_layers=cfg["NL"], hidden_act="relu",
+                  hidden_dropout_rate=0.0, num_cross_layers=cfg["NC"], pt_neg_num=cfg["K"],
+                  proj_size=cfg["P"], pretrain=(mode != "CTR"),
+                  pt_type=("RFD" if mode == "RFD" else "MFP"), RFD_replace="Unigram",
+                  feat_count=None if feat_count is None else torch.as_tensor(feat_count),
+                  device=None, n_gpu=1, idx_low=None, idx_high=None, feat_num_per_field=None, seed=seed)
+
+
+def build_model(cfg, mode, params, feat_count, device="cuda"):
+    """DCNV2 with the fixture's reproducible parameters loaded."""
+    from mapx.models import BaseModel
+    model = BaseModel.from_config(make_config(cfg, mode, feat_count))
+    with torch.no_grad():
+        sd = model.state_dict()
+        for k, v in params.items():
+            sd[k].copy_(torch.from_numpy(v))
+    return model.to(device)
