@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Headline benchmark: DCNv2 + MFP pretraining samples/s on Avazu-shaped synthetic data
+(BASELINE.json configs[1]: F=23, V=9 449 445, E=16, H=1000x3, 3 cross layers, P=32, K=25,
+batch 4096 per GPU, fp32), one process per GPU.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = dynamic_mask (on device) -> forward -> backward -> gradient exchange (N>1) ->
+AdamW (dense groups fused; tables row-sparse with exact lazy replay) -> schedule -> zero_grad,
+over one batch already resident in HBM.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "map-code_amd"))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+
+WORKLOADS = {
+    "avazu": dict(F=23, V=9449445),
+    "criteo": dict(F=39, V=33762577),
+    "small": dict(F=23, V=200000),          # smoke-sized
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="avazu", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--rows", type=int, default=1 << 20, help="synthetic training rows resident in HBM")
+    ap.add_argument("--uniform", action="store_true", help="uniform ids inside a field instead of Zipf(1.1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=6)
+    return ap.parse_args()
+
+
+def build(args, device, rank):
+    from mapx.arguments import Config, TrainingArguments
+    from mapx.dataset import OurDataset, synth_table
+    from mapx.models import BaseModel
+    from mapx.trainer import Trainer
+    wl = WORKLOADS[args.workload]
+    F, V = wl["F"], wl["V"]
+    ids, labels, _, _ = synth_table(args.rows, F, V, seed=42, uniform=args.uniform)
+    feat_count = torch.from_numpy(np.bincount(ids.reshape(-1), minlength=V).astype(np.float32))
+    cfg = Config(model_name="DCNv2", data_dir=None, input_size=V, num_fields=F, embed_size=16,
+                 embed_dropout_rate=0.0, embed_norm=False, hidden_size=1000, num_hidden_layers=3,
+                 hidden_act="relu", hidden_dropout_rate=0.0, num_cross_layers=3, pt_neg_num=25,
+                 proj_size=32, pretrain=True, pt_type="MFP", RFD_replace="Unigram",
+                 feat_count=feat_count, seed=42, rank=rank)
+    torch.manual_seed(42)
+    model = BaseModel.from_config(cfg)
+    targs = TrainingArguments(output_dir="/tmp/mapx_bench", per_gpu_train_batch_size=args.batch,
+                              per_gpu_eval_batch_size=args.batch, learning_rate=1e-3, lr_sched="cosine",
+                              weight_decay=5e-2, num_train_epochs=3, pretrain=True, pt_type="MFP",
+                              sampling_method="randint", mask_ratio=0.3, seed=42)
+    targs._device = device
+    tr = Trainer(model, cfg, targs, OurDataset(ids, labels), OurDataset(ids[:args.batch], labels[:args.batch]))
+    return tr, cfg, ids, labels, feat_count
+
+
+def mfp_step(tr, X, Y):
+    inputs = tr.dynamic_mask({"input_ids": X, "labels": Y}, "randint")
+    loss, count, acc = tr.model(**inputs)
+    loss.backward()
+    tr._optimizer_step()
+    return loss
+
+
+def cpu_baseline(cfg, ids, labels, feat_count, batch, steps):
+    """The oracle (CPU restatement of the reference step, dense HF-AdamW over every parameter
+    as the reference does) timed on this box's host cores on `steps` batches of the same
+    synthetic stream."""
+    from oracle import ref_model as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    F, V, E, H, P, K = cfg.num_fields, cfg.input_size, cfg.embed_size, cfg.hidden_size, cfg.proj_size, cfg.pt_neg_num
+    D = F * E
+    shapes = {"embed.embedding.weight": (V, E), "feat_encoder.weight": (F * P, D + H), "feat_encoder.bias": (F * P,),
+              "mfp_criterion.emb.weight": (V, P), "mfp_criterion.bias.weight": (V, 1)}
+    for i in range(cfg.num_cross_layers):
+        shapes[f"cross_net.cross_layers.{i}.weight"] = (D, D)
+        shapes[f"cross_net.cross_layers.{i}.bias"] = (D,)
+    d_in = D
+    for i in range(cfg.num_hidden_layers):
+        shapes[f"parallel_dnn.dnn.{3 * i}.weight"] = (H, d_in)
+        shapes[f"parallel_dnn.dnn.{3 * i}.bias"] = (H,)
+        d_in = H
+    params = {k: (0.05 * torch.randn(*s, generator=g)).requires_grad_(True) for k, s in shapes.items()}
+    m = {k: torch.zeros_like(p) for k, p in params.items()}
+    v = {k: torch.zeros_like(p) for k, p in params.items()}
+    logq, _, q = R.nce_buffers(feat_count)
+    from mapx import ops
+    prob, alias = ops.alias_build(q)                      # host C++ builder (python loop = minutes)
+    L = int(F * 0.3)
+    X = torch.from_numpy(ids)
+
+    def one(step):
+        xb = X[step * batch:(step + 1) * batch]
+        mi = torch.randint(0, F, (batch, L), generator=g)
+        masked, lab = R.dynamic_mask_mfp(xb, mi)
+        kk = torch.randint(0, V, (batch, L, K), generator=g)
+        noise = R.alias_draw(prob, alias, kk, torch.rand(batch, L, K, generator=g))
+        fin = R.trunk(params, masked, cfg.num_cross_layers, cfg.num_hidden_layers)
+        loss, _, _ = R.mfp_head(params, fin, lab, mi, noise, logq, F, P, K)
+        loss.backward()
+        with torch.no_grad():
+            for k, p in params.items():
+                R.hf_adamw_step(p, p.grad, m[k], v[k], step + 1, 1e-3, wd=5e-2 if R.decays(k) else 0.0)
+                p.grad = None
+    one(0)                                               # warm-up (allocations, thread pool)
+    t0 = time.perf_counter()
+    for s in range(1, steps + 1):
+        one(s)
+    dt = time.perf_counter() - t0
+    return dict(value=batch * steps / dt, unit="samples/s", cores=cores, kind="port",
+                sample=f"{steps} steps of batch {batch} (fwd+bwd+dense AdamW over all {sum(p.numel() for p in params.values())} "
+                       f"parameters, oracle/ref_model.py, torch CPU fp32, {cores} threads), {dt:.1f} s")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible and mapx has no CPU path")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        torch.distributed.init_process_group(backend="nccl", device_id=device)
+    from mapx import ops, parallel
+    tr, cfg, ids, labels, feat_count = build(args, device, rank)
+    train = tr._begin("bench")
+    B = args.batch
+    gen = tr._generator()
+    batches = train.batches(B, True, gen, (rank, world))
+    tr.model.train()
+
+    def next_batch():
+        nonlocal batches
+        try:
+            return next(batches)
+        except StopIteration:
+            batches = train.batches(B, True, gen, (rank, world))
+            return next(batches)
+
+    for _ in range(args.warmup):
+        mfp_step(tr, *next_batch())
+    staged = [next_batch() for _ in range(args.steps)]      # inputs resident before the clock starts
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with ops.Timers() as timers:
+        for X, Y in staged:
+            loss = mfp_step(tr, X, Y)
+    parallel.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    final_loss = float(loss.detach())
+    if rank != 0:
+        return
+    ksum = timers.summary()
+    kernels = {}
+    for name, s in ksum.items():
+        per_launch = s["work"] / s["launches"]
+        rate = per_launch / (s["avg_us"] * 1e-6)
+        if name.startswith("gemm"):
+            kernels[name] = dict(bound="mfma", achieved=rate / 1e12, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                                 frac=rate / 1e12 / MFMA_F32_PEAK_TFLOPS)
+        else:
+            kernels[name] = dict(bound="hbm", achieved=rate / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                 frac=rate / 1e9 / HBM_PEAK_GBS)
+        kernels[name].update(avg_us=s["avg_us"], launches_per_step=s["launches"] / args.steps,
+                             ms_per_step=s["total_ms"] / args.steps, traffic=None)
+    dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+    roofline = dict(kernel=dominant, **{k: kernels[dominant][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")})
+    hbm_name = "nce_fwd"
+    out = {
+        "metric": "pretrain samples/sec (DCNv2+MFP, Avazu, bs4096)", "value": world * B * args.steps / dt,
+        "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"DCNv2+MFP pretrain step, {args.workload}-shaped synthetic ids "
+                               f"({'uniform' if args.uniform else 'Zipf(1.1)'} per field), F={cfg.num_fields}, "
+                               f"V={cfg.input_size}, E=16, H=1000x3, cross x3, P=32, K=25, mask_ratio 0.3",
+                   "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                   "table_optimizer": "row-sparse AdamW with exact lazy replay (max gap 256 steps)"},
+        "roofline": roofline,
+        "roofline_hbm": dict(kernel=hbm_name, **{k: kernels[hbm_name][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}),
+        "kernels": kernels, "final_loss": final_loss,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        del tr
+        torch.cuda.empty_cache()
+        out["cpu_baseline"] = cpu_baseline(cfg, ids, labels, feat_count, B, args.cpu_steps)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,50 @@ from .native import check, lib, ptr, require_gpu, stream
 
 _scratch = {}
 
+# --------------------------------------------------------------------------- live kernel timing
+# bench.py brackets kernel classes with HIP events on the launch stream (torch's current
+# stream) while the timed region runs; nothing is recorded unless a Timers object is active.
+_timers = None
+
+
+class Timers:
+    def __init__(self):
+        self.events = {}          # name -> [(start, stop, work)]
+
+    def __enter__(self):
+        global _timers
+        _timers = self
+        return self
+
+    def __exit__(self, *a):
+        global _timers
+        _timers = None
+
+    def summary(self):
+        """name -> dict(launches, total_ms, avg_us, work) after a device sync."""
+        out = {}
+        for name, evs in self.events.items():
+            ms = [a.elapsed_time(b) for a, b, _ in evs]
+            out[name] = dict(launches=len(evs), total_ms=sum(ms), avg_us=1e3 * sum(ms) / len(evs),
+                             work=sum(w for _, _, w in evs))
+        return out
+
+
+class _timed:
+    def __init__(self, name, work=0.0):
+        self.name, self.work = name, work
+
+    def __enter__(self):
+        if _timers is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *e):
+        if _timers is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            _timers.events.setdefault(self.name, []).append((self.a, b, self.work))
+
 
 def scratch(nbytes, device):
     key = (device.index, stream())
@@ -34,8 +78,9 @@ def emb_gather(ids, table, validate=False):
     ids = ids.contiguous()
     out = torch.empty(*ids.shape, table.shape[1], dtype=torch.float32, device=table.device)
     err = _err_flag(table.device) if validate else None
-    check(lib.mapx_emb_gather_fwd(ptr(ids), ids.numel(), ptr(table), table.shape[0], table.shape[1],
-                                  ptr(out), ptr(err), stream()))
+    with _timed("emb_gather", ids.numel() * (8 + 2 * 4 * table.shape[1])):
+        check(lib.mapx_emb_gather_fwd(ptr(ids), ids.numel(), ptr(table), table.shape[0], table.shape[1],
+                                      ptr(out), ptr(err), stream()))
     if validate and int(err.item()):
         raise IndexError("index out of range in self")          # reference CPU behaviour
     return out
@@ -68,9 +113,10 @@ class SegPlan:
         self.n_uniq = torch.empty(1, **i32)
         nb = lib.mapx_seg_plan_workspace_bytes(n, V)
         ws = scratch(nb, dev)
-        check(lib.mapx_seg_plan(ptr(keys_i32), n, V, ptr(ws), ws.numel(), ptr(self.sorted_keys),
-                                ptr(self.perm), ptr(self.rank), ptr(self.uniq), ptr(self.seg_start),
-                                ptr(self.n_uniq), stream()))
+        with _timed("seg_plan", n * 4.0):
+            check(lib.mapx_seg_plan(ptr(keys_i32), n, V, ptr(ws), ws.numel(), ptr(self.sorted_keys),
+                                    ptr(self.perm), ptr(self.rank), ptr(self.uniq), ptr(self.seg_start),
+                                    ptr(self.n_uniq), stream()))
 
     def count(self):
         """Number of unique keys (host sync)."""
@@ -83,8 +129,9 @@ def seg_reduce_rows(plan, src, W):
     out = torch.empty(max(plan.n, 1), W, dtype=torch.float32, device=src.device)
     nb = lib.mapx_seg_reduce_workspace_bytes(plan.n, W)
     ws = scratch(nb, src.device)
-    check(lib.mapx_seg_reduce_rows(plan.n, ptr(plan.perm), ptr(plan.rank), ptr(plan.seg_start),
-                                   ptr(src), W, ptr(out), ptr(ws), ws.numel(), stream()))
+    with _timed("seg_reduce_rows", plan.n * (4.0 * W + 8)):
+        check(lib.mapx_seg_reduce_rows(plan.n, ptr(plan.perm), ptr(plan.rank), ptr(plan.seg_start),
+                                       ptr(src), W, ptr(out), ptr(ws), ws.numel(), stream()))
     return out
 
 
@@ -142,10 +189,12 @@ def nce_fwd(enc, masked_index, idx, emb, bias, logq, F, P, want_logits=False):
                dh=torch.empty(T, P, **f32),
                logits=torch.empty(T, K1, **f32) if want_logits else None)
     ws = scratch(lib.mapx_nce_fwd_workspace_bytes(), dev)
-    check(lib.mapx_nce_fwd(ptr(enc), B, L, F, P, ptr(masked_index.contiguous()), ptr(idx), K1 - 1,
-                           ptr(emb), ptr(bias), ptr(logq), emb.shape[0], ptr(out["h"]),
-                           ptr(out["dlogit"]), ptr(out["dh"]), ptr(out["logits"]), ptr(out["loss"]),
-                           ptr(out["acc"]), ptr(ws), ws.numel(), stream()))
+    # algorithmic bytes: per (target, sample) one table row + bias + log q + id
+    with _timed("nce_fwd", T * K1 * (4.0 * P + 8 + 4)):
+        check(lib.mapx_nce_fwd(ptr(enc), B, L, F, P, ptr(masked_index.contiguous()), ptr(idx), K1 - 1,
+                               ptr(emb), ptr(bias), ptr(logq), emb.shape[0], ptr(out["h"]),
+                               ptr(out["dlogit"]), ptr(out["dh"]), ptr(out["logits"]), ptr(out["loss"]),
+                               ptr(out["acc"]), ptr(ws), ws.numel(), stream()))
     return out
 
 
@@ -165,9 +214,10 @@ def nce_table_grad(plan, dlogit, h, K, P):
     out_bias = torch.empty(max(plan.n, 1), dtype=torch.float32, device=dev)
     nb = lib.mapx_nce_table_grad_workspace_bytes(plan.n, P)
     ws = scratch(nb, dev)
-    check(lib.mapx_nce_table_grad(plan.n, ptr(plan.perm), ptr(plan.rank), ptr(plan.seg_start),
-                                  ptr(dlogit), ptr(h), K, P, ptr(out_emb), ptr(out_bias), ptr(ws),
-                                  ws.numel(), stream()))
+    with _timed("nce_table_grad", plan.n * (4.0 * P + 4)):
+        check(lib.mapx_nce_table_grad(plan.n, ptr(plan.perm), ptr(plan.rank), ptr(plan.seg_start),
+                                      ptr(dlogit), ptr(h), K, P, ptr(out_emb), ptr(out_bias), ptr(ws),
+                                      ws.numel(), stream()))
     return out_emb, out_bias
 
 
@@ -195,12 +245,14 @@ def gemm(a, b, a_kc, b_kc, M, N, K, out=None, ldc=None, epi=N.EPI_NONE, bias=Non
     ld1 = aux1.stride(0) if aux1 is not None else 0
     ld2 = aux2.stride(0) if aux2 is not None else 0
     ldo2 = out2.stride(0) if out2 is not None else 0
-    check(lib.mapx_gemm_f32(int(a_kc), int(b_kc), M, N, K, a.data_ptr(), lda, b.data_ptr(), ldb,
-                            out.data_ptr(), ldc, epi, ptr(bias),
-                            aux1.data_ptr() if aux1 is not None else None, ld1,
-                            aux2.data_ptr() if aux2 is not None else None, ld2,
-                            out2.data_ptr() if out2 is not None else None, ldo2, nsplit,
-                            ws.data_ptr() if ws is not None else None, wsn, stream()))
+    kind = "gemm_fwd_nt" if (a_kc and b_kc) else ("gemm_dx_nn" if a_kc else "gemm_dw_tn")
+    with _timed(kind, 2.0 * M * N * K):
+        check(lib.mapx_gemm_f32(int(a_kc), int(b_kc), M, N, K, a.data_ptr(), lda, b.data_ptr(), ldb,
+                                out.data_ptr(), ldc, epi, ptr(bias),
+                                aux1.data_ptr() if aux1 is not None else None, ld1,
+                                aux2.data_ptr() if aux2 is not None else None, ld2,
+                                out2.data_ptr() if out2 is not None else None, ldo2, nsplit,
+                                ws.data_ptr() if ws is not None else None, wsn, stream()))
     return out
 
 
@@ -335,8 +387,9 @@ def make_sched(lr0, lambdas, beta1, beta2):
 
 def adamw_dense(p, g, m, v, sched, done, beta1, beta2, eps, wd):
     require_gpu(p, g, m, v, sched, done)
-    check(lib.mapx_adamw_dense(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(sched), sched.shape[0],
-                               ptr(done), beta1, beta2, eps, wd, stream()))
+    with _timed("adamw_dense", p.numel() * 28.0):
+        check(lib.mapx_adamw_dense(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(sched), sched.shape[0],
+                                   ptr(done), beta1, beta2, eps, wd, stream()))
 
 
 def step_advance(done):
@@ -349,7 +402,10 @@ def table_adam(p0, m0, v0, wd0, last, sched, done, beta1, beta2, eps, p1=None, m
     W0 = p0.shape[1]
     if n_rows is None:
         n_rows = rows.numel() if rows is not None else p0.shape[0] - row_begin
-    check(lib.mapx_table_adam(ptr(p0), ptr(m0), ptr(v0), W0, wd0, ptr(p1), ptr(m1), ptr(v1), wd1,
-                              ptr(last), ptr(rows), row_begin, n_rows, ptr(n_rows_dev), ptr(grad0),
-                              ptr(grad1), ptr(sched), sched.shape[0], ptr(done), beta1, beta2, eps,
-                              stream()))
+    kind = "table_adam_update" if grad0 is not None else ("table_adam_catchup" if rows is not None
+                                                           else "table_adam_sweep")
+    with _timed(kind, float(n_rows) * (W0 + (1 if p1 is not None else 0)) * 4.0 * 7):
+        check(lib.mapx_table_adam(ptr(p0), ptr(m0), ptr(v0), W0, wd0, ptr(p1), ptr(m1), ptr(v1), wd1,
+                                  ptr(last), ptr(rows), row_begin, n_rows, ptr(n_rows_dev), ptr(grad0),
+                                  ptr(grad1), ptr(sched), sched.shape[0], ptr(done), beta1, beta2, eps,
+                                  stream()))
