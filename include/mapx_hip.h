@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 1
+#define MAPX_ABI_VERSION 3
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -123,7 +123,8 @@ int mapx_scale_inplace(float* x, int64_t n, const float* g, hipStream_t stream);
  * Epilogues: NONE; BIAS (+bias[n]); BIAS_RELU; BIAS_CROSS: u = acc + bias, out2 = u,
  * C = aux1 + aux2 * u  (CrossNetV2 layer, layers.py:200: aux1 = Xi, aux2 = X0);
  * ADD: C = acc + aux1; RELU_MASK: C = aux1 > 0 ? acc : 0 (ReLU backward).
- * nsplit > 1: deterministic split-K through `ws` (EPI_NONE, ldc == N). */
+ * nsplit > 1: deterministic split-K through `ws` (EPI_NONE, ldc == N).
+ * tile_hint: -1 = choose from the grid size; 2 / 1 / 0 = force 128x128 / 128x64 / 64x64. */
 #define MAPX_EPI_NONE 0
 #define MAPX_EPI_BIAS 1
 #define MAPX_EPI_BIAS_RELU 2
@@ -134,7 +135,8 @@ size_t mapx_gemm_splitk_workspace_bytes(int M, int N, int nsplit);
 int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, int64_t lda,
                   const float* B, int64_t ldb, float* C, int64_t ldc, int epi, const float* bias,
                   const float* aux1, int64_t ld1, const float* aux2, int64_t ld2, float* out2,
-                  int64_t ldo2, int nsplit, void* ws, size_t ws_bytes, hipStream_t stream);
+                  int64_t ldo2, int nsplit, int tile_hint, void* ws, size_t ws_bytes,
+                  hipStream_t stream);
 /* out[n] = sum_m x[m*ld + n]  (bias gradients), deterministic two-stage. */
 size_t mapx_colsum_workspace_bytes(int N);
 int mapx_colsum(const float* x, int64_t ld, int M, int N, float* out, void* ws, size_t ws_bytes,
@@ -168,8 +170,8 @@ int mapx_dynamic_mask_rfd(const int64_t* ids, int64_t B, int F, int L,
  * transformers-4.26 AdamW semantics (trainer.py:60-85).  sched [sched_len][2] f32 =
  * {lr_s*sqrt(1-b2^s)/(1-b1^s), lr_s} for update s = index+1; *done = updates applied. */
 int mapx_adamw_dense(float* p, const float* g, float* m, float* v, int64_t n, const float* sched,
-                     int sched_len, const int32_t* done, float beta1, float beta2, float eps,
-                     float weight_decay, hipStream_t stream);
+                     int sched_len, const int32_t* done, double beta1, double beta2, double eps,
+                     double weight_decay, hipStream_t stream);
 int mapx_step_advance(int32_t* done, hipStream_t stream);
 /* Lazy exact row-sparse AdamW on a table group {p0 [V,W0] (+ optional p1 [V])} sharing
  * last[V].  rows NULL: rows row_begin..row_begin+n_rows-1 (flush / sweep); else rows[i],
@@ -179,7 +181,7 @@ int mapx_table_adam(float* p0, float* m0, float* v0, int W0, float wd0, float* p
                     float* v1, float wd1, int32_t* last, const int32_t* rows, int64_t row_begin,
                     int64_t n_rows, const int32_t* n_rows_dev, const float* grad0,
                     const float* grad1, const float* sched, int sched_len, const int32_t* done,
-                    float beta1, float beta2, float eps, hipStream_t stream);
+                    double beta1, double beta2, double eps, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -13,14 +13,20 @@
 //   dX = dY W               : A_KC (dY [B,out]), B_NC (W [out,in] read as [K=out, N=in])
 //   dW = dY^T X             : A_MC (dY [B,out] read as [K=B, M=out]), B_NC (X [B,in])
 //
-// Tiling: 256 threads = 2x2 waves (one wave per SIMD); a wave owns WMT x WNT MFMA tiles of
-// 32x32; block tile (64*WMT) x (64*WNT), BK = 16.  Operands are staged in LDS as
-// [k][m|n] (+4 pad) so that the 32 lanes of an MFMA operand fetch read 32 consecutive
-// floats (conflict-free ds_read_b32) whatever the global layout; k-contiguous global tiles
-// are transposed on the way in (4 x ds_write_b32, 2-way conflict = free).  Global loads of
-// tile t+1 are issued into registers before the MFMAs of tile t and written to the other
-// LDS buffer after them: one barrier per K-step.  Block ids are remapped so that each
-// XCD (private 4 MiB L2) works on consecutive tiles of the same A row-panel.
+// Tiling: 256 threads = 2x2 waves; a wave owns WMT x WNT MFMA tiles of 32x32; block tile
+// (64*WMT) x (64*WNT), BK = 32.  Each operand keeps its GLOBAL orientation in LDS, so the
+// global->LDS path is a straight 16-byte copy (global_load_dwordx4 -> ds_write_b128, whole
+// 128-B lines per 8 lanes) for every layout:
+//   k-contiguous operand  -> LDS [row][BK+4]: a lane fetches 4 consecutive k with ONE
+//                            ds_read_b128 (row stride 36 floats = conflict-free);
+//   k-strided operand     -> LDS [k][rows+4]: a lane fetches its k values with ds_read_b32
+//                            (32 consecutive floats per half-wave = conflict-free).
+// The MFMA contracts k in a permuted order that both layouts share: within a group of 8 k
+// values, MFMA s (0..3) pairs k = 8q+s on lanes 0-31 with k = 8q+4+s on lanes 32-63.
+// Global loads of tile t+1 are issued before the MFMAs of tile t and written to the other
+// LDS buffer after them (one barrier per K-step); operand fragments of k-group q+1 are
+// fetched before the MFMAs of group q.  Block ids are remapped so that each XCD (private
+// 4 MiB L2) works on consecutive tiles of the same A row-panel.
 #include "../../include/mapx_hip.h"
 #include "common.h"
 
@@ -43,80 +49,151 @@ struct GemmArgs {
   int tiles_m, tiles_n;
 };
 
-constexpr int BK = 16;
+constexpr int BK = 32;
 
-template <int ROWS /*BM or BN*/, bool KC, bool VEC>
-struct TileLoader {
-  // ROWS*BK floats per tile, 256 threads -> ROWS/16 floats = ROWS/64 float4 per thread
-  static constexpr int NV = ROWS / 64;
+// One operand's staging: global tile -> registers -> LDS, and LDS -> MFMA fragments.
+// Branch-free loads: every lane always loads (from a clamped, valid address); what lies
+// outside the matrix is zeroed when the registers are written to LDS, so no ALU op touches
+// the loaded registers before the MFMAs of the current tile have been issued.
+// VEC requires: leading dimension % 4 == 0, 16-B aligned base, and the contiguous extent
+// (K for k-contiguous operands, M|N otherwise) % 4 == 0: a float4 is all-in or all-out.
+template <int ROWS /*BM or BN*/, int T /*32-row MFMA tiles per wave*/, bool KC, bool VEC>
+struct Operand {
+  static constexpr int LD = KC ? BK + 4 : ROWS + 4;
+  static constexpr int LDS_FLOATS = KC ? ROWS * LD : BK * LD;
+  static constexpr int NV = ROWS * BK / 4 / 256;   // float4 per thread per tile
   float4 r[NV];
+  bool ok[NV];
+  // loop-invariant per-thread state (set once by init): element offset of float4 #i inside
+  // K-step 0 with the out-of-matrix direction clamped, and whether that direction is valid.
+  unsigned off[NV];
+  bool inb[NV];
 
+  __device__ static inline void coords(int f, int& row, int& col) {
+    // (row, col) of float4 #f in the tile's storage order; col is the contiguous index
+    if (KC) { row = f >> 3; col = (f & 7) << 2; }                    // [ROWS][BK]
+    else { constexpr int PER = ROWS / 4; row = f / PER; col = (f % PER) << 2; }   // [BK][ROWS]
+  }
+
+  __device__ inline void init(int64_t ld, int row0, int nrows) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int tr, tc;
+      coords(threadIdx.x + i * 256, tr, tc);
+      if (KC) {
+        inb[i] = row0 + tr < nrows;
+        off[i] = (unsigned)((inb[i] ? row0 + tr : 0) * ld + tc);
+      } else {
+        inb[i] = row0 + tc < nrows;
+        off[i] = (unsigned)(tr * ld + (inb[i] ? row0 + tc : 0));
+      }
+    }
+  }
+
+  // Full K-step (k0 + BK <= kend): `gk` = operand base advanced to this K-step, wave-uniform
+  // (g + k0 for k-contiguous storage, g + k0*ld otherwise): no per-lane address arithmetic.
+  __device__ inline void load_full(const float* __restrict__ gk) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      ok[i] = inb[i];
+      r[i] = *reinterpret_cast<const float4*>(gk + off[i]);
+    }
+  }
+
+  // General K-step (K tail, unaligned operands): clamped addresses + per-element predicates.
   __device__ inline void load(const float* __restrict__ g, int64_t ld, int row0, int nrows,
                               int k0, int kend) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int f = threadIdx.x + i * 256;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (KC) {
-        const int m = f >> 2, kc = (f & 3) << 2;
-        const int gm = row0 + m, gk = k0 + kc;
-        if (gm < nrows) {
-          const float* p = g + (int64_t)gm * ld + gk;
-          if (VEC && gk + 4 <= kend) {
-            v = *reinterpret_cast<const float4*>(p);
-          } else {
-            if (gk + 0 < kend) v.x = p[0];
-            if (gk + 1 < kend) v.y = p[1];
-            if (gk + 2 < kend) v.z = p[2];
-            if (gk + 3 < kend) v.w = p[3];
-          }
-        }
+      int tr, tc;
+      coords(threadIdx.x + i * 256, tr, tc);
+      const int gr = (KC ? row0 : k0) + tr, gc = (KC ? k0 : row0) + tc;
+      const int rlim = KC ? nrows : kend, clim = KC ? kend : nrows;
+      const bool rok = gr < rlim;
+      const float* p = g + (int64_t)(rok ? gr : 0) * ld;
+      if (VEC) {
+        ok[i] = rok && (gc < clim);
+        r[i] = *reinterpret_cast<const float4*>(p + (ok[i] ? gc : 0));
       } else {
-        constexpr int PER_K = ROWS / 4;
-        const int kk = f / PER_K, mc = (f % PER_K) << 2;
-        const int gk = k0 + kk, gm = row0 + mc;
-        if (gk < kend) {
-          const float* p = g + (int64_t)gk * ld + gm;
-          if (VEC && gm + 4 <= nrows) {
-            v = *reinterpret_cast<const float4*>(p);
-          } else {
-            if (gm + 0 < nrows) v.x = p[0];
-            if (gm + 1 < nrows) v.y = p[1];
-            if (gm + 2 < nrows) v.z = p[2];
-            if (gm + 3 < nrows) v.w = p[3];
-          }
-        }
+        ok[i] = true;
+        const bool o0 = rok && gc + 0 < clim, o1 = rok && gc + 1 < clim;
+        const bool o2 = rok && gc + 2 < clim, o3 = rok && gc + 3 < clim;
+        const float x0 = p[o0 ? gc + 0 : 0], x1 = p[o1 ? gc + 1 : 0];
+        const float x2 = p[o2 ? gc + 2 : 0], x3 = p[o3 ? gc + 3 : 0];
+        r[i] = make_float4(o0 ? x0 : 0.f, o1 ? x1 : 0.f, o2 ? x2 : 0.f, o3 ? x3 : 0.f);
       }
-      r[i] = v;
     }
   }
 
-  __device__ inline void store(float* __restrict__ s /* [BK][ROWS+4] */) const {
-    constexpr int LD = ROWS + 4;
+  template <bool MASK>
+  __device__ inline void store(float* __restrict__ s) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int f = threadIdx.x + i * 256;
+      int tr, tc;
+      coords(threadIdx.x + i * 256, tr, tc);
+      const float4 v = (!MASK || ok[i]) ? r[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(s + tr * LD + tc) = v;
+    }
+  }
+
+  // fragments of k-group q (8 k values) for this wave's T tiles: f[t][s], s = MFMA step
+  __device__ static inline void frags(const float* __restrict__ s, int base, int l31, int kh,
+                                      int q, float (&f)[T][4]) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
       if (KC) {
-        const int m = f >> 2, kc = (f & 3) << 2;
-        s[(kc + 0) * LD + m] = r[i].x;
-        s[(kc + 1) * LD + m] = r[i].y;
-        s[(kc + 2) * LD + m] = r[i].z;
-        s[(kc + 3) * LD + m] = r[i].w;
+        const float4 v =
+            *reinterpret_cast<const float4*>(s + (base + 32 * t + l31) * LD + 8 * q + 4 * kh);
+        f[t][0] = v.x; f[t][1] = v.y; f[t][2] = v.z; f[t][3] = v.w;
       } else {
-        constexpr int PER_K = ROWS / 4;
-        const int kk = f / PER_K, mc = (f % PER_K) << 2;
-        *reinterpret_cast<float4*>(s + kk * LD + mc) = r[i];
+        const float* p = s + (8 * q + 4 * kh) * LD + base + 32 * t + l31;
+        f[t][0] = p[0]; f[t][1] = p[LD]; f[t][2] = p[2 * LD]; f[t][3] = p[3 * LD];
       }
     }
   }
 };
 
+template <int EPI>
+__device__ inline void epilogue_store(const GemmArgs& a, float* __restrict__ C, int m, int n,
+                                      float acc, float bn) {
+  float v = acc + bn;
+  if (EPI == MAPX_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+  if (EPI == MAPX_EPI_BIAS_CROSS) {
+    a.out2[(int64_t)m * a.ldo2 + n] = v;
+    v = a.aux1[(int64_t)m * a.ld1 + n] + a.aux2[(int64_t)m * a.ld2 + n] * v;
+  }
+  if (EPI == MAPX_EPI_ADD) v += a.aux1[(int64_t)m * a.ld1 + n];
+  if (EPI == MAPX_EPI_RELU_MASK) v = a.aux1[(int64_t)m * a.ld1 + n] > 0.f ? v : 0.f;
+  C[(int64_t)m * a.ldc + n] = v;
+}
+
+// C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+template <int EPI, int WMT, int WNT>
+__device__ inline void epilogue(const GemmArgs& a, float* __restrict__ C, f32x16 (&acc)[WMT][WNT],
+                                int mbase, int nbase, int l31, int kh) {
+#pragma unroll
+  for (int i = 0; i < WMT; ++i) {
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) {
+      const int n = nbase + 32 * j + l31;
+      if (n >= a.N) continue;
+      const float bn = (EPI >= MAPX_EPI_BIAS && EPI <= MAPX_EPI_BIAS_CROSS) ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mbase + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (m < a.M) epilogue_store<EPI>(a, C, m, n, acc[i][j][r], bn);
+      }
+    }
+  }
+}
+
 template <int WMT, int WNT, bool A_KC, bool B_KC, bool VEC>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs a) {
   constexpr int BM = 64 * WMT, BN = 64 * WNT;
-  constexpr int LDA_S = BM + 4, LDB_S = BN + 4;
-  __shared__ __attribute__((aligned(16))) float As[2][BK * LDA_S];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB_S];
+  using OpA = Operand<BM, WMT, A_KC, VEC>;
+  using OpB = Operand<BN, WNT, B_KC, VEC>;
+  __shared__ __attribute__((aligned(16))) float As[2][OpA::LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float Bs[2][OpB::LDS_FLOATS];
 
   // XCD-aware tile order: blocks b, b+8, ... share an XCD; give each XCD a contiguous run
   // of tiles so that the tiles of one A row-panel hit the same L2.
@@ -134,6 +211,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int l31 = lane & 31, kh = lane >> 5;
+  const int abase = wr * 32 * WMT, bbase = wc * 32 * WNT;
 
   f32x16 acc[WMT][WNT];
 #pragma unroll
@@ -143,72 +221,78 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  TileLoader<BM, A_KC, VEC> la;
-  TileLoader<BN, B_KC, VEC> lb;
+  OpA la;
+  OpB lb;
+  la.init(a.lda, m0, a.M);
+  lb.init(a.ldb, n0, a.N);
   const int nk = (kend - kbeg + BK - 1) / BK;
+  const int nk_full = VEC ? (kend - kbeg) / BK : 0;          // K-steps on the fast load path
+  // interior tiles need no zero-fill of out-of-matrix rows (block-uniform -> scalar branch)
+  const bool interior = VEC && (m0 + BM <= a.M) && (n0 + BN <= a.N);
+  const int64_t astep = A_KC ? 1 : a.lda, bstep = B_KC ? 1 : a.ldb;
+#define MAPX_LOAD_TILE(kt_)                                                         \
+  do {                                                                              \
+    const int k0_ = kbeg + (kt_) * BK;                                              \
+    if ((kt_) < nk_full) {                                                          \
+      la.load_full(a.A + (int64_t)k0_ * astep);                                     \
+      lb.load_full(a.B + (int64_t)k0_ * bstep);                                     \
+    } else {                                                                        \
+      la.load(a.A, a.lda, m0, a.M, k0_, kend);                                      \
+      lb.load(a.B, a.ldb, n0, a.N, k0_, kend);                                      \
+    }                                                                               \
+  } while (0)
+#define MAPX_STORE_TILE(kt_, buf_)                                                  \
+  do {                                                                              \
+    if (interior && (kt_) < nk_full) {                                              \
+      la.template store<false>(As[buf_]);                                           \
+      lb.template store<false>(Bs[buf_]);                                           \
+    } else {                                                                        \
+      la.template store<true>(As[buf_]);                                            \
+      lb.template store<true>(Bs[buf_]);                                            \
+    }                                                                               \
+  } while (0)
   if (nk > 0) {
-    la.load(a.A, a.lda, m0, a.M, kbeg, kend);
-    lb.load(a.B, a.ldb, n0, a.N, kbeg, kend);
-    la.store(As[0]);
-    lb.store(Bs[0]);
+    MAPX_LOAD_TILE(0);
+    MAPX_STORE_TILE(0, 0);
   }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      la.load(a.A, a.lda, m0, a.M, kbeg + (kt + 1) * BK, kend);
-      lb.load(a.B, a.ldb, n0, a.N, kbeg + (kt + 1) * BK, kend);
+    if (kt + 1 < nk) MAPX_LOAD_TILE(kt + 1);   // next tile's loads fly under this tile's MFMAs
+    float af[2][WMT][4], bf[2][WNT][4];
+    OpA::frags(As[cur], abase, l31, kh, 0, af[0]);
+    OpB::frags(Bs[cur], bbase, l31, kh, 0, bf[0]);
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q) {
+      const int c = q & 1;
+      if (q + 1 < BK / 8) {   // fragments one k-group ahead of the MFMAs that consume them
+        OpA::frags(As[cur], abase, l31, kh, q + 1, af[c ^ 1]);
+        OpB::frags(Bs[cur], bbase, l31, kh, q + 1, bf[c ^ 1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < WMT; ++i)
+#pragma unroll
+          for (int j = 0; j < WNT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i][s], bf[c][j][s], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    const float* __restrict__ as = As[cur] + wr * 32 * WMT + l31;
-    const float* __restrict__ bs = Bs[cur] + wc * 32 * WNT + l31;
-#pragma unroll
-    for (int kp = 0; kp < BK / 2; ++kp) {
-      const int k = 2 * kp + kh;
-      float av[WMT], bv[WNT];
-#pragma unroll
-      for (int i = 0; i < WMT; ++i) av[i] = as[k * LDA_S + 32 * i];
-#pragma unroll
-      for (int j = 0; j < WNT; ++j) bv[j] = bs[k * LDB_S + 32 * j];
-#pragma unroll
-      for (int i = 0; i < WMT; ++i)
-#pragma unroll
-        for (int j = 0; j < WNT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < nk) {
-      la.store(As[cur ^ 1]);
-      lb.store(Bs[cur ^ 1]);
-    }
+    if (kt + 1 < nk) MAPX_STORE_TILE(kt + 1, cur ^ 1);
     __syncthreads();
   }
+#undef MAPX_LOAD_TILE
+#undef MAPX_STORE_TILE
 
-  // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-#pragma unroll
-  for (int i = 0; i < WMT; ++i) {
-#pragma unroll
-    for (int j = 0; j < WNT; ++j) {
-      const int n = n0 + wc * 32 * WNT + 32 * j + l31;
-      if (n >= a.N) continue;
-      const float bn = (a.epi >= MAPX_EPI_BIAS && a.epi <= MAPX_EPI_BIAS_CROSS) ? a.bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wr * 32 * WMT + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (m >= a.M) continue;
-        float v = acc[i][j][r] + bn;
-        switch (a.epi) {
-          case MAPX_EPI_BIAS_RELU: v = fmaxf(v, 0.f); break;
-          case MAPX_EPI_BIAS_CROSS: {
-            a.out2[(int64_t)m * a.ldo2 + n] = v;
-            v = a.aux1[(int64_t)m * a.ld1 + n] + a.aux2[(int64_t)m * a.ld2 + n] * v;
-            break;
-          }
-          case MAPX_EPI_ADD: v += a.aux1[(int64_t)m * a.ld1 + n]; break;
-          case MAPX_EPI_RELU_MASK: v = a.aux1[(int64_t)m * a.ld1 + n] > 0.f ? v : 0.f; break;
-          default: break;
-        }
-        C[(int64_t)m * a.ldc + n] = v;
-      }
-    }
+  const int mbase = m0 + abase, nbase = n0 + bbase;
+  switch (a.epi) {
+    case MAPX_EPI_BIAS: epilogue<MAPX_EPI_BIAS>(a, C, acc, mbase, nbase, l31, kh); break;
+    case MAPX_EPI_BIAS_RELU: epilogue<MAPX_EPI_BIAS_RELU>(a, C, acc, mbase, nbase, l31, kh); break;
+    case MAPX_EPI_BIAS_CROSS: epilogue<MAPX_EPI_BIAS_CROSS>(a, C, acc, mbase, nbase, l31, kh); break;
+    case MAPX_EPI_ADD: epilogue<MAPX_EPI_ADD>(a, C, acc, mbase, nbase, l31, kh); break;
+    case MAPX_EPI_RELU_MASK: epilogue<MAPX_EPI_RELU_MASK>(a, C, acc, mbase, nbase, l31, kh); break;
+    default: epilogue<MAPX_EPI_NONE>(a, C, acc, mbase, nbase, l31, kh); break;
   }
 }
 
@@ -307,8 +391,8 @@ extern "C" size_t mapx_gemm_splitk_workspace_bytes(int M, int N, int nsplit) {
 extern "C" int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, int64_t lda,
                              const float* B, int64_t ldb, float* C, int64_t ldc, int epi,
                              const float* bias, const float* aux1, int64_t ld1, const float* aux2,
-                             int64_t ld2, float* out2, int64_t ldo2, int nsplit, void* ws,
-                             size_t ws_bytes, hipStream_t stream) {
+                             int64_t ld2, float* out2, int64_t ldo2, int nsplit, int tile_hint,
+                             void* ws, size_t ws_bytes, hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm_f32: negative size");
   if (M == 0 || N == 0) return MAPX_OK;
@@ -339,12 +423,17 @@ extern "C" int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
     g.ldc = N;
     g.slab_stride = (int64_t)M * N;
   }
+  // float4 loads need every float4 to be wholly inside or outside the matrix
   const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && ((uintptr_t)A % 16 == 0) &&
-                   ((uintptr_t)B % 16 == 0) && (g.k_chunk % 4 == 0);
-  // tile choice: biggest tile that still gives every CU a block
+                   ((uintptr_t)B % 16 == 0) && (g.k_chunk % 4 == 0) &&
+                   (a_kc ? (K % 4 == 0) : (M % 4 == 0)) && (b_kc ? (K % 4 == 0) : (N % 4 == 0));
+  // tile choice (measured on MI355X, tools/gemm_bench.py): 128x128 tiles only when they fill
+  // the 256 CUs evenly; otherwise 64x64 tiles (4 blocks per CU hide the per-tile
+  // prologue/epilogue).  128x64 never won by more than 2 %.
   auto blocks = [&](int bm, int bn) { return ceil_div(M, bm) * ceil_div(N, bn) * nsplit; };
-  int tile = 2;
-  if (blocks(128, 128) < 224) tile = blocks(128, 64) >= 224 ? 1 : 0;
+  const int64_t big = blocks(128, 128);
+  int tile = (big >= 240 && (big % 256 == 0 || big % 256 >= 224 || big >= 1024)) ? 2 : 0;
+  if (tile_hint >= 0 && tile_hint <= 2) tile = tile_hint;   // 2: 128x128, 1: 128x64, 0: 64x64
   if (a_kc && b_kc) launch_layout<true, true>(g, vec, tile, nsplit, stream);
   else if (a_kc) launch_layout<true, false>(g, vec, tile, nsplit, stream);
   else launch_layout<false, false>(g, vec, tile, nsplit, stream);

@@ -161,11 +161,13 @@ __global__ void __launch_bounds__(256) table_adam_kernel(TableGroup tg, const in
   }
 }
 
-static AdamHyper make_hyper(float b1, float b2, float eps) {
+// betas arrive as doubles: the reference computes (1 - beta) in Python double precision and
+// only then rounds to fp32 (1 - 0.999 != 1 - float(0.999) at the 1e-5 level).
+static AdamHyper make_hyper(double b1, double b2, double eps) {
   AdamHyper h;
-  h.beta1 = b1; h.beta2 = b2; h.eps = eps;
-  h.one_m_b1 = (float)(1.0 - (double)b1);
-  h.one_m_b2 = (float)(1.0 - (double)b2);
+  h.beta1 = (float)b1; h.beta2 = (float)b2; h.eps = (float)eps;
+  h.one_m_b1 = (float)(1.0 - b1);
+  h.one_m_b2 = (float)(1.0 - b2);
   return h;
 }
 
@@ -173,7 +175,7 @@ static AdamHyper make_hyper(float b1, float b2, float eps) {
 
 extern "C" int mapx_adamw_dense(float* p, const float* g, float* m, float* v, int64_t n,
                                 const float* sched, int sched_len, const int32_t* done,
-                                float beta1, float beta2, float eps, float weight_decay,
+                                double beta1, double beta2, double eps, double weight_decay,
                                 hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(p && g && m && v && sched && done && n >= 0 && sched_len > 0, "adamw_dense: bad arguments");
@@ -183,7 +185,7 @@ extern "C" int mapx_adamw_dense(float* p, const float* g, float* m, float* v, in
   if (n == 0) return MAPX_OK;
   hipLaunchKernelGGL(adamw_dense_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, stream, p, g, m,
                      v, n, reinterpret_cast<const float2*>(sched), sched_len, done,
-                     make_hyper(beta1, beta2, eps), weight_decay);
+                     make_hyper(beta1, beta2, eps), (float)weight_decay);
   return check_launch("adamw_dense");
 }
 
@@ -197,8 +199,8 @@ extern "C" int mapx_table_adam(float* p0, float* m0, float* v0, int W0, float wd
                                float* m1, float* v1, float wd1, int32_t* last,
                                const int32_t* rows, int64_t row_begin, int64_t n_rows,
                                const int32_t* n_rows_dev, const float* grad0, const float* grad1,
-                               const float* sched, int sched_len, const int32_t* done, float beta1,
-                               float beta2, float eps, hipStream_t stream) {
+                               const float* sched, int sched_len, const int32_t* done, double beta1,
+                               double beta2, double eps, hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(p0 && m0 && v0 && last && sched && done, "table_adam: null pointer");
   MAPX_REQUIRE(W0 > 0 && W0 % 4 == 0, "table_adam: row width %d must be a multiple of 4", W0);

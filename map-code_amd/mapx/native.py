@@ -11,10 +11,11 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmapx_hip.so")
 
-MAPX_ABI_VERSION = 1
+MAPX_ABI_VERSION = 3
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_CROSS, EPI_ADD, EPI_RELU_MASK = range(6)
 
-_p, _i, _i64, _u64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
+_p, _i, _i64, _u64, _f, _d, _sz = (C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double,
+                                   C.c_size_t)
 
 # name -> (restype, argtypes); mirrors include/mapx_hip.h one-to-one
 SIGNATURES = {
@@ -39,7 +40,7 @@ SIGNATURES = {
     "mapx_scale_inplace": (_i, [_p, _i64, _p, _p]),
     "mapx_gemm_splitk_workspace_bytes": (_sz, [_i, _i, _i]),
     "mapx_gemm_f32": (_i, [_i, _i, _i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _i, _p, _p, _i64, _p,
-                           _i64, _p, _i64, _i, _p, _sz, _p]),
+                           _i64, _p, _i64, _i, _i, _p, _sz, _p]),
     "mapx_colsum_workspace_bytes": (_sz, [_i]),
     "mapx_colsum": (_i, [_p, _i64, _i, _i, _p, _p, _sz, _p]),
     "mapx_cross_bwd_pre": (_i, [_p, _p, _p, _i64, _p, _p, _i, _p]),
@@ -48,10 +49,10 @@ SIGNATURES = {
     "mapx_bce_with_logits": (_i, [_p, _p, _i64, _p, _p, _p, _sz, _p]),
     "mapx_dynamic_mask_mfp": (_i, [_p, _i64, _i, _i, _p, _u64, _u64, _p, _p, _p, _p]),
     "mapx_dynamic_mask_rfd": (_i, [_p, _i64, _i, _i, _p, _p, _p, _i64, _u64, _u64, _p, _p, _p, _p]),
-    "mapx_adamw_dense": (_i, [_p, _p, _p, _p, _i64, _p, _i, _p, _f, _f, _f, _f, _p]),
+    "mapx_adamw_dense": (_i, [_p, _p, _p, _p, _i64, _p, _i, _p, _d, _d, _d, _d, _p]),
     "mapx_step_advance": (_i, [_p, _p]),
     "mapx_table_adam": (_i, [_p, _p, _p, _i, _f, _p, _p, _p, _f, _p, _p, _i64, _i64, _p, _p, _p, _p,
-                             _i, _p, _f, _f, _f, _p]),
+                             _i, _p, _d, _d, _d, _p]),
 }
 
 

@@ -228,7 +228,7 @@ def scale_(x, g):
 
 # --------------------------------------------------------------------------- dense
 def gemm(a, b, a_kc, b_kc, M, N, K, out=None, ldc=None, epi=N.EPI_NONE, bias=None, aux1=None,
-         aux2=None, out2=None, nsplit=1, lda=None, ldb=None):
+         aux2=None, out2=None, nsplit=1, lda=None, ldb=None, tile=-1):
     """C[M,N] = epi(sum_k A(m,k) B(k,n)); see include/mapx_hip.h: mapx_gemm_f32."""
     require_gpu(a, b)
     dev = a.device
@@ -251,7 +251,7 @@ def gemm(a, b, a_kc, b_kc, M, N, K, out=None, ldc=None, epi=N.EPI_NONE, bias=Non
                                 out.data_ptr(), ldc, epi, ptr(bias),
                                 aux1.data_ptr() if aux1 is not None else None, ld1,
                                 aux2.data_ptr() if aux2 is not None else None, ld2,
-                                out2.data_ptr() if out2 is not None else None, ldo2, nsplit,
+                                out2.data_ptr() if out2 is not None else None, ldo2, nsplit, tile,
                                 ws.data_ptr() if ws is not None else None, wsn, stream()))
     return out
 
@@ -277,11 +277,15 @@ def linear_bwd_input(dy, w, out=None, add=None, relu_of=None):
 
 
 def _splits_for(M, Nn, Kred):
-    """split-K factor for weight-gradient GEMMs (output [M,Nn] small, reduction Kred long)."""
-    blocks = math.ceil(M / 64) * math.ceil(Nn / 64)
-    if blocks >= 192 or Kred < 1024:
-        return 1
-    return max(1, min(16, 256 // max(blocks, 1), Kred // 256))
+    """split-K factor for weight-gradient GEMMs (output [M,Nn] small, reduction Kred = batch
+    long): aim at ~1024 blocks of 64x64 (4 per CU), power of two, K chunk >= 256
+    (tools/gemm_bench.py sweep on MI355X)."""
+    tiles = math.ceil(M / 64) * math.ceil(Nn / 64)
+    want = max(1.0, 1024.0 / tiles)
+    ns = 1
+    while ns * 2 <= want + 1e-9 and ns < 16 and Kred // (ns * 2) >= 256:
+        ns *= 2
+    return ns
 
 
 def linear_bwd_weight(dy, x, out=None):
