@@ -1,0 +1,100 @@
+"""Data-parallel gradient exchange (mapx/parallel.py) on 2 gloo ranks, CPU only: the wire
+logic (counts, padding, all-gather, mean) with an injected torch merge — the product merge
+is the HIP reduce-by-key, exercised on the GPU box by tests/test_dp_gpu.py."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class _Plan:
+    def __init__(self, uniq, cap):
+        self.n = cap
+        self.uniq = torch.zeros(cap, dtype=torch.int32)
+        self.uniq[:uniq.numel()] = uniq.to(torch.int32)
+        self.n_uniq = torch.tensor([uniq.numel()], dtype=torch.int32)
+
+    def count(self):
+        return int(self.n_uniq)
+
+
+class _Table:
+    def __init__(self, V, W, with_bias):
+        self.num_rows, self.sparse_grad = V, None
+        self.W, self.with_bias = W, with_bias
+
+
+def _torch_merge(keys, rows, num_rows):
+    """Test-side stand-in for parallel.hip_merge (sort + reduce-by-key)."""
+    uniq, inv = torch.unique(keys.long(), return_inverse=True)
+    out = torch.zeros(keys.numel(), rows.shape[1]).index_add_(0, inv, rows)
+    return _Plan(uniq, keys.numel()), out
+
+
+def _local_grad(rank, V, W, with_bias):
+    g = torch.Generator().manual_seed(100 + rank)
+    n = 5 + 3 * rank                                   # ranks hold different counts
+    uniq = torch.randperm(V, generator=g)[:n].sort().values
+    r0 = torch.randn(n + 4, W, generator=g)            # capacity > count: tail is garbage
+    r1 = torch.randn(n + 4, generator=g) if with_bias else None
+    return uniq, n, r0, r1
+
+
+def _worker(rank, world, port, V, W, with_bias, out):
+    sys.path.insert(0, os.path.join(ROOT, "map-code_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mapx import parallel
+    uniq, n, r0, r1 = _local_grad(rank, V, W, with_bias)
+    table = _Table(V, W, with_bias)
+    table.sparse_grad = (_Plan(uniq, n + 4), r0, r1)
+    parallel.sync_table_grad(table, merge_fn=_torch_merge)
+    plan, m0, m1 = table.sparse_grad
+    U = plan.count()
+    dense0 = torch.zeros(V, W).index_add_(0, plan.uniq[:U].long(), m0[:U])
+    dense1 = torch.zeros(V).index_add_(0, plan.uniq[:U].long(), m1[:U]) if with_bias else torch.zeros(V)
+    flat = torch.full((10,), float(rank + 1))
+    parallel.allreduce_mean_(flat)
+    torch.save((dense0, dense1, flat), f"{out}.{rank}")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("W,with_bias", [(16, False), (32, True)])
+def test_sparse_gradient_exchange_two_ranks(tmp_path, W, with_bias):
+    V, world = 50, 2
+    out = str(tmp_path / "res")
+    mp.spawn(_worker, args=(world, _free_port(), V, W, with_bias, out), nprocs=world, join=True)
+    exp0, exp1 = torch.zeros(V, W), torch.zeros(V)
+    for r in range(world):
+        uniq, n, r0, r1 = _local_grad(r, V, W, with_bias)
+        exp0.index_add_(0, uniq, r0[:n])
+        if with_bias:
+            exp1.index_add_(0, uniq, r1[:n])
+    exp0 /= world
+    exp1 /= world
+    for r in range(world):
+        d0, d1, flat = torch.load(f"{out}.{r}")
+        assert torch.allclose(d0, exp0, atol=1e-6), "every rank must hold the same merged mean"
+        assert torch.allclose(d1, exp1, atol=1e-6)
+        assert torch.allclose(flat, torch.full((10,), 1.5))
+
+
+def test_single_process_is_a_no_op():
+    sys.path.insert(0, os.path.join(ROOT, "map-code_amd"))
+    from mapx import parallel
+    assert parallel.world() == 1 and parallel.rank() == 0
+    t = torch.ones(3)
+    assert parallel.allreduce_mean_(t) is t
+    parallel.barrier()

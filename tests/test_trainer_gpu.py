@@ -1,0 +1,213 @@
+"""Step-loop parity on the GPU: several optimizer steps of mapx (HIP kernels, row-sparse lazy
+AdamW) against the oracle running the reference's semantics (dense gradients, dense
+transformers-4.26 AdamW over EVERY parameter every step), on identical injected masks and
+negatives; run.py end to end; checkpoint layout; 2-rank data parallelism on one GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import paramgen as pg
+from util import build_model, load_case, t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _targs(**kw):
+    from mapx.arguments import TrainingArguments
+    base = dict(output_dir="/tmp/mapx_test", learning_rate=1e-3, weight_decay=5e-2, lr_sched="cosine",
+                warmup_ratio=0.0, mask_ratio=0.3, sampling_method="randint", pt_type="MFP", pretrain=True)
+    base.update(kw)
+    return TrainingArguments(**base)
+
+
+def _step_inputs(case, cfg, step):
+    """Per-step reproducible batch: rows permuted, fresh masks / negatives / replacements."""
+    inp = pg.make_inputs(case, cfg)
+    r = np.random.default_rng(1000 + step)
+    B, F, K, V = cfg["B"], cfg["F"], cfg["K"], cfg["V"]
+    L = int(F * cfg["mask_ratio"])
+    ids = inp["input_ids"][r.permutation(B)]
+    lo, hi = pg.field_ranges(F, V)
+    ids = np.where(r.random((B, F)) < 0.3, lo[None, :] + r.integers(0, 1 << 30, (B, F)) % (hi - lo)[None, :], ids)
+    return dict(ids=ids.astype(np.int64), mi=r.integers(0, F, (B, L)).astype(np.int64),
+                noise=r.integers(0, V, (B, L, K)).astype(np.int64),
+                repl=ids[r.integers(0, B, (B, L)), r.integers(0, F, (B, L))].astype(np.int64),
+                y=(r.random(B) < 0.3).astype(np.int64), feat_count=inp["feat_count"])
+
+
+def _oracle_loop(mode, cfg, params, steps, case, total, warmup, kind, lr0, wd):
+    from oracle import ref_model as R
+    P = {k: t(v).clone().requires_grad_(True) for k, v in params.items()}
+    m = {k: torch.zeros_like(p) for k, p in P.items()}
+    v = {k: torch.zeros_like(p) for k, p in P.items()}
+    losses = []
+    for s in range(steps):
+        si = _step_inputs(case, cfg, s)
+        ids = t(si["ids"])
+        if mode == "MFP":
+            logq, _, _ = R.nce_buffers(si["feat_count"])
+            masked, labels = R.dynamic_mask_mfp(ids, t(si["mi"]))
+            fin = R.trunk(P, masked, cfg["NC"], cfg["NL"])
+            loss, _, _ = R.mfp_head(P, fin, labels, t(si["mi"]), t(si["noise"]), logq, cfg["F"], cfg["P"], cfg["K"])
+        elif mode == "RFD":
+            rep, labels = R.dynamic_mask_rfd(ids, t(si["mi"]), t(si["repl"]))
+            loss = R.rfd_head(P, R.trunk(P, rep, cfg["NC"], cfg["NL"]), labels)[0]
+        else:
+            loss = R.ctr_head(P, R.trunk(P, ids, cfg["NC"], cfg["NL"]), t(si["y"]))[0]
+        loss.backward()
+        losses.append(float(loss.detach()))
+        lr = lr0 * R.lr_lambda(kind, s, total, warmup)
+        with torch.no_grad():
+            for k, p in P.items():      # the reference: dense grads, every parameter, every step
+                R.hf_adamw_step(p, p.grad, m[k], v[k], s + 1, lr, wd=wd if R.decays(k) else 0.0)
+                p.grad = None
+    return losses, {k: p.detach() for k, p in P.items()}
+
+
+@pytest.mark.parametrize("mode,kind,warm", [("MFP", "cosine", 0.2), ("RFD", "cosine", 0.0), ("CTR", "const", 0.0)])
+def test_training_trajectory_matches_reference_semantics(mode, kind, warm):
+    from mapx import ops
+    from mapx.optim import MapxOptimizer
+    case = "B_f25_b64"
+    cfg = pg.CASES[case]
+    _, _, inp, params = load_case(case, mode)
+    steps, total = 8, 10
+    warmup = int(total * warm)
+    lr0, wd = 1e-3, 5e-2
+    ref_losses, ref_params = _oracle_loop(mode, cfg, params, steps, case, total, warmup, kind, lr0, wd)
+
+    model = build_model(cfg, mode, params, inp["feat_count"] if mode == "MFP" else None)
+    targs = _targs(lr_sched=kind, learning_rate=lr0, weight_decay=wd)
+    opt = MapxOptimizer(model, targs, num_training_steps=total, num_warmup_steps=warmup, max_gap=3)
+    model.train()
+    L = int(cfg["F"] * cfg["mask_ratio"])
+    losses = []
+    for s in range(steps):
+        si = _step_inputs(case, cfg, s)
+        ids = t(si["ids"], DEV)
+        if mode == "MFP":
+            masked, labels, mi = ops.dynamic_mask_mfp(ids, L, masked_index=t(si["mi"], DEV))
+            loss = model(input_ids=masked, labels=labels, masked_index=mi, noise_samples=t(si["noise"], DEV))[0]
+        elif mode == "RFD":
+            rep, labels, _ = ops.dynamic_mask_rfd(ids, L, masked_index=t(si["mi"], DEV), replace_feat=t(si["repl"], DEV))
+            loss = model(input_ids=rep, labels=labels)[0]
+        else:
+            loss = model(input_ids=ids, labels=t(si["y"], DEV))[0]
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+        assert opt.get_last_lr()[0] == pytest.approx(lr0 * __import__("mapx.optim", fromlist=["x"]).lr_lambda(kind, s + 1, total, warmup))
+    np.testing.assert_allclose(losses, ref_losses, rtol=2e-5)
+    opt.flush()                       # lazy rows -> reference-equivalent weights
+    sd = model.state_dict()
+    for k, ref in ref_params.items():
+        got = sd[k].cpu()
+        # 8 AdamW steps move parameters by ~8e-3; fp32 parity of the whole trajectory
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
+
+
+def test_untouched_rows_still_decay_like_the_reference():
+    """A row that never receives a gradient must end where dense AdamW puts it: p * prod(1 - lr_s*wd)."""
+    from mapx.optim import MapxOptimizer, lr_lambda
+    case = "A_f23_b7"
+    cfg = pg.CASES[case]
+    _, _, inp, params = load_case(case, "CTR")
+    model = build_model(cfg, "CTR", params, None)
+    opt = MapxOptimizer(model, _targs(lr_sched="cosine"), num_training_steps=6, num_warmup_steps=0, max_gap=1000)
+    ids = t(inp["input_ids"], DEV)
+    untouched = sorted(set(range(100, cfg["V"])) - set(inp["input_ids"].reshape(-1).tolist()))[:50]   # beyond the 5 swept rows
+    w0 = model.embed.embedding.weight.detach().cpu()[untouched].double()
+    model.train()
+    for _ in range(5):
+        model(input_ids=ids, labels=t(inp["y"], DEV))[0].backward()
+        opt.step()
+    stale = model.embed.embedding.weight.detach().cpu()[untouched].double()
+    assert torch.equal(stale, w0)                       # lazy: not yet applied ...
+    opt.flush()
+    w = model.embed.embedding.weight.detach().cpu()[untouched].double()
+    factor = np.prod([1 - 1e-3 * lr_lambda("cosine", s, 6, 0) * 5e-2 for s in range(5)])
+    np.testing.assert_allclose(w.numpy(), (w0 * factor).numpy(), rtol=1e-6)   # ... until flushed
+
+
+def test_dynamic_mask_normal_mode_has_distinct_fields():
+    from mapx.dataset import OurDataset
+    from mapx.trainer import Trainer
+    case = "A_f23_b7"
+    cfg = pg.CASES[case]
+    _, _, inp, params = load_case(case, "MFP")
+    model = build_model(cfg, "MFP", params, inp["feat_count"])
+    targs = _targs()
+    targs._device = torch.device(DEV)
+    ds = OurDataset(inp["input_ids"], inp["y"])
+    tr = Trainer(model, model.config, targs, ds, ds)
+    out = tr.dynamic_mask({"input_ids": t(inp["input_ids"], DEV), "labels": None}, "normal")
+    mi = out["masked_index"].cpu()
+    assert all(len(set(r.tolist())) == mi.shape[1] for r in mi)
+    with pytest.raises(NotImplementedError):
+        tr.dynamic_mask({"input_ids": t(inp["input_ids"], DEV)}, "bogus")
+
+
+def _run_py(args, cwd):
+    cmd = [sys.executable, os.path.join(ROOT, "map-code_amd", "run.py")] + args
+    return subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, timeout=600)
+
+
+def test_run_py_pretrain_then_finetune(tmp_path):
+    """The four run scripts' flow on a small synthetic dataset in the reference's on-disk layout."""
+    from mapx.dataset import write_synth_dataset
+    data = write_synth_dataset(str(tmp_path / "data" / "avazu"), num_rows=6000, num_fields=23, vocab=3000)
+    common = ["--dataset_name=avazu", f"--data_dir={data}", "--per_gpu_train_batch_size=512",
+              "--per_gpu_eval_batch_size=512", "--learning_rate=1e-3", "--model_name=DCNv2", "--embed_size=16",
+              "--hidden_size=64", "--num_hidden_layers=3", "--num_cross_layers=3", "--hidden_dropout_rate=0.0",
+              "--logging_steps=5"]
+    for pt in ("MFP", "RFD"):
+        out = str(tmp_path / "out" / pt)
+        r = _run_py(["--pretrain=True", f"--output_dir={out}", "--num_train_epochs=2", "--lr_sched=cosine",
+                     "--weight_decay=5e-2", f"--pt_type={pt}", "--sampling_method=randint", "--mask_ratio=0.3",
+                     "--pt_neg_num=25", "--proj_size=32"] + common, str(tmp_path))
+        assert r.returncode == 0, r.stderr[-3000:]
+        steps = 2 * ((4800 + 511) // 512)
+        ckpt = os.path.join(out, f"{steps}.model")
+        assert os.path.exists(ckpt) and os.path.exists(os.path.join(out, "results.log"))
+        sd = torch.load(ckpt)
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_manifest.json")))[f"A_f23_b7_{pt}"]
+        assert set(sd) == set(gold) and all(v.dtype in (torch.float32, torch.int64) for v in sd.values())
+        log = open(os.path.join(out, "train.log")).read()
+        assert "window_" in log and "eval_" in log
+    r2 = _run_py(["--pretrain=True", f"--output_dir={tmp_path / 'out' / 'MFP'}", "--pt_type=MFP"] + common, str(tmp_path))
+    assert r2.returncode == 0 and "job already finished" in r2.stdout
+    fo = str(tmp_path / "out" / "finetune")
+    r3 = _run_py(["--finetune", f"--pretrained_model_path={tmp_path / 'out' / 'MFP' / f'{steps}.model'}",
+                  f"--output_dir={fo}", "--num_train_epochs=1", "--lr_sched=const", "--weight_decay=1e-1"] + common,
+                 str(tmp_path))
+    assert r3.returncode == 0, r3.stderr[-3000:]
+    log = open(os.path.join(fo, "results.log")).read()
+    assert "Load tensor: embed.embedding.weight" in log and "Unmatched tensor in the target model: feat_encoder.weight" in log
+    assert "eval_auc" in log and "running TEST" in log
+    assert any(f.endswith(".model") for f in os.listdir(fo))
+
+
+def test_data_parallel_two_ranks_equal_single_process(tmp_path):
+    """2 ranks (gloo rendezvous, both on this GPU), each with half of the batch, must produce the
+    same parameters as one process with the whole batch."""
+    worker = os.path.join(ROOT, "tests", "dp_worker.py")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "map-code_amd"),
+                                                        os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]))
+    one = subprocess.run([sys.executable, worker, str(tmp_path / "single.pt")], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", worker, str(tmp_path / "dp.pt")],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-3000:]
+    a, b0, b1 = (torch.load(str(tmp_path / n)) for n in ("single.pt", "dp.pt.0", "dp.pt.1"))
+    for k in a:
+        assert torch.equal(b0[k], b1[k]), f"replicas diverged on {k}"
+        np.testing.assert_allclose(b0[k].numpy(), a[k].numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
