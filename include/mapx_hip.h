@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 3
+#define MAPX_ABI_VERSION 4
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -176,12 +176,15 @@ int mapx_step_advance(int32_t* done, hipStream_t stream);
 /* Lazy exact row-sparse AdamW on a table group {p0 [V,W0] (+ optional p1 [V])} sharing
  * last[V].  rows NULL: rows row_begin..row_begin+n_rows-1 (flush / sweep); else rows[i],
  * i < *n_rows_dev (or n_rows if NULL).  grad0 NULL: catch-up to *done only; else catch-up
- * then update *done+1 with grad0 [*, W0] (grad1 [*]) and last = *done+1. */
+ * then update *done+1 with grad0 [*, W0] (grad1 [*]) and last = *done+1.
+ * aux [3][aux_len] f64 (device): prefix products prod_{i<s}(1 - lr_i*wd), beta1^n, beta2^n —
+ * the closed-form tail of a replay once the Adam term can no longer move p (csrc/optim.hip). */
 int mapx_table_adam(float* p0, float* m0, float* v0, int W0, float wd0, float* p1, float* m1,
                     float* v1, float wd1, int32_t* last, const int32_t* rows, int64_t row_begin,
                     int64_t n_rows, const int32_t* n_rows_dev, const float* grad0,
                     const float* grad1, const float* sched, int sched_len, const int32_t* done,
-                    double beta1, double beta2, double eps, hipStream_t stream);
+                    const double* aux, int aux_len, double beta1, double beta2, double eps,
+                    hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,11 @@
 // zero-gradient updates IN REGISTERS, with the same fp32 operations in the same order,
 // when the row is next needed (catch-up before the forward gather; again, as a no-op,
 // inside the gradient update) or when the table is flushed (checkpoint / eval).
+// A replay runs step by step only while the Adam term can still move p (|term| >= 2^-26 |p|,
+// about 150 steps after the row's last gradient); the remaining steps are pure geometric
+// decay (m *= b1, v *= b2, p *= 1 - lr_s*wd) and are applied in closed form from prefix
+// tables accumulated in fp64 (`aux`): p * prod(1 - lr_s*wd), m * b1^n, v * b2^n.  That last
+// part differs from the reference's n successive fp32 roundings by <= n * 2^-24 relative.
 #include "../../include/mapx_hip.h"
 #include "common.h"
 
@@ -37,13 +42,41 @@ __device__ inline void adam_elem(float& p, float& m, float& v, float g, float st
   if (decay != 0.f) p = p + (-decay) * p;
 }
 
-__device__ inline void adam_elem_zero_grad(float& p, float& m, float& v, float step, float decay,
+// Zero-gradient update (the replayed steps of the lazy tables).  The Adam term uses the
+// hardware sqrt / reciprocal (1 ulp each) instead of the correctly-rounded sequences: the
+// term is <= lr in magnitude, so the deviation from the reference's arithmetic is <= ~1e-7*lr
+// per replayed step, far inside the fp32 parity budget, at a third of the instruction count.
+// Returns true when the Adam term was too small to change p (|term| < 2^-26 |p|: the fp32
+// add is then a no-op, and stays one for all later zero-gradient steps because m shrinks by
+// beta1 per step while sqrt(v) shrinks only by sqrt(beta2)).
+__device__ inline bool adam_elem_zero_grad(float& p, float& m, float& v, float step, float decay,
                                            const AdamHyper& h) {
   m = m * h.beta1;
   v = v * h.beta2;
-  const float denom = sqrtf(v) + h.eps;
-  p = p + ((-step) * m) / denom;
+  const float denom = __builtin_amdgcn_sqrtf(v) + h.eps;
+  const float term = ((-step) * m) * __builtin_amdgcn_rcpf(denom);
+  const bool dead = fabsf(term) < 1.4901161e-8f * fabsf(p);
+  p = p + term;
   if (decay != 0.f) p = p + (-decay) * p;
+  return dead;
+}
+
+// Prefix tables for the closed-form tail of a replay (host fp64):
+//   aux[0*len + s] = prod_{i<s} (1 - lr_i * wd)   (wd = the optimizer's weight decay)
+//   aux[1*len + n] = beta1^n,  aux[2*len + n] = beta2^n
+struct ReplayAux {
+  const double* t;
+  int len;
+};
+
+__device__ inline void closed_form_tail(int s, int to, const ReplayAux& ax, bool decayed,
+                                        float& fp, float& fm, float& fv) {
+  const int n = to - s;
+  const int a = s < ax.len ? s : ax.len - 1, b = to < ax.len ? to : ax.len - 1;
+  const int nn = n < ax.len ? n : ax.len - 1;
+  fp = decayed ? (float)(ax.t[b] / ax.t[a]) : 1.f;
+  fm = (float)ax.t[ax.len + nn];
+  fv = (float)ax.t[2 * ax.len + nn];
 }
 
 __global__ void __launch_bounds__(256) adamw_dense_kernel(float* __restrict__ p,
@@ -89,14 +122,23 @@ struct TableGroup {
 // Replay zero-gradient updates (from+1 .. to) on one float4 of a row.
 __device__ inline void replay4(float4& p, float4& m, float4& v, int from, int to,
                                const float2* __restrict__ sched, int sched_len, float wd,
-                               const AdamHyper& h) {
-  for (int s = from; s < to; ++s) {  // update s+1 uses sched[s]
+                               const AdamHyper& h, const ReplayAux& ax) {
+  int s = from;
+  for (; s < to; ++s) {  // update s+1 uses sched[s]
     const float2 sc = sched[s < sched_len ? s : sched_len - 1];
     const float decay = sc.y * wd;
-    adam_elem_zero_grad(p.x, m.x, v.x, sc.x, decay, h);
-    adam_elem_zero_grad(p.y, m.y, v.y, sc.x, decay, h);
-    adam_elem_zero_grad(p.z, m.z, v.z, sc.x, decay, h);
-    adam_elem_zero_grad(p.w, m.w, v.w, sc.x, decay, h);
+    bool dead = adam_elem_zero_grad(p.x, m.x, v.x, sc.x, decay, h);
+    dead &= adam_elem_zero_grad(p.y, m.y, v.y, sc.x, decay, h);
+    dead &= adam_elem_zero_grad(p.z, m.z, v.z, sc.x, decay, h);
+    dead &= adam_elem_zero_grad(p.w, m.w, v.w, sc.x, decay, h);
+    if (dead) { ++s; break; }
+  }
+  if (s < to) {
+    float fp, fm, fv;
+    closed_form_tail(s, to, ax, wd != 0.f, fp, fm, fv);
+    p.x *= fp; p.y *= fp; p.z *= fp; p.w *= fp;
+    m.x *= fm; m.y *= fm; m.z *= fm; m.w *= fm;
+    v.x *= fv; v.y *= fv; v.z *= fv; v.w *= fv;
   }
 }
 
@@ -113,7 +155,7 @@ __global__ void __launch_bounds__(256) table_adam_kernel(TableGroup tg, const in
                                                          const float* __restrict__ grad1,
                                                          const float2* __restrict__ sched,
                                                          int sched_len, const int32_t* __restrict__ done,
-                                                         AdamHyper h) {
+                                                         AdamHyper h, ReplayAux ax) {
   const int64_t count = n_rows_dev ? (int64_t)*n_rows_dev : n_rows;
   const int target = *done;
   const int lig = threadIdx.x % LG;
@@ -129,7 +171,7 @@ __global__ void __launch_bounds__(256) table_adam_kernel(TableGroup tg, const in
       float4 p = *reinterpret_cast<float4*>(pp);
       float4 m = *reinterpret_cast<float4*>(pm);
       float4 v = *reinterpret_cast<float4*>(pv);
-      replay4(p, m, v, from, target, sched, sched_len, tg.wd0, h);
+      replay4(p, m, v, from, target, sched, sched_len, tg.wd0, h, ax);
       if (grad0) {
         const float2 sc = sched[target < sched_len ? target : sched_len - 1];
         const float4 g = *reinterpret_cast<const float4*>(grad0 + i * tg.W0 + 4 * sub);
@@ -145,9 +187,15 @@ __global__ void __launch_bounds__(256) table_adam_kernel(TableGroup tg, const in
     }
     if (tg.p1 && lig == 0) {
       float p = tg.p1[r], m = tg.m1[r], v = tg.v1[r];
-      for (int s = from; s < target; ++s) {
+      int s = from;
+      for (; s < target; ++s) {
         const float2 sc = sched[s < sched_len ? s : sched_len - 1];
-        adam_elem_zero_grad(p, m, v, sc.x, sc.y * tg.wd1, h);
+        if (adam_elem_zero_grad(p, m, v, sc.x, sc.y * tg.wd1, h)) { ++s; break; }
+      }
+      if (s < target) {
+        float fp, fm, fv;
+        closed_form_tail(s, target, ax, tg.wd1 != 0.f, fp, fm, fv);
+        p *= fp; m *= fm; v *= fv;
       }
       if (grad1) {
         const float2 sc = sched[target < sched_len ? target : sched_len - 1];
@@ -199,10 +247,12 @@ extern "C" int mapx_table_adam(float* p0, float* m0, float* v0, int W0, float wd
                                float* m1, float* v1, float wd1, int32_t* last,
                                const int32_t* rows, int64_t row_begin, int64_t n_rows,
                                const int32_t* n_rows_dev, const float* grad0, const float* grad1,
-                               const float* sched, int sched_len, const int32_t* done, double beta1,
-                               double beta2, double eps, hipStream_t stream) {
+                               const float* sched, int sched_len, const int32_t* done,
+                               const double* aux, int aux_len, double beta1, double beta2,
+                               double eps, hipStream_t stream) {
   using namespace mapx;
-  MAPX_REQUIRE(p0 && m0 && v0 && last && sched && done, "table_adam: null pointer");
+  MAPX_REQUIRE(p0 && m0 && v0 && last && sched && done && aux && aux_len > 1,
+               "table_adam: null pointer");
   MAPX_REQUIRE(W0 > 0 && W0 % 4 == 0, "table_adam: row width %d must be a multiple of 4", W0);
   MAPX_REQUIRE(!p1 || (m1 && v1), "table_adam: secondary state missing");
   MAPX_REQUIRE(!(grad0 && p1) || grad1, "table_adam: secondary gradient missing");
@@ -212,9 +262,10 @@ extern "C" int mapx_table_adam(float* p0, float* m0, float* v0, int W0, float wd
   const int grid = grid_for(n_rows * lg, 256, 4096);
   const AdamHyper h = make_hyper(beta1, beta2, eps);
   const float2* sc = reinterpret_cast<const float2*>(sched);
+  const ReplayAux ax{aux, aux_len};
 #define MAPX_TA(LG_)                                                                              \
   hipLaunchKernelGGL(table_adam_kernel<LG_>, dim3(grid), dim3(256), 0, stream, tg, rows, row_begin, \
-                     n_rows, n_rows_dev, grad0, grad1, sc, sched_len, done, h)
+                     n_rows, n_rows_dev, grad0, grad1, sc, sched_len, done, h, ax)
   if (lg == 4) MAPX_TA(4);
   else if (lg == 8) MAPX_TA(8);
   else MAPX_TA(16);

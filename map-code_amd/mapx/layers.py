@@ -107,23 +107,33 @@ class Embeddings(nn.Module):
 
 
 # ----------------------------------------------------------------------------- dense layers
+def _grad_slot(p):
+    """MapxOptimizer gives every dense parameter a slice of its flat gradient buffer
+    (`p._mapx_grad`).  When present, backward kernels write the gradient straight into it
+    (overwrite, one backward per step) and return None to autograd: no per-parameter
+    accumulate kernel, no flat-buffer copy."""
+    return getattr(p, "_mapx_grad", None)
+
+
 class _Linear(Function):
     @staticmethod
     def forward(ctx, x, w, b, relu):
         x = x.contiguous()
         y = ops.linear_fwd(x, w, b, relu=relu)
         ctx.relu = relu
+        ctx.slots = (_grad_slot(w), _grad_slot(b))
         ctx.save_for_backward(x, w, y if relu else None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
+        sw, sb = ctx.slots
         dz = ops.relu_mask(gy.contiguous(), y) if ctx.relu else gy.contiguous()
         dx = ops.linear_bwd_input(dz, w) if ctx.needs_input_grad[0] else None
-        dw = ops.linear_bwd_weight(dz, x) if ctx.needs_input_grad[1] else None
-        db = ops.colsum(dz) if ctx.needs_input_grad[2] else None
-        return dx, dw, db, None
+        dw = ops.linear_bwd_weight(dz, x, out=sw) if ctx.needs_input_grad[1] else None
+        db = ops.colsum(dz, out=sb) if ctx.needs_input_grad[2] else None
+        return dx, (None if sw is not None else dw), (None if sb is not None else db), None
 
 
 class HipLinear(nn.Module):
@@ -171,6 +181,7 @@ class _CrossLayer(Function):
     def forward(ctx, x0, xi, w, b):
         x0, xi = x0.contiguous(), xi.contiguous()
         y, u = ops.cross_layer_fwd(x0, xi, w, b)
+        ctx.slots = (_grad_slot(w), _grad_slot(b))
         ctx.save_for_backward(x0, xi, w, u)
         return y
 
@@ -180,9 +191,10 @@ class _CrossLayer(Function):
         g = g.contiguous()
         t, dx0 = ops.cross_bwd_pre(g, x0, u)              # t = g*x0, dx0 = g*u
         dxi = ops.linear_bwd_input(t, w, add=g)           # g + t W
-        dw = ops.linear_bwd_weight(t, xi)                 # t^T xi
-        db = ops.colsum(t)
-        return dx0, dxi, dw, db
+        sw, sb = ctx.slots
+        dw = ops.linear_bwd_weight(t, xi, out=sw)         # t^T xi
+        db = ops.colsum(t, out=sb)
+        return dx0, dxi, (None if sw is not None else dw), (None if sb is not None else db)
 
 
 class CrossNetV2(nn.Module):

@@ -389,6 +389,18 @@ def make_sched(lr0, lambdas, beta1, beta2):
     return torch.tensor(rows, dtype=torch.float64).to(torch.float32)
 
 
+def make_replay_aux(lr0, lambdas, beta1, beta2, wd):
+    """Host fp64 prefix tables [3, T+1] for the closed-form tail of lazy replays:
+    prod_{i<s}(1 - lr_i*wd), beta1^n, beta2^n (see csrc/optim.hip)."""
+    T = len(lambdas)
+    lr = torch.tensor([lr0 * l for l in lambdas], dtype=torch.float64)
+    cum = torch.ones(T + 1, dtype=torch.float64)
+    cum[1:] = torch.cumprod(1.0 - lr * wd, 0)
+    n = torch.arange(T + 1, dtype=torch.float64)
+    return torch.stack([cum, torch.pow(torch.tensor(beta1, dtype=torch.float64), n),
+                        torch.pow(torch.tensor(beta2, dtype=torch.float64), n)]).contiguous()
+
+
 def adamw_dense(p, g, m, v, sched, done, beta1, beta2, eps, wd):
     require_gpu(p, g, m, v, sched, done)
     with _timed("adamw_dense", p.numel() * 28.0):
@@ -400,7 +412,7 @@ def step_advance(done):
     check(lib.mapx_step_advance(ptr(done), stream()))
 
 
-def table_adam(p0, m0, v0, wd0, last, sched, done, beta1, beta2, eps, p1=None, m1=None, v1=None,
+def table_adam(p0, m0, v0, wd0, last, sched, done, aux, beta1, beta2, eps, p1=None, m1=None, v1=None,
                wd1=0.0, rows=None, n_rows_dev=None, row_begin=0, n_rows=None, grad0=None, grad1=None):
     require_gpu(p0, m0, v0, last, sched, done)
     W0 = p0.shape[1]
@@ -411,5 +423,5 @@ def table_adam(p0, m0, v0, wd0, last, sched, done, beta1, beta2, eps, p1=None, m
     with _timed(kind, float(n_rows) * (W0 + (1 if p1 is not None else 0)) * 4.0 * 7):
         check(lib.mapx_table_adam(ptr(p0), ptr(m0), ptr(v0), W0, wd0, ptr(p1), ptr(m1), ptr(v1), wd1,
                                   ptr(last), ptr(rows), row_begin, n_rows, ptr(n_rows_dev), ptr(grad0),
-                                  ptr(grad1), ptr(sched), sched.shape[0], ptr(done), beta1, beta2, eps,
-                                  stream()))
+                                  ptr(grad1), ptr(sched), sched.shape[0], ptr(done), ptr(aux),
+                                  aux.shape[1], beta1, beta2, eps, stream()))

@@ -37,8 +37,8 @@ def lr_lambda(kind, step, total, warmup):
 class TableAdam:
     """Lazy exact AdamW state of one RowTable."""
 
-    def __init__(self, table, wd0, wd1, hyper, sched, done, max_gap):
-        self.table, self.wd0, self.wd1 = table, wd0, wd1
+    def __init__(self, table, wd0, wd1, hyper, sched, done, aux, max_gap):
+        self.table, self.wd0, self.wd1, self.aux = table, wd0, wd1, aux
         self.b1, self.b2, self.eps = hyper
         self.sched, self.done = sched, done
         p0, p1 = table.p0.data, (table.p1.data if table.p1 is not None else None)
@@ -48,13 +48,15 @@ class TableAdam:
         self.last = torch.zeros(p0.shape[0], dtype=torch.int32, device=p0.device)
         self.stale = False
         self.cursor = 0
-        self.sweep = max(1, math.ceil(p0.shape[0] / max(1, max_gap)))
+        # max_gap > 0: also bring V/max_gap rows up to date every step (round robin).  Not needed
+        # for speed since replays have a closed-form tail (csrc/optim.hip); kept for testing.
+        self.sweep = math.ceil(p0.shape[0] / max_gap) if max_gap > 0 else 0
         table.lazy = self
 
     def _call(self, **kw):
         t = self.table
         ops.table_adam(t.p0.data, self.m0, self.v0, self.wd0, self.last, self.sched, self.done,
-                       self.b1, self.b2, self.eps,
+                       self.aux, self.b1, self.b2, self.eps,
                        p1=t.p1.data.view(-1) if t.p1 is not None else None,
                        m1=self.m1, v1=self.v1, wd1=self.wd1, **kw)
 
@@ -72,6 +74,8 @@ class TableAdam:
 
     def sweep_some(self):
         """Bound the replay length: every row is brought up to date at least every max_gap steps."""
+        if self.sweep <= 0:
+            return
         V = self.table.num_rows
         n = min(self.sweep, V - self.cursor)
         self._call(row_begin=self.cursor, n_rows=n)
@@ -87,7 +91,7 @@ class MapxOptimizer:
     """optimizer + scheduler of reference Trainer.get_optimizer, fused.  `step()` = the
     reference's optimizer.step(); scheduler.step(); model.zero_grad()."""
 
-    def __init__(self, model, args, num_training_steps, num_warmup_steps, max_gap=256):
+    def __init__(self, model, args, num_training_steps, num_warmup_steps, max_gap=0):
         b1, b2 = (float(x) for x in args.adam_betas.split(","))
         self.hyper = (b1, b2, float(args.adam_epsilon))
         self.lr0, self.wd = float(args.learning_rate), float(args.weight_decay)
@@ -98,6 +102,7 @@ class MapxOptimizer:
         if dev.type != "cuda":
             raise RuntimeError("MapxOptimizer needs the model on the GPU (call model.to(device) first)")
         self.sched = ops.make_sched(self.lr0, lambdas, b1, b2).to(dev)
+        self.aux = ops.make_replay_aux(self.lr0, lambdas, b1, b2, self.wd).to(dev)
         self.done = torch.zeros(1, dtype=torch.int32, device=dev)
         self.steps_done = 0
         table_ids = model.table_parameter_ids()
@@ -112,7 +117,7 @@ class MapxOptimizer:
         for t in model.row_tables():
             wd0 = self.wd if decays(names[id(t.p0)]) else 0.0
             wd1 = (self.wd if decays(names[id(t.p1)]) else 0.0) if t.p1 is not None else 0.0
-            self.tables.append(TableAdam(t, wd0, wd1, self.hyper, self.sched, self.done, max_gap))
+            self.tables.append(TableAdam(t, wd0, wd1, self.hyper, self.sched, self.done, self.aux, max_gap))
 
     @staticmethod
     def _flatten(members, wd, dev):
@@ -125,7 +130,8 @@ class MapxOptimizer:
             view = flat_p[off:off + p.numel()].view_as(p)
             view.copy_(p.data)
             p.data = view
-            p.grad = flat_g[off:off + p.numel()].view_as(p)
+            p.grad = None
+            p._mapx_grad = flat_g[off:off + p.numel()].view_as(p)   # backward kernels write here
             off += sz
         return dict(p=flat_p, g=flat_g, m=torch.zeros_like(flat_p), v=torch.zeros_like(flat_p), wd=wd,
                     names=[n for n, _ in members])
@@ -165,8 +171,8 @@ class MapxOptimizer:
         self.zero_grad()
 
     def zero_grad(self):
-        for g in self.groups:
-            g["g"].zero_()
+        """Dense gradients are overwritten by the next backward (see layers._grad_slot); only
+        the sparse side channel needs clearing."""
         for t in self.tables:
             t.table.sparse_grad = None
 

@@ -354,6 +354,7 @@ def test_lazy_table_adam_equals_dense_reference(ops, W, with_bias):
     from oracle import ref_model as R
     T, V = 40, 257
     sched, lambdas = _sched(ops, T, kind="cosine")
+    aux = ops.make_replay_aux(1e-3, lambdas, 0.9, 0.999, 0.05).to(DEV)
     g = torch.Generator().manual_seed(W)
     p0, b0 = torch.randn(V, W, generator=g), torch.randn(V, generator=g)
     pr, mr, vr = p0.clone(), torch.zeros(V, W), torch.zeros(V, W)
@@ -377,19 +378,52 @@ def test_lazy_table_adam_equals_dense_reference(ops, W, with_bias):
         rows_d = rows.to(torch.int32).to(DEV)
         nrd = torch.tensor([nrow], dtype=torch.int32, device=DEV)
         # catch-up before "forward": touched rows must already equal the dense reference
-        ops.table_adam(p, m, v, 0.05, last, sched, done, 0.9, 0.999, 1e-8, rows=rows_d,
+        ops.table_adam(p, m, v, 0.05, last, sched, done, aux, 0.9, 0.999, 1e-8, rows=rows_d,
                        n_rows_dev=nrd, **kw)
-        ops.table_adam(p, m, v, 0.05, last, sched, done, 0.9, 0.999, 1e-8, rows=rows_d,
+        ops.table_adam(p, m, v, 0.05, last, sched, done, aux, 0.9, 0.999, 1e-8, rows=rows_d,
                        n_rows_dev=nrd, grad0=grad.to(DEV), grad1=gb.to(DEV) if with_bias else None, **kw)
         ops.step_advance(done)
         np.testing.assert_allclose(_cpu(p)[rows].numpy(), pr[rows].numpy(), rtol=5e-6, atol=1e-7)
-    ops.table_adam(p, m, v, 0.05, last, sched, done, 0.9, 0.999, 1e-8, **kw)       # flush all rows
+    ops.table_adam(p, m, v, 0.05, last, sched, done, aux, 0.9, 0.999, 1e-8, **kw)       # flush all rows
     assert bool((_cpu(last) == T).all())
     np.testing.assert_allclose(_cpu(p).numpy(), pr.numpy(), rtol=5e-6, atol=1e-7)
     np.testing.assert_allclose(_cpu(m).numpy(), mr.numpy(), rtol=5e-6, atol=2e-8)
     np.testing.assert_allclose(_cpu(v).numpy(), vr.numpy(), rtol=5e-6, atol=1e-10)
     if with_bias:
         np.testing.assert_allclose(_cpu(b).numpy(), br.numpy(), rtol=5e-6, atol=1e-7)
+
+
+def test_lazy_replay_long_gap_closed_form_tail(ops):
+    """Rows left untouched for thousands of steps: the step-by-step replay hands over to the
+    closed-form tail (fp64 prefix products); the result must stay within fp32 rounding noise of
+    the reference's dense step-by-step AdamW."""
+    from oracle import ref_model as R
+    T, V, W = 3000, 12, 16
+    sched, lambdas = _sched(ops, T, kind="cosine", warm=100)
+    aux = ops.make_replay_aux(1e-3, lambdas, 0.9, 0.999, 0.05).to(DEV)
+    g = torch.Generator().manual_seed(9)
+    p0 = torch.randn(V, W, generator=g)
+    p0[0, :4] = 0.0                                        # exact zeros never satisfy |term| < c|p|
+    pr, mr, vr = p0.clone(), torch.zeros(V, W), torch.zeros(V, W)
+    p, m, v = p0.to(DEV).clone(), torch.zeros(V, W, device=DEV), torch.zeros(V, W, device=DEV)
+    last = torch.zeros(V, dtype=torch.int32, device=DEV)
+    done = torch.zeros(1, dtype=torch.int32, device=DEV)
+    touch = {1: [0, 1, 2, 3], 2: [2, 3, 4], 700: [3, 5], 2999: [1]}
+    for s in range(1, T + 1):
+        dense_g = torch.zeros(V, W)
+        if s in touch:
+            rows = torch.tensor(touch[s])
+            grad = 0.05 * torch.randn(len(rows), W, generator=g)
+            dense_g.index_copy_(0, rows, grad)
+            ops.table_adam(p, m, v, 0.05, last, sched, done, aux, 0.9, 0.999, 1e-8,
+                           rows=rows.to(torch.int32).to(DEV), grad0=grad.to(DEV))
+        R.hf_adamw_step(pr, dense_g, mr, vr, s, 1e-3 * lambdas[s - 1], wd=0.05)
+        ops.step_advance(done)
+    ops.table_adam(p, m, v, 0.05, last, sched, done, aux, 0.9, 0.999, 1e-8)         # flush
+    assert bool((_cpu(last) == T).all())
+    np.testing.assert_allclose(_cpu(p).numpy(), pr.numpy(), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(_cpu(v).numpy(), vr.numpy(), rtol=1e-4, atol=1e-12)
+    np.testing.assert_allclose(_cpu(m).numpy(), mr.numpy(), rtol=1e-4, atol=1e-12)
 
 
 def test_errors_are_loud(ops):
