@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 4
+#define MAPX_ABI_VERSION 5
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -80,9 +80,12 @@ int mapx_alias_build_host(const float* probs_host, int64_t n, float* out_prob_ho
 int mapx_alias_pack(const float* prob, const int64_t* alias, int64_t V, void* packed,
                     hipStream_t stream);
 /* nce/alias_multinomial.py:81-97 + nce_loss.py:146-156: idx[t,0] = targets[t],
- * idx[t,1+k] = k-th negative (Philox4x32-10 keyed by (seed, offset)).  idx int32 [T, K+1]. */
+ * idx[t,1+k] = k-th negative (Philox4x32-10 keyed by (seed, offset + *offset_dev); offset_dev
+ * may be NULL: a device step counter keeps captured hipGraph replays on fresh streams).
+ * idx int32 [T, K+1]. */
 int mapx_alias_draw(const void* packed, int64_t V, const int64_t* targets, int64_t T, int K,
-                    uint64_t seed, uint64_t offset, int32_t* idx, hipStream_t stream);
+                    uint64_t seed, uint64_t offset, const int32_t* offset_dev, int32_t* idx,
+                    hipStream_t stream);
 /* Same index matrix from caller-provided negatives noise[T,K] (parity tests). */
 int mapx_nce_pack_idx(const int64_t* targets, const int64_t* noise, int64_t T, int K, int64_t V,
                       int32_t* idx, int* err_flag, hipStream_t stream);
@@ -157,14 +160,14 @@ int mapx_bce_with_logits(const float* logits, const float* labels, int64_t n, fl
 /* trainer.py:217-232 (MFP, sampling_method="randint"): masked_index_in NULL -> Philox. */
 int mapx_dynamic_mask_mfp(const int64_t* ids, int64_t B, int F, int L,
                           const int64_t* masked_index_in, uint64_t seed, uint64_t offset,
-                          int64_t* ids_out, int64_t* labels, int64_t* masked_index_out,
-                          hipStream_t stream);
+                          const int32_t* offset_dev, int64_t* ids_out, int64_t* labels,
+                          int64_t* masked_index_out, hipStream_t stream);
 /* trainer.py:233-240 (RFD, RFD_replace="Unigram"): x_train [N,F] device-resident; labels f32 [B,F]. */
 int mapx_dynamic_mask_rfd(const int64_t* ids, int64_t B, int F, int L,
                           const int64_t* masked_index_in, const int64_t* replace_in,
                           const int64_t* x_train, int64_t N, uint64_t seed, uint64_t offset,
-                          int64_t* ids_out, float* labels, int64_t* masked_index_out,
-                          hipStream_t stream);
+                          const int32_t* offset_dev, int64_t* ids_out, float* labels,
+                          int64_t* masked_index_out, hipStream_t stream);
 
 /* ------------------------------------------------------------------ optimizer (a13)
  * transformers-4.26 AdamW semantics (trainer.py:60-85).  sched [sched_len][2] f32 =

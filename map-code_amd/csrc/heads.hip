@@ -61,9 +61,11 @@ __global__ void __launch_bounds__(256) mask_mfp_kernel(const int64_t* __restrict
                                                        int F, int L,
                                                        const int64_t* __restrict__ mi_in,
                                                        uint64_t seed, uint64_t offset,
+                                                       const int32_t* __restrict__ offset_dev,
                                                        int64_t* __restrict__ ids_out,
                                                        int64_t* __restrict__ labels,
                                                        int64_t* __restrict__ mi_out) {
+  if (offset_dev) offset += (uint64_t)(uint32_t)*offset_dev;   // graph-replay safe stream offset
   for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B;
        b += (int64_t)gridDim.x * blockDim.x) {
     const int64_t* row = ids + b * F;
@@ -94,9 +96,11 @@ __global__ void __launch_bounds__(256) mask_rfd_kernel(const int64_t* __restrict
                                                        const int64_t* __restrict__ replace_in,
                                                        const int64_t* __restrict__ x_train, int64_t N,
                                                        uint64_t seed, uint64_t offset,
+                                                       const int32_t* __restrict__ offset_dev,
                                                        int64_t* __restrict__ ids_out,
                                                        float* __restrict__ labels,
                                                        int64_t* __restrict__ mi_out) {
+  if (offset_dev) offset += (uint64_t)(uint32_t)*offset_dev;
   for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B;
        b += (int64_t)gridDim.x * blockDim.x) {
     const int64_t* row = ids + b * F;
@@ -163,29 +167,29 @@ extern "C" int mapx_bce_with_logits(const float* logits, const float* labels, in
 
 extern "C" int mapx_dynamic_mask_mfp(const int64_t* ids, int64_t B, int F, int L,
                                      const int64_t* masked_index_in, uint64_t seed, uint64_t offset,
-                                     int64_t* ids_out, int64_t* labels, int64_t* masked_index_out,
-                                     hipStream_t stream) {
+                                     const int32_t* offset_dev, int64_t* ids_out, int64_t* labels,
+                                     int64_t* masked_index_out, hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(ids && ids_out && labels && B >= 0 && F > 0 && L >= 0, "dynamic_mask_mfp: bad arguments");
   MAPX_REQUIRE(ids != ids_out, "dynamic_mask_mfp: in-place masking is not supported");
   if (B == 0) return MAPX_OK;
   hipLaunchKernelGGL(mask_mfp_kernel, dim3(grid_for(B, 256)), dim3(256), 0, stream, ids, B, F, L,
-                     masked_index_in, seed, offset, ids_out, labels, masked_index_out);
+                     masked_index_in, seed, offset, offset_dev, ids_out, labels, masked_index_out);
   return check_launch("dynamic_mask_mfp");
 }
 
 extern "C" int mapx_dynamic_mask_rfd(const int64_t* ids, int64_t B, int F, int L,
                                      const int64_t* masked_index_in, const int64_t* replace_in,
                                      const int64_t* x_train, int64_t N, uint64_t seed,
-                                     uint64_t offset, int64_t* ids_out, float* labels,
-                                     int64_t* masked_index_out, hipStream_t stream) {
+                                     uint64_t offset, const int32_t* offset_dev, int64_t* ids_out,
+                                     float* labels, int64_t* masked_index_out, hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(ids && ids_out && labels && B >= 0 && F > 0 && L >= 0, "dynamic_mask_rfd: bad arguments");
   MAPX_REQUIRE(replace_in || (x_train && N > 0), "dynamic_mask_rfd: need replace_in or x_train");
   MAPX_REQUIRE(ids != ids_out, "dynamic_mask_rfd: in-place replacement is not supported");
   if (B == 0) return MAPX_OK;
   hipLaunchKernelGGL(mask_rfd_kernel, dim3(grid_for(B, 256)), dim3(256), 0, stream, ids, B, F, L,
-                     masked_index_in, replace_in, x_train, N, seed, offset, ids_out, labels,
+                     masked_index_in, replace_in, x_train, N, seed, offset, offset_dev, ids_out, labels,
                      masked_index_out);
   return check_launch("dynamic_mask_rfd");
 }

@@ -32,7 +32,12 @@ __global__ void __launch_bounds__(256) alias_pack_kernel(const float* __restrict
 __global__ void __launch_bounds__(256) alias_draw_kernel(const AliasRec* __restrict__ table,
                                                          int64_t V, const int64_t* __restrict__ targets,
                                                          int64_t T, int K, uint64_t seed,
-                                                         uint64_t offset, int32_t* __restrict__ idx) {
+                                                         uint64_t offset,
+                                                         const int32_t* __restrict__ offset_dev,
+                                                         int32_t* __restrict__ idx) {
+  // offset_dev: device-resident step counter added to the stream offset, so that a captured
+  // hipGraph draws fresh negatives on every replay
+  if (offset_dev) offset += (uint64_t)(uint32_t)*offset_dev;
   const int K1 = K + 1;
   const int64_t pairs_per_t = (K + 1) / 2;  // pairs of negatives per target (K odd -> exact)
   const int64_t total = T * pairs_per_t;
@@ -204,15 +209,15 @@ extern "C" int mapx_alias_pack(const float* prob, const int64_t* alias, int64_t 
 }
 
 extern "C" int mapx_alias_draw(const void* packed, int64_t V, const int64_t* targets, int64_t T,
-                               int K, uint64_t seed, uint64_t offset, int32_t* idx,
-                               hipStream_t stream) {
+                               int K, uint64_t seed, uint64_t offset, const int32_t* offset_dev,
+                               int32_t* idx, hipStream_t stream) {
   MAPX_REQUIRE(packed && targets && idx, "alias_draw: null pointer");
   MAPX_REQUIRE(V > 0 && V < (1LL << 31) && T >= 0 && K >= 1, "alias_draw: bad sizes");
   if (T == 0) return MAPX_OK;
   const int64_t work = T * ((K + 1) / 2);
   hipLaunchKernelGGL(mapx::alias_draw_kernel, dim3(mapx::grid_for(work, 256)), dim3(256), 0,
                      stream, static_cast<const mapx::AliasRec*>(packed), V, targets, T, K, seed,
-                     offset, idx);
+                     offset, offset_dev, idx);
   return mapx::check_launch("alias_draw");
 }
 

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmapx_hip.so")
 
-MAPX_ABI_VERSION = 4
+MAPX_ABI_VERSION = 5
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_CROSS, EPI_ADD, EPI_RELU_MASK = range(6)
 
 _p, _i, _i64, _u64, _f, _d, _sz = (C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double,
@@ -29,7 +29,7 @@ SIGNATURES = {
     "mapx_seg_reduce_rows": (_i, [_i64, _p, _p, _p, _p, _i, _p, _p, _sz, _p]),
     "mapx_alias_build_host": (_i, [_p, _i64, _p, _p]),
     "mapx_alias_pack": (_i, [_p, _p, _i64, _p, _p]),
-    "mapx_alias_draw": (_i, [_p, _i64, _p, _i64, _i, _u64, _u64, _p, _p]),
+    "mapx_alias_draw": (_i, [_p, _i64, _p, _i64, _i, _u64, _u64, _p, _p, _p]),
     "mapx_nce_pack_idx": (_i, [_p, _p, _i64, _i, _i64, _p, _p, _p]),
     "mapx_nce_fwd_workspace_bytes": (_sz, []),
     "mapx_nce_fwd": (_i, [_p, _i64, _i, _i, _i, _p, _p, _i, _p, _p, _p, _i64, _p, _p, _p, _p, _p,
@@ -47,8 +47,8 @@ SIGNATURES = {
     "mapx_relu_mask": (_i, [_p, _p, _i64, _p, _p]),
     "mapx_bce_workspace_bytes": (_sz, []),
     "mapx_bce_with_logits": (_i, [_p, _p, _i64, _p, _p, _p, _sz, _p]),
-    "mapx_dynamic_mask_mfp": (_i, [_p, _i64, _i, _i, _p, _u64, _u64, _p, _p, _p, _p]),
-    "mapx_dynamic_mask_rfd": (_i, [_p, _i64, _i, _i, _p, _p, _p, _i64, _u64, _u64, _p, _p, _p, _p]),
+    "mapx_dynamic_mask_mfp": (_i, [_p, _i64, _i, _i, _p, _u64, _u64, _p, _p, _p, _p, _p]),
+    "mapx_dynamic_mask_rfd": (_i, [_p, _i64, _i, _i, _p, _p, _p, _i64, _u64, _u64, _p, _p, _p, _p, _p]),
     "mapx_adamw_dense": (_i, [_p, _p, _p, _p, _i64, _p, _i, _p, _d, _d, _d, _d, _p]),
     "mapx_step_advance": (_i, [_p, _p]),
     "mapx_table_adam": (_i, [_p, _p, _p, _i, _f, _p, _p, _p, _f, _p, _p, _i64, _i64, _p, _p, _p, _p,

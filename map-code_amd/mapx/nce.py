@@ -50,9 +50,9 @@ class AliasMultinomial(nn.Module):
             self._packed = ops.alias_pack(self.prob, self.alias)
         return self._packed
 
-    def draw_index_matrix(self, targets, K, seed, offset):
+    def draw_index_matrix(self, targets, K, seed, offset, offset_dev=None):
         """idx int32 [T, K+1]: column 0 = targets, then K negatives."""
-        return ops.alias_draw(self.packed(), targets, K, seed, offset)
+        return ops.alias_draw(self.packed(), targets, K, seed, offset, offset_dev)
 
 
 class _NceLoss(Function):
@@ -103,6 +103,8 @@ class IndexLinear(nn.Module):
         self.seed = int(getattr(config, "seed", 42))
         self.rank = int(getattr(config, "rank", 0))
         self._draws = 0
+        self.step_counter = None     # int32 device scalar (the optimizer's update counter): when set
+                                     # and training, it advances the Philox stream (graph-replay safe)
         self.return_logits = False
 
     def reset_parameters(self):
@@ -113,9 +115,12 @@ class IndexLinear(nn.Module):
             self.bias.weight.copy_((self.logprob_noise + self.norm_term).unsqueeze(1))
 
     def get_noise_index(self, target):
-        self._draws += 1
-        offset = (self.rank << 40) + self._draws
-        return self.alias.draw_index_matrix(target.reshape(-1), self.noise_ratio, self.seed, offset)
+        if self.training and self.step_counter is not None:
+            offset, dev = (self.rank << 40) + (1 << 36), self.step_counter
+        else:
+            self._draws += 1
+            offset, dev = (self.rank << 40) + self._draws, None
+        return self.alias.draw_index_matrix(target.reshape(-1), self.noise_ratio, self.seed, offset, dev)
 
     def forward(self, target, input, masked_index=None, noise_samples=None):
         """target [B,L] i64.  `input` is either the selected hidden [B,L,P] (reference call

@@ -153,14 +153,15 @@ def alias_pack(prob, alias):
     return packed
 
 
-def alias_draw(packed, targets, K, seed, offset):
-    """-> idx int32 [T, K+1]; column 0 = targets."""
+def alias_draw(packed, targets, K, seed, offset, offset_dev=None):
+    """-> idx int32 [T, K+1]; column 0 = targets.  offset_dev: int32 device scalar added to
+    `offset` inside the kernel (hipGraph-replay safe)."""
     require_gpu(packed, targets)
     targets = targets.contiguous()
     T = targets.numel()
     idx = torch.empty(T, K + 1, dtype=torch.int32, device=targets.device)
     check(lib.mapx_alias_draw(ptr(packed), packed.shape[0], ptr(targets), T, K, seed, offset,
-                              ptr(idx), stream()))
+                              ptr(offset_dev), ptr(idx), stream()))
     return idx
 
 
@@ -348,7 +349,7 @@ def bce_with_logits(logits, labels, want_grad=True):
     return out3, dl
 
 
-def dynamic_mask_mfp(ids, L, masked_index=None, seed=0, offset=0):
+def dynamic_mask_mfp(ids, L, masked_index=None, seed=0, offset=0, offset_dev=None):
     """-> (masked ids [B,F], labels [B,L], masked_index [B,L])  (trainer.py:217-232)."""
     require_gpu(ids)
     ids = ids.contiguous()
@@ -357,12 +358,13 @@ def dynamic_mask_mfp(ids, L, masked_index=None, seed=0, offset=0):
     labels = torch.empty(B, L, dtype=torch.int64, device=ids.device)
     mi_out = torch.empty(B, L, dtype=torch.int64, device=ids.device)
     mi_in = masked_index.contiguous() if masked_index is not None else None
-    check(lib.mapx_dynamic_mask_mfp(ptr(ids), B, F, L, ptr(mi_in), seed, offset, ptr(out), ptr(labels),
-                                    ptr(mi_out), stream()))
+    check(lib.mapx_dynamic_mask_mfp(ptr(ids), B, F, L, ptr(mi_in), seed, offset, ptr(offset_dev), ptr(out),
+                                    ptr(labels), ptr(mi_out), stream()))
     return out, labels, mi_out
 
 
-def dynamic_mask_rfd(ids, L, masked_index=None, replace_feat=None, x_train=None, seed=0, offset=0):
+def dynamic_mask_rfd(ids, L, masked_index=None, replace_feat=None, x_train=None, seed=0, offset=0,
+                     offset_dev=None):
     """-> (replaced ids [B,F], labels f32 [B,F], masked_index [B,L])  (trainer.py:233-240)."""
     require_gpu(ids)
     ids = ids.contiguous()
@@ -374,7 +376,7 @@ def dynamic_mask_rfd(ids, L, masked_index=None, replace_feat=None, x_train=None,
     rep = replace_feat.contiguous() if replace_feat is not None else None
     nrows = x_train.shape[0] if x_train is not None else 0
     check(lib.mapx_dynamic_mask_rfd(ptr(ids), B, F, L, ptr(mi_in), ptr(rep), ptr(x_train), nrows,
-                                    seed, offset, ptr(out), ptr(labels), ptr(mi_out), stream()))
+                                    seed, offset, ptr(offset_dev), ptr(out), ptr(labels), ptr(mi_out), stream()))
     return out, labels, mi_out
 
 

@@ -50,6 +50,36 @@ class DeviceSplit:
         return nb // world if world > 1 else nb
 
 
+class GraphedStep:
+    """One whole training step (mask -> forward -> backward -> optimizer -> schedule) captured
+    in a hipGraph and replayed on static input buffers: ~115 kernel launches per step cost one
+    graph launch, and the step runs at GPU speed instead of Python launch speed.  Everything
+    that varies per step lives on the device (update counter, Philox offsets, LR table)."""
+
+    def __init__(self, trainer, step_fn, X, Y):
+        self.trainer = trainer
+        self.X, self.Y = X.clone(), Y.clone()
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        gs, sd = trainer.global_step, trainer.optimizer.steps_done
+        with torch.cuda.graph(self.graph):
+            self.out = step_fn(self.X, self.Y)
+        # the capture pass ran the Python bookkeeping but no kernel
+        trainer.global_step, trainer.optimizer.steps_done = gs, sd
+
+    def __call__(self, X, Y):
+        self.X.copy_(X)
+        self.Y.copy_(Y)
+        self.graph.replay()
+        # the step's host-side effects (a replay runs no Python)
+        opt = self.trainer.optimizer
+        opt.steps_done += 1
+        for t in opt.tables:
+            t.stale = True
+        self.trainer.global_step += 1
+        return self.out
+
+
 class Trainer:
     def __init__(self, model, model_config, training_args, train_dataset, eval_dataset):
         self.model, self.model_config, self.args = model, model_config, training_args
@@ -60,6 +90,8 @@ class Trainer:
         self.optimizer = None
         self.best_eval_auc, self.best_eval_step = 0, -1
         self.rank, self.world = parallel.rank(), parallel.world()
+        self.use_graph = os.environ.get("MAPX_GRAPH", "1") != "0"
+        self._graphs = {}
         self._splits = {}
         self._mask_calls = 0
         self._gen = None
@@ -89,6 +121,9 @@ class Trainer:
         self.model.to(self.device)
         self.optimizer = self.get_optimizer(t_total, t_warmup)
         self.scheduler = self.optimizer                      # get_last_lr() lives there
+        if hasattr(self.model, "mfp_criterion"):
+            self.model.mfp_criterion.step_counter = self.optimizer.done
+        self._graphs = {}
         logger.info(f"***** running {what} *****")
         for k, v in (("dataset_name", self.args.dataset_name), ("input_size", self.model_config.input_size),
                      ("num_fields", self.model_config.num_fields), ("num_examples", len(self.train_dataset)),
@@ -107,13 +142,60 @@ class Trainer:
         self.optimizer.step()                                # + scheduler.step() + zero_grad()
         self.global_step += 1
 
+    def _mfp_step(self, X, Y):
+        inputs = self.dynamic_mask({"input_ids": X, "labels": Y}, self.args.sampling_method)
+        loss, count, acc = self.model(**inputs)
+        loss.backward()
+        self._optimizer_step()
+        return loss.detach(), acc.float() / count
+
+    def _rfd_step(self, X, Y):
+        inputs = self.dynamic_mask({"input_ids": X, "labels": Y}, self.args.sampling_method)
+        loss, count, acc, pos_ratio = self.model(**inputs)
+        loss.backward()
+        self._optimizer_step()
+        return loss.detach(), acc
+
+    def _ctr_step(self, X, Y):
+        loss, logits = self.model(input_ids=X, labels=Y)
+        loss.backward()
+        self._optimizer_step()
+        return loss.detach(), logits.detach().view(-1)
+
+    GRAPH_AFTER = 3      # eager steps per (kind, shape) before capture (allocator / workspace warm-up)
+
+    def run_step(self, kind, X, Y):
+        """One training step.  Full-size single-GPU batches run from a captured hipGraph after a
+        few eager steps; ragged batches, multi-GPU steps (host-side exchange sizes), gradient
+        clipping and host-side mask sampling ("normal") stay eager."""
+        fn = {"mfp": self._mfp_step, "rfd": self._rfd_step, "ctr": self._ctr_step}[kind]
+        graphable = (self.use_graph and self.world == 1 and self.optimizer.max_grad_norm <= 0
+                     and X.shape[0] == self.args.per_gpu_train_batch_size
+                     and (kind == "ctr" or self.args.sampling_method == "randint"))
+        if not graphable:
+            return fn(X, Y)
+        key = (kind, tuple(X.shape))
+        g = self._graphs.get(key, 0)
+        if isinstance(g, int):
+            if g < self.GRAPH_AFTER:
+                self._graphs[key] = g + 1
+                return fn(X, Y)
+            g = self._graphs[key] = GraphedStep(self, fn, X, Y)
+        return g(X, Y)
+
     # ------------------------------------------------------------------ masking (a1, a2)
     def dynamic_mask(self, inputs, sampling_method="normal", masked_index=None, replace_feat=None):
         ids = inputs["input_ids"]
         F = self.model_config.num_fields
         L = int(F * self.args.mask_ratio)
-        self._mask_calls += 1
-        seed, offset = int(self.args.seed), (self.rank << 40) + self._mask_calls
+        seed = int(self.args.seed)
+        if self.model.training and self.optimizer is not None:
+            # training: the stream offset advances with the optimizer's device-side update counter,
+            # so a captured step replays with fresh masks
+            offset, offset_dev = (self.rank << 40) + (2 << 36), self.optimizer.done
+        else:
+            self._mask_calls += 1
+            offset, offset_dev = (self.rank << 40) + (3 << 36) + self._mask_calls, None
         if masked_index is None:
             if sampling_method == "normal":        # L distinct fields per row (trainer.py:222)
                 masked_index = torch.rand(ids.shape[0], F, device=ids.device,
@@ -122,7 +204,7 @@ class Trainer:
                 raise NotImplementedError(sampling_method)
         if self.args.pt_type == "MFP":
             inputs["input_ids"], inputs["labels"], inputs["masked_index"] = ops.dynamic_mask_mfp(
-                ids, L, masked_index=masked_index, seed=seed, offset=offset)
+                ids, L, masked_index=masked_index, seed=seed, offset=offset, offset_dev=offset_dev)
         elif self.args.pt_type == "RFD":
             if self.args.RFD_replace != "Unigram" and replace_feat is None:
                 if self.args.RFD_replace in ("Uniform", "Whole-Uniform", "Whole-Unigram"):
@@ -132,7 +214,7 @@ class Trainer:
             x_train = self._split(self.train_dataset).X
             inputs["input_ids"], inputs["labels"], _ = ops.dynamic_mask_rfd(
                 ids, L, masked_index=masked_index, replace_feat=replace_feat, x_train=x_train,
-                seed=seed, offset=offset)
+                seed=seed, offset=offset, offset_dev=offset_dev)
         else:
             raise NotImplementedError(self.args.pt_type)
         return inputs
@@ -151,12 +233,9 @@ class Trainer:
             logger.info(f"-------------------- epoch-{epoch} --------------------")
             self.model.train()
             for X, Y in train.batches(B, True, self._generator(), (self.rank, self.world)):
-                inputs = self.dynamic_mask({"input_ids": X, "labels": Y}, self.args.sampling_method)
-                loss, count, acc = self.model(**inputs)
-                loss.backward()
-                self._optimizer_step()
-                win_loss += loss.detach()
-                win_acc += acc.float() / count
+                loss, step_acc = self.run_step("mfp", X, Y)
+                win_loss += loss
+                win_acc += step_acc
                 if self.global_step % self.args.logging_steps == 0:
                     n = self.args.logging_steps
                     _log = {"window_loss": float(win_loss) / n, "window_acc": float(win_acc) / n,
@@ -206,11 +285,8 @@ class Trainer:
             logger.info(f"-------------------- epoch-{epoch} --------------------")
             self.model.train()
             for X, Y in train.batches(B, True, self._generator(), (self.rank, self.world)):
-                inputs = self.dynamic_mask({"input_ids": X, "labels": Y}, self.args.sampling_method)
-                loss, count, acc, pos_ratio = self.model(**inputs)
-                loss.backward()
-                self._optimizer_step()
-                win += torch.stack([loss.detach(), acc])
+                loss, acc = self.run_step("rfd", X, Y)
+                win += torch.stack([loss, acc])
                 if self.global_step % self.args.logging_steps == 0:
                     n = self.args.logging_steps
                     w = win.tolist()
@@ -259,11 +335,9 @@ class Trainer:
             logger.info(f"-------------------- epoch-{epoch} --------------------")
             self.model.train()
             for X, Y in train.batches(B, True, self._generator(), (self.rank, self.world)):
-                loss, logits = self.model(input_ids=X, labels=Y)
-                loss.backward()
-                self._optimizer_step()
-                win_loss += loss.detach()
-                win_logits.append(logits.detach().view(-1))
+                loss, logits = self.run_step("ctr", X, Y)
+                win_loss += loss
+                win_logits.append(logits.clone())
                 win_labels.append(Y)
                 if self.global_step % self.args.logging_steps == 0:
                     probs = torch.sigmoid(torch.cat(win_logits)).cpu().numpy()

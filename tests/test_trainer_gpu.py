@@ -211,3 +211,36 @@ def test_data_parallel_two_ranks_equal_single_process(tmp_path):
     for k in a:
         assert torch.equal(b0[k], b1[k]), f"replicas diverged on {k}"
         np.testing.assert_allclose(b0[k].numpy(), a[k].numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+def test_graph_replay_equals_eager_bitwise():
+    """The captured-hipGraph step and the eager step draw the same Philox streams (device-side
+    counter) and run the same kernels: identical parameters after two epochs, bit for bit."""
+    from mapx.arguments import TrainingArguments
+    from mapx.dataset import OurDataset, synth_table
+    from mapx.models import BaseModel
+    from mapx.trainer import Trainer
+    from util import make_config
+    cfg = dict(F=23, V=3000, E=16, H=64, NL=3, NC=3, P=32, K=25)
+    ids, labels, _, _ = synth_table(512 * 9 + 100, 23, cfg["V"], seed=3)       # ragged last batch
+    cnt = np.bincount(ids.reshape(-1), minlength=cfg["V"]).astype(np.float32)
+    out = []
+    for use_graph in (True, False):
+        torch.manual_seed(5)
+        config = make_config(cfg, "MFP", cnt)
+        model = BaseModel.from_config(config)
+        targs = TrainingArguments(output_dir="/tmp/mapx_graph_test", per_gpu_train_batch_size=512,
+                                  per_gpu_eval_batch_size=512, learning_rate=1e-3, lr_sched="cosine",
+                                  weight_decay=5e-2, num_train_epochs=2, pretrain=True, pt_type="MFP",
+                                  sampling_method="randint", mask_ratio=0.3, logging_steps=7, seed=11)
+        targs._device = torch.device(DEV)
+        os.makedirs(targs.output_dir, exist_ok=True)
+        ds = OurDataset(ids, labels)
+        tr = Trainer(model, config, targs, ds, OurDataset(ids[:600], labels[:600]))
+        tr.use_graph = use_graph
+        tr.MFP_pretrain()
+        assert tr.global_step == 2 * 10
+        assert (len(tr._graphs) == 1 and not isinstance(next(iter(tr._graphs.values())), int)) == use_graph
+        out.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    for k in out[0]:
+        assert torch.equal(out[0][k], out[1][k]), k
