@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 5
+#define MAPX_ABI_VERSION 6
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -181,13 +181,15 @@ int mapx_step_advance(int32_t* done, hipStream_t stream);
  * i < *n_rows_dev (or n_rows if NULL).  grad0 NULL: catch-up to *done only; else catch-up
  * then update *done+1 with grad0 [*, W0] (grad1 [*]) and last = *done+1.
  * aux [3][aux_len] f64 (device): prefix products prod_{i<s}(1 - lr_i*wd), beta1^n, beta2^n —
- * the closed-form tail of a replay once the Adam term can no longer move p (csrc/optim.hip). */
+ * the closed-form tail of a replay once the Adam term can no longer move p (csrc/optim.hip).
+ * rows_may_repeat (catch-up only): rows[] is the raw id list of the batch; one lane group per
+ * stale row wins an atomicCAS on last[row], so no sort is needed before the forward pass. */
 int mapx_table_adam(float* p0, float* m0, float* v0, int W0, float wd0, float* p1, float* m1,
                     float* v1, float wd1, int32_t* last, const int32_t* rows, int64_t row_begin,
                     int64_t n_rows, const int32_t* n_rows_dev, const float* grad0,
                     const float* grad1, const float* sched, int sched_len, const int32_t* done,
                     const double* aux, int aux_len, double beta1, double beta2, double eps,
-                    hipStream_t stream);
+                    int rows_may_repeat, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -142,6 +142,59 @@ __device__ inline void replay4(float4& p, float4& m, float4& v, int from, int to
   }
 }
 
+constexpr int kRowBusy = -1;
+
+// One row's worth of work for one lane group: catch-up through `target` updates, then (grad0)
+// update target+1.  gi = index of the row's gradient in grad0/grad1.
+template <int LG>
+__device__ inline void table_adam_row(const TableGroup& tg, int64_t r, int from, int target,
+                                      int64_t gi, const float* __restrict__ grad0,
+                                      const float* __restrict__ grad1,
+                                      const float2* __restrict__ sched, int sched_len,
+                                      const AdamHyper& h, const ReplayAux& ax, int lig) {
+  for (int sub = lig; sub * 4 < tg.W0; sub += LG) {
+    float* pp = tg.p0 + r * tg.W0 + 4 * sub;
+    float* pm = tg.m0 + r * tg.W0 + 4 * sub;
+    float* pv = tg.v0 + r * tg.W0 + 4 * sub;
+    float4 p = *reinterpret_cast<float4*>(pp);
+    float4 m = *reinterpret_cast<float4*>(pm);
+    float4 v = *reinterpret_cast<float4*>(pv);
+    replay4(p, m, v, from, target, sched, sched_len, tg.wd0, h, ax);
+    if (grad0) {
+      const float2 sc = sched[target < sched_len ? target : sched_len - 1];
+      const float4 g = *reinterpret_cast<const float4*>(grad0 + gi * tg.W0 + 4 * sub);
+      const float decay = sc.y * tg.wd0;
+      adam_elem(p.x, m.x, v.x, g.x, sc.x, decay, h);
+      adam_elem(p.y, m.y, v.y, g.y, sc.x, decay, h);
+      adam_elem(p.z, m.z, v.z, g.z, sc.x, decay, h);
+      adam_elem(p.w, m.w, v.w, g.w, sc.x, decay, h);
+    }
+    *reinterpret_cast<float4*>(pp) = p;
+    *reinterpret_cast<float4*>(pm) = m;
+    *reinterpret_cast<float4*>(pv) = v;
+  }
+  if (tg.p1 && lig == 0) {
+    float p = tg.p1[r], m = tg.m1[r], v = tg.v1[r];
+    int s = from;
+    for (; s < target; ++s) {
+      const float2 sc = sched[s < sched_len ? s : sched_len - 1];
+      if (adam_elem_zero_grad(p, m, v, sc.x, sc.y * tg.wd1, h)) { ++s; break; }
+    }
+    if (s < target) {
+      float fp, fm, fv;
+      closed_form_tail(s, target, ax, tg.wd1 != 0.f, fp, fm, fv);
+      p *= fp; m *= fm; v *= fv;
+    }
+    if (grad1) {
+      const float2 sc = sched[target < sched_len ? target : sched_len - 1];
+      adam_elem(p, m, v, grad1[gi], sc.x, sc.y * tg.wd1, h);
+    }
+    tg.p1[r] = p; tg.m1[r] = m; tg.v1[r] = v;
+  }
+  // the row's lanes sit in one wave and have all read `from` already (program order)
+  if (lig == 0) tg.last[r] = grad0 ? target + 1 : target;
+}
+
 // rows == nullptr: rows are row_begin + i (range sweep / flush), count = n_rows.
 // rows != nullptr: rows[i], count = *n_rows_dev (device, <= capacity n_rows).
 // grad == nullptr: catch-up only, rows become current through `*done` updates.
@@ -164,48 +217,45 @@ __global__ void __launch_bounds__(256) table_adam_kernel(TableGroup tg, const in
     const int64_t r = rows ? (int64_t)rows[i] : row_begin + i;
     const int from = tg.last[r];
     if (from >= target && !grad0) continue;
-    for (int sub = lig; sub * 4 < tg.W0; sub += LG) {
-      float* pp = tg.p0 + r * tg.W0 + 4 * sub;
-      float* pm = tg.m0 + r * tg.W0 + 4 * sub;
-      float* pv = tg.v0 + r * tg.W0 + 4 * sub;
-      float4 p = *reinterpret_cast<float4*>(pp);
-      float4 m = *reinterpret_cast<float4*>(pm);
-      float4 v = *reinterpret_cast<float4*>(pv);
-      replay4(p, m, v, from, target, sched, sched_len, tg.wd0, h, ax);
-      if (grad0) {
-        const float2 sc = sched[target < sched_len ? target : sched_len - 1];
-        const float4 g = *reinterpret_cast<const float4*>(grad0 + i * tg.W0 + 4 * sub);
-        const float decay = sc.y * tg.wd0;
-        adam_elem(p.x, m.x, v.x, g.x, sc.x, decay, h);
-        adam_elem(p.y, m.y, v.y, g.y, sc.x, decay, h);
-        adam_elem(p.z, m.z, v.z, g.z, sc.x, decay, h);
-        adam_elem(p.w, m.w, v.w, g.w, sc.x, decay, h);
+    table_adam_row<LG>(tg, r, from, target, i, grad0, grad1, sched, sched_len, h, ax, lig);
+  }
+}
+
+// Catch-up straight from the RAW id list of a batch (rows may repeat; no sort is needed
+// before the forward pass).  Phase 1, one entry per lane: a stale row is claimed with one
+// atomicCAS on last[row] (old value -> BUSY; repeats and other blocks lose and skip) and
+// pushed on the block's LDS work list.  Rows touched by the previous step are already
+// current and cost one read of last[], so the hot ids never reach the CAS.  Phase 2: the
+// block's lane groups drain the list, dense, so a wave is not held up by skipped entries.
+template <int LG>
+__global__ void __launch_bounds__(256) table_adam_raw_kernel(TableGroup tg, const int32_t* __restrict__ rows,
+                                                             int64_t n_rows,
+                                                             const float2* __restrict__ sched,
+                                                             int sched_len, const int32_t* __restrict__ done,
+                                                             AdamHyper h, ReplayAux ax) {
+  __shared__ int list_row[256];
+  __shared__ int list_from[256];
+  __shared__ int list_n;
+  const int target = *done;
+  for (int64_t base = (int64_t)blockIdx.x * 256; base < n_rows; base += (int64_t)gridDim.x * 256) {
+    if (threadIdx.x == 0) list_n = 0;
+    __syncthreads();
+    const int64_t i = base + threadIdx.x;
+    if (i < n_rows) {
+      const int r = rows[i];
+      const int from = tg.last[r];
+      if (from >= 0 && from < target && atomicCAS(&tg.last[r], from, kRowBusy) == from) {
+        const int k = atomicAdd(&list_n, 1);
+        list_row[k] = r;
+        list_from[k] = from;
       }
-      *reinterpret_cast<float4*>(pp) = p;
-      *reinterpret_cast<float4*>(pm) = m;
-      *reinterpret_cast<float4*>(pv) = v;
     }
-    if (tg.p1 && lig == 0) {
-      float p = tg.p1[r], m = tg.m1[r], v = tg.v1[r];
-      int s = from;
-      for (; s < target; ++s) {
-        const float2 sc = sched[s < sched_len ? s : sched_len - 1];
-        if (adam_elem_zero_grad(p, m, v, sc.x, sc.y * tg.wd1, h)) { ++s; break; }
-      }
-      if (s < target) {
-        float fp, fm, fv;
-        closed_form_tail(s, target, ax, tg.wd1 != 0.f, fp, fm, fv);
-        p *= fp; m *= fm; v *= fv;
-      }
-      if (grad1) {
-        const float2 sc = sched[target < sched_len ? target : sched_len - 1];
-        adam_elem(p, m, v, grad1[i], sc.x, sc.y * tg.wd1, h);
-      }
-      tg.p1[r] = p; tg.m1[r] = m; tg.v1[r] = v;
-    }
-    // all lanes of the row have read `from`; the row's lanes sit in one wave, so the store
-    // below cannot overtake their reads of tg.last[r] (program order within the wave)
-    if (lig == 0) tg.last[r] = grad0 ? target + 1 : target;
+    __syncthreads();
+    const int n = list_n;
+    for (int k = threadIdx.x / LG; k < n; k += 256 / LG)
+      table_adam_row<LG>(tg, list_row[k], list_from[k], target, 0, nullptr, nullptr, sched, sched_len,
+                         h, ax, threadIdx.x % LG);
+    __syncthreads();
   }
 }
 
@@ -249,13 +299,14 @@ extern "C" int mapx_table_adam(float* p0, float* m0, float* v0, int W0, float wd
                                const int32_t* n_rows_dev, const float* grad0, const float* grad1,
                                const float* sched, int sched_len, const int32_t* done,
                                const double* aux, int aux_len, double beta1, double beta2,
-                               double eps, hipStream_t stream) {
+                               double eps, int rows_may_repeat, hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(p0 && m0 && v0 && last && sched && done && aux && aux_len > 1,
                "table_adam: null pointer");
   MAPX_REQUIRE(W0 > 0 && W0 % 4 == 0, "table_adam: row width %d must be a multiple of 4", W0);
   MAPX_REQUIRE(!p1 || (m1 && v1), "table_adam: secondary state missing");
   MAPX_REQUIRE(!(grad0 && p1) || grad1, "table_adam: secondary gradient missing");
+  MAPX_REQUIRE(!rows_may_repeat || (rows && !grad0), "table_adam: repeated rows only in catch-up mode");
   if (n_rows <= 0) return MAPX_OK;
   TableGroup tg{p0, m0, v0, W0, wd0, p1, m1, v1, wd1, last};
   const int lg = (W0 <= 16) ? 4 : (W0 <= 32 ? 8 : 16);
@@ -264,8 +315,14 @@ extern "C" int mapx_table_adam(float* p0, float* m0, float* v0, int W0, float wd
   const float2* sc = reinterpret_cast<const float2*>(sched);
   const ReplayAux ax{aux, aux_len};
 #define MAPX_TA(LG_)                                                                              \
-  hipLaunchKernelGGL(table_adam_kernel<LG_>, dim3(grid), dim3(256), 0, stream, tg, rows, row_begin, \
-                     n_rows, n_rows_dev, grad0, grad1, sc, sched_len, done, h, ax)
+  do {                                                                                            \
+    if (rows_may_repeat)                                                                          \
+      hipLaunchKernelGGL(table_adam_raw_kernel<LG_>, dim3(grid_for(n_rows, 256, 4096)), dim3(256), 0, \
+                         stream, tg, rows, n_rows, sc, sched_len, done, h, ax);                    \
+    else                                                                                          \
+      hipLaunchKernelGGL(table_adam_kernel<LG_>, dim3(grid), dim3(256), 0, stream, tg, rows,       \
+                         row_begin, n_rows, n_rows_dev, grad0, grad1, sc, sched_len, done, h, ax);  \
+  } while (0)
   if (lg == 4) MAPX_TA(4);
   else if (lg == 8) MAPX_TA(8);
   else MAPX_TA(16);

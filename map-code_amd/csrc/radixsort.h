@@ -1,0 +1,94 @@
+// Stable LSD radix sort of (int32 key, int32 value = original position) pairs, 8 bits per
+// pass, for the segment plans (n <= ~1 M keys of <= 26 bits).  rocPRIM's device sort picks
+// block-sort + ~13 merge launches per sort at these sizes (0.11 ms per call, launch-latency
+// bound); three passes of {histogram, scan, scatter} do the same job in short launches.
+//
+//   histogram  one block per tile of 4096 keys: LDS histogram of the pass digit, written
+//              digit-major [digit][block] so that an exclusive scan gives every (digit, block)
+//              its base offset;
+//   scatter    the block re-reads its tile; each of the 4 waves ranks its own contiguous
+//              quarter with wave ballots (lanes holding equal digits find each other in 8
+//              ballots, rank = popcount of lower lanes) on a private LDS counter row, so no
+//              barrier is needed inside the ranking; after one barrier every item knows
+//              offset[digit][block] + counts of earlier waves + its own rank.  Equal keys keep
+//              their input order (stable), which makes the later reduce-by-key deterministic.
+#pragma once
+#include "common.h"
+
+namespace mapx {
+
+constexpr int kSortTile = 4096;   // keys per block
+constexpr int kSortItems = 16;    // per thread
+constexpr int kSortBits = 8;      // digit width (12-bit digits: 4096x156 scattered histogram cells cost more than the extra pass)
+
+__global__ void __launch_bounds__(256) radix_hist_kernel(const int32_t* __restrict__ keys, int64_t n,
+                                                         int shift, int bins, int nblocks,
+                                                         int32_t* __restrict__ bh) {
+  __shared__ int h[1 << kSortBits];
+  for (int d = threadIdx.x; d < bins; d += 256) h[d] = 0;
+  __syncthreads();
+  const int64_t t0 = (int64_t)blockIdx.x * kSortTile;
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    const int64_t i = t0 + r * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&h[((uint32_t)keys[i] >> shift) & (bins - 1)], 1);
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < bins; d += 256) bh[(int64_t)d * nblocks + blockIdx.x] = h[d];
+}
+
+template <bool IOTA>
+__global__ void __launch_bounds__(256) radix_scatter_kernel(const int32_t* __restrict__ keys,
+                                                            const int32_t* __restrict__ vals,
+                                                            int64_t n, int shift, int bits, int nblocks,
+                                                            const int32_t* __restrict__ off,
+                                                            int32_t* __restrict__ keys_out,
+                                                            int32_t* __restrict__ vals_out) {
+  extern __shared__ int cntw[];   // [4 waves][bins]
+  const int bins = 1 << bits;
+  for (int d = threadIdx.x; d < 4 * bins; d += 256) cntw[d] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int64_t seg0 = (int64_t)blockIdx.x * kSortTile + w * (kSortTile / 4);
+  int32_t key[kSortItems], val[kSortItems], lr[kSortItems];
+  int* mine = cntw + w * bins;
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    const int64_t i = seg0 + r * 64 + lane;
+    const bool valid = i < n;
+    key[r] = valid ? keys[i] : 0;
+    val[r] = valid ? (IOTA ? (int32_t)i : vals[i]) : 0;
+    const int d = ((uint32_t)key[r] >> shift) & (bins - 1);
+    uint64_t m = __ballot(valid);
+    for (int k = 0; k < bits; ++k) {
+      const bool bit = (d >> k) & 1;
+      const uint64_t b = __ballot(bit);
+      m &= bit ? b : ~b;
+    }
+    const int base = valid ? mine[d] : 0;                    // all lanes of a group read first ...
+    lr[r] = base + __popcll(m & lt);
+    if (valid && (m & lt) == 0) mine[d] = base + __popcll(m);   // ... then its lowest lane updates
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    const int64_t i = seg0 + r * 64 + lane;
+    if (i < n) {
+      const int d = ((uint32_t)key[r] >> shift) & (bins - 1);
+      int pos = off[(int64_t)d * nblocks + blockIdx.x] + lr[r];
+      for (int ww = 0; ww < w; ++ww) pos += cntw[ww * bins + d];
+      keys_out[pos] = key[r];
+      vals_out[pos] = val[r];
+    }
+  }
+}
+
+inline int radix_passes(int bits) { return (bits + kSortBits - 1) / kSortBits; }
+inline int radix_blocks(int64_t n) { return (int)ceil_div(n > 0 ? n : 1, kSortTile); }
+// ints of workspace: two ping-pong arrays + histogram + offsets
+inline size_t radix_ws_ints(int64_t n) {
+  return 2 * (size_t)n + 2 * (size_t)(1 << kSortBits) * radix_blocks(n);
+}
+
+}  // namespace mapx

@@ -3,14 +3,15 @@
 // plan serves the lazy-optimizer catch-up of the touched rows (optim.hip) and the
 // deterministic gradient reduce-by-key after the backward pass (segreduce.h).
 //
-// The radix sort and the prefix scan are rocPRIM device primitives (header-only, compiled
-// into this library); everything downstream is hand-written.
+// The sort is the hand-written 12-bit LSD radix sort of radixsort.h; the prefix scans are
+// rocPRIM device scans (header-only, compiled into this library).
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
 
 #include "../../include/mapx_hip.h"
 #include "common.h"
+#include "radixsort.h"
 #include "segreduce.h"
 
 namespace mapx {
@@ -49,11 +50,10 @@ static int key_bits_for(int64_t V) {
   return b;
 }
 
-static size_t sort_temp_bytes(int64_t n, int bits) {
+static size_t offsets_scan_temp_bytes(int64_t m) {
   size_t sz = 0;
-  rocprim::counting_iterator<int32_t> iota(0);
-  (void)rocprim::radix_sort_pairs(nullptr, sz, (const int32_t*)nullptr, (int32_t*)nullptr, iota,
-                                  (int32_t*)nullptr, (size_t)n, 0u, (unsigned)bits, hipStream_t(0));
+  (void)rocprim::exclusive_scan(nullptr, sz, (const int32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)m,
+                                rocprim::plus<int32_t>(), hipStream_t(0));
   return sz;
 }
 
@@ -68,16 +68,40 @@ static size_t scan_temp_bytes(int64_t n) {
 
 }  // namespace mapx
 
+namespace mapx {
+struct PlanWs {   // carve-up of the caller's workspace
+  int32_t *tk, *tv, *bh, *off;
+  void* scan;
+  size_t scan_bytes, total;
+};
+static PlanWs plan_ws(void* ws, int64_t n) {
+  PlanWs w;
+  const size_t hist = (size_t)(1 << kSortBits) * radix_blocks(n);
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes); return at; };
+  char* base = static_cast<char*>(ws);
+  w.tk = reinterpret_cast<int32_t*>(base + take((size_t)n * 4));
+  w.tv = reinterpret_cast<int32_t*>(base + take((size_t)n * 4));
+  w.bh = reinterpret_cast<int32_t*>(base + take(hist * 4));
+  w.off = reinterpret_cast<int32_t*>(base + take(hist * 4));
+  const size_t a = offsets_scan_temp_bytes((int64_t)hist), b = scan_temp_bytes(n);
+  w.scan_bytes = a > b ? a : b;
+  w.scan = base + take(w.scan_bytes);
+  w.total = o;
+  return w;
+}
+}  // namespace mapx
+
 extern "C" size_t mapx_seg_plan_workspace_bytes(int64_t n, int64_t V) {
+  (void)V;
   if (n <= 0) return 256;
-  const int bits = mapx::key_bits_for(V);
-  size_t a = mapx::sort_temp_bytes(n, bits), b = mapx::scan_temp_bytes(n);
-  return mapx::align_up(a > b ? a : b) + 256;
+  return mapx::plan_ws(nullptr, n).total + 256;
 }
 
 extern "C" int mapx_seg_plan(const int32_t* keys, int64_t n, int64_t V, void* ws, size_t ws_bytes,
                              int32_t* sorted_keys, int32_t* perm, int32_t* rank, int32_t* uniq,
                              int32_t* seg_start, int32_t* n_uniq, hipStream_t stream) {
+  using namespace mapx;
   MAPX_REQUIRE(n >= 0 && n < (1LL << 31) && V > 0 && V < (1LL << 31), "seg_plan: bad sizes");
   MAPX_REQUIRE(n_uniq && seg_start, "seg_plan: null output");
   if (n == 0) {
@@ -86,23 +110,45 @@ extern "C" int mapx_seg_plan(const int32_t* keys, int64_t n, int64_t V, void* ws
     return MAPX_OK;
   }
   MAPX_REQUIRE(keys && sorted_keys && perm && rank && uniq && ws, "seg_plan: null pointer");
-  const int bits = mapx::key_bits_for(V);
-  size_t need_sort = mapx::sort_temp_bytes(n, bits), need_scan = mapx::scan_temp_bytes(n);
-  if (ws_bytes < need_sort || ws_bytes < need_scan) {
-    mapx::set_error("seg_plan: workspace %zu < %zu bytes", ws_bytes,
-                    need_sort > need_scan ? need_sort : need_scan);
+  MAPX_REQUIRE((uintptr_t)ws % 256 == 0, "seg_plan: workspace must be 256-byte aligned");
+  const PlanWs w = plan_ws(ws, n);
+  if (ws_bytes < w.total) {
+    set_error("seg_plan: workspace %zu < %zu bytes", ws_bytes, w.total);
     return MAPX_EWORKSPACE;
   }
-  rocprim::counting_iterator<int32_t> iota(0);
-  MAPX_HIP(rocprim::radix_sort_pairs(ws, need_sort, keys, sorted_keys, iota, perm, (size_t)n, 0u,
-                                     (unsigned)bits, stream));
+  const int bits = key_bits_for(V), passes = radix_passes(bits), nblocks = radix_blocks(n);
+  // ping-pong so that the last pass lands in (sorted_keys, perm)
+  const int32_t* src_k = keys;
+  const int32_t* src_v = nullptr;
+  for (int p = 0; p < passes; ++p) {
+    const int shift = p * kSortBits;
+    const int db = (bits - shift) < kSortBits ? (bits - shift) : kSortBits;
+    const int bins = 1 << db;
+    const bool to_out = ((passes - 1 - p) % 2) == 0;
+    int32_t* dst_k = to_out ? sorted_keys : w.tk;
+    int32_t* dst_v = to_out ? perm : w.tv;
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(256), 0, stream, src_k, n, shift, bins,
+                       nblocks, w.bh);
+    size_t sb = w.scan_bytes;
+    MAPX_HIP(rocprim::exclusive_scan(w.scan, sb, (const int32_t*)w.bh, w.off, 0, (size_t)bins * nblocks,
+                                     rocprim::plus<int32_t>(), stream));
+    const size_t lds = (size_t)4 * bins * sizeof(int);
+    if (p == 0)
+      hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nblocks), dim3(256), lds, stream, src_k, src_v,
+                         n, shift, db, nblocks, w.off, dst_k, dst_v);
+    else
+      hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nblocks), dim3(256), lds, stream, src_k, src_v,
+                         n, shift, db, nblocks, w.off, dst_k, dst_v);
+    src_k = dst_k;
+    src_v = dst_v;
+  }
   auto flags = rocprim::make_transform_iterator(rocprim::counting_iterator<int32_t>(0),
-                                                mapx::HeadFlag{sorted_keys});
-  MAPX_HIP(rocprim::inclusive_scan(ws, need_scan, flags, rank, (size_t)n, rocprim::plus<int32_t>(),
-                                   stream));
-  hipLaunchKernelGGL(mapx::seg_mark_kernel, dim3(mapx::grid_for(n, 256)), dim3(256), 0, stream,
-                     sorted_keys, rank, n, uniq, seg_start, n_uniq);
-  return mapx::check_launch("seg_plan");
+                                                HeadFlag{sorted_keys});
+  size_t sb = w.scan_bytes;
+  MAPX_HIP(rocprim::inclusive_scan(w.scan, sb, flags, rank, (size_t)n, rocprim::plus<int32_t>(), stream));
+  hipLaunchKernelGGL(seg_mark_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, sorted_keys, rank, n,
+                     uniq, seg_start, n_uniq);
+  return check_launch("seg_plan");
 }
 
 // Generic reduce-by-key of dense rows: out[u, :] = sum over the positions of key uniq[u] of

@@ -11,6 +11,16 @@ from . import ops
 
 
 # ----------------------------------------------------------------------------- row tables
+_side_streams = {}
+
+
+def _side_stream(device):
+    s = _side_streams.get(device.index)
+    if s is None:
+        s = _side_streams[device.index] = torch.cuda.Stream(device=device)
+    return s
+
+
 class RowTable:
     """A [V, W] parameter table read by row id, with row-sparse gradients.
 
@@ -31,15 +41,30 @@ class RowTable:
         return self.p0.shape[0]
 
     def prepare(self, keys_i32, need_plan):
-        """Sort this step's row ids; bring exactly those rows up to date.  Returns the plan."""
-        stale = self.lazy is not None and self.lazy.stale
-        if not (need_plan or stale):
-            self.plan = None
-            return None
-        self.plan = ops.SegPlan(keys_i32, self.num_rows)
-        if stale:
-            self.lazy.catch_up(self.plan)
+        """Called by the forward pass with this step's row ids (repeats allowed).
+        * stale rows among them are brought up to date on the current stream, straight from the
+          raw id list (ownership by atomicCAS in the kernel): nothing on the critical path
+          waits for a sort;
+        * when gradients will be needed, the segment plan (sort + runs) is built on a side
+          stream, concurrently with the forward/backward GEMMs, and joined in backward."""
+        if self.lazy is not None and self.lazy.stale:
+            self.lazy.catch_up_raw(keys_i32)
+        self.plan = None
+        if need_plan:
+            main = torch.cuda.current_stream()
+            side = _side_stream(keys_i32.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.plan = ops.SegPlan(keys_i32, self.num_rows)
+            keys_i32.record_stream(side)
+            for t in self.plan.tensors():
+                t.record_stream(main)
         return self.plan
+
+    @staticmethod
+    def join_plan(device):
+        """Make the current stream wait for the plans being built on the side stream."""
+        torch.cuda.current_stream().wait_stream(_side_stream(device))
 
     def dense_grad(self):
         """Reference-layout dense gradients [(V,W), (V,1)|None] from the sparse ones (tests)."""
@@ -75,6 +100,7 @@ class _Gather(Function):
     def backward(ctx, g):
         if ctx.plan is None:
             raise RuntimeError("embedding backward without a segment plan")
+        RowTable.join_plan(g.device)
         g = g.contiguous().view(-1, ctx.width)
         ctx.table.sparse_grad = (ctx.plan, ops.seg_reduce_rows(ctx.plan, g, ctx.width), None)
         return None, None, None

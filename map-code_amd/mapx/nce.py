@@ -74,6 +74,7 @@ class _NceLoss(Function):
         denc = ops.nce_scatter_dh(dh, mi, ctx.F, ctx.P, gscale=gl)
         if ctx.plan is None:
             raise RuntimeError("NCE backward without a segment plan")
+        RowTable.join_plan(dlogit.device)
         ops.scale_(dlogit, gl)
         ge, gb = ops.nce_table_grad(ctx.plan, dlogit, h, ctx.K, ctx.P)
         ctx.crit.table.sparse_grad = (ctx.plan, ge, gb)

@@ -118,6 +118,9 @@ class SegPlan:
                                     ptr(self.perm), ptr(self.rank), ptr(self.uniq), ptr(self.seg_start),
                                     ptr(self.n_uniq), stream()))
 
+    def tensors(self):
+        return (self.sorted_keys, self.perm, self.rank, self.uniq, self.seg_start, self.n_uniq)
+
     def count(self):
         """Number of unique keys (host sync)."""
         return int(self.n_uniq.item())
@@ -415,7 +418,8 @@ def step_advance(done):
 
 
 def table_adam(p0, m0, v0, wd0, last, sched, done, aux, beta1, beta2, eps, p1=None, m1=None, v1=None,
-               wd1=0.0, rows=None, n_rows_dev=None, row_begin=0, n_rows=None, grad0=None, grad1=None):
+               wd1=0.0, rows=None, n_rows_dev=None, row_begin=0, n_rows=None, grad0=None, grad1=None,
+               rows_may_repeat=False):
     require_gpu(p0, m0, v0, last, sched, done)
     W0 = p0.shape[1]
     if n_rows is None:
@@ -426,4 +430,4 @@ def table_adam(p0, m0, v0, wd0, last, sched, done, aux, beta1, beta2, eps, p1=No
         check(lib.mapx_table_adam(ptr(p0), ptr(m0), ptr(v0), W0, wd0, ptr(p1), ptr(m1), ptr(v1), wd1,
                                   ptr(last), ptr(rows), row_begin, n_rows, ptr(n_rows_dev), ptr(grad0),
                                   ptr(grad1), ptr(sched), sched.shape[0], ptr(done), ptr(aux),
-                                  aux.shape[1], beta1, beta2, eps, stream()))
+                                  aux.shape[1], beta1, beta2, eps, int(rows_may_repeat), stream()))

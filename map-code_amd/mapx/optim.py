@@ -63,6 +63,10 @@ class TableAdam:
     def catch_up(self, plan):
         self._call(rows=plan.uniq, n_rows=plan.n, n_rows_dev=plan.n_uniq)
 
+    def catch_up_raw(self, keys_i32):
+        """Catch-up straight from a raw id list (repeats allowed; no sort on the critical path)."""
+        self._call(rows=keys_i32, n_rows=keys_i32.numel(), rows_may_repeat=True)
+
     def update(self):
         sg = self.table.sparse_grad
         if sg is None:

@@ -434,3 +434,35 @@ def test_errors_are_loud(ops):
         ops.nce_fwd(torch.zeros(2, 23 * 12, device=DEV), torch.zeros(2, 6, dtype=torch.int64, device=DEV),
                     torch.zeros(12, 26, dtype=torch.int32, device=DEV), torch.zeros(10, 12, device=DEV),
                     torch.zeros(10, device=DEV), torch.zeros(10, device=DEV), 23, 12)   # P = 12 unsupported
+
+
+def test_catch_up_from_raw_repeating_ids(ops):
+    """table_adam with rows_may_repeat: the raw batch id list (heavy repeats, hot id) brings every
+    distinct stale row up to date exactly once."""
+    from oracle import ref_model as R
+    T, V, W = 30, 500, 16
+    sched, lambdas = _sched(ops, T + 5)
+    aux = ops.make_replay_aux(1e-3, lambdas, 0.9, 0.999, 0.05).to(DEV)
+    g = torch.Generator().manual_seed(2)
+    p0 = torch.randn(V, W, generator=g)
+    m0, v0 = 0.01 * torch.randn(V, W, generator=g), 1e-4 * torch.rand(V, W, generator=g)
+    pr, mr, vr = p0.clone(), m0.clone(), v0.clone()
+    for s in range(1, T + 1):
+        R.hf_adamw_step(pr, torch.zeros(V, W), mr, vr, s, 1e-3 * lambdas[s - 1], wd=0.05)
+    p, m, v = p0.to(DEV).clone(), m0.to(DEV).clone(), v0.to(DEV).clone()
+    last = torch.zeros(V, dtype=torch.int32, device=DEV)
+    done = torch.full((1,), T, dtype=torch.int32, device=DEV)
+    ids = torch.randint(0, 200, (50000,), generator=g)
+    ids[:20000] = 3
+    ops.table_adam(p, m, v, 0.05, last, sched, done, aux, 0.9, 0.999, 1e-8,
+                   rows=ids.to(torch.int32).to(DEV), rows_may_repeat=True)
+    touched = torch.zeros(V, dtype=torch.bool).index_fill_(0, ids.unique(), True)
+    lc = _cpu(last)
+    assert bool((lc[touched] == T).all()) and bool((lc[~touched] == 0).all())
+    np.testing.assert_allclose(_cpu(p)[touched].numpy(), pr[touched].numpy(), rtol=1e-5, atol=1e-7)
+    assert torch.equal(_cpu(p)[~touched], p0[~touched])
+    # second call: everything current -> no change at all
+    before = p.clone()
+    ops.table_adam(p, m, v, 0.05, last, sched, done, aux, 0.9, 0.999, 1e-8,
+                   rows=ids.to(torch.int32).to(DEV), rows_may_repeat=True)
+    assert torch.equal(p, before)
