@@ -47,9 +47,10 @@ struct GemmArgs {
   int k_chunk;                       // split-K: K range per blockIdx.y (multiple of BK)
   int64_t slab_stride;               // split-K: C offset per split
   int tiles_m, tiles_n;
+  int dbg;                           // timing experiments only (tile_hint >> 8): 1 = no loads in the loop, 2 = no LDS stores
 };
 
-constexpr int BK = 32;
+constexpr int kBK = 32;   // default K-step
 
 // One operand's staging: global tile -> registers -> LDS, and LDS -> MFMA fragments.
 // Branch-free loads: every lane always loads (from a clamped, valid address); what lies
@@ -57,7 +58,7 @@ constexpr int BK = 32;
 // the loaded registers before the MFMAs of the current tile have been issued.
 // VEC requires: leading dimension % 4 == 0, 16-B aligned base, and the contiguous extent
 // (K for k-contiguous operands, M|N otherwise) % 4 == 0: a float4 is all-in or all-out.
-template <int ROWS /*BM or BN*/, int T /*32-row MFMA tiles per wave*/, bool KC, bool VEC>
+template <int ROWS /*BM or BN*/, int T /*32-row MFMA tiles per wave*/, bool KC, bool VEC, int BK>
 struct Operand {
   static constexpr int LD = KC ? BK + 4 : ROWS + 4;
   static constexpr int LDS_FLOATS = KC ? ROWS * LD : BK * LD;
@@ -71,7 +72,7 @@ struct Operand {
 
   __device__ static inline void coords(int f, int& row, int& col) {
     // (row, col) of float4 #f in the tile's storage order; col is the contiguous index
-    if (KC) { row = f >> 3; col = (f & 7) << 2; }                    // [ROWS][BK]
+    if (KC) { row = f / (BK / 4); col = (f % (BK / 4)) << 2; }       // [ROWS][BK]
     else { constexpr int PER = ROWS / 4; row = f / PER; col = (f % PER) << 2; }   // [BK][ROWS]
   }
 
@@ -92,19 +93,24 @@ struct Operand {
 
   // Full K-step (k0 + BK <= kend): `gk` = operand base advanced to this K-step, wave-uniform
   // (g + k0 for k-contiguous storage, g + k0*ld otherwise): no per-lane address arithmetic.
+  __device__ inline void load_full_one(const float* __restrict__ gk, int i) {
+    ok[i] = inb[i];
+    r[i] = *reinterpret_cast<const float4*>(gk + off[i]);
+  }
   __device__ inline void load_full(const float* __restrict__ gk) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      ok[i] = inb[i];
-      r[i] = *reinterpret_cast<const float4*>(gk + off[i]);
-    }
+    for (int i = 0; i < NV; ++i) load_full_one(gk, i);
   }
 
   // General K-step (K tail, unaligned operands): clamped addresses + per-element predicates.
   __device__ inline void load(const float* __restrict__ g, int64_t ld, int row0, int nrows,
                               int k0, int kend) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
+    for (int i = 0; i < NV; ++i) load_one(g, ld, row0, nrows, k0, kend, i);
+  }
+  __device__ inline void load_one(const float* __restrict__ g, int64_t ld, int row0, int nrows,
+                                  int k0, int kend, int i) {
+    {
       int tr, tc;
       coords(threadIdx.x + i * 256, tr, tc);
       const int gr = (KC ? row0 : k0) + tr, gc = (KC ? k0 : row0) + tc;
@@ -126,14 +132,16 @@ struct Operand {
   }
 
   template <bool MASK>
+  __device__ inline void store_one(float* __restrict__ s, int i) const {
+    int tr, tc;
+    coords(threadIdx.x + i * 256, tr, tc);
+    const float4 v = (!MASK || ok[i]) ? r[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(s + tr * LD + tc) = v;
+  }
+  template <bool MASK>
   __device__ inline void store(float* __restrict__ s) const {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      int tr, tc;
-      coords(threadIdx.x + i * 256, tr, tc);
-      const float4 v = (!MASK || ok[i]) ? r[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(s + tr * LD + tc) = v;
-    }
+    for (int i = 0; i < NV; ++i) store_one<MASK>(s, i);
   }
 
   // fragments of k-group q (8 k values) for this wave's T tiles: f[t][s], s = MFMA step
@@ -187,11 +195,11 @@ __device__ inline void epilogue(const GemmArgs& a, float* __restrict__ C, f32x16
   }
 }
 
-template <int WMT, int WNT, bool A_KC, bool B_KC, bool VEC>
+template <int WMT, int WNT, bool A_KC, bool B_KC, bool VEC, int BK>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs a) {
   constexpr int BM = 64 * WMT, BN = 64 * WNT;
-  using OpA = Operand<BM, WMT, A_KC, VEC>;
-  using OpB = Operand<BN, WNT, B_KC, VEC>;
+  using OpA = Operand<BM, WMT, A_KC, VEC, BK>;
+  using OpB = Operand<BN, WNT, B_KC, VEC, BK>;
   __shared__ __attribute__((aligned(16))) float As[2][OpA::LDS_FLOATS];
   __shared__ __attribute__((aligned(16))) float Bs[2][OpB::LDS_FLOATS];
 
@@ -221,69 +229,113 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  OpA la;
-  OpB lb;
-  la.init(a.lda, m0, a.M);
-  lb.init(a.ldb, n0, a.N);
+  // Two register sets per operand: set (t & 1) carries tile t from its global load (issued during
+  // K-step t-2) to its LDS store (during K-step t-1).  Loads and stores are cut into per-k-group
+  // slices and interleaved with the MFMAs of the tile being computed, so that they issue in
+  // the shadow of the 64-cycle MFMAs instead of before / after the MFMA block.
+  OpA la[2];
+  OpB lb[2];
+  la[0].init(a.lda, m0, a.M);
+  lb[0].init(a.ldb, n0, a.N);
+#pragma unroll
+  for (int i = 0; i < OpA::NV; ++i) { la[1].off[i] = la[0].off[i]; la[1].inb[i] = la[0].inb[i]; }
+#pragma unroll
+  for (int i = 0; i < OpB::NV; ++i) { lb[1].off[i] = lb[0].off[i]; lb[1].inb[i] = lb[0].inb[i]; }
   const int nk = (kend - kbeg + BK - 1) / BK;
   const int nk_full = VEC ? (kend - kbeg) / BK : 0;          // K-steps on the fast load path
   // interior tiles need no zero-fill of out-of-matrix rows (block-uniform -> scalar branch)
   const bool interior = VEC && (m0 + BM <= a.M) && (n0 + BN <= a.N);
   const int64_t astep = A_KC ? 1 : a.lda, bstep = B_KC ? 1 : a.ldb;
-#define MAPX_LOAD_TILE(kt_)                                                         \
-  do {                                                                              \
-    const int k0_ = kbeg + (kt_) * BK;                                              \
-    if ((kt_) < nk_full) {                                                          \
-      la.load_full(a.A + (int64_t)k0_ * astep);                                     \
-      lb.load_full(a.B + (int64_t)k0_ * bstep);                                     \
-    } else {                                                                        \
-      la.load(a.A, a.lda, m0, a.M, k0_, kend);                                      \
-      lb.load(a.B, a.ldb, n0, a.N, k0_, kend);                                      \
-    }                                                                               \
+  constexpr int NQ = BK / 8;                                  // k-groups per K-step
+  constexpr int SA = (OpA::NV + NQ - 1) / NQ, SB = (OpB::NV + NQ - 1) / NQ;   // slice sizes
+
+  // slice `q` of the global loads of tile `t` into register set `set`.  FULL (literal true):
+  // the caller guarantees a full K-step -> no branch, the slice stays in the MFMAs' basic block.
+#define MAPX_LOAD_SLICE(set, t, q, FULL)                                                         \
+  do {                                                                                           \
+    const int k0_ = kbeg + (t) * BK;                                                             \
+    const bool full_ = (FULL) || (t) < nk_full;                                                  \
+    _Pragma("unroll") for (int i_ = (q) * SA; i_ < ((q) + 1) * SA && i_ < OpA::NV; ++i_) {       \
+      if (full_) la[set].load_full_one(a.A + (int64_t)k0_ * astep, i_);                          \
+      else la[set].load_one(a.A, a.lda, m0, a.M, k0_, kend, i_);                                 \
+    }                                                                                            \
+    _Pragma("unroll") for (int i_ = (q) * SB; i_ < ((q) + 1) * SB && i_ < OpB::NV; ++i_) {       \
+      if (full_) lb[set].load_full_one(a.B + (int64_t)k0_ * bstep, i_);                          \
+      else lb[set].load_one(a.B, a.ldb, n0, a.N, k0_, kend, i_);                                 \
+    }                                                                                            \
   } while (0)
-#define MAPX_STORE_TILE(kt_, buf_)                                                  \
-  do {                                                                              \
-    if (interior && (kt_) < nk_full) {                                              \
-      la.template store<false>(As[buf_]);                                           \
-      lb.template store<false>(Bs[buf_]);                                           \
-    } else {                                                                        \
-      la.template store<true>(As[buf_]);                                            \
-      lb.template store<true>(Bs[buf_]);                                            \
-    }                                                                               \
+  // slice `q` of the LDS stores of the tile held in register set `set` into buffer `buf`
+#define MAPX_STORE_SLICE(set, buf, q, MASK)                                                      \
+  do {                                                                                           \
+    _Pragma("unroll") for (int i_ = (q) * SA; i_ < ((q) + 1) * SA && i_ < OpA::NV; ++i_)         \
+      la[set].template store_one<MASK>(As[buf], i_);                                             \
+    _Pragma("unroll") for (int i_ = (q) * SB; i_ < ((q) + 1) * SB && i_ < OpB::NV; ++i_)         \
+      lb[set].template store_one<MASK>(Bs[buf], i_);                                             \
   } while (0)
+
   if (nk > 0) {
-    MAPX_LOAD_TILE(0);
-    MAPX_STORE_TILE(0, 0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) MAPX_LOAD_SLICE(0, 0, q, false);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) MAPX_STORE_SLICE(0, 0, q, true);
+    if (nk > 1) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) MAPX_LOAD_SLICE(1, 1, q, false);
+    }
   }
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) MAPX_LOAD_TILE(kt + 1);   // next tile's loads fly under this tile's MFMAs
-    float af[2][WMT][4], bf[2][WNT][4];
-    OpA::frags(As[cur], abase, l31, kh, 0, af[0]);
-    OpB::frags(Bs[cur], bbase, l31, kh, 0, bf[0]);
-#pragma unroll
-    for (int q = 0; q < BK / 8; ++q) {
-      const int c = q & 1;
-      if (q + 1 < BK / 8) {   // fragments one k-group ahead of the MFMAs that consume them
-        OpA::frags(As[cur], abase, l31, kh, q + 1, af[c ^ 1]);
-        OpB::frags(Bs[cur], bbase, l31, kh, q + 1, bf[c ^ 1]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < WMT; ++i)
-#pragma unroll
-          for (int j = 0; j < WNT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i][s], bf[c][j][s], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+
+  // One K-step: MFMAs on LDS buffer SET; store tile kt+1 (register set SET^1) into the other
+  // buffer; load tile kt+2 into set SET.  SET = kt & 1 is a literal (loop unrolled by 2).
+  // STEADY (literal): tiles kt+1 and kt+2 exist and are full K-steps -> the body is one basic
+  // block and the sched_group_barrier pattern puts one memory instruction behind every MFMA.
+#define MAPX_KSTEP(SET, kt, STEADY, MASK)                                                        \
+  do {                                                                                           \
+    float af[2][WMT][4], bf[2][WNT][4];                                                          \
+    OpA::frags(As[SET], abase, l31, kh, 0, af[0]);                                               \
+    OpB::frags(Bs[SET], bbase, l31, kh, 0, bf[0]);                                               \
+    _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                             \
+      const int c = q & 1;                                                                       \
+      if (q + 1 < NQ) {                                                                          \
+        OpA::frags(As[SET], abase, l31, kh, q + 1, af[c ^ 1]);                                   \
+        OpB::frags(Bs[SET], bbase, l31, kh, q + 1, bf[c ^ 1]);                                   \
+      }                                                                                          \
+      if ((STEADY) || (kt) + 1 < nk) MAPX_STORE_SLICE((SET) ^ 1, (SET) ^ 1, q, MASK);            \
+      if ((STEADY) || (kt) + 2 < nk) MAPX_LOAD_SLICE(SET, (kt) + 2, q, STEADY);                  \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s)                                              \
+        _Pragma("unroll") for (int i = 0; i < WMT; ++i)                                          \
+          _Pragma("unroll") for (int j = 0; j < WNT; ++j)                                        \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i][s], bf[c][j][s], acc[i][j], 0, 0, 0); \
+      if (STEADY) {                                                                              \
+        _Pragma("unroll") for (int z = 0; z < 4 * WMT * WNT; ++z) {                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
+          __builtin_amdgcn_sched_group_barrier(0x330, 1, 0);                                     \
+        }                                                                                        \
+      }                                                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+    }                                                                                            \
+    __syncthreads();                                                                             \
+  } while (0)
+
+  int kt = 0;
+  if (interior) {
+    for (; kt + 3 < nk_full; kt += 2) {
+      MAPX_KSTEP(0, kt, true, false);
+      MAPX_KSTEP(1, kt + 1, true, false);
     }
-    if (kt + 1 < nk) MAPX_STORE_TILE(kt + 1, cur ^ 1);
-    __syncthreads();
+  } else {
+    for (; kt + 3 < nk_full; kt += 2) {
+      MAPX_KSTEP(0, kt, true, true);
+      MAPX_KSTEP(1, kt + 1, true, true);
+    }
   }
-#undef MAPX_LOAD_TILE
-#undef MAPX_STORE_TILE
+  for (; kt < nk; kt += 2) {
+    MAPX_KSTEP(0, kt, false, true);
+    if (kt + 1 < nk) MAPX_KSTEP(1, kt + 1, false, true);
+  }
+#undef MAPX_KSTEP
+#undef MAPX_LOAD_SLICE
+#undef MAPX_STORE_SLICE
 
   const int mbase = m0 + abase, nbase = n0 + bbase;
   switch (a.epi) {
@@ -359,26 +411,28 @@ __global__ void __launch_bounds__(256) cross_bwd_pre_kernel(const float* __restr
   }
 }
 
-template <int WMT, int WNT, bool A_KC, bool B_KC>
+template <int WMT, int WNT, bool A_KC, bool B_KC, int BK>
 static void launch_tile(const GemmArgs& a, bool vec, int nsplit, hipStream_t stream) {
   dim3 grid(a.tiles_m * a.tiles_n, nsplit);
   if (vec)
-    hipLaunchKernelGGL((gemm_f32_kernel<WMT, WNT, A_KC, B_KC, true>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((gemm_f32_kernel<WMT, WNT, A_KC, B_KC, true, BK>), grid, dim3(256), 0, stream, a);
   else
-    hipLaunchKernelGGL((gemm_f32_kernel<WMT, WNT, A_KC, B_KC, false>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((gemm_f32_kernel<WMT, WNT, A_KC, B_KC, false, BK>), grid, dim3(256), 0, stream, a);
 }
 
 template <bool A_KC, bool B_KC>
 static void launch_layout(GemmArgs& a, bool vec, int tile, int nsplit, hipStream_t stream) {
-  if (tile == 2) {
+  if (tile == 2 || tile == 3) {
     a.tiles_m = (a.M + 127) / 128; a.tiles_n = (a.N + 127) / 128;
-    launch_tile<2, 2, A_KC, B_KC>(a, vec, nsplit, stream);
+    if (tile == 3) launch_tile<2, 2, A_KC, B_KC, 64>(a, vec, nsplit, stream);
+    else launch_tile<2, 2, A_KC, B_KC, 32>(a, vec, nsplit, stream);
   } else if (tile == 1) {
     a.tiles_m = (a.M + 127) / 128; a.tiles_n = (a.N + 63) / 64;
-    launch_tile<2, 1, A_KC, B_KC>(a, vec, nsplit, stream);
+    launch_tile<2, 1, A_KC, B_KC, 32>(a, vec, nsplit, stream);
   } else {
     a.tiles_m = (a.M + 63) / 64; a.tiles_n = (a.N + 63) / 64;
-    launch_tile<1, 1, A_KC, B_KC>(a, vec, nsplit, stream);
+    if (tile == 4) launch_tile<1, 1, A_KC, B_KC, 64>(a, vec, nsplit, stream);
+    else launch_tile<1, 1, A_KC, B_KC, 32>(a, vec, nsplit, stream);
   }
 }
 
@@ -409,14 +463,14 @@ extern "C" int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
   g.M = M; g.N = N; g.K = K; g.epi = epi; g.bias = bias;
   g.aux1 = aux1; g.ld1 = ld1; g.aux2 = aux2; g.ld2 = ld2; g.out2 = out2; g.ldo2 = ldo2;
-  g.k_chunk = K > 0 ? K : BK; g.slab_stride = 0;
+  g.k_chunk = K > 0 ? K : kBK; g.slab_stride = 0;
   if (nsplit > 1) {
     const size_t need = mapx_gemm_splitk_workspace_bytes(M, N, nsplit);
     if (!ws || ws_bytes < need) {
       set_error("gemm_f32: split-K workspace %zu < %zu", ws_bytes, need);
       return MAPX_EWORKSPACE;
     }
-    int kc = (int)ceil_div(ceil_div(K, nsplit), BK) * BK;
+    int kc = (int)ceil_div(ceil_div(K, nsplit), 64) * 64;
     g.k_chunk = kc;
     nsplit = (int)ceil_div(K, kc);
     g.C = static_cast<float*>(ws);
@@ -433,7 +487,9 @@ extern "C" int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   auto blocks = [&](int bm, int bn) { return ceil_div(M, bm) * ceil_div(N, bn) * nsplit; };
   const int64_t big = blocks(128, 128);
   int tile = (big >= 240 && (big % 256 == 0 || big % 256 >= 224 || big >= 1024)) ? 2 : 0;
-  if (tile_hint >= 0 && tile_hint <= 2) tile = tile_hint;   // 2: 128x128, 1: 128x64, 0: 64x64
+  g.dbg = tile_hint >= 0 ? (tile_hint >> 8) : 0;
+  if (tile_hint >= 0) tile_hint &= 255;
+  if (tile_hint >= 0 && tile_hint <= 4) tile = tile_hint;   // 2: 128x128, 1: 128x64, 0: 64x64; 3/4: 128x128 / 64x64 with BK = 64
   if (a_kc && b_kc) launch_layout<true, true>(g, vec, tile, nsplit, stream);
   else if (a_kc) launch_layout<true, false>(g, vec, tile, nsplit, stream);
   else launch_layout<false, false>(g, vec, tile, nsplit, stream);

@@ -286,9 +286,9 @@ def _splits_for(M, Nn, Kred):
     (tools/gemm_bench.py sweep on MI355X)."""
     tiles = math.ceil(M / 64) * math.ceil(Nn / 64)
     want = max(1.0, 1024.0 / tiles)
-    ns = 1
-    while ns * 2 <= want + 1e-9 and ns < 16 and Kred // (ns * 2) >= 256:
-        ns *= 2
+    ns = min(16, 2 ** int(round(math.log2(want))))
+    while ns > 1 and Kred // ns < 256:
+        ns //= 2
     return ns
 
 

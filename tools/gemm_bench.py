@@ -45,7 +45,7 @@ def main():
                 akc, bkc = False, False
             out = torch.empty(M, N, device=dev)
             res = []
-            for tile in (2, 1, 0):
+            for tile in (2, 3, 0, 4):
                 for ns in ((1,) if kind != "dw" else (1, 2, 4, 8, 16)):
                     us = timeit(lambda: ops.gemm(a, b, akc, bkc, M, N, K, out=out, nsplit=ns, tile=tile))
                     res.append((us, tile, ns))
