@@ -177,10 +177,12 @@ def main():
     # per-kernel durations: HIP events on the launch stream around every kernel class, taken on
     # the same step run eagerly right after the timed region (a graph replay has no
     # per-kernel launch points to bracket; kernel durations do not depend on the launch mode)
+    ops.serialize_streams = True          # no side streams: every kernel is timed running alone
     with ops.Timers() as timers:
         for X, Y in staged[:max(5, min(20, args.steps))]:
             tr._mfp_step(X, Y)
     torch.cuda.synchronize()
+    ops.serialize_streams = False
     ksteps = max(5, min(20, args.steps))
     if rank != 0:
         return

@@ -6,6 +6,7 @@ import logging
 import torch
 from torch import nn
 
+from . import ops
 from .arguments import Config
 from .layers import CrossNetV2, Embeddings, HipLinear, MLPBlock, bce_with_logits
 from .nce import IndexLinear
@@ -139,11 +140,23 @@ class DCNV2(BaseModel):
 
     def forward(self, input_ids, labels=None, masked_index=None, noise_samples=None):
         feat_embed = self.embed(input_ids).flatten(start_dim=1)
-        cross_output = self.cross_net(feat_embed)
         if self.config.num_hidden_layers > 0:
-            final_output = torch.cat([cross_output, self.parallel_dnn(feat_embed)], dim=-1)
+            # the two towers are independent: the cross tower's small GEMMs (D x D) run on a
+            # second stream and fill the tails of the deep tower's big ones (autograd replays
+            # the same stream assignment in backward)
+            main = torch.cuda.current_stream()
+            tower = ops.aux_stream("tower", feat_embed.device)
+            tower.wait_stream(main)
+            with torch.cuda.stream(tower):
+                cross_output = self.cross_net(feat_embed)
+            dnn_output = self.parallel_dnn(feat_embed)
+            main.wait_stream(tower)
+            if tower is not main:
+                feat_embed.record_stream(tower)
+                cross_output.record_stream(main)
+            final_output = torch.cat([cross_output, dnn_output], dim=-1)
         else:
-            final_output = cross_output
+            final_output = self.cross_net(feat_embed)
         if self.config.pretrain:
             return self.get_outputs(final_output, labels, masked_index, noise_samples=noise_samples)
         return self.get_outputs(self.fc_out(final_output), labels)

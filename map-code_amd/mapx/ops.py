@@ -58,6 +58,25 @@ class _timed:
             _timers.events.setdefault(self.name, []).append((self.a, b, self.work))
 
 
+# --------------------------------------------------------------------------- auxiliary streams
+# Independent pieces of a step run on named side streams so that small or tail-heavy kernels
+# fill the gaps of the big GEMMs: "plan" (sort + runs of the row ids) and "tower" (DCNv2's cross
+# tower next to the deep tower).
+# serialize_streams = True maps them all onto the current stream (per-kernel timing passes).
+_aux_streams = {}
+serialize_streams = False
+
+
+def aux_stream(name, device):
+    if serialize_streams:
+        return torch.cuda.current_stream()
+    key = (name, device.index)
+    st = _aux_streams.get(key)
+    if st is None:
+        st = _aux_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 def scratch(nbytes, device):
     key = (device.index, stream())
     buf = _scratch.get(key)
