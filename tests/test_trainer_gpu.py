@@ -106,6 +106,22 @@ def test_training_trajectory_matches_reference_semantics(mode, kind, warm):
         assert opt.get_last_lr()[0] == pytest.approx(lr0 * __import__("mapx.optim", fromlist=["x"]).lr_lambda(kind, s + 1, total, warmup))
     np.testing.assert_allclose(losses, ref_losses, rtol=2e-5)
     opt.flush()                       # lazy rows -> reference-equivalent weights
+    if mode == "CTR":
+        # BASELINE config 5: AUC on held-out rows after the same training within 1e-4 of the
+        # reference path (here: identical to ~1e-6 because the parameters agree to 1e-4)
+        from sklearn.metrics import roc_auc_score
+        from oracle import ref_model as R
+        held = _step_inputs(case, cfg, 999)
+        model.eval()
+        with torch.no_grad():
+            (logits,) = model(input_ids=t(held["ids"], DEV))
+            ref_logits = R.ctr_head(ref_params, R.trunk(ref_params, t(held["ids"]), cfg["NC"], cfg["NL"]))[0]
+        y = held["y"]
+        auc = roc_auc_score(y, torch.sigmoid(logits.view(-1)).cpu().numpy())
+        auc_ref = roc_auc_score(y, torch.sigmoid(ref_logits.view(-1)).numpy())
+        assert abs(auc - auc_ref) < 1e-4, (auc, auc_ref)
+        np.testing.assert_allclose(logits.cpu().numpy(), ref_logits.numpy(), rtol=1e-4, atol=1e-5)
+        model.train()
     sd = model.state_dict()
     for k, ref in ref_params.items():
         got = sd[k].cpu()
