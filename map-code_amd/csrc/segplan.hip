@@ -5,6 +5,7 @@
 //
 // The sort is the hand-written 12-bit LSD radix sort of radixsort.h; the prefix scans are
 // rocPRIM device scans (header-only, compiled into this library).
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -69,6 +70,24 @@ static size_t scan_temp_bytes(int64_t n) {
 }  // namespace mapx
 
 namespace mapx {
+// rocPRIM's radix sort with the merge-sort shortcut disabled (MergeSortLimit = 0): Onesweep
+// (one histogram launch + one scan + one decoupled-look-back pass per digit) at every size.
+using OnesweepCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                               rocprim::default_config, 0>;
+static size_t onesweep_temp_bytes(int64_t n, int bits) {
+  size_t sz = 0;
+  rocprim::counting_iterator<int32_t> iota(0);
+  (void)rocprim::radix_sort_pairs<OnesweepCfg>(nullptr, sz, (const int32_t*)nullptr, (int32_t*)nullptr, iota,
+                                               (int32_t*)nullptr, (size_t)n, 0u, (unsigned)bits,
+                                               hipStream_t(0));
+  return sz;
+}
+// measured inside the full step (MI355X): hand-written passes 1.70 ms/step, Onesweep 1.76 ms/step
+static int sort_mode() {   // 0 = hand-written LSD passes (radixsort.h, default), 1 = rocPRIM Onesweep
+  static int m = [] { const char* e = getenv("MAPX_SORT"); return e ? atoi(e) : 0; }();
+  return m;
+}
+
 struct PlanWs {   // carve-up of the caller's workspace
   int32_t *tk, *tv, *bh, *off;
   void* scan;
@@ -85,7 +104,9 @@ static PlanWs plan_ws(void* ws, int64_t n) {
   w.bh = reinterpret_cast<int32_t*>(base + take(hist * 4));
   w.off = reinterpret_cast<int32_t*>(base + take(hist * 4));
   const size_t a = offsets_scan_temp_bytes((int64_t)hist), b = scan_temp_bytes(n);
+  const size_t c = onesweep_temp_bytes(n, 31);
   w.scan_bytes = a > b ? a : b;
+  if (c > w.scan_bytes) w.scan_bytes = c;
   w.scan = base + take(w.scan_bytes);
   w.total = o;
   return w;
@@ -117,10 +138,16 @@ extern "C" int mapx_seg_plan(const int32_t* keys, int64_t n, int64_t V, void* ws
     return MAPX_EWORKSPACE;
   }
   const int bits = key_bits_for(V), passes = radix_passes(bits), nblocks = radix_blocks(n);
+  if (sort_mode() == 1) {
+    rocprim::counting_iterator<int32_t> iota(0);
+    size_t sb = w.scan_bytes;
+    MAPX_HIP(rocprim::radix_sort_pairs<OnesweepCfg>(w.scan, sb, keys, sorted_keys, iota, perm, (size_t)n, 0u,
+                                                    (unsigned)bits, stream));
+  }
   // ping-pong so that the last pass lands in (sorted_keys, perm)
   const int32_t* src_k = keys;
   const int32_t* src_v = nullptr;
-  for (int p = 0; p < passes; ++p) {
+  for (int p = 0; p < passes && sort_mode() == 0; ++p) {
     const int shift = p * kSortBits;
     const int db = (bits - shift) < kSortBits ? (bits - shift) : kSortBits;
     const int bins = 1 << db;
