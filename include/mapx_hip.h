@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 6
+#define MAPX_ABI_VERSION 8
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -148,6 +148,13 @@ int mapx_colsum(const float* x, int64_t ld, int M, int N, float* out, void* ws, 
 int mapx_cross_bwd_pre(const float* g, const float* x0, const float* u, int64_t n, float* t,
                        float* dx0, int accumulate, hipStream_t stream);
 
+/* The two elementwise backward steps fused with the bias-gradient column sum (one pass):
+ * dz = y > 0 ? dy : 0, db = colsum(dz)  /  t = g*x0, dx0 (+)= g*u, db = colsum(t).  [M,N] dense. */
+int mapx_relu_mask_colsum(const float* dy, const float* y, int M, int N, float* dz, float* db, void* ws,
+                          size_t ws_bytes, hipStream_t stream);
+int mapx_cross_bwd_pre_colsum(const float* g, const float* x0, const float* u, int M, int N, float* t,
+                              float* dx0, int accumulate, float* db, void* ws, size_t ws_bytes,
+                              hipStream_t stream);
 /* ReLU backward: out = y > 0 ? dy : 0 (y = activated output of layers.py:178-185). */
 int mapx_relu_mask(const float* dy, const float* y, int64_t n, float* out, hipStream_t stream);
 
@@ -162,10 +169,12 @@ int mapx_dynamic_mask_mfp(const int64_t* ids, int64_t B, int F, int L,
                           const int64_t* masked_index_in, uint64_t seed, uint64_t offset,
                           const int32_t* offset_dev, int64_t* ids_out, int64_t* labels,
                           int64_t* masked_index_out, hipStream_t stream);
-/* trainer.py:233-240 (RFD, RFD_replace="Unigram"): x_train [N,F] device-resident; labels f32 [B,F]. */
+/* trainer.py:233-262 (RFD).  mode = RFD_replace: 0 Unigram, 1 Uniform (idx_low/idx_high [F]),
+ * 2 Whole-Uniform (ids 10..V-1), 3 Whole-Unigram; x_train [N,F] device-resident; labels f32 [B,F]. */
 int mapx_dynamic_mask_rfd(const int64_t* ids, int64_t B, int F, int L,
                           const int64_t* masked_index_in, const int64_t* replace_in,
-                          const int64_t* x_train, int64_t N, uint64_t seed, uint64_t offset,
+                          const int64_t* x_train, int64_t N, int mode, const int64_t* idx_low,
+                          const int64_t* idx_high, int64_t V, uint64_t seed, uint64_t offset,
                           const int32_t* offset_dev, int64_t* ids_out, float* labels,
                           int64_t* masked_index_out, hipStream_t stream);
 

@@ -411,6 +411,48 @@ __global__ void __launch_bounds__(256) cross_bwd_pre_kernel(const float* __restr
   }
 }
 
+// Elementwise backward steps fused with the bias-gradient column sum (one pass over the
+// data instead of elementwise kernel + colsum stage 1):
+//   OP 0 (ReLU layer):   dz = y > 0 ? dy : 0                      db = colsum(dz)
+//   OP 1 (cross layer):  t = g * x0 ; dx0 (+)= g * u              db = colsum(t)
+// Block = 64 columns x 4 row lanes over one of kColChunks row chunks; stage 2 adds the chunks.
+template <int OP>
+__global__ void __launch_bounds__(256) ew_colsum_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        const float* __restrict__ c, int M, int N,
+                                                        float* __restrict__ o1, float* __restrict__ o2,
+                                                        int accumulate, float* __restrict__ part) {
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int rows_per = (M + kColChunks - 1) / kColChunks;
+  const int r0 = blockIdx.y * rows_per;
+  const int r1 = (r0 + rows_per < M) ? r0 + rows_per : M;
+  float v = 0.f;
+  if (col < N) {
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const int64_t i = (int64_t)r * N + col;
+      if (OP == 0) {
+        const float dz = b[i] > 0.f ? a[i] : 0.f;
+        o1[i] = dz;
+        v += dz;
+      } else {
+        const float g = a[i];
+        const float t = g * b[i];
+        float d = g * c[i];
+        if (accumulate) d += o2[i];
+        o1[i] = t;
+        o2[i] = d;
+        v += t;
+      }
+    }
+  }
+  __shared__ float s[4][64];
+  s[rl][threadIdx.x & 63] = v;
+  __syncthreads();
+  if (rl == 0 && col < N)
+    part[(int64_t)blockIdx.y * N + col] = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] +
+                                          s[3][threadIdx.x];
+}
+
 template <int WMT, int WNT, bool A_KC, bool B_KC, int BK>
 static void launch_tile(const GemmArgs& a, bool vec, int nsplit, hipStream_t stream) {
   dim3 grid(a.tiles_m * a.tiles_n, nsplit);
@@ -520,6 +562,37 @@ extern "C" int mapx_colsum(const float* x, int64_t ld, int M, int N, float* out,
                      ld, M, N, part);
   hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, out);
   return check_launch("colsum");
+}
+
+extern "C" int mapx_relu_mask_colsum(const float* dy, const float* y, int M, int N, float* dz, float* db,
+                                      void* ws, size_t ws_bytes, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(dy && y && dz && db && M >= 0 && N > 0, "relu_mask_colsum: bad arguments");
+  if (!ws || ws_bytes < mapx_colsum_workspace_bytes(N)) {
+    set_error("relu_mask_colsum: workspace too small");
+    return MAPX_EWORKSPACE;
+  }
+  float* part = static_cast<float*>(ws);
+  hipLaunchKernelGGL(ew_colsum_kernel<0>, dim3((N + 63) / 64, kColChunks), dim3(256), 0, stream, dy, y,
+                     (const float*)nullptr, M, N, dz, (float*)nullptr, 0, part);
+  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, db);
+  return check_launch("relu_mask_colsum");
+}
+
+extern "C" int mapx_cross_bwd_pre_colsum(const float* g, const float* x0, const float* u, int M, int N,
+                                         float* t, float* dx0, int accumulate, float* db, void* ws,
+                                         size_t ws_bytes, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(g && x0 && u && t && dx0 && db && M >= 0 && N > 0, "cross_bwd_pre_colsum: bad arguments");
+  if (!ws || ws_bytes < mapx_colsum_workspace_bytes(N)) {
+    set_error("cross_bwd_pre_colsum: workspace too small");
+    return MAPX_EWORKSPACE;
+  }
+  float* part = static_cast<float*>(ws);
+  hipLaunchKernelGGL(ew_colsum_kernel<1>, dim3((N + 63) / 64, kColChunks), dim3(256), 0, stream, g, x0, u, M,
+                     N, t, dx0, accumulate, part);
+  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, db);
+  return check_launch("cross_bwd_pre_colsum");
 }
 
 extern "C" int mapx_cross_bwd_pre(const float* g, const float* x0, const float* u, int64_t n,

@@ -86,15 +86,21 @@ __global__ void __launch_bounds__(256) mask_mfp_kernel(const int64_t* __restrict
   }
 }
 
-// RFD / Unigram branch (trainer.py:234-240): replacement ids are the masked field's column
-// of B*L rows drawn uniformly from the training matrix x_train [N,F] (resident in HBM), or
-// caller-injected replace_in [B,L].  Duplicate fields in masked_index: the LAST l wins (CPU
+// RFD branch of dynamic_mask (trainer.py:233-262), all four replacement generators:
+//   mode 0 Unigram        replacement = column f of a uniformly drawn training row (x_train [N,F]
+//                         resident in HBM), f = the masked field                 (:234-240)
+//   mode 1 Uniform        replacement ~ U{idx_low[f] .. idx_high[f]-1}            (:241-246)
+//   mode 2 Whole-Uniform  replacement ~ U{10 .. V-1}                              (:247-252)
+//   mode 3 Whole-Unigram  replacement = column f' ~ U{0..F-1} of a drawn row      (:253-260)
+// or caller-injected replace_in [B,L].  Duplicate fields in masked_index: the LAST l wins (CPU
 // scatter order).  labels[b,f] = (ids[b,f] != ids_out[b,f]).
 __global__ void __launch_bounds__(256) mask_rfd_kernel(const int64_t* __restrict__ ids, int64_t B,
                                                        int F, int L,
                                                        const int64_t* __restrict__ mi_in,
                                                        const int64_t* __restrict__ replace_in,
                                                        const int64_t* __restrict__ x_train, int64_t N,
+                                                       int mode, const int64_t* __restrict__ idx_low,
+                                                       const int64_t* __restrict__ idx_high, int64_t V,
                                                        uint64_t seed, uint64_t offset,
                                                        const int32_t* __restrict__ offset_dev,
                                                        int64_t* __restrict__ ids_out,
@@ -113,10 +119,17 @@ __global__ void __launch_bounds__(256) mask_rfd_kernel(const int64_t* __restrict
       if (replace_in) {
         rep = replace_in[b * L + l];
       } else {
-        // 64-bit row index from two words (N may exceed 2^32 in principle)
+        // 64-bit draw from two words (N and V may exceed 2^32 in principle)
         const uint64_t w = ((uint64_t)r.y << 32) | r.z;
-        const uint64_t hi = (uint64_t)(((unsigned __int128)w * (unsigned __int128)N) >> 64);
-        rep = x_train[(int64_t)hi * F + f];
+        if (mode == 0 || mode == 3) {
+          const uint64_t hi = (uint64_t)(((unsigned __int128)w * (unsigned __int128)N) >> 64);
+          const int64_t col = mode == 0 ? f : (int64_t)bounded(r.w, (uint32_t)F);
+          rep = x_train[(int64_t)hi * F + col];
+        } else {
+          const int64_t lo = mode == 1 ? idx_low[f] : 10;
+          const int64_t span = (mode == 1 ? idx_high[f] : V) - lo;
+          rep = lo + (int64_t)(((unsigned __int128)w * (unsigned __int128)span) >> 64);
+        }
       }
       if (mi_out) mi_out[b * L + l] = f;
       orow[f] = rep;
@@ -180,16 +193,23 @@ extern "C" int mapx_dynamic_mask_mfp(const int64_t* ids, int64_t B, int F, int L
 
 extern "C" int mapx_dynamic_mask_rfd(const int64_t* ids, int64_t B, int F, int L,
                                      const int64_t* masked_index_in, const int64_t* replace_in,
-                                     const int64_t* x_train, int64_t N, uint64_t seed,
-                                     uint64_t offset, const int32_t* offset_dev, int64_t* ids_out,
-                                     float* labels, int64_t* masked_index_out, hipStream_t stream) {
+                                     const int64_t* x_train, int64_t N, int mode,
+                                     const int64_t* idx_low, const int64_t* idx_high, int64_t V,
+                                     uint64_t seed, uint64_t offset, const int32_t* offset_dev,
+                                     int64_t* ids_out, float* labels, int64_t* masked_index_out,
+                                     hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(ids && ids_out && labels && B >= 0 && F > 0 && L >= 0, "dynamic_mask_rfd: bad arguments");
-  MAPX_REQUIRE(replace_in || (x_train && N > 0), "dynamic_mask_rfd: need replace_in or x_train");
+  MAPX_REQUIRE(mode >= 0 && mode <= 3, "dynamic_mask_rfd: mode %d", mode);
+  if (!replace_in) {
+    if (mode == 0 || mode == 3) MAPX_REQUIRE(x_train && N > 0, "dynamic_mask_rfd: Unigram modes need x_train");
+    if (mode == 1) MAPX_REQUIRE(idx_low && idx_high, "dynamic_mask_rfd: Uniform needs idx_low/idx_high");
+    if (mode == 2) MAPX_REQUIRE(V > 10, "dynamic_mask_rfd: Whole-Uniform needs the vocabulary size");
+  }
   MAPX_REQUIRE(ids != ids_out, "dynamic_mask_rfd: in-place replacement is not supported");
   if (B == 0) return MAPX_OK;
   hipLaunchKernelGGL(mask_rfd_kernel, dim3(grid_for(B, 256)), dim3(256), 0, stream, ids, B, F, L,
-                     masked_index_in, replace_in, x_train, N, seed, offset, offset_dev, ids_out, labels,
-                     masked_index_out);
+                     masked_index_in, replace_in, x_train, N, mode, idx_low, idx_high, V, seed, offset,
+                     offset_dev, ids_out, labels, masked_index_out);
   return check_launch("dynamic_mask_rfd");
 }

@@ -160,8 +160,13 @@ class _Linear(Function):
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
         sw, sb = ctx.slots
-        dz = ops.relu_mask(gy.contiguous(), y) if ctx.relu else gy.contiguous()
-        dw, db = _weight_grads(ctx, dz, x, sw, sb)
+        if ctx.relu:      # ReLU mask and bias gradient in one pass over dY
+            dz, db = ops.relu_mask_colsum(gy.contiguous(), y, db=sb)
+            dw = ops.linear_bwd_weight(dz, x, out=sw) if ctx.needs_input_grad[1] else None
+            dw, db = (None if sw is not None else dw), (None if sb is not None else db)
+        else:
+            dz = gy.contiguous()
+            dw, db = _weight_grads(ctx, dz, x, sw, sb)
         dx = ops.linear_bwd_input(dz, w) if ctx.needs_input_grad[0] else None
         return dx, dw, db, None
 
@@ -219,11 +224,11 @@ class _CrossLayer(Function):
     def backward(ctx, g):
         x0, xi, w, u = ctx.saved_tensors
         g = g.contiguous()
-        t, dx0 = ops.cross_bwd_pre(g, x0, u)              # t = g*x0, dx0 = g*u
-        dxi = ops.linear_bwd_input(t, w, add=g)           # g + t W
         sw, sb = ctx.slots
-        dw, db = _weight_grads(ctx, t, xi, sw, sb, need=(True, True))     # t^T xi, colsum(t)
-        return dx0, dxi, dw, db
+        t, dx0, db = ops.cross_bwd_pre_colsum(g, x0, u, db=sb)   # t = g*x0, dx0 = g*u, db = colsum(t)
+        dxi = ops.linear_bwd_input(t, w, add=g)                  # g + t W
+        dw = ops.linear_bwd_weight(t, xi, out=sw)                # t^T xi
+        return dx0, dxi, (None if sw is not None else dw), (None if sb is not None else db)
 
 
 class CrossNetV2(nn.Module):

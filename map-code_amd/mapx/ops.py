@@ -351,6 +351,32 @@ def cross_bwd_pre(g, x0, u, dx0=None):
     return t, dx0
 
 
+def relu_mask_colsum(dy, y, db=None):
+    """-> (dz = y > 0 ? dy : 0, db = colsum(dz)) in one pass."""
+    M, Nn = dy.shape
+    dz = torch.empty_like(dy)
+    if db is None:
+        db = torch.empty(Nn, dtype=torch.float32, device=dy.device)
+    ws = scratch(lib.mapx_colsum_workspace_bytes(Nn), dy.device)
+    check(lib.mapx_relu_mask_colsum(ptr(dy), ptr(y), M, Nn, ptr(dz), ptr(db), ptr(ws), ws.numel(), stream()))
+    return dz, db
+
+
+def cross_bwd_pre_colsum(g, x0, u, dx0=None, db=None):
+    """-> (t = g*x0, dx0 (+)= g*u, db = colsum(t)) in one pass."""
+    M, Nn = g.shape
+    t = torch.empty_like(g)
+    acc = dx0 is not None
+    if dx0 is None:
+        dx0 = torch.empty_like(g)
+    if db is None:
+        db = torch.empty(Nn, dtype=torch.float32, device=g.device)
+    ws = scratch(lib.mapx_colsum_workspace_bytes(Nn), g.device)
+    check(lib.mapx_cross_bwd_pre_colsum(ptr(g), ptr(x0), ptr(u), M, Nn, ptr(t), ptr(dx0), int(acc), ptr(db),
+                                        ptr(ws), ws.numel(), stream()))
+    return t, dx0, db
+
+
 def relu_mask(dy, y):
     out = torch.empty_like(dy)
     check(lib.mapx_relu_mask(ptr(dy), ptr(y), dy.numel(), ptr(out), stream()))
@@ -385,8 +411,11 @@ def dynamic_mask_mfp(ids, L, masked_index=None, seed=0, offset=0, offset_dev=Non
     return out, labels, mi_out
 
 
+RFD_MODES = {"Unigram": 0, "Uniform": 1, "Whole-Uniform": 2, "Whole-Unigram": 3}
+
+
 def dynamic_mask_rfd(ids, L, masked_index=None, replace_feat=None, x_train=None, seed=0, offset=0,
-                     offset_dev=None):
+                     offset_dev=None, mode="Unigram", idx_low=None, idx_high=None, vocab=0):
     """-> (replaced ids [B,F], labels f32 [B,F], masked_index [B,L])  (trainer.py:233-240)."""
     require_gpu(ids)
     ids = ids.contiguous()
@@ -397,8 +426,11 @@ def dynamic_mask_rfd(ids, L, masked_index=None, replace_feat=None, x_train=None,
     mi_in = masked_index.contiguous() if masked_index is not None else None
     rep = replace_feat.contiguous() if replace_feat is not None else None
     nrows = x_train.shape[0] if x_train is not None else 0
+    if mode not in RFD_MODES:
+        raise NotImplementedError(mode)                     # trainer.py:261-262
     check(lib.mapx_dynamic_mask_rfd(ptr(ids), B, F, L, ptr(mi_in), ptr(rep), ptr(x_train), nrows,
-                                    seed, offset, ptr(offset_dev), ptr(out), ptr(labels), ptr(mi_out), stream()))
+                                    RFD_MODES[mode], ptr(idx_low), ptr(idx_high), int(vocab), seed, offset,
+                                    ptr(offset_dev), ptr(out), ptr(labels), ptr(mi_out), stream()))
     return out, labels, mi_out
 
 

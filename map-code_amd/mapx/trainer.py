@@ -206,15 +206,17 @@ class Trainer:
             inputs["input_ids"], inputs["labels"], inputs["masked_index"] = ops.dynamic_mask_mfp(
                 ids, L, masked_index=masked_index, seed=seed, offset=offset, offset_dev=offset_dev)
         elif self.args.pt_type == "RFD":
-            if self.args.RFD_replace != "Unigram" and replace_feat is None:
-                if self.args.RFD_replace in ("Uniform", "Whole-Uniform", "Whole-Unigram"):
-                    raise NotImplementedError(
-                        f"RFD_replace={self.args.RFD_replace}: only Unigram (the run scripts' generator) is built")
-                raise NotImplementedError
             x_train = self._split(self.train_dataset).X
+            cfg = self.model_config
+            low = getattr(cfg, "idx_low", None)
+            high = getattr(cfg, "idx_high", None)
+            if self.args.RFD_replace == "Uniform" and replace_feat is None:
+                low, high = low.to(ids.device).contiguous(), high.to(ids.device).contiguous()
             inputs["input_ids"], inputs["labels"], _ = ops.dynamic_mask_rfd(
                 ids, L, masked_index=masked_index, replace_feat=replace_feat, x_train=x_train,
-                seed=seed, offset=offset, offset_dev=offset_dev)
+                seed=seed, offset=offset, offset_dev=offset_dev, mode=self.args.RFD_replace,
+                idx_low=low if self.args.RFD_replace == "Uniform" else None,
+                idx_high=high if self.args.RFD_replace == "Uniform" else None, vocab=cfg.input_size)
         else:
             raise NotImplementedError(self.args.pt_type)
         return inputs

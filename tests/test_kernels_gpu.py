@@ -466,3 +466,54 @@ def test_catch_up_from_raw_repeating_ids(ops):
     ops.table_adam(p, m, v, 0.05, last, sched, done, aux, 0.9, 0.999, 1e-8,
                    rows=ids.to(torch.int32).to(DEV), rows_may_repeat=True)
     assert torch.equal(p, before)
+
+
+@pytest.mark.parametrize("M,N", [(7, 368), (4096, 1000), (333, 65)])
+def test_fused_elementwise_colsum(ops, M, N):
+    g = torch.Generator().manual_seed(M + N)
+    dy, y = torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+    dz, db = ops.relu_mask_colsum(dy.to(DEV), y.to(DEV))
+    ref = dy * (y > 0)
+    assert torch.equal(_cpu(dz), ref)
+    np.testing.assert_allclose(_cpu(db).double().numpy(), ref.double().sum(0).numpy(), rtol=0,
+                               atol=2e-6 * float(ref.abs().sum(0).max()) + 1e-6)
+    x0, u, prev = torch.randn(M, N, generator=g), torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+    t, dx0, dbc = ops.cross_bwd_pre_colsum(dy.to(DEV), x0.to(DEV), u.to(DEV), dx0=prev.to(DEV).clone())
+    assert torch.equal(_cpu(t), dy * x0)
+    np.testing.assert_allclose(_cpu(dx0).numpy(), (dy * u + prev).numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(_cpu(dbc).double().numpy(), (dy * x0).double().sum(0).numpy(), rtol=0,
+                               atol=2e-6 * float((dy * x0).abs().sum(0).max()) + 1e-6)
+
+
+def test_rfd_replacement_generators(ops):
+    """The four RFD_replace generators of trainer.py:233-262 (statistical properties)."""
+    B, F, L, Ntrain, V = 2048, 23, 6, 5000, 10 + 23 * 100
+    g = torch.Generator().manual_seed(8)
+    lo = torch.arange(F) * 100 + 10
+    x_train = (lo[None, :] + torch.randint(0, 100, (Ntrain, F), generator=g)).to(DEV)
+    ids = x_train[:B].clone()
+    ids_c = ids.cpu()
+    field_of = lambda t: (t - 10) // 100
+    # Uniform: inside the masked field's own [idx_low, idx_high)
+    r, y, mi = ops.dynamic_mask_rfd(ids, L, seed=1, offset=1, mode="Uniform", idx_low=lo.to(DEV),
+                                    idx_high=(lo + 100).to(DEV))
+    assert torch.equal(field_of(r.cpu()), torch.arange(F).expand(B, F))
+    assert torch.equal(y.cpu(), (r.cpu() != ids_c).float())
+    # Whole-Uniform: anything in [10, V) -> mostly a foreign field
+    r, y, mi = ops.dynamic_mask_rfd(ids, L, seed=1, offset=2, mode="Whole-Uniform", vocab=V)
+    rc = r.cpu()
+    changed = rc != ids_c
+    assert int(rc.min()) >= 10 and int(rc.max()) < V
+    foreign = (field_of(rc) != torch.arange(F).expand(B, F)) & changed
+    assert 0.9 < float(foreign.sum()) / float(changed.sum()) <= 1.0
+    # Whole-Unigram: ids that occur in the training matrix, from a random column
+    r, y, mi = ops.dynamic_mask_rfd(ids, L, x_train=x_train, seed=1, offset=3, mode="Whole-Unigram")
+    rc = r.cpu()
+    changed = rc != ids_c
+    foreign = (field_of(rc) != torch.arange(F).expand(B, F)) & changed
+    assert 0.85 < float(foreign.sum()) / float(changed.sum()) <= 1.0
+    with pytest.raises(NotImplementedError):
+        ops.dynamic_mask_rfd(ids, L, x_train=x_train, mode="Bogus")
+    from mapx.native import MapxError
+    with pytest.raises(MapxError):
+        ops.dynamic_mask_rfd(ids, L, mode="Uniform")          # idx_low / idx_high missing
