@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
 }
 
 // column sums of X [M,N] (bias gradients): stage 1 = 32 row chunks -> partial[32][N]
-constexpr int kColChunks = 32;
+constexpr int kColChunks = 64;
 __global__ void __launch_bounds__(256) colsum_stage1_kernel(const float* __restrict__ x, int64_t ld,
                                                             int M, int N, float* __restrict__ part) {
   // block = 64 columns x 4 row lanes
@@ -421,36 +421,50 @@ __global__ void __launch_bounds__(256) ew_colsum_kernel(const float* __restrict_
                                                         const float* __restrict__ c, int M, int N,
                                                         float* __restrict__ o1, float* __restrict__ o2,
                                                         int accumulate, float* __restrict__ part) {
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  // 64 lanes x float4 = 256 columns per block row; 4 row lanes; N % 4 == 0 (host-checked)
+  const int col = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
   const int rl = threadIdx.x >> 6;
   const int rows_per = (M + kColChunks - 1) / kColChunks;
   const int r0 = blockIdx.y * rows_per;
   const int r1 = (r0 + rows_per < M) ? r0 + rows_per : M;
-  float v = 0.f;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (col < N) {
+#pragma unroll 4
     for (int r = r0 + rl; r < r1; r += 4) {
-      const int64_t i = (int64_t)r * N + col;
+      const int64_t i = ((int64_t)r * N + col) >> 2;
+      const float4 av = reinterpret_cast<const float4*>(a)[i];
+      const float4 bv = reinterpret_cast<const float4*>(b)[i];
       if (OP == 0) {
-        const float dz = b[i] > 0.f ? a[i] : 0.f;
-        o1[i] = dz;
-        v += dz;
+        const float4 dz = make_float4(bv.x > 0.f ? av.x : 0.f, bv.y > 0.f ? av.y : 0.f,
+                                      bv.z > 0.f ? av.z : 0.f, bv.w > 0.f ? av.w : 0.f);
+        reinterpret_cast<float4*>(o1)[i] = dz;
+        v.x += dz.x; v.y += dz.y; v.z += dz.z; v.w += dz.w;
       } else {
-        const float g = a[i];
-        const float t = g * b[i];
-        float d = g * c[i];
-        if (accumulate) d += o2[i];
-        o1[i] = t;
-        o2[i] = d;
-        v += t;
+        const float4 cv = reinterpret_cast<const float4*>(c)[i];
+        const float4 t = make_float4(av.x * bv.x, av.y * bv.y, av.z * bv.z, av.w * bv.w);
+        float4 d = make_float4(av.x * cv.x, av.y * cv.y, av.z * cv.z, av.w * cv.w);
+        if (accumulate) {
+          const float4 o = reinterpret_cast<const float4*>(o2)[i];
+          d.x += o.x; d.y += o.y; d.z += o.z; d.w += o.w;
+        }
+        reinterpret_cast<float4*>(o1)[i] = t;
+        reinterpret_cast<float4*>(o2)[i] = d;
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
       }
     }
   }
-  __shared__ float s[4][64];
+  __shared__ float4 s[4][64];
   s[rl][threadIdx.x & 63] = v;
   __syncthreads();
-  if (rl == 0 && col < N)
-    part[(int64_t)blockIdx.y * N + col] = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] +
-                                          s[3][threadIdx.x];
+  if (rl == 0 && col < N) {
+    float4 t = s[0][threadIdx.x];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      const float4 q = s[k][threadIdx.x];
+      t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+    }
+    *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * N + col) = t;
+  }
 }
 
 template <int WMT, int WNT, bool A_KC, bool B_KC, int BK>
@@ -568,12 +582,13 @@ extern "C" int mapx_relu_mask_colsum(const float* dy, const float* y, int M, int
                                       void* ws, size_t ws_bytes, hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(dy && y && dz && db && M >= 0 && N > 0, "relu_mask_colsum: bad arguments");
+  MAPX_REQUIRE(N % 4 == 0, "relu_mask_colsum: N %% 4 != 0");
   if (!ws || ws_bytes < mapx_colsum_workspace_bytes(N)) {
     set_error("relu_mask_colsum: workspace too small");
     return MAPX_EWORKSPACE;
   }
   float* part = static_cast<float*>(ws);
-  hipLaunchKernelGGL(ew_colsum_kernel<0>, dim3((N + 63) / 64, kColChunks), dim3(256), 0, stream, dy, y,
+  hipLaunchKernelGGL(ew_colsum_kernel<0>, dim3((N + 255) / 256, kColChunks), dim3(256), 0, stream, dy, y,
                      (const float*)nullptr, M, N, dz, (float*)nullptr, 0, part);
   hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, db);
   return check_launch("relu_mask_colsum");
@@ -584,12 +599,13 @@ extern "C" int mapx_cross_bwd_pre_colsum(const float* g, const float* x0, const 
                                          size_t ws_bytes, hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(g && x0 && u && t && dx0 && db && M >= 0 && N > 0, "cross_bwd_pre_colsum: bad arguments");
+  MAPX_REQUIRE(N % 4 == 0, "cross_bwd_pre_colsum: N %% 4 != 0");
   if (!ws || ws_bytes < mapx_colsum_workspace_bytes(N)) {
     set_error("cross_bwd_pre_colsum: workspace too small");
     return MAPX_EWORKSPACE;
   }
   float* part = static_cast<float*>(ws);
-  hipLaunchKernelGGL(ew_colsum_kernel<1>, dim3((N + 63) / 64, kColChunks), dim3(256), 0, stream, g, x0, u, M,
+  hipLaunchKernelGGL(ew_colsum_kernel<1>, dim3((N + 255) / 256, kColChunks), dim3(256), 0, stream, g, x0, u, M,
                      N, t, dx0, accumulate, part);
   hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, db);
   return check_launch("cross_bwd_pre_colsum");

@@ -155,6 +155,119 @@ __global__ void __launch_bounds__(256) nce_fwd_kernel(
   }
 }
 
+// P = 32 fast path (the reference default, proj_size=32): same arithmetic, organised for
+// memory-level parallelism.  A lane group (8 lanes) handles one target; rows are processed in
+// batches of 8: the 8 row loads of a batch are issued together (8 x 128 B in flight per group,
+// 64 rows per wave), the 8 dot products are reduced with a transposing butterfly (7 shuffles
+// for 8 rows) that leaves row j's score in lane j%8 — the lane that also loaded that row's
+// bias and log q — so logit, loss term and gradient are computed once per row, not once
+// per lane.
+__global__ void __launch_bounds__(256) nce_fwd_p32_kernel(
+    const float* __restrict__ enc, int64_t enc_stride, const int64_t* __restrict__ masked_index,
+    int L, const int32_t* __restrict__ idx, int64_t T, int K1, const float* __restrict__ emb,
+    const float* __restrict__ bias, const float* __restrict__ logq, float lnV, float lnK,
+    float invT, float* __restrict__ h_out, float* __restrict__ dlogit, float* __restrict__ dh,
+    float* __restrict__ logits, float* __restrict__ loss_partial, int* __restrict__ acc_count) {
+  constexpr int LG = 8, P = 32, GPB = 256 / LG, MAXB = 4;   // up to 32 rows per target
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & 7, gbase = lane & ~7;
+  const int gib = threadIdx.x / LG;
+  float loss_acc = 0.f;
+  int acc_acc = 0;
+  for (int64_t t = (int64_t)blockIdx.x * GPB + gib; t < T; t += (int64_t)gridDim.x * GPB) {
+    const int64_t b = t / L;
+    const int64_t mi = masked_index[t];
+    const float4 h4 = *reinterpret_cast<const float4*>(enc + b * enc_stride + mi * P + 4 * sub);
+    *reinterpret_cast<float4*>(h_out + t * P + 4 * sub) = h4;
+    const int32_t* ix = idx + t * K1;
+    int myid[MAXB];
+    float mybq[MAXB], mylq[MAXB];
+#pragma unroll
+    for (int c = 0; c < MAXB; ++c) {
+      const int j = 8 * c + sub;
+      myid[c] = j < K1 ? ix[j] : 0;
+    }
+#pragma unroll
+    for (int c = 0; c < MAXB; ++c) {
+      mybq[c] = bias[myid[c]];
+      mylq[c] = logq[myid[c]];
+    }
+    float4 dh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float loss_l = 0.f, smax_l = -INFINITY, s0 = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXB; ++c) {
+      if (8 * c >= K1) break;
+      float4 r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int id = __shfl(myid[c], gbase + u, kWave);
+        r[u] = *reinterpret_cast<const float4*>(emb + (int64_t)id * P + 4 * sub);
+      }
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = h4.x * r[u].x + h4.y * r[u].y + h4.z * r[u].z + h4.w * r[u].w;
+      // transposing butterfly: after 3 steps lane `sub` holds the full dot product of row `sub`
+      float w4[4], w2[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float keep = (sub & 4) ? v[i + 4] : v[i], send = (sub & 4) ? v[i] : v[i + 4];
+        w4[i] = keep + __shfl_xor(send, 4, kWave);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float keep = (sub & 2) ? w4[i + 2] : w4[i], send = (sub & 2) ? w4[i] : w4[i + 2];
+        w2[i] = keep + __shfl_xor(send, 2, kWave);
+      }
+      const float keep = (sub & 1) ? w2[1] : w2[0], send = (sub & 1) ? w2[0] : w2[1];
+      const float dot = keep + __shfl_xor(send, 1, kWave);
+      const int j = 8 * c + sub;
+      const bool live = j < K1;
+      const float sc = dot + mybq[c] - lnV;
+      const float lt = sc - mylq[c] - lnK;
+      const float sig = 1.f / (1.f + __expf(-lt));
+      float d = 0.f;
+      if (live) {
+        if (j == 0) {
+          loss_l += softplus_f(-lt);
+          d = (sig - 1.f) * invT;
+        } else {
+          smax_l = fmaxf(smax_l, sc);
+          loss_l += softplus_f(lt);
+          d = sig * invT;
+        }
+        dlogit[t * K1 + j] = d;
+        if (logits) logits[t * K1 + j] = sc;
+      }
+      if (c == 0) s0 = __shfl(sc, gbase, kWave);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float du = __shfl(d, gbase + u, kWave);     // 0 for rows beyond K1
+        dh4.x += du * r[u].x; dh4.y += du * r[u].y; dh4.z += du * r[u].z; dh4.w += du * r[u].w;
+      }
+    }
+    *reinterpret_cast<float4*>(dh + t * P + 4 * sub) = dh4;
+    const float loss_t = group_sum<LG>(loss_l);
+    float smax = smax_l;
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) smax = fmaxf(smax, __shfl_xor(smax, o, kWave));
+    if (sub == 0) {
+      loss_acc += loss_t;
+      acc_acc += (s0 >= smax) ? 1 : 0;
+    }
+  }
+  __shared__ float sl[GPB];
+  __shared__ int sa[GPB];
+  if (sub == 0) { sl[gib] = loss_acc; sa[gib] = acc_acc; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float l = 0.f;
+    int a = 0;
+    for (int i = 0; i < GPB; ++i) { l += sl[i]; a += sa[i]; }
+    loss_partial[blockIdx.x] = l;
+    if (a) atomicAdd(acc_count, a);
+  }
+}
+
 __global__ void nce_loss_finalize_kernel(const float* __restrict__ partial, int n, float invT,
                                          float* __restrict__ loss) {
   // single wave, fixed order: lane i sums partial[i], partial[i+64], ...; then butterfly
@@ -267,7 +380,14 @@ extern "C" int mapx_nce_fwd(const float* enc, int64_t B, int L, int F, int P,
   switch (LG) {
     case 2: MAPX_NCE(2); break;
     case 4: MAPX_NCE(4); break;
-    case 8: MAPX_NCE(8); break;
+    case 8:
+      if (K + 1 <= 32)
+        hipLaunchKernelGGL(mapx::nce_fwd_p32_kernel, dim3(grid), dim3(256), 0, stream, enc, enc_stride,
+                           masked_index, L, idx, T, K + 1, emb, bias, logq, lnV, lnK, invT, h_out, dlogit,
+                           dh, logits_opt, partial, acc_out);
+      else
+        MAPX_NCE(8);
+      break;
     case 16: MAPX_NCE(16); break;
     default: MAPX_NCE(32); break;
   }

@@ -37,6 +37,39 @@ __global__ void __launch_bounds__(256) radix_hist_kernel(const int32_t* __restri
   for (int d = threadIdx.x; d < bins; d += 256) bh[(int64_t)d * nblocks + blockIdx.x] = h[d];
 }
 
+// Exclusive scan of the digit-major histogram matrix (bins x nblocks <= 64 K ints) by ONE block:
+// replaces a rocPRIM device scan (2 launches) by a 3-us kernel.
+__global__ void __launch_bounds__(1024) radix_scan_kernel(const int32_t* __restrict__ bh, int total,
+                                                          int32_t* __restrict__ off) {
+  __shared__ int wsum[16];
+  const int per = (total + 1023) / 1024;
+  const int lo = threadIdx.x * per;
+  const int hi = lo + per < total ? lo + per : total;
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += bh[i];
+  // block exclusive scan of the 1024 thread sums: wave scan + scan of the 16 wave totals
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int incl = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, kWave);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int i = 0; i < w; ++i) base += wsum[i];
+  int run = base + incl - s;
+  for (int i = lo; i < hi; ++i) {
+    off[i] = run;
+    run += bh[i];
+  }
+}
+
+// Scatter of one pass.  Ranking as described above (per-wave ballots on private counters);
+// then the tile is laid out in LDS in its block-local sorted order and written from there, so
+// that consecutive lanes store to consecutive global addresses (runs of one digit) instead of
+// 4096 scattered 4-byte stores per block.
 template <bool IOTA>
 __global__ void __launch_bounds__(256) radix_scatter_kernel(const int32_t* __restrict__ keys,
                                                             const int32_t* __restrict__ vals,
@@ -44,13 +77,18 @@ __global__ void __launch_bounds__(256) radix_scatter_kernel(const int32_t* __res
                                                             const int32_t* __restrict__ off,
                                                             int32_t* __restrict__ keys_out,
                                                             int32_t* __restrict__ vals_out) {
-  extern __shared__ int cntw[];   // [4 waves][bins]
+  constexpr int MAXB = 1 << kSortBits;
+  __shared__ int cntw[4 * MAXB];       // per-wave digit counts -> per-wave exclusive prefixes
+  __shared__ int lbase[MAXB];          // block-local exclusive start of every digit
+  __shared__ int wtot[4];
+  __shared__ int32_t skey[kSortTile], sval[kSortTile];
   const int bins = 1 << bits;
   for (int d = threadIdx.x; d < 4 * bins; d += 256) cntw[d] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const int64_t seg0 = (int64_t)blockIdx.x * kSortTile + w * (kSortTile / 4);
+  const int64_t tile0 = (int64_t)blockIdx.x * kSortTile;
+  const int64_t seg0 = tile0 + w * (kSortTile / 4);
   int32_t key[kSortItems], val[kSortItems], lr[kSortItems];
   int* mine = cntw + w * bins;
 #pragma unroll
@@ -71,16 +109,48 @@ __global__ void __launch_bounds__(256) radix_scatter_kernel(const int32_t* __res
     if (valid && (m & lt) == 0) mine[d] = base + __popcll(m);   // ... then its lowest lane updates
   }
   __syncthreads();
+  // digit d = threadIdx.x (bins <= 256): wave prefixes in place, block-local exclusive base
+  {
+    int tot = 0;
+    if (threadIdx.x < bins) {
+#pragma unroll
+      for (int ww = 0; ww < 4; ++ww) {
+        const int c = cntw[ww * bins + threadIdx.x];
+        cntw[ww * bins + threadIdx.x] = tot;
+        tot += c;
+      }
+    }
+    int incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, kWave);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) wtot[w] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < w; ++i) base += wtot[i];
+    if (threadIdx.x < bins) lbase[threadIdx.x] = base + incl - tot;
+  }
+  __syncthreads();
 #pragma unroll
   for (int r = 0; r < kSortItems; ++r) {
     const int64_t i = seg0 + r * 64 + lane;
     if (i < n) {
       const int d = ((uint32_t)key[r] >> shift) & (bins - 1);
-      int pos = off[(int64_t)d * nblocks + blockIdx.x] + lr[r];
-      for (int ww = 0; ww < w; ++ww) pos += cntw[ww * bins + d];
-      keys_out[pos] = key[r];
-      vals_out[pos] = val[r];
+      const int pos = lbase[d] + cntw[w * bins + d] + lr[r];
+      skey[pos] = key[r];
+      sval[pos] = val[r];
     }
+  }
+  __syncthreads();
+  const int count = (int)((n - tile0 < kSortTile) ? (n - tile0) : kSortTile);
+  for (int i = threadIdx.x; i < count; i += 256) {
+    const int32_t k = skey[i];
+    const int d = ((uint32_t)k >> shift) & (bins - 1);
+    const int64_t g = (int64_t)off[(int64_t)d * nblocks + blockIdx.x] + (i - lbase[d]);
+    keys_out[g] = k;
+    vals_out[g] = sval[i];
   }
 }
 

@@ -156,15 +156,19 @@ extern "C" int mapx_seg_plan(const int32_t* keys, int64_t n, int64_t V, void* ws
     int32_t* dst_v = to_out ? perm : w.tv;
     hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(256), 0, stream, src_k, n, shift, bins,
                        nblocks, w.bh);
-    size_t sb = w.scan_bytes;
-    MAPX_HIP(rocprim::exclusive_scan(w.scan, sb, (const int32_t*)w.bh, w.off, 0, (size_t)bins * nblocks,
-                                     rocprim::plus<int32_t>(), stream));
-    const size_t lds = (size_t)4 * bins * sizeof(int);
+    if (false && (int64_t)bins * nblocks <= 65536) {   // single-block scan measured slower (serial load latency)
+      hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, stream, (const int32_t*)w.bh,
+                         bins * nblocks, w.off);
+    } else {
+      size_t sb = w.scan_bytes;
+      MAPX_HIP(rocprim::exclusive_scan(w.scan, sb, (const int32_t*)w.bh, w.off, 0, (size_t)bins * nblocks,
+                                       rocprim::plus<int32_t>(), stream));
+    }
     if (p == 0)
-      hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nblocks), dim3(256), lds, stream, src_k, src_v,
+      hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nblocks), dim3(256), 0, stream, src_k, src_v,
                          n, shift, db, nblocks, w.off, dst_k, dst_v);
     else
-      hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nblocks), dim3(256), lds, stream, src_k, src_v,
+      hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nblocks), dim3(256), 0, stream, src_k, src_v,
                          n, shift, db, nblocks, w.off, dst_k, dst_v);
     src_k = dst_k;
     src_v = dst_v;

@@ -11,9 +11,9 @@
 //           inside the chunk go straight to out[rank-1]; the piece that continues from
 //           the previous chunk goes to part_head[chunk], the piece that continues into
 //           the next chunk to part_tail[chunk].
-//   pass B  one wave per chunk; the chunk whose tail piece STARTS a spanning segment owns
-//           it and sums tail + the following chunks' head pieces, strided over the wave's
-//           lane groups and combined in a fixed order.
+//   pass B  one wave per OWNER chunk (the chunk whose tail piece starts a spanning segment;
+//           pass A lists them): tail + the following chunks' head pieces, strided over the
+//           wave's lane groups and combined in a fixed order.
 // No float atomics anywhere: sums are bit-reproducible, so data-parallel replicas that
 // apply the same merged gradient stay bit-identical.
 #pragma once
@@ -62,45 +62,77 @@ __device__ inline void add4(float4& a, const float4& b) {
 
 // W = row width in floats (multiple of 4, <= 256).  Row layout of out/part_*: WS floats
 // per row where WS = W (+4 if EXTRA: the extra scalar lives at column W).
+// The chunk's 32 (rank, perm) pairs are loaded once, LG-wide, and handed round by shuffles;
+// contributions are fetched 8 entries ahead of the accumulate/flush walk (which is serial by
+// nature), so the random reads behind `perm` overlap instead of paying their latency 32 times.
+// A chunk whose tail run continues into the next chunk appends itself to `owners`.
 template <int LG, bool EXTRA, class Contrib>
 __global__ void __launch_bounds__(256) seg_reduce_pass_a(SegPlanView pl, Contrib contrib, int W,
                                                          float* __restrict__ out,
                                                          float* __restrict__ out_extra,
                                                          float* __restrict__ part_head,
-                                                         float* __restrict__ part_tail) {
+                                                         float* __restrict__ part_tail,
+                                                         int32_t* __restrict__ owners,
+                                                         int32_t* __restrict__ n_owners) {
+  constexpr int NPL = kSegChunk / LG;          // entries each lane preloads
+  constexpr int BATCH = 8;                     // contributions in flight per walk step
   const int WS = EXTRA ? W + 4 : W;
-  const int lane_in_group = threadIdx.x % LG;
+  const int lane = threadIdx.x % kWave;
+  const int lig = lane % LG, gbase = lane - lig;
   const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LG;
   const int64_t ngroups = ceil_div(pl.n, kSegChunk);
-  if (group >= ngroups) return;
-  // LG lanes cover W/4 float4 columns, possibly in several rounds (W > 4*LG)
-  for (int sub = lane_in_group; sub * 4 < W; sub += LG) {
-    const int64_t j0 = group * kSegChunk;
-    const int64_t j1 = (j0 + kSegChunk < pl.n) ? j0 + kSegChunk : pl.n;
-    int cur = pl.rank[j0];
-    bool started_inside = (j0 == 0) || (pl.rank[j0 - 1] != cur);
+  const bool active = group < ngroups;         // whole groups are active or not; shuffles need all lanes
+  const int64_t j0 = active ? group * kSegChunk : 0;
+  const int64_t j1 = active ? ((j0 + kSegChunk < pl.n) ? j0 + kSegChunk : pl.n) : 0;
+  int myrank[NPL], myperm[NPL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int64_t j = j0 + i * LG + lig;
+    myrank[i] = (j < j1) ? pl.rank[j] : -1;
+    myperm[i] = (j < j1) ? pl.perm[j] : 0;
+  }
+  const int prev_rank = (active && j0 > 0) ? pl.rank[j0 - 1] : -1;
+  const int next_rank = (active && j1 < pl.n) ? pl.rank[j1] : -2;
+  for (int sub0 = 0; sub0 * 4 < W; sub0 += LG) {   // wave-uniform rounds (shuffles inside);
+    const int sub = sub0 + lig;                    // W > 4*LG: further column rounds
+    const bool live = sub * 4 < W;                 // W < 4*LG: idle lanes still take part in shuffles
+    int cur = __shfl(myrank[0], gbase, kWave);
+    bool started_inside = (j0 == 0) || (prev_rank != cur);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float accx = 0.f;
-    for (int64_t j = j0; j < j1; ++j) {
-      const int r = pl.rank[j];
-      if (r != cur) {
-        float* dst = started_inside ? out + (int64_t)(cur - 1) * W : part_head + group * WS;
-        *reinterpret_cast<float4*>(dst + 4 * sub) = acc;
-        if (EXTRA && sub == 0) {
-          if (started_inside) out_extra[cur - 1] = accx;
-          else part_head[group * WS + W] = accx;
-        }
-        acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        accx = 0.f;
-        cur = r;
-        started_inside = true;
+#pragma unroll
+    for (int e0 = 0; e0 < kSegChunk; e0 += BATCH) {
+      float4 v[BATCH];
+      float ex[BATCH];
+      int rk[BATCH];
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int e = e0 + u;
+        rk[u] = __shfl(myrank[e / LG], gbase + (e % LG), kWave);
+        const int p = __shfl(myperm[e / LG], gbase + (e % LG), kWave);
+        if (rk[u] >= 0 && live) v[u] = contrib(p, sub, ex[u]);
       }
-      float ex;
-      const float4 v = contrib(pl.perm[j], sub, ex);
-      add4(acc, v);
-      if (EXTRA) accx += ex;
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        if (rk[u] < 0) continue;                 // past the end of the array
+        if (rk[u] != cur) {
+          float* dst = started_inside ? out + (int64_t)(cur - 1) * W : part_head + group * WS;
+          if (live) *reinterpret_cast<float4*>(dst + 4 * sub) = acc;
+          if (EXTRA && sub == 0) {
+            if (started_inside) out_extra[cur - 1] = accx;
+            else part_head[group * WS + W] = accx;
+          }
+          acc = make_float4(0.f, 0.f, 0.f, 0.f);
+          accx = 0.f;
+          cur = rk[u];
+          started_inside = true;
+        }
+        add4(acc, v[u]);
+        if (EXTRA) accx += ex[u];
+      }
     }
-    const bool ends = (j1 == pl.n) || (pl.rank[j1] != cur);
+    if (!active || !live) continue;
+    const bool ends = (j1 == pl.n) || (next_rank != cur);
     float* dst;
     float* dstx;
     if (started_inside && ends) {
@@ -112,31 +144,30 @@ __global__ void __launch_bounds__(256) seg_reduce_pass_a(SegPlanView pl, Contrib
     } else {
       dst = part_tail + group * WS;
       dstx = part_tail + group * WS + W;
+      if (sub == 0) owners[atomicAdd(n_owners, 1)] = (int32_t)group;   // this chunk owns a spanning run
     }
     *reinterpret_cast<float4*>(dst + 4 * sub) = acc;
     if (EXTRA && sub == 0) *dstx = accx;
   }
 }
 
-// One wave per chunk.  Owner test: the chunk's last segment started inside the chunk and
-// continues past its end.  Sum = tail[c] + head[c+1] + ... + head[c_last].
+// One wave per OWNER chunk (listed by pass A): sum = tail[c] + head[c+1] + ... + head[c_last].
 template <int LG, bool EXTRA>
 __global__ void __launch_bounds__(256) seg_reduce_pass_b(SegPlanView pl, int W,
                                                          float* __restrict__ out,
                                                          float* __restrict__ out_extra,
                                                          const float* __restrict__ part_head,
-                                                         const float* __restrict__ part_tail) {
+                                                         const float* __restrict__ part_tail,
+                                                         const int32_t* __restrict__ owners,
+                                                         const int32_t* __restrict__ n_owners) {
   const int WS = EXTRA ? W + 4 : W;
   const int lane = threadIdx.x % kWave;
-  const int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
-  const int64_t nchunks = ceil_div(pl.n, kSegChunk);
-  if (c >= nchunks) return;
-  const int64_t j0 = c * kSegChunk, j1 = j0 + kSegChunk;
-  if (j1 >= pl.n) return;                       // last chunk cannot have a continuing tail
+  const int nown = *n_owners;
+  for (int64_t oi = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave; oi < nown;
+       oi += ((int64_t)gridDim.x * blockDim.x) / kWave) {
+  const int64_t c = owners[oi];
+  const int64_t j1 = c * kSegChunk + kSegChunk;
   const int cur = pl.rank[j1 - 1];
-  if (pl.rank[j1] != cur) return;               // tail segment ends with the chunk
-  const int64_t s0 = pl.seg_start[cur - 1];
-  if (s0 < j0) return;                          // it started in an earlier chunk: not the owner
   const int64_t c_last = (pl.seg_start[cur] - 1) / kSegChunk;
   constexpr int G = kWave / LG;                 // lane groups per wave
   const int g = lane / LG, lig = lane % LG;
@@ -146,7 +177,21 @@ __global__ void __launch_bounds__(256) seg_reduce_pass_b(SegPlanView pl, int W,
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float accx = 0.f;
     if (live) {
-      for (int64_t cc = c + 1 + g; cc <= c_last; cc += G) {
+      int64_t cc = c + 1 + g;
+      for (; cc + 3 * G <= c_last; cc += 4 * G) {   // 4 loads in flight, added in order
+        const float4 l0 = *reinterpret_cast<const float4*>(part_head + cc * WS + 4 * sub);
+        const float4 l1 = *reinterpret_cast<const float4*>(part_head + (cc + G) * WS + 4 * sub);
+        const float4 l2 = *reinterpret_cast<const float4*>(part_head + (cc + 2 * G) * WS + 4 * sub);
+        const float4 l3 = *reinterpret_cast<const float4*>(part_head + (cc + 3 * G) * WS + 4 * sub);
+        float x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f;
+        if (EXTRA && sub == 0) {
+          x0 = part_head[cc * WS + W]; x1 = part_head[(cc + G) * WS + W];
+          x2 = part_head[(cc + 2 * G) * WS + W]; x3 = part_head[(cc + 3 * G) * WS + W];
+        }
+        add4(acc, l0); add4(acc, l1); add4(acc, l2); add4(acc, l3);
+        accx += x0; accx += x1; accx += x2; accx += x3;
+      }
+      for (; cc <= c_last; cc += G) {
         add4(acc, *reinterpret_cast<const float4*>(part_head + cc * WS + 4 * sub));
         if (EXTRA && sub == 0) accx += part_head[cc * WS + W];
       }
@@ -172,12 +217,14 @@ __global__ void __launch_bounds__(256) seg_reduce_pass_b(SegPlanView pl, int W,
       if (EXTRA && sub == 0) out_extra[cur - 1] = totx;
     }
   }
+  }
 }
 
 // Bytes of partial storage seg_reduce needs for n keys of row width W (+extra).
 inline size_t seg_reduce_partial_bytes(int64_t n, int W, bool extra) {
   const int WS = extra ? W + 4 : W;
-  return (size_t)ceil_div(n > 0 ? n : 1, kSegChunk) * WS * sizeof(float) * 2;
+  const size_t chunks = (size_t)ceil_div(n > 0 ? n : 1, kSegChunk);
+  return chunks * WS * sizeof(float) * 2 + (chunks + 64) * sizeof(int32_t);   // + owner list, counter
 }
 
 template <bool EXTRA, class Contrib>
@@ -195,16 +242,24 @@ int seg_reduce_launch(const SegPlanView& pl, const Contrib& contrib, int W, floa
   const int64_t nchunks = ceil_div(pl.n, kSegChunk);
   float* part_head = static_cast<float*>(ws);
   float* part_tail = part_head + nchunks * WS;
+  int32_t* n_owners = reinterpret_cast<int32_t*>(part_tail + nchunks * WS);
+  int32_t* owners = n_owners + 16;
+  if (hipMemsetAsync(n_owners, 0, sizeof(int32_t), stream) != hipSuccess) {
+    set_error("%s: memset failed", what);
+    return MAPX_EHIP;
+  }
   // lane-group width: 4 lanes for 16-float rows, 8 for 32-float rows, 16 beyond
   const int lg = (W <= 16) ? 4 : (W <= 32 ? 8 : 16);
   const int64_t threads_a = nchunks * lg;
   const int grid_a = (int)ceil_div(threads_a, 256);
-  const int grid_b = (int)ceil_div(nchunks * kWave, 256);
+  int64_t gb = ceil_div(nchunks * kWave, 256);
+  const int grid_b = (int)(gb > 1024 ? 1024 : gb);
 #define MAPX_SEG_LAUNCH(LG_)                                                                    \
   hipLaunchKernelGGL((seg_reduce_pass_a<LG_, EXTRA, Contrib>), dim3(grid_a), dim3(256), 0,      \
-                     stream, pl, contrib, W, out, out_extra, part_head, part_tail);             \
+                     stream, pl, contrib, W, out, out_extra, part_head, part_tail, owners,     \
+                     n_owners);                                                                 \
   hipLaunchKernelGGL((seg_reduce_pass_b<LG_, EXTRA>), dim3(grid_b), dim3(256), 0, stream, pl,   \
-                     W, out, out_extra, part_head, part_tail)
+                     W, out, out_extra, part_head, part_tail, owners, n_owners)
   if (lg == 4) { MAPX_SEG_LAUNCH(4); }
   else if (lg == 8) { MAPX_SEG_LAUNCH(8); }
   else { MAPX_SEG_LAUNCH(16); }

@@ -160,12 +160,12 @@ class _Linear(Function):
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
         sw, sb = ctx.slots
-        if ctx.relu:      # ReLU mask and bias gradient in one pass over dY
+        if ctx.relu and gy.shape[1] % 4 == 0:      # ReLU mask and bias gradient in one pass over dY
             dz, db = ops.relu_mask_colsum(gy.contiguous(), y, db=sb)
             dw = ops.linear_bwd_weight(dz, x, out=sw) if ctx.needs_input_grad[1] else None
             dw, db = (None if sw is not None else dw), (None if sb is not None else db)
         else:
-            dz = gy.contiguous()
+            dz = ops.relu_mask(gy.contiguous(), y) if ctx.relu else gy.contiguous()
             dw, db = _weight_grads(ctx, dz, x, sw, sb)
         dx = ops.linear_bwd_input(dz, w) if ctx.needs_input_grad[0] else None
         return dx, dw, db, None

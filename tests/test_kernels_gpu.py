@@ -468,7 +468,7 @@ def test_catch_up_from_raw_repeating_ids(ops):
     assert torch.equal(p, before)
 
 
-@pytest.mark.parametrize("M,N", [(7, 368), (4096, 1000), (333, 65)])
+@pytest.mark.parametrize("M,N", [(7, 368), (4096, 1000), (333, 68), (70, 4)])
 def test_fused_elementwise_colsum(ops, M, N):
     g = torch.Generator().manual_seed(M + N)
     dy, y = torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
@@ -483,6 +483,9 @@ def test_fused_elementwise_colsum(ops, M, N):
     np.testing.assert_allclose(_cpu(dx0).numpy(), (dy * u + prev).numpy(), rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(_cpu(dbc).double().numpy(), (dy * x0).double().sum(0).numpy(), rtol=0,
                                atol=2e-6 * float((dy * x0).abs().sum(0).max()) + 1e-6)
+    from mapx.native import MapxError
+    with pytest.raises(MapxError):                       # float4 kernels: N % 4 == 0 only
+        ops.relu_mask_colsum(torch.zeros(3, 65, device=DEV), torch.zeros(3, 65, device=DEV))
 
 
 def test_rfd_replacement_generators(ops):
