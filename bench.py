@@ -216,7 +216,12 @@ def main():
     ops.serialize_streams = True          # no side streams: every kernel is timed running alone
     with ops.Timers() as timers:
         for X, Y in staged[:max(5, min(20, args.steps))]:
+            # park the GPU for ~4 ms first so that the host enqueues the whole step ahead of it:
+            # the event pairs then bracket back-to-back kernels, not host launch gaps
+            torch.cuda._sleep(8_000_000)
             tr._mfp_step(X, Y)
+        torch.cuda._sleep(8_000_000)
+        timers.calibrate()
     torch.cuda.synchronize()
     ops.serialize_streams = False
     ksteps = max(5, min(20, args.steps))

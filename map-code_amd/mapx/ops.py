@@ -5,6 +5,7 @@ Scratch memory is a per-(device, stream) byte buffer grown on demand; kernels th
 run in stream order, so one buffer suffices.
 """
 import math
+import os
 
 import torch
 
@@ -32,13 +33,22 @@ class Timers:
         global _timers
         _timers = None
 
+    def calibrate(self, n=32):
+        """Record `n` empty brackets: their mean is the cost of the event pair itself (two
+        event commands + one dependent dispatch gap), subtracted from every interval."""
+        for _ in range(n):
+            with _timed("__empty__"):
+                pass
+
     def summary(self):
         """name -> dict(launches, total_ms, avg_us, work) after a device sync."""
         out = {}
+        empty = self.events.pop("__empty__", None)
+        over_ms = sum(a.elapsed_time(b) for a, b, _ in empty) / len(empty) if empty else 0.0
         for name, evs in self.events.items():
-            ms = [a.elapsed_time(b) for a, b, _ in evs]
+            ms = [max(a.elapsed_time(b) - over_ms, 0.0) for a, b, _ in evs]
             out[name] = dict(launches=len(evs), total_ms=sum(ms), avg_us=1e3 * sum(ms) / len(evs),
-                             work=sum(w for _, _, w in evs))
+                             work=sum(w for _, _, w in evs), bracket_overhead_us=1e3 * over_ms)
         return out
 
 
@@ -64,7 +74,7 @@ class _timed:
 # tower next to the deep tower).
 # serialize_streams = True maps them all onto the current stream (per-kernel timing passes).
 _aux_streams = {}
-serialize_streams = False
+serialize_streams = os.environ.get("MAPX_SERIAL", "0") == "1"
 
 
 def aux_stream(name, device):
