@@ -185,5 +185,31 @@ class MapxOptimizer:
         for t in self.tables:
             t.flush()
 
+    # ------------------------------------------------------------------ resume state
+    def state_dict(self):
+        """Everything needed to continue training bit-exactly: dense and table Adam moments, the
+        per-row replay clocks, the update counter.  (The reference saves model weights only and
+        cannot resume mid-run: trainer.py:517-519.)"""
+        return dict(steps_done=self.steps_done, done=self.done.cpu(),
+                    groups=[dict(names=g["names"], m=g["m"].cpu(), v=g["v"].cpu()) for g in self.groups],
+                    tables=[dict(name=t.table.name, m0=t.m0.cpu(), v0=t.v0.cpu(),
+                                 m1=None if t.m1 is None else t.m1.cpu(),
+                                 v1=None if t.v1 is None else t.v1.cpu(), last=t.last.cpu(),
+                                 stale=t.stale, cursor=t.cursor) for t in self.tables])
+
+    def load_state_dict(self, sd):
+        self.steps_done = int(sd["steps_done"])
+        self.done.copy_(sd["done"])
+        for g, s in zip(self.groups, sd["groups"]):
+            assert g["names"] == s["names"], "parameter layout changed since the state was saved"
+            g["m"].copy_(s["m"])
+            g["v"].copy_(s["v"])
+        for t, s in zip(self.tables, sd["tables"]):
+            assert t.table.name == s["name"]
+            t.m0.copy_(s["m0"]); t.v0.copy_(s["v0"]); t.last.copy_(s["last"])
+            if t.m1 is not None:
+                t.m1.copy_(s["m1"]); t.v1.copy_(s["v1"])
+            t.stale, t.cursor = bool(s["stale"]), int(s["cursor"])
+
     def get_last_lr(self):
         return [self.lr0 * lr_lambda(self.kind, self.steps_done, self.total, self.warmup)]

@@ -397,6 +397,22 @@ class Trainer:
         sd = {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}
         torch.save(sd, os.path.join(model_dir, f"{self.global_step}.model"))
 
+    def save_training_state(self, path):
+        """Full resume state, beyond the reference's weights-only checkpoint: raw (un-flushed)
+        weights, optimizer state, step counters."""
+        torch.save(dict(model={k: v.detach().cpu() for k, v in self.model.state_dict().items()},
+                        optimizer=self.optimizer.state_dict(), global_step=self.global_step), path)
+
+    def load_training_state(self, path):
+        st = torch.load(path, map_location="cpu")
+        with torch.no_grad():
+            own = self.model.state_dict()
+            for k, v in st["model"].items():
+                own[k].copy_(v)
+        self.optimizer.load_state_dict(st["optimizer"])
+        self.global_step = int(st["global_step"])
+        self._graphs = {}
+
     def load_model(self, load_step, model_dir):
         sd = torch.load(os.path.join(model_dir, f"{load_step}.model"), map_location="cpu")
         with torch.no_grad():

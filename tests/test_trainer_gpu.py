@@ -260,3 +260,50 @@ def test_graph_replay_equals_eager_bitwise():
         out.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
     for k in out[0]:
         assert torch.equal(out[0][k], out[1][k]), k
+
+
+def test_resume_state_continues_bit_exactly(tmp_path):
+    """save_training_state / load_training_state: 6 steps == 3 steps + save + fresh trainer + load + 3 steps."""
+    from mapx.arguments import TrainingArguments
+    from mapx.dataset import OurDataset, synth_table
+    from mapx.models import BaseModel
+    from mapx.trainer import Trainer
+    from util import make_config
+    cfg = dict(F=23, V=3000, E=16, H=64, NL=3, NC=3, P=32, K=25)
+    ids, labels, _, _ = synth_table(512 * 6, 23, cfg["V"], seed=4)
+    cnt = np.bincount(ids.reshape(-1), minlength=cfg["V"]).astype(np.float32)
+
+    def make():
+        torch.manual_seed(9)
+        config = make_config(cfg, "MFP", cnt)
+        model = BaseModel.from_config(config)
+        targs = TrainingArguments(output_dir=str(tmp_path), per_gpu_train_batch_size=512,
+                                  per_gpu_eval_batch_size=512, learning_rate=1e-3, lr_sched="cosine",
+                                  weight_decay=5e-2, num_train_epochs=1, pretrain=True, pt_type="MFP",
+                                  sampling_method="randint", mask_ratio=0.3, seed=3)
+        targs._device = torch.device(DEV)
+        ds = OurDataset(ids, labels)
+        tr = Trainer(model, config, targs, ds, ds)
+        tr.use_graph = False
+        train = tr._begin("test")
+        model.train()
+        return tr, list(train.batches(512, True, tr._generator(), (0, 1)))
+
+    tr_a, batches = make()
+    for X, Y in batches:
+        tr_a.run_step("mfp", X, Y)
+    tr_a.optimizer.flush()
+    ref = {k: v.detach().cpu().clone() for k, v in tr_a.model.state_dict().items()}
+
+    tr_b, batches_b = make()
+    for X, Y in batches_b[:3]:
+        tr_b.run_step("mfp", X, Y)
+    tr_b.save_training_state(str(tmp_path / "state.pt"))
+    tr_c, batches_c = make()
+    tr_c.load_training_state(str(tmp_path / "state.pt"))
+    assert tr_c.global_step == 3 and tr_c.optimizer.steps_done == 3
+    for X, Y in batches_c[3:]:
+        tr_c.run_step("mfp", X, Y)
+    tr_c.optimizer.flush()
+    for k, v in tr_c.model.state_dict().items():
+        assert torch.equal(v.detach().cpu(), ref[k]), k
