@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 8
+#define MAPX_ABI_VERSION 9
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -134,12 +134,29 @@ int mapx_scale_inplace(float* x, int64_t n, const float* g, hipStream_t stream);
 #define MAPX_EPI_BIAS_CROSS 3
 #define MAPX_EPI_ADD 4
 #define MAPX_EPI_RELU_MASK 5
+/* nsplit_deferred != NULL: the split-K slabs stay in `ws` ([nsplit][M*N], dense) and
+ * *nsplit_deferred receives the slab count (0 = C already final): the caller sums them later
+ * with mapx_sum_tasks, together with every other deferred sum of the backward pass. */
 size_t mapx_gemm_splitk_workspace_bytes(int M, int N, int nsplit);
 int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, int64_t lda,
                   const float* B, int64_t ldb, float* C, int64_t ldc, int epi, const float* bias,
                   const float* aux1, int64_t ld1, const float* aux2, int64_t ld2, float* out2,
                   int64_t ldo2, int nsplit, int tile_hint, void* ws, size_t ws_bytes,
-                  hipStream_t stream);
+                  int* nsplit_deferred, hipStream_t stream);
+/* dst[i] = sum_{s < nsplit} src[s*stride + i], i < n, for up to 32 tasks in ONE launch.  The
+ * task list is HOST memory (copied into the kernel arguments). */
+typedef struct mapx_sum_task {
+  float* dst;
+  const float* src;
+  int64_t stride;
+  int64_t n;
+  int32_t nsplit;
+  int32_t pad_;
+} mapx_sum_task;
+int mapx_sum_tasks(const mapx_sum_task* tasks_host, int ntasks, hipStream_t stream);
+/* row chunks of the column-sum kernels: with out/db == NULL they leave `chunks` partial rows
+ * [chunks][N] in `ws` for a later mapx_sum_tasks (stride N, nsplit = chunks). */
+int mapx_colsum_chunks(void);
 /* out[n] = sum_m x[m*ld + n]  (bias gradients), deterministic two-stage. */
 size_t mapx_colsum_workspace_bytes(int N);
 int mapx_colsum(const float* x, int64_t ld, int M, int N, float* out, void* ws, size_t ws_bytes,

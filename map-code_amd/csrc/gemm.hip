@@ -360,6 +360,31 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
   }
 }
 
+// Deferred slab sums: dst[i] = sum_s src[s*stride + i] for up to kMaxSumTasks independent
+// tasks in ONE launch (split-K slabs of the weight-gradient GEMMs and the row-chunk partials
+// of the bias-gradient column sums of a whole backward pass; 14 tiny launches -> 1).
+constexpr int kMaxSumTasks = 32;
+struct SumTasks {
+  mapx_sum_task t[kMaxSumTasks];
+};
+__global__ void __launch_bounds__(256) sum_tasks_kernel(SumTasks tasks) {
+  const mapx_sum_task tk = tasks.t[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tk.n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    int s = 0;
+    for (; s + 8 <= tk.nsplit; s += 8) {        // 8 loads in flight, added in slab order
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = tk.src[(s + u) * tk.stride + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += x[u];
+    }
+    for (; s < tk.nsplit; ++s) v += tk.src[s * tk.stride + i];
+    tk.dst[i] = v;
+  }
+}
+
 // column sums of X [M,N] (bias gradients): stage 1 = 32 row chunks -> partial[32][N]
 constexpr int kColChunks = 64;
 __global__ void __launch_bounds__(256) colsum_stage1_kernel(const float* __restrict__ x, int64_t ld,
@@ -502,7 +527,7 @@ extern "C" int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
                              const float* B, int64_t ldb, float* C, int64_t ldc, int epi,
                              const float* bias, const float* aux1, int64_t ld1, const float* aux2,
                              int64_t ld2, float* out2, int64_t ldo2, int nsplit, int tile_hint,
-                             void* ws, size_t ws_bytes, hipStream_t stream) {
+                             void* ws, size_t ws_bytes, int* nsplit_deferred, hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm_f32: negative size");
   if (M == 0 || N == 0) return MAPX_OK;
@@ -549,7 +574,8 @@ extern "C" int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   if (a_kc && b_kc) launch_layout<true, true>(g, vec, tile, nsplit, stream);
   else if (a_kc) launch_layout<true, false>(g, vec, tile, nsplit, stream);
   else launch_layout<false, false>(g, vec, tile, nsplit, stream);
-  if (nsplit > 1) {
+  if (nsplit_deferred) *nsplit_deferred = nsplit > 1 ? nsplit : 0;   // caller sums the slabs later
+  if (nsplit > 1 && !nsplit_deferred) {
     // slabs are dense [M,N]; combine into the caller's C (ldc must equal N for split-K)
     MAPX_REQUIRE(ldc == N, "gemm_f32: split-K output must be dense (ldc == N)");
     const int64_t n = (int64_t)M * N;
@@ -563,10 +589,28 @@ extern "C" size_t mapx_colsum_workspace_bytes(int N) {
   return (size_t)mapx::kColChunks * N * sizeof(float);
 }
 
+extern "C" int mapx_sum_tasks(const mapx_sum_task* tasks_host, int ntasks, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(ntasks >= 0 && ntasks <= kMaxSumTasks, "sum_tasks: at most %d tasks per call", kMaxSumTasks);
+  if (ntasks == 0) return MAPX_OK;
+  MAPX_REQUIRE(tasks_host, "sum_tasks: null task list");
+  SumTasks t;
+  memset(&t, 0, sizeof(t));
+  for (int i = 0; i < ntasks; ++i) {
+    MAPX_REQUIRE(tasks_host[i].dst && tasks_host[i].src && tasks_host[i].nsplit >= 1 && tasks_host[i].n >= 0,
+                 "sum_tasks: bad task %d", i);
+    t.t[i] = tasks_host[i];
+  }
+  hipLaunchKernelGGL(sum_tasks_kernel, dim3(96, ntasks), dim3(256), 0, stream, t);
+  return check_launch("sum_tasks");
+}
+
+extern "C" int mapx_colsum_chunks(void) { return mapx::kColChunks; }
+
 extern "C" int mapx_colsum(const float* x, int64_t ld, int M, int N, float* out, void* ws,
                            size_t ws_bytes, hipStream_t stream) {
   using namespace mapx;
-  MAPX_REQUIRE(x && out && M >= 0 && N > 0, "colsum: bad arguments");
+  MAPX_REQUIRE(x && M >= 0 && N > 0, "colsum: bad arguments");
   if (!ws || ws_bytes < mapx_colsum_workspace_bytes(N)) {
     set_error("colsum: workspace too small");
     return MAPX_EWORKSPACE;
@@ -574,14 +618,15 @@ extern "C" int mapx_colsum(const float* x, int64_t ld, int M, int N, float* out,
   float* part = static_cast<float*>(ws);
   hipLaunchKernelGGL(colsum_stage1_kernel, dim3((N + 63) / 64, kColChunks), dim3(256), 0, stream, x,
                      ld, M, N, part);
-  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, out);
+  if (out)   // out == NULL: the caller sums the kColChunks partial rows later (mapx_sum_tasks)
+    hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, out);
   return check_launch("colsum");
 }
 
 extern "C" int mapx_relu_mask_colsum(const float* dy, const float* y, int M, int N, float* dz, float* db,
                                       void* ws, size_t ws_bytes, hipStream_t stream) {
   using namespace mapx;
-  MAPX_REQUIRE(dy && y && dz && db && M >= 0 && N > 0, "relu_mask_colsum: bad arguments");
+  MAPX_REQUIRE(dy && y && dz && M >= 0 && N > 0, "relu_mask_colsum: bad arguments");
   MAPX_REQUIRE(N % 4 == 0, "relu_mask_colsum: N %% 4 != 0");
   if (!ws || ws_bytes < mapx_colsum_workspace_bytes(N)) {
     set_error("relu_mask_colsum: workspace too small");
@@ -590,7 +635,7 @@ extern "C" int mapx_relu_mask_colsum(const float* dy, const float* y, int M, int
   float* part = static_cast<float*>(ws);
   hipLaunchKernelGGL(ew_colsum_kernel<0>, dim3((N + 255) / 256, kColChunks), dim3(256), 0, stream, dy, y,
                      (const float*)nullptr, M, N, dz, (float*)nullptr, 0, part);
-  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, db);
+  if (db) hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, db);
   return check_launch("relu_mask_colsum");
 }
 
@@ -598,7 +643,7 @@ extern "C" int mapx_cross_bwd_pre_colsum(const float* g, const float* x0, const 
                                          float* t, float* dx0, int accumulate, float* db, void* ws,
                                          size_t ws_bytes, hipStream_t stream) {
   using namespace mapx;
-  MAPX_REQUIRE(g && x0 && u && t && dx0 && db && M >= 0 && N > 0, "cross_bwd_pre_colsum: bad arguments");
+  MAPX_REQUIRE(g && x0 && u && t && dx0 && M >= 0 && N > 0, "cross_bwd_pre_colsum: bad arguments");
   MAPX_REQUIRE(N % 4 == 0, "cross_bwd_pre_colsum: N %% 4 != 0");
   if (!ws || ws_bytes < mapx_colsum_workspace_bytes(N)) {
     set_error("cross_bwd_pre_colsum: workspace too small");
@@ -607,7 +652,7 @@ extern "C" int mapx_cross_bwd_pre_colsum(const float* g, const float* x0, const 
   float* part = static_cast<float*>(ws);
   hipLaunchKernelGGL(ew_colsum_kernel<1>, dim3((N + 255) / 256, kColChunks), dim3(256), 0, stream, g, x0, u, M,
                      N, t, dx0, accumulate, part);
-  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, db);
+  if (db) hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, db);
   return check_launch("cross_bwd_pre_colsum");
 }
 

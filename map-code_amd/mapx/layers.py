@@ -132,7 +132,8 @@ def _grad_slot(p):
     """MapxOptimizer gives every dense parameter a slice of its flat gradient buffer
     (`p._mapx_grad`).  When present, backward kernels write the gradient straight into it
     (overwrite, one backward per step) and return None to autograd: no per-parameter
-    accumulate kernel, no flat-buffer copy."""
+    accumulate kernel, no flat-buffer copy.  The final slab / partial sums of those gradients
+    are deferred (ops.defer_sum) and done by one launch in MapxOptimizer.step()."""
     return getattr(p, "_mapx_grad", None)
 
 
@@ -141,8 +142,8 @@ def _weight_grads(ctx, dz, x, sw, sb, need=None):
     (Measured: moving these onto a side stream next to the dX chain made the step 5 % SLOWER —
     both are full-GPU GEMMs and only steal each other's CUs — so they stay on the main stream.)"""
     need_w, need_b = need if need is not None else (ctx.needs_input_grad[1], ctx.needs_input_grad[2])
-    dw = ops.linear_bwd_weight(dz, x, out=sw) if need_w else None
-    db = ops.colsum(dz, out=sb) if need_b else None
+    dw = ops.linear_bwd_weight(dz, x, out=sw, defer=True) if need_w else None
+    db = ops.colsum(dz, out=sb, defer=True) if need_b else None
     return (None if sw is not None else dw), (None if sb is not None else db)
 
 
@@ -161,8 +162,8 @@ class _Linear(Function):
         x, w, y = ctx.saved_tensors
         sw, sb = ctx.slots
         if ctx.relu and gy.shape[1] % 4 == 0:      # ReLU mask and bias gradient in one pass over dY
-            dz, db = ops.relu_mask_colsum(gy.contiguous(), y, db=sb)
-            dw = ops.linear_bwd_weight(dz, x, out=sw) if ctx.needs_input_grad[1] else None
+            dz, db = ops.relu_mask_colsum(gy.contiguous(), y, db=sb, defer=True)
+            dw = ops.linear_bwd_weight(dz, x, out=sw, defer=True) if ctx.needs_input_grad[1] else None
             dw, db = (None if sw is not None else dw), (None if sb is not None else db)
         else:
             dz = ops.relu_mask(gy.contiguous(), y) if ctx.relu else gy.contiguous()
@@ -225,9 +226,9 @@ class _CrossLayer(Function):
         x0, xi, w, u = ctx.saved_tensors
         g = g.contiguous()
         sw, sb = ctx.slots
-        t, dx0, db = ops.cross_bwd_pre_colsum(g, x0, u, db=sb)   # t = g*x0, dx0 = g*u, db = colsum(t)
-        dxi = ops.linear_bwd_input(t, w, add=g)                  # g + t W
-        dw = ops.linear_bwd_weight(t, xi, out=sw)                # t^T xi
+        t, dx0, db = ops.cross_bwd_pre_colsum(g, x0, u, db=sb, defer=True)   # t = g*x0, dx0 = g*u, colsum(t)
+        dxi = ops.linear_bwd_input(t, w, add=g)                              # g + t W
+        dw = ops.linear_bwd_weight(t, xi, out=sw, defer=True)                # t^T xi
         return dx0, dxi, (None if sw is not None else dw), (None if sb is not None else db)
 
 

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmapx_hip.so")
 
-MAPX_ABI_VERSION = 8
+MAPX_ABI_VERSION = 9
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_CROSS, EPI_ADD, EPI_RELU_MASK = range(6)
 
 _p, _i, _i64, _u64, _f, _d, _sz = (C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double,
@@ -40,7 +40,9 @@ SIGNATURES = {
     "mapx_scale_inplace": (_i, [_p, _i64, _p, _p]),
     "mapx_gemm_splitk_workspace_bytes": (_sz, [_i, _i, _i]),
     "mapx_gemm_f32": (_i, [_i, _i, _i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _i, _p, _p, _i64, _p,
-                           _i64, _p, _i64, _i, _i, _p, _sz, _p]),
+                           _i64, _p, _i64, _i, _i, _p, _sz, _p, _p]),
+    "mapx_sum_tasks": (_i, [_p, _i, _p]),
+    "mapx_colsum_chunks": (_i, []),
     "mapx_colsum_workspace_bytes": (_sz, [_i]),
     "mapx_colsum": (_i, [_p, _i64, _i, _i, _p, _p, _sz, _p]),
     "mapx_cross_bwd_pre": (_i, [_p, _p, _p, _i64, _p, _p, _i, _p]),
@@ -57,6 +59,12 @@ SIGNATURES = {
     "mapx_table_adam": (_i, [_p, _p, _p, _i, _f, _p, _p, _p, _f, _p, _p, _i64, _i64, _p, _p, _p, _p,
                              _i, _p, _p, _i, _d, _d, _d, _i, _p]),
 }
+
+
+class SumTask(C.Structure):
+    """mapx_sum_task (include/mapx_hip.h)."""
+    _fields_ = [("dst", _p), ("src", _p), ("stride", _i64), ("n", _i64), ("nsplit", C.c_int32),
+                ("pad_", C.c_int32)]
 
 
 class MapxError(RuntimeError):

@@ -9,8 +9,18 @@ import os
 
 import torch
 
+import ctypes
+
 from . import native as N
 from .native import check, lib, ptr, require_gpu, stream
+
+
+def native_int():
+    return ctypes.c_int(0)
+
+
+def native_byref(x):
+    return ctypes.byref(x)
 
 _scratch = {}
 
@@ -85,6 +95,35 @@ def aux_stream(name, device):
     if st is None:
         st = _aux_streams[key] = torch.cuda.Stream(device=device)
     return st
+
+
+# --------------------------------------------------------------------------- deferred sums
+# Split-K slabs (weight gradients) and row-chunk partials (bias gradients) of a backward pass
+# are summed by ONE kernel launch right before their consumer (optimizer / gradient exchange)
+# instead of one tiny launch each.  Only used when the destination is an optimizer-owned slot.
+_deferred = []
+COLSUM_CHUNKS = lib.mapx_colsum_chunks()
+
+
+# measured on MI355X inside the full step: deferring is 2 % SLOWER (1.71 vs 1.68 ms) — the tiny sums
+# run in the shadow of side-stream work and read L2-hot slabs — so it is off by default.
+DEFER = os.environ.get("MAPX_DEFER", "0") == "1"
+
+
+def defer_sum(dst, src, stride, nsplit, n):
+    _deferred.append((dst, src, int(stride), int(nsplit), int(n)))
+
+
+def flush_deferred():
+    """Launch the pending slab sums (32 tasks per launch)."""
+    global _deferred
+    while _deferred:
+        batch, _deferred = _deferred[:32], _deferred[32:]
+        arr = (N.SumTask * len(batch))()
+        for i, (dst, src, stride, nsplit, n) in enumerate(batch):
+            arr[i].dst, arr[i].src = dst.data_ptr(), src.data_ptr()
+            arr[i].stride, arr[i].n, arr[i].nsplit = stride, n, nsplit
+        check(lib.mapx_sum_tasks(arr, len(batch), stream()))
 
 
 def scratch(nbytes, device):
@@ -261,7 +300,7 @@ def scale_(x, g):
 
 # --------------------------------------------------------------------------- dense
 def gemm(a, b, a_kc, b_kc, M, N, K, out=None, ldc=None, epi=N.EPI_NONE, bias=None, aux1=None,
-         aux2=None, out2=None, nsplit=1, lda=None, ldb=None, tile=-1):
+         aux2=None, out2=None, nsplit=1, lda=None, ldb=None, tile=-1, defer=False):
     """C[M,N] = epi(sum_k A(m,k) B(k,n)); see include/mapx_hip.h: mapx_gemm_f32."""
     require_gpu(a, b)
     dev = a.device
@@ -273,8 +312,10 @@ def gemm(a, b, a_kc, b_kc, M, N, K, out=None, ldc=None, epi=N.EPI_NONE, bias=Non
     ws, wsn = None, 0
     if nsplit > 1:
         wsn = lib.mapx_gemm_splitk_workspace_bytes(M, N, nsplit)
-        ws = scratch(wsn, dev)
+        # deferred slabs must outlive this call: their own buffer, not the shared scratch
+        ws = torch.empty(wsn, dtype=torch.uint8, device=dev) if defer else scratch(wsn, dev)
         wsn = ws.numel()
+    got = native_int() if (defer and nsplit > 1) else None
     ld1 = aux1.stride(0) if aux1 is not None else 0
     ld2 = aux2.stride(0) if aux2 is not None else 0
     ldo2 = out2.stride(0) if out2 is not None else 0
@@ -285,7 +326,10 @@ def gemm(a, b, a_kc, b_kc, M, N, K, out=None, ldc=None, epi=N.EPI_NONE, bias=Non
                                 aux1.data_ptr() if aux1 is not None else None, ld1,
                                 aux2.data_ptr() if aux2 is not None else None, ld2,
                                 out2.data_ptr() if out2 is not None else None, ldo2, nsplit, tile,
-                                ws.data_ptr() if ws is not None else None, wsn, stream()))
+                                ws.data_ptr() if ws is not None else None, wsn,
+                                None if got is None else native_byref(got), stream()))
+    if got is not None and got.value > 1:
+        defer_sum(out, ws.view(torch.float32), M * N, got.value, M * N)
     return out
 
 
@@ -321,23 +365,33 @@ def _splits_for(M, Nn, Kred):
     return ns
 
 
-def linear_bwd_weight(dy, x, out=None):
-    """dW = dY^T X.  dy [B,N], x [B,K] -> [N,K]."""
+def linear_bwd_weight(dy, x, out=None, defer=False):
+    """dW = dY^T X.  dy [B,N], x [B,K] -> [N,K].  defer: leave split-K slabs for flush_deferred()."""
     Bn, Nn = dy.shape
     K = x.shape[1]
     ns = _splits_for(Nn, K, Bn)
     if out is not None and out.stride(0) != K:
         ns = 1
-    return gemm(dy, x, False, False, Nn, K, Bn, out=out, nsplit=ns)
+    return gemm(dy, x, False, False, Nn, K, Bn, out=out, nsplit=ns, defer=DEFER and defer and out is not None)
 
 
-def colsum(x, out=None):
+def _partials(Nn, device, defer):
+    nb = lib.mapx_colsum_workspace_bytes(Nn)
+    return torch.empty(nb, dtype=torch.uint8, device=device) if defer else scratch(nb, device)
+
+
+def colsum(x, out=None, defer=False):
+    """Column sums; defer (needs out): leave the row-chunk partials for flush_deferred()."""
     require_gpu(x)
     M, Nn = x.shape
+    defer = DEFER and defer and out is not None
     if out is None:
         out = torch.empty(Nn, dtype=torch.float32, device=x.device)
-    ws = scratch(lib.mapx_colsum_workspace_bytes(Nn), x.device)
-    check(lib.mapx_colsum(x.data_ptr(), x.stride(0), M, Nn, ptr(out), ptr(ws), ws.numel(), stream()))
+    ws = _partials(Nn, x.device, defer)
+    check(lib.mapx_colsum(x.data_ptr(), x.stride(0), M, Nn, None if defer else ptr(out), ptr(ws),
+                          ws.numel(), stream()))
+    if defer:
+        defer_sum(out, ws.view(torch.float32), Nn, COLSUM_CHUNKS, Nn)
     return out
 
 
@@ -361,29 +415,36 @@ def cross_bwd_pre(g, x0, u, dx0=None):
     return t, dx0
 
 
-def relu_mask_colsum(dy, y, db=None):
+def relu_mask_colsum(dy, y, db=None, defer=False):
     """-> (dz = y > 0 ? dy : 0, db = colsum(dz)) in one pass."""
     M, Nn = dy.shape
     dz = torch.empty_like(dy)
+    defer = DEFER and defer and db is not None
     if db is None:
         db = torch.empty(Nn, dtype=torch.float32, device=dy.device)
-    ws = scratch(lib.mapx_colsum_workspace_bytes(Nn), dy.device)
-    check(lib.mapx_relu_mask_colsum(ptr(dy), ptr(y), M, Nn, ptr(dz), ptr(db), ptr(ws), ws.numel(), stream()))
+    ws = _partials(Nn, dy.device, defer)
+    check(lib.mapx_relu_mask_colsum(ptr(dy), ptr(y), M, Nn, ptr(dz), None if defer else ptr(db), ptr(ws),
+                                    ws.numel(), stream()))
+    if defer:
+        defer_sum(db, ws.view(torch.float32), Nn, COLSUM_CHUNKS, Nn)
     return dz, db
 
 
-def cross_bwd_pre_colsum(g, x0, u, dx0=None, db=None):
+def cross_bwd_pre_colsum(g, x0, u, dx0=None, db=None, defer=False):
     """-> (t = g*x0, dx0 (+)= g*u, db = colsum(t)) in one pass."""
     M, Nn = g.shape
     t = torch.empty_like(g)
     acc = dx0 is not None
     if dx0 is None:
         dx0 = torch.empty_like(g)
+    defer = DEFER and defer and db is not None
     if db is None:
         db = torch.empty(Nn, dtype=torch.float32, device=g.device)
-    ws = scratch(lib.mapx_colsum_workspace_bytes(Nn), g.device)
-    check(lib.mapx_cross_bwd_pre_colsum(ptr(g), ptr(x0), ptr(u), M, Nn, ptr(t), ptr(dx0), int(acc), ptr(db),
-                                        ptr(ws), ws.numel(), stream()))
+    ws = _partials(Nn, g.device, defer)
+    check(lib.mapx_cross_bwd_pre_colsum(ptr(g), ptr(x0), ptr(u), M, Nn, ptr(t), ptr(dx0), int(acc),
+                                        None if defer else ptr(db), ptr(ws), ws.numel(), stream()))
+    if defer:
+        defer_sum(db, ws.view(torch.float32), Nn, COLSUM_CHUNKS, Nn)
     return t, dx0, db
 
 

@@ -161,6 +161,7 @@ class MapxOptimizer:
                     r1.mul_(coef)
 
     def step(self):
+        ops.flush_deferred()            # split-K slabs / colsum partials of this backward pass
         if self.max_grad_norm > 0:
             self.clip_grad_norm_()
         b1, b2, eps = self.hyper

@@ -98,6 +98,8 @@ def sync_gradients(optimizer, merge_fn=hip_merge):
     """Call between backward() and optimizer.step()."""
     if world() == 1:
         return
+    from . import ops
+    ops.flush_deferred()                # dense gradients must be final before the all-reduce
     for g in optimizer.groups:
         allreduce_mean_(g["g"])
     for t in optimizer.tables:
