@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 9
+#define MAPX_ABI_VERSION 10
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -96,13 +96,15 @@ int mapx_nce_pack_idx(const int64_t* targets, const int64_t* noise, int64_t T, i
  *   emb [V,P], bias [V], logq [V] (= logprob_noise).
  * Outputs: h_out [B*L,P] (gathered hidden), dlogit [B*L,K+1] = dLoss/dlogit (mean over
  * B*L folded in), dh [B*L,P] = dLoss/dh, logits_opt [B*L,K+1] or NULL (the reference's
- * `logits`, i.e. score - ln V), loss_out[1] (mean), acc_out[1] (# targets ranked first). */
+ * `logits`, i.e. score - ln V), loss_out[1] (mean), acc_out[1] (# targets ranked first).
+ * hpos_opt != NULL (grouped encoder, P = 32): `enc` is h_slots [slots, P] and target t reads
+ * slot hpos_opt[t]; dh_slots_opt then also receives dh at the slot (for mapx_enc_grouped_dw). */
 size_t mapx_nce_fwd_workspace_bytes(void);
 int mapx_nce_fwd(const float* enc, int64_t B, int L, int F, int P, const int64_t* masked_index,
                  const int32_t* idx, int K, const float* emb, const float* bias,
                  const float* logq, int64_t V, float* h_out, float* dlogit, float* dh,
                  float* logits_opt, float* loss_out, int32_t* acc_out, void* ws, size_t ws_bytes,
-                 hipStream_t stream);
+                 const int32_t* hpos_opt, float* dh_slots_opt, hipStream_t stream);
 /* Backward of the field gather: denc[b, f*P+p] = g * sum_{l: mi[b,l]==f} dh[b,l,p]; denc
  * [B, F*P] fully written.  gscale_opt: device scalar (upstream dLoss) or NULL = 1. */
 int mapx_nce_scatter_dh(const float* dh, const int64_t* masked_index, const float* gscale_opt,
@@ -157,6 +159,24 @@ int mapx_sum_tasks(const mapx_sum_task* tasks_host, int ntasks, hipStream_t stre
 /* row chunks of the column-sum kernels: with out/db == NULL they leave `chunks` partial rows
  * [chunks][N] in `ws` for a later mapx_sum_tasks (stride N, nsplit = chunks). */
 int mapx_colsum_chunks(void);
+/* Grouped feat_encoder (models.py:74-75; proj_size P = 32): only the L masked fields' P-blocks of
+ * the encoder output are ever read, so targets are sorted by field and only those are computed.
+ * mapx_enc_group_layout: from the segment plan over masked_index.flatten() (keys = field ids,
+ *   V = F) build the padded slot layout: rowmap[cap_slots] (batch row or -1), hpos[T] (slot of
+ *   target t), tile_group[cap_slots/128] (field of each 128-slot tile or -1), group_start[F+1].
+ *   cap_slots = a multiple of 128 >= T + 127*F.
+ * mapx_enc_grouped_fwd: h_slots[slot, 0:32] = final[rowmap[slot], :] . W[f*32:(f+1)*32, :]^T + bias.
+ * mapx_enc_grouped_dw:  dW[f*32 + p, :] = sum_{slot in group f} dh_slots[slot, p] * final[rowmap[slot], :]
+ *   (all F*32 rows written; dh_slots must be zero in unused slots). */
+int mapx_enc_group_layout(const int32_t* perm, const int32_t* uniq, const int32_t* seg_start,
+                          const int32_t* n_uniq, int T, int L, int F, int cap_slots, int32_t* rowmap,
+                          int32_t* hpos, int32_t* tile_group, int32_t* group_start, hipStream_t stream);
+int mapx_enc_grouped_fwd(const float* final_act, int64_t ld_final, int nrows, int K, const float* W,
+                         int64_t ldw, const float* bias, const int32_t* rowmap,
+                         const int32_t* tile_group, int cap_slots, float* h_slots, hipStream_t stream);
+int mapx_enc_grouped_dw(const float* dh_slots, const float* final_act, int64_t ld_final, int nrows, int N,
+                        const int32_t* rowmap, const int32_t* group_start, int F, float* dW, int64_t ldw,
+                        hipStream_t stream);
 /* out[n] = sum_m x[m*ld + n]  (bias gradients), deterministic two-stage. */
 size_t mapx_colsum_workspace_bytes(int N);
 int mapx_colsum(const float* x, int64_t ld, int M, int N, float* out, void* ws, size_t ws_bytes,

@@ -348,6 +348,188 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Grouped GEMMs of the MFP head's feat_encoder (models.py:74-75).  The reference computes all
+// F*P encoder outputs per row and then gathers the L masked fields' P-blocks: 74 % of the
+// forward GEMM and of its weight-gradient GEMM is never read.  Here targets (b, l) are sorted
+// by field (groups padded to 128 slots; rowmap[slot] = batch row or -1), and
+//   FWD  h[slot, :]      = final[rowmap[slot], :] . W[f*P:(f+1)*P, :]^T + bias[f*P:(f+1)*P]
+//        one block per 128-slot tile (single field f = tile_group[tile]); 4x1 waves, tile 128x32;
+//        A rows gathered through rowmap, B = the field's 32 weight rows.
+//   DW   dW[f*P + p, n]  = sum_{slot in group f} dh[slot, p] * final[rowmap[slot], n]
+//        one block per (field, 128-column tile); 1x4 waves, tile 32x128; K runs over the group's
+//        slots, B rows gathered through rowmap.  Every weight row is written (zeros for fields
+//        nobody masked), so no split-K and no zero-fill pass.
+// P = 32 only (the reference default); other proj sizes use the dense path.
+struct GroupedArgs {
+  const float* A; int64_t lda;       // FWD: final [B, K]          DW: dh [slots, 32]
+  const float* B; int64_t ldb;       // FWD: W [F*32, K]           DW: final [B, N]
+  float* C; int64_t ldc;             // FWD: h [slots, 32]         DW: dW [F*32, N]
+  const float* bias;                 // FWD only
+  const int32_t* rowmap;             // [slots]
+  const int32_t* tile_group;         // FWD: [slots/128] field of the tile, -1 = unused
+  const int32_t* group_start;        // DW: [F+1] first slot of each field's group (multiples of 128)
+  int K, N, nrows;                   // FWD: K = D+H;  DW: N = D+H;  nrows = B (bounds of rowmap values)
+};
+
+template <bool DW>
+__global__ void __launch_bounds__(256) gemm_grouped_kernel(GroupedArgs a) {
+  constexpr int BK = 32;
+  constexpr int BM = DW ? 32 : 128, BN = DW ? 128 : 32;
+  using OpA = Operand<BM, 1, !DW, true, BK>;     // FWD: k-contiguous rows; DW: [k][m] storage
+  using OpB = Operand<BN, 1, !DW, true, BK>;     // FWD: k-contiguous rows; DW: [k][n] storage
+  __shared__ __attribute__((aligned(16))) float As[2][OpA::LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float Bs[2][OpB::LDS_FLOATS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int abase = DW ? 0 : wave * 32, bbase = DW ? wave * 32 : 0;
+
+  int f, kbeg, kend, n0 = 0, slot0 = 0;
+  if (DW) {
+    f = blockIdx.y;
+    kbeg = a.group_start[f];
+    kend = a.group_start[f + 1];
+    n0 = blockIdx.x * BN;
+  } else {
+    f = a.tile_group[blockIdx.x];
+    if (f < 0) return;               // capacity tile beyond the used slots
+    slot0 = blockIdx.x * BM;
+    kbeg = 0;
+    kend = a.K;
+  }
+  const float* __restrict__ Ab = DW ? a.A : a.A;
+  const float* __restrict__ Bb = DW ? a.B : a.B + (int64_t)f * 32 * a.ldb;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  OpA la;
+  OpB lb;
+  // one K-step of loads into the register sets
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < OpA::NV; ++i) {
+      int tr, tc;
+      OpA::coords(threadIdx.x + i * 256, tr, tc);
+      if (DW) {          // A(m = p, k = slot): dh[slot*32 + p]; storage row = slot (k), col = p
+        la.ok[i] = true;
+        la.r[i] = *reinterpret_cast<const float4*>(Ab + (int64_t)(k0 + tr) * a.lda + tc);
+      } else {           // A row = final[rowmap[slot]], k-contiguous; K tail zero-filled
+        const int row = a.rowmap[slot0 + tr];
+        la.ok[i] = row >= 0 && (k0 + tc) < kend;
+        la.r[i] = *reinterpret_cast<const float4*>(Ab + (la.ok[i] ? (int64_t)row * a.lda + k0 + tc : 0));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < OpB::NV; ++i) {
+      int tr, tc;
+      OpB::coords(threadIdx.x + i * 256, tr, tc);
+      if (DW) {          // B(k = slot, n): final[rowmap[slot]][n0 + tc]
+        const int row = a.rowmap[k0 + tr];
+        lb.ok[i] = row >= 0 && (n0 + tc) < a.N;
+        lb.r[i] = *reinterpret_cast<const float4*>(Bb + (lb.ok[i] ? (int64_t)row * a.ldb + n0 + tc : 0));
+      } else {           // B row = W[f*32 + tr], k-contiguous
+        lb.ok[i] = (k0 + tc) < kend;
+        lb.r[i] = *reinterpret_cast<const float4*>(Bb + (int64_t)tr * a.ldb + (lb.ok[i] ? k0 + tc : 0));
+      }
+    }
+  };
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (nk > 0) {
+    load_tile(kbeg);
+    la.template store<true>(As[0]);
+    lb.template store<true>(Bs[0]);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile(kbeg + (kt + 1) * BK);
+    float af[2][1][4], bf[2][1][4];
+    OpA::frags(As[cur], abase, l31, kh, 0, af[0]);
+    OpB::frags(Bs[cur], bbase, l31, kh, 0, bf[0]);
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q) {
+      const int c = q & 1;
+      if (q + 1 < BK / 8) {
+        OpA::frags(As[cur], abase, l31, kh, q + 1, af[c ^ 1]);
+        OpB::frags(Bs[cur], bbase, l31, kh, q + 1, bf[c ^ 1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][0][s], bf[c][0][s], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kt + 1 < nk) {
+      la.template store<true>(As[cur ^ 1]);
+      lb.template store<true>(Bs[cur ^ 1]);
+    }
+    __syncthreads();
+  }
+  // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int n = (DW ? n0 : 0) + bbase + l31;
+  if (DW ? (n < a.N) : true) {
+    const float bn = DW ? 0.f : a.bias[f * 32 + n];
+    float* __restrict__ Cb = DW ? a.C + (int64_t)f * 32 * a.ldc : a.C + (int64_t)slot0 * a.ldc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = abase + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      Cb[(int64_t)m * a.ldc + n] = acc[r] + bn;
+    }
+  }
+}
+
+// Padded by-field layout of the targets from the sorted plan over masked_index (keys = field id):
+// group u (field uniq[u], sorted positions seg_start[u]..seg_start[u+1]) gets ceil128(len) slots.
+__global__ void __launch_bounds__(256) enc_group_layout_kernel(
+    const int32_t* __restrict__ perm, const int32_t* __restrict__ uniq, const int32_t* __restrict__ seg_start,
+    const int32_t* __restrict__ n_uniq, int T, int L, int F, int cap_slots, int32_t* __restrict__ rowmap,
+    int32_t* __restrict__ hpos, int32_t* __restrict__ tile_group, int32_t* __restrict__ group_start) {
+  __shared__ int gstart[64 + 1];   // padded start of every present group (F <= 64)
+  __shared__ int gfield[64];
+  const int U = *n_uniq;
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    // per-field starts (absent fields: empty range)
+    int run = 0, u = 0;
+    for (int f = 0; f < F; ++f) {
+      group_start[f] = run;
+      if (u < U && uniq[u] == f) {
+        run += ((seg_start[u + 1] - seg_start[u] + 127) / 128) * 128;
+        ++u;
+      }
+    }
+    group_start[F] = run;
+  }
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int u = 0; u < U; ++u) {
+      gstart[u] = run;
+      gfield[u] = uniq[u];
+      run += ((seg_start[u + 1] - seg_start[u] + 127) / 128) * 128;
+    }
+    gstart[U] = run;
+  }
+  __syncthreads();
+  const int used = gstart[U];
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+  for (int s = tid; s < cap_slots; s += nth) {
+    // which group does slot s belong to, and is it a real entry?
+    int u = 0;
+    while (u + 1 <= U && gstart[u + 1] <= s && u < U) ++u;
+    int row = -1;
+    if (s < used) {
+      const int j = seg_start[u] + (s - gstart[u]);
+      if (j < seg_start[u + 1]) {
+        const int t = perm[j];
+        row = t / L;
+        hpos[t] = s;
+      }
+    }
+    rowmap[s] = row;
+    if ((s & 127) == 0) tile_group[s >> 7] = s < used ? gfield[u] : -1;
+  }
+}
+
 // out[i] = sum_s slabs[s][i] in slab order (deterministic split-K combine)
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ slabs,
                                                             int64_t slab_stride, int nsplit,
@@ -583,6 +765,48 @@ extern "C" int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
                        static_cast<const float*>(ws), g.slab_stride, nsplit, n, C);
   }
   return check_launch("gemm_f32");
+}
+
+extern "C" int mapx_enc_group_layout(const int32_t* perm, const int32_t* uniq, const int32_t* seg_start,
+                                     const int32_t* n_uniq, int T, int L, int F, int cap_slots,
+                                     int32_t* rowmap, int32_t* hpos, int32_t* tile_group,
+                                     int32_t* group_start, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(perm && uniq && seg_start && n_uniq && rowmap && hpos && tile_group && group_start,
+               "enc_group_layout: null pointer");
+  MAPX_REQUIRE(F >= 1 && F <= 64 && L >= 1 && T >= 0 && cap_slots % 128 == 0 && cap_slots >= T + 127 * 1,
+               "enc_group_layout: bad sizes (F <= 64, cap_slots multiple of 128)");
+  hipLaunchKernelGGL(enc_group_layout_kernel, dim3(grid_for(cap_slots, 256, 256)), dim3(256), 0, stream, perm,
+                     uniq, seg_start, n_uniq, T, L, F, cap_slots, rowmap, hpos, tile_group, group_start);
+  return check_launch("enc_group_layout");
+}
+
+extern "C" int mapx_enc_grouped_fwd(const float* final_act, int64_t ld_final, int nrows, int K, const float* W,
+                                    int64_t ldw, const float* bias, const int32_t* rowmap,
+                                    const int32_t* tile_group, int cap_slots, float* h_slots,
+                                    hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(final_act && W && bias && rowmap && tile_group && h_slots, "enc_grouped_fwd: null pointer");
+  MAPX_REQUIRE(K % 4 == 0 && ld_final % 4 == 0 && ldw % 4 == 0 && cap_slots % 128 == 0,
+               "enc_grouped_fwd: K, leading dimensions %% 4 and cap_slots %% 128 must be 0");
+  GroupedArgs g{};
+  g.A = final_act; g.lda = ld_final; g.B = W; g.ldb = ldw; g.C = h_slots; g.ldc = 32; g.bias = bias;
+  g.rowmap = rowmap; g.tile_group = tile_group; g.K = K; g.N = 32; g.nrows = nrows;
+  hipLaunchKernelGGL(gemm_grouped_kernel<false>, dim3(cap_slots / 128), dim3(256), 0, stream, g);
+  return check_launch("enc_grouped_fwd");
+}
+
+extern "C" int mapx_enc_grouped_dw(const float* dh_slots, const float* final_act, int64_t ld_final, int nrows,
+                                   int N, const int32_t* rowmap, const int32_t* group_start, int F,
+                                   float* dW, int64_t ldw, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(dh_slots && final_act && rowmap && group_start && dW, "enc_grouped_dw: null pointer");
+  MAPX_REQUIRE(N % 4 == 0 && ld_final % 4 == 0 && F >= 1, "enc_grouped_dw: N, ld %% 4 must be 0");
+  GroupedArgs g{};
+  g.A = dh_slots; g.lda = 32; g.B = final_act; g.ldb = ld_final; g.C = dW; g.ldc = ldw;
+  g.rowmap = rowmap; g.group_start = group_start; g.K = 0; g.N = N; g.nrows = nrows;
+  hipLaunchKernelGGL(gemm_grouped_kernel<true>, dim3((N + 127) / 128, F), dim3(256), 0, stream, g);
+  return check_launch("enc_grouped_dw");
 }
 
 extern "C" size_t mapx_colsum_workspace_bytes(int N) {

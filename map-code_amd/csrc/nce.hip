@@ -167,7 +167,8 @@ __global__ void __launch_bounds__(256) nce_fwd_p32_kernel(
     int L, const int32_t* __restrict__ idx, int64_t T, int K1, const float* __restrict__ emb,
     const float* __restrict__ bias, const float* __restrict__ logq, float lnV, float lnK,
     float invT, float* __restrict__ h_out, float* __restrict__ dlogit, float* __restrict__ dh,
-    float* __restrict__ logits, float* __restrict__ loss_partial, int* __restrict__ acc_count) {
+    float* __restrict__ logits, float* __restrict__ loss_partial, int* __restrict__ acc_count,
+    const int32_t* __restrict__ hpos, float* __restrict__ dh_slots) {
   constexpr int LG = 8, P = 32, GPB = 256 / LG, MAXB = 4;   // up to 32 rows per target
   const int lane = threadIdx.x & 63;
   const int sub = lane & 7, gbase = lane & ~7;
@@ -175,9 +176,9 @@ __global__ void __launch_bounds__(256) nce_fwd_p32_kernel(
   float loss_acc = 0.f;
   int acc_acc = 0;
   for (int64_t t = (int64_t)blockIdx.x * GPB + gib; t < T; t += (int64_t)gridDim.x * GPB) {
-    const int64_t b = t / L;
-    const int64_t mi = masked_index[t];
-    const float4 h4 = *reinterpret_cast<const float4*>(enc + b * enc_stride + mi * P + 4 * sub);
+    // grouped encoder: `enc` holds only the needed P-blocks, one per slot; hpos[t] = slot of t
+    const int64_t hoff = hpos ? (int64_t)hpos[t] * P : (t / L) * enc_stride + masked_index[t] * P;
+    const float4 h4 = *reinterpret_cast<const float4*>(enc + hoff + 4 * sub);
     *reinterpret_cast<float4*>(h_out + t * P + 4 * sub) = h4;
     const int32_t* ix = idx + t * K1;
     int myid[MAXB];
@@ -246,6 +247,7 @@ __global__ void __launch_bounds__(256) nce_fwd_p32_kernel(
       }
     }
     *reinterpret_cast<float4*>(dh + t * P + 4 * sub) = dh4;
+    if (dh_slots) *reinterpret_cast<float4*>(dh_slots + (int64_t)hpos[t] * P + 4 * sub) = dh4;
     const float loss_t = group_sum<LG>(loss_l);
     float smax = smax_l;
 #pragma unroll
@@ -350,13 +352,15 @@ extern "C" int mapx_nce_fwd(const float* enc, int64_t B, int L, int F, int P,
                             const float* emb, const float* bias, const float* logq, int64_t V,
                             float* h_out, float* dlogit, float* dh, float* logits_opt,
                             float* loss_out, int32_t* acc_out, void* ws, size_t ws_bytes,
-                            hipStream_t stream) {
+                            const int32_t* hpos_opt, float* dh_slots_opt, hipStream_t stream) {
   MAPX_REQUIRE(enc && masked_index && idx && emb && bias && logq && h_out && dlogit && dh &&
                    loss_out && acc_out && ws,
                "nce_fwd: null pointer");
   MAPX_REQUIRE(B >= 0 && L >= 1 && F >= 1 && K >= 1 && V > 0, "nce_fwd: bad sizes");
   MAPX_REQUIRE(P == 8 || P == 16 || P == 32 || P == 64 || P == 128,
                "nce_fwd: proj_size %d unsupported (8, 16, 32, 64, 128)", P);
+  MAPX_REQUIRE(!hpos_opt || (P == 32 && K + 1 <= 32), "nce_fwd: slot-indexed hidden needs P = 32, K <= 31");
+  MAPX_REQUIRE(!dh_slots_opt || hpos_opt, "nce_fwd: dh_slots needs hpos");
   if (ws_bytes < mapx_nce_fwd_workspace_bytes()) {
     mapx::set_error("nce_fwd: workspace too small");
     return MAPX_EWORKSPACE;
@@ -384,7 +388,7 @@ extern "C" int mapx_nce_fwd(const float* enc, int64_t B, int L, int F, int P,
       if (K + 1 <= 32)
         hipLaunchKernelGGL(mapx::nce_fwd_p32_kernel, dim3(grid), dim3(256), 0, stream, enc, enc_stride,
                            masked_index, L, idx, T, K + 1, emb, bias, logq, lnV, lnK, invT, h_out, dlogit,
-                           dh, logits_opt, partial, acc_out);
+                           dh, logits_opt, partial, acc_out, hpos_opt, dh_slots_opt);
       else
         MAPX_NCE(8);
       break;

@@ -2,6 +2,7 @@
 same forward signature and output tuples, same state_dict key layout; every arithmetic step
 is a gfx950 kernel."""
 import logging
+import os
 
 import torch
 from torch import nn
@@ -12,6 +13,7 @@ from .layers import CrossNetV2, Embeddings, HipLinear, MLPBlock, bce_with_logits
 from .nce import IndexLinear
 
 logger = logging.getLogger(__name__)
+GROUPED_ENCODER = os.environ.get("MAPX_GROUPED_ENC", "1") == "1"
 
 _OTHER_BACKBONES = ("dnn", "autoint", "trans", "fignn", "fgcnn", "deepfm", "xdeepfm")
 
@@ -61,9 +63,15 @@ class BaseModel(nn.Module):
         cfg = self.config
         if (is_pretrain is None and cfg.pretrain) or is_pretrain:
             if cfg.pt_type == "MFP":
-                enc = self.feat_encoder(inputs)
-                loss, _logits, _idx = self.mfp_criterion(labels, enc, masked_index=masked_index,
-                                                         noise_samples=noise_samples)
+                crit = self.mfp_criterion
+                if GROUPED_ENCODER and crit.supports_grouped_encoder() and inputs.shape[1] % 4 == 0:
+                    # only the L masked fields' blocks of feat_encoder are computed (26 %)
+                    loss, _logits, _idx = crit.forward_with_encoder(labels, inputs, self.feat_encoder,
+                                                                    masked_index, noise_samples=noise_samples)
+                else:
+                    enc = self.feat_encoder(inputs)
+                    loss, _logits, _idx = crit(labels, enc, masked_index=masked_index,
+                                               noise_samples=noise_samples)
                 return (loss, labels.shape[0] * labels.shape[1], self.mfp_criterion.last_acc)
             if cfg.pt_type == "RFD":
                 logits = self.pred_rfd(inputs)

@@ -81,6 +81,47 @@ class _NceLoss(Function):
         return denc, None, None, None, None, None, None, None, None, None
 
 
+class _EncNceLoss(Function):
+    """feat_encoder + field gather + NCE loss in one autograd node, computing only the encoder
+    blocks that targets select (reference models.py:74-76 computes all F blocks and gathers L).
+    Backward: dX through the dense scattered d_enc (unchanged), dW through the grouped GEMM."""
+
+    @staticmethod
+    def forward(ctx, final, w_enc, b_enc, emb_w, bias_w, logq, masked_index, idx, crit, F, P, want_logits):
+        final = final.contiguous()
+        groups = ops.EncGroups(masked_index, F)
+        h_slots = ops.enc_grouped_fwd(final, w_enc, b_enc, groups)
+        dh_slots = torch.zeros(groups.cap, P, dtype=torch.float32, device=final.device)
+        o = ops.nce_fwd(h_slots, masked_index, idx, emb_w, bias_w.view(-1), logq, F, P,
+                        want_logits=want_logits, hpos=groups.hpos, dh_slots=dh_slots)
+        ctx.crit, ctx.F, ctx.P, ctx.K, ctx.groups = crit, F, P, idx.shape[1] - 1, groups
+        ctx.plan = crit.table.plan
+        ctx.slots = (getattr(w_enc, "_mapx_grad", None), getattr(b_enc, "_mapx_grad", None))
+        ctx.save_for_backward(final, w_enc, o["dlogit"], o["dh"], o["h"], masked_index, dh_slots)
+        logits = o["logits"] if want_logits else torch.empty(0, device=final.device)
+        ctx.mark_non_differentiable(o["acc"], logits)
+        return o["loss"].view(()), o["acc"].view(()), logits
+
+    @staticmethod
+    def backward(ctx, gl, _a, _l):
+        final, w_enc, dlogit, dh, h, mi, dh_slots = ctx.saved_tensors
+        sw, sb = ctx.slots
+        gl = gl.contiguous().float()
+        denc = ops.nce_scatter_dh(dh, mi, ctx.F, ctx.P, gscale=gl)          # dense [B, F*P]
+        dfinal = ops.linear_bwd_input(denc, w_enc) if ctx.needs_input_grad[0] else None
+        ops.scale_(dh_slots, gl)
+        dw = ops.enc_grouped_dw(dh_slots, final, ctx.groups, out=sw)
+        db = ops.colsum(denc, out=sb)
+        if ctx.plan is None:
+            raise RuntimeError("NCE backward without a segment plan")
+        RowTable.join_plan(dlogit.device)
+        ops.scale_(dlogit, gl)
+        ge, gb = ops.nce_table_grad(ctx.plan, dlogit, h, ctx.K, ctx.P)
+        ctx.crit.table.sparse_grad = (ctx.plan, ge, gb)
+        return (dfinal, None if sw is not None else dw, None if sb is not None else db,
+                None, None, None, None, None, None, None, None, None)
+
+
 class IndexLinear(nn.Module):
     """Output embedding emb [V,P] + bias [V,1] scored only at the target and K sampled
     negatives, with the NCE binary loss.  Buffers/parameters keep the reference names:
@@ -146,6 +187,29 @@ class IndexLinear(nn.Module):
         self.table.prepare(idx.view(-1), need_grad)
         loss, acc, logits = _NceLoss.apply(enc, self.emb.weight, self.bias.weight, self.logprob_noise,
                                            masked_index, idx, self, F, P, self.return_logits)
+        self.last_acc = acc
+        if self.return_logits:
+            logits = logits.view(B, L, -1)
+        return loss, logits, idx.view(B, L, -1)
+
+    def supports_grouped_encoder(self):
+        return self.proj_size == 32 and self.noise_ratio + 1 <= 32
+
+    def forward_with_encoder(self, target, final, encoder, masked_index, noise_samples=None):
+        """The MFP head from the trunk output: `encoder` (feat_encoder) is applied only to the
+        field blocks that `masked_index` selects.  Same returns as forward()."""
+        B, L = target.shape
+        P, F = self.proj_size, encoder.out_features // self.proj_size
+        V = self.emb.weight.shape[0]
+        if noise_samples is not None:
+            idx = ops.nce_pack_idx(target.reshape(-1), noise_samples.reshape(B * L, -1), V)
+        else:
+            idx = self.get_noise_index(target)
+        need_grad = torch.is_grad_enabled() and self.emb.weight.requires_grad
+        self.table.prepare(idx.view(-1), need_grad)
+        loss, acc, logits = _EncNceLoss.apply(final, encoder.weight, encoder.bias, self.emb.weight,
+                                              self.bias.weight, self.logprob_noise, masked_index, idx, self,
+                                              F, P, self.return_logits)
         self.last_acc = acc
         if self.return_logits:
             logits = logits.view(B, L, -1)

@@ -248,12 +248,13 @@ def nce_pack_idx(targets, noise, V, validate=False):
     return idx
 
 
-def nce_fwd(enc, masked_index, idx, emb, bias, logq, F, P, want_logits=False):
-    """-> dict(loss [1], acc [1] i32, h [T,P], dlogit [T,K+1], dh [T,P], logits or None)."""
+def nce_fwd(enc, masked_index, idx, emb, bias, logq, F, P, want_logits=False, hpos=None, dh_slots=None):
+    """-> dict(loss [1], acc [1] i32, h [T,P], dlogit [T,K+1], dh [T,P], logits or None).
+    hpos (grouped encoder): `enc` is h_slots [slots,P]; dh_slots receives dh at the slots too."""
     require_gpu(enc, masked_index, idx, emb, bias, logq)
     B, L = masked_index.shape
     T, K1 = idx.shape
-    assert T == B * L and enc.shape == (B, F * P)
+    assert T == B * L and (hpos is not None or enc.shape == (B, F * P))
     dev = enc.device
     f32 = dict(dtype=torch.float32, device=dev)
     out = dict(loss=torch.empty(1, **f32), acc=torch.empty(1, dtype=torch.int32, device=dev),
@@ -266,7 +267,51 @@ def nce_fwd(enc, masked_index, idx, emb, bias, logq, F, P, want_logits=False):
         check(lib.mapx_nce_fwd(ptr(enc), B, L, F, P, ptr(masked_index.contiguous()), ptr(idx), K1 - 1,
                                ptr(emb), ptr(bias), ptr(logq), emb.shape[0], ptr(out["h"]),
                                ptr(out["dlogit"]), ptr(out["dh"]), ptr(out["logits"]), ptr(out["loss"]),
-                               ptr(out["acc"]), ptr(ws), ws.numel(), stream()))
+                               ptr(out["acc"]), ptr(ws), ws.numel(), ptr(hpos), ptr(dh_slots), stream()))
+    return out
+
+
+class EncGroups:
+    """Padded by-field slot layout of the B*L targets (csrc/gemm.hip: grouped feat_encoder)."""
+
+    def __init__(self, masked_index, F):
+        require_gpu(masked_index)
+        B, L = masked_index.shape
+        T, dev = B * L, masked_index.device
+        self.T, self.L, self.F = T, L, F
+        self.cap = (T + 127 * F + 127) // 128 * 128
+        plan = SegPlan(ids_to_i32(masked_index, F), F)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.rowmap = torch.empty(self.cap, **i32)
+        self.hpos = torch.empty(T, **i32)
+        self.tile_group = torch.empty(self.cap // 128, **i32)
+        self.group_start = torch.empty(F + 1, **i32)
+        check(lib.mapx_enc_group_layout(ptr(plan.perm), ptr(plan.uniq), ptr(plan.seg_start), ptr(plan.n_uniq),
+                                        T, L, F, self.cap, ptr(self.rowmap), ptr(self.hpos),
+                                        ptr(self.tile_group), ptr(self.group_start), stream()))
+
+
+def enc_grouped_fwd(final, w, b, groups):
+    """h_slots [cap, 32]: the masked fields' encoder blocks only (26 % of the dense GEMM)."""
+    require_gpu(final, w, b)
+    h = torch.empty(groups.cap, 32, dtype=torch.float32, device=final.device)
+    with _timed("gemm_enc_grouped_fwd", 2.0 * groups.T * 32 * final.shape[1]):
+        check(lib.mapx_enc_grouped_fwd(final.data_ptr(), final.stride(0), final.shape[0], final.shape[1],
+                                       ptr(w), w.stride(0), ptr(b), ptr(groups.rowmap), ptr(groups.tile_group),
+                                       groups.cap, ptr(h), stream()))
+    return h
+
+
+def enc_grouped_dw(dh_slots, final, groups, out=None):
+    """dW [F*32, D+H] of feat_encoder from the slot-ordered dh (every row written)."""
+    require_gpu(dh_slots, final)
+    Nn = final.shape[1]
+    if out is None:
+        out = torch.empty(groups.F * 32, Nn, dtype=torch.float32, device=final.device)
+    with _timed("gemm_enc_grouped_dw", 2.0 * groups.T * 32 * Nn):
+        check(lib.mapx_enc_grouped_dw(ptr(dh_slots), final.data_ptr(), final.stride(0), final.shape[0], Nn,
+                                      ptr(groups.rowmap), ptr(groups.group_start), groups.F, ptr(out),
+                                      out.stride(0), stream()))
     return out
 
 

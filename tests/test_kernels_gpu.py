@@ -520,3 +520,41 @@ def test_rfd_replacement_generators(ops):
     from mapx.native import MapxError
     with pytest.raises(MapxError):
         ops.dynamic_mask_rfd(ids, L, mode="Uniform")          # idx_low / idx_high missing
+
+
+@pytest.mark.parametrize("B,F,D", [(64, 23, 432), (4096, 23, 1368), (100, 39, 688)])
+def test_grouped_feat_encoder_matches_dense(ops, B, F, D):
+    """Grouped forward / dW of feat_encoder == dense GEMM + field gather (models.py:74-75)."""
+    g = torch.Generator().manual_seed(B + F)
+    P, L = 32, int(F * 0.3)
+    final = torch.randn(B, D, generator=g)
+    w = torch.randn(F * P, D, generator=g) / math.sqrt(D)
+    b = torch.randn(F * P, generator=g)
+    mi = torch.randint(0, F, (B, L), generator=g)
+    mi[0, 1] = mi[0, 0]
+    if F > 30:
+        mi[mi == 5] = 6                                   # a field nobody masks
+    groups = ops.EncGroups(mi.to(DEV), F)
+    h_slots = ops.enc_grouped_fwd(final.to(DEV), w.to(DEV), b.to(DEV), groups)
+    enc = (final.double() @ w.double().t() + b.double()).view(B, F, P)
+    want = torch.gather(enc, 1, mi.unsqueeze(-1).expand(-1, -1, P)).view(B * L, P)
+    hpos = _cpu(groups.hpos).long()
+    assert len(set(hpos.tolist())) == B * L               # every target has its own slot
+    got = _cpu(h_slots)[hpos].double()
+    bound = 2e-6 * (final.abs().double() @ w.abs().double().t()).max() + 1e-6
+    assert float((got - want).abs().max()) <= float(bound)
+    rowmap = _cpu(groups.rowmap)
+    assert torch.equal(rowmap[hpos].long(), torch.arange(B).repeat_interleave(L))
+    assert int((rowmap >= 0).sum()) == B * L
+    # dW from slot-ordered dh
+    dh = torch.randn(B * L, P, generator=g)
+    dh_slots = torch.zeros(groups.cap, P)
+    dh_slots[hpos] = dh
+    dw = ops.enc_grouped_dw(dh_slots.to(DEV), final.to(DEV), groups)
+    denc = torch.zeros(B, F, P, dtype=torch.float64)
+    denc.scatter_add_(1, mi.unsqueeze(-1).expand(-1, -1, P), dh.view(B, L, P).double())
+    want_dw = denc.view(B, F * P).t() @ final.double()
+    np.testing.assert_allclose(_cpu(dw).double().numpy(), want_dw.numpy(), rtol=0,
+                               atol=4e-6 * float((denc.view(B, -1).abs().t() @ final.abs().double()).max()) + 1e-6)
+    if F > 30:
+        assert float(_cpu(dw)[5 * P:6 * P].abs().max()) == 0.0       # unmasked field: exact zeros
