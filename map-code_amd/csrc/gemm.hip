@@ -403,69 +403,109 @@ __global__ void __launch_bounds__(256) gemm_grouped_kernel(GroupedArgs a) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  OpA la;
-  OpB lb;
-  // one K-step of loads into the register sets
-  auto load_tile = [&](int k0) {
+  // two register sets: tile t+2 is loaded while tile t is computed and tile t+1 is stored, so a
+  // gathered load (rowmap, then the row it names) has two K-steps to land (one wave per SIMD)
+  OpA la[2];
+  OpB lb[2];
+  // FWD: the gathered A rows do not change along K -> resolve rowmap once
+  int64_t arow[OpA::NV];
+  bool arow_ok[OpA::NV];
+  if (!DW) {
 #pragma unroll
     for (int i = 0; i < OpA::NV; ++i) {
       int tr, tc;
       OpA::coords(threadIdx.x + i * 256, tr, tc);
-      if (DW) {          // A(m = p, k = slot): dh[slot*32 + p]; storage row = slot (k), col = p
-        la.ok[i] = true;
-        la.r[i] = *reinterpret_cast<const float4*>(Ab + (int64_t)(k0 + tr) * a.lda + tc);
-      } else {           // A row = final[rowmap[slot]], k-contiguous; K tail zero-filled
-        const int row = a.rowmap[slot0 + tr];
-        la.ok[i] = row >= 0 && (k0 + tc) < kend;
-        la.r[i] = *reinterpret_cast<const float4*>(Ab + (la.ok[i] ? (int64_t)row * a.lda + k0 + tc : 0));
-      }
+      const int row = a.rowmap[slot0 + tr];
+      arow_ok[i] = row >= 0;
+      arow[i] = (int64_t)(row >= 0 ? row : 0) * a.lda + tc;
     }
-#pragma unroll
-    for (int i = 0; i < OpB::NV; ++i) {
-      int tr, tc;
-      OpB::coords(threadIdx.x + i * 256, tr, tc);
-      if (DW) {          // B(k = slot, n): final[rowmap[slot]][n0 + tc]
-        const int row = a.rowmap[k0 + tr];
-        lb.ok[i] = row >= 0 && (n0 + tc) < a.N;
-        lb.r[i] = *reinterpret_cast<const float4*>(Bb + (lb.ok[i] ? (int64_t)row * a.ldb + n0 + tc : 0));
-      } else {           // B row = W[f*32 + tr], k-contiguous
-        lb.ok[i] = (k0 + tc) < kend;
-        lb.r[i] = *reinterpret_cast<const float4*>(Bb + (int64_t)tr * a.ldb + (lb.ok[i] ? k0 + tc : 0));
-      }
-    }
-  };
+  }
+  // DW: the gathered B rows change every K-step -> their rowmap entries are fetched one K-step
+  // before the row loads that need them, so no load waits on another load
+  int brow[2][OpB::NV];
+#define MAPX_G_ROWS(set, k0_)                                                                     \
+  do {                                                                                            \
+    if (DW) {                                                                                     \
+      _Pragma("unroll") for (int i = 0; i < OpB::NV; ++i) {                                       \
+        int tr, tc;                                                                               \
+        OpB::coords(threadIdx.x + i * 256, tr, tc);                                               \
+        brow[set][i] = ((k0_) + tr) < kend ? a.rowmap[(k0_) + tr] : -1;                           \
+      }                                                                                           \
+    }                                                                                             \
+  } while (0)
+#define MAPX_G_LOAD(set, k0_)                                                                     \
+  do {                                                                                            \
+    const int k0 = (k0_);                                                                         \
+    _Pragma("unroll") for (int i = 0; i < OpA::NV; ++i) {                                         \
+      int tr, tc;                                                                                 \
+      OpA::coords(threadIdx.x + i * 256, tr, tc);                                                 \
+      if (DW) {                                                                                   \
+        la[set].ok[i] = true;                                                                     \
+        la[set].r[i] = *reinterpret_cast<const float4*>(Ab + (int64_t)(k0 + tr) * a.lda + tc);    \
+      } else {                                                                                    \
+        la[set].ok[i] = arow_ok[i] && (k0 + tc) < kend;                                           \
+        la[set].r[i] = *reinterpret_cast<const float4*>(Ab + (la[set].ok[i] ? arow[i] + k0 : 0));  \
+      }                                                                                           \
+    }                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < OpB::NV; ++i) {                                         \
+      int tr, tc;                                                                                 \
+      OpB::coords(threadIdx.x + i * 256, tr, tc);                                                 \
+      if (DW) {                                                                                   \
+        const int row = brow[set][i];           /* resolved one K-step earlier */                 \
+        lb[set].ok[i] = row >= 0 && (n0 + tc) < a.N;                                              \
+        lb[set].r[i] = *reinterpret_cast<const float4*>(                                          \
+            Bb + (lb[set].ok[i] ? (int64_t)row * a.ldb + n0 + tc : 0));                           \
+      } else {                                                                                    \
+        lb[set].ok[i] = (k0 + tc) < kend;                                                         \
+        lb[set].r[i] = *reinterpret_cast<const float4*>(                                          \
+            Bb + (int64_t)tr * a.ldb + (lb[set].ok[i] ? k0 + tc : 0));                            \
+      }                                                                                           \
+    }                                                                                             \
+  } while (0)
   const int nk = (kend - kbeg + BK - 1) / BK;
   if (nk > 0) {
-    load_tile(kbeg);
-    la.template store<true>(As[0]);
-    lb.template store<true>(Bs[0]);
+    MAPX_G_ROWS(0, kbeg);
+    MAPX_G_LOAD(0, kbeg);
+    la[0].template store<true>(As[0]);
+    lb[0].template store<true>(Bs[0]);
+    if (nk > 1) {
+      MAPX_G_ROWS(1, kbeg + BK);
+      MAPX_G_LOAD(1, kbeg + BK);
+    }
+    if (nk > 2) MAPX_G_ROWS(0, kbeg + 2 * BK);
   }
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) load_tile(kbeg + (kt + 1) * BK);
-    float af[2][1][4], bf[2][1][4];
-    OpA::frags(As[cur], abase, l31, kh, 0, af[0]);
-    OpB::frags(Bs[cur], bbase, l31, kh, 0, bf[0]);
-#pragma unroll
-    for (int q = 0; q < BK / 8; ++q) {
-      const int c = q & 1;
-      if (q + 1 < BK / 8) {
-        OpA::frags(As[cur], abase, l31, kh, q + 1, af[c ^ 1]);
-        OpB::frags(Bs[cur], bbase, l31, kh, q + 1, bf[c ^ 1]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][0][s], bf[c][0][s], acc, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (kt + 1 < nk) {
-      la.template store<true>(As[cur ^ 1]);
-      lb.template store<true>(Bs[cur ^ 1]);
-    }
-    __syncthreads();
+#define MAPX_G_KSTEP(SET, kt)                                                                     \
+  do {                                                                                            \
+    if ((kt) + 2 < nk) MAPX_G_LOAD(SET, kbeg + ((kt) + 2) * BK);                                  \
+    if ((kt) + 3 < nk) MAPX_G_ROWS((SET) ^ 1, kbeg + ((kt) + 3) * BK);                            \
+    float af[2][1][4], bf[2][1][4];                                                               \
+    OpA::frags(As[SET], abase, l31, kh, 0, af[0]);                                                \
+    OpB::frags(Bs[SET], bbase, l31, kh, 0, bf[0]);                                                \
+    _Pragma("unroll") for (int q = 0; q < BK / 8; ++q) {                                          \
+      const int c = q & 1;                                                                        \
+      if (q + 1 < BK / 8) {                                                                       \
+        OpA::frags(As[SET], abase, l31, kh, q + 1, af[c ^ 1]);                                    \
+        OpB::frags(Bs[SET], bbase, l31, kh, q + 1, bf[c ^ 1]);                                    \
+      }                                                                                           \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s)                                               \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][0][s], bf[c][0][s], acc, 0, 0, 0);       \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
+    }                                                                                             \
+    if ((kt) + 1 < nk) {                                                                          \
+      la[(SET) ^ 1].template store<true>(As[(SET) ^ 1]);                                          \
+      lb[(SET) ^ 1].template store<true>(Bs[(SET) ^ 1]);                                          \
+    }                                                                                             \
+    __syncthreads();                                                                              \
+  } while (0)
+  for (int kt = 0; kt < nk; kt += 2) {
+    MAPX_G_KSTEP(0, kt);
+    if (kt + 1 < nk) MAPX_G_KSTEP(1, kt + 1);
   }
+#undef MAPX_G_KSTEP
+#undef MAPX_G_LOAD
+#undef MAPX_G_ROWS
   // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int n = (DW ? n0 : 0) + bbase + l31;
   if (DW ? (n < a.N) : true) {
