@@ -64,11 +64,11 @@ def pmc_traffic(name):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="avazu", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=4096)
-    ap.add_argument("--rows", type=int, default=1 << 20, help="synthetic training rows resident in HBM")
+    ap.add_argument("--rows", type=int, default=1 << 22, help="synthetic training rows resident in HBM")
     ap.add_argument("--uniform", action="store_true", help="uniform ids inside a field instead of Zipf(1.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preroll", type=int, default=400,
@@ -94,9 +94,15 @@ def build(args, device, rank):
                  feat_count=feat_count, seed=42, rank=rank)
     torch.manual_seed(42)
     model = BaseModel.from_config(cfg)
+    # the cosine schedule must outlast the run at every world size (the sharded epoch shrinks with N),
+    # else the measured steps would be lr=0 steps whose table updates are cheaper than real ones
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    steps_per_epoch = max(1, args.rows // (args.batch * world))
+    need = 2 * (args.preroll + args.warmup + args.steps + 64)
+    epochs = max(3, -(-need // steps_per_epoch))
     targs = TrainingArguments(output_dir="/tmp/mapx_bench", per_gpu_train_batch_size=args.batch,
                               per_gpu_eval_batch_size=args.batch, learning_rate=1e-3, lr_sched="cosine",
-                              weight_decay=5e-2, num_train_epochs=3, pretrain=True, pt_type="MFP",
+                              weight_decay=5e-2, num_train_epochs=epochs, pretrain=True, pt_type="MFP",
                               sampling_method="randint", mask_ratio=0.3, seed=42)
     targs._device = device
     tr = Trainer(model, cfg, targs, OurDataset(ids, labels), OurDataset(ids[:args.batch], labels[:args.batch]))
