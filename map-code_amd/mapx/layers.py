@@ -47,10 +47,10 @@ class RowTable:
         if need_plan:
             main = torch.cuda.current_stream()
             side = _side_stream(keys_i32.device)
-            side.wait_stream(main)
+            forked = ops.stream_wait(side, main)
             with torch.cuda.stream(side):
                 self.plan = ops.SegPlan(keys_i32, self.num_rows)
-            if side is not main:
+            if forked:
                 keys_i32.record_stream(side)
                 for t in self.plan.tensors():
                     t.record_stream(main)
@@ -59,7 +59,7 @@ class RowTable:
     @staticmethod
     def join_plan(device):
         """Make the current stream wait for the plans being built on the side stream."""
-        torch.cuda.current_stream().wait_stream(_side_stream(device))
+        ops.stream_wait(torch.cuda.current_stream(), _side_stream(device))
 
     def dense_grad(self):
         """Reference-layout dense gradients [(V,W), (V,1)|None] from the sparse ones (tests)."""

@@ -154,12 +154,12 @@ class DCNV2(BaseModel):
             # the same stream assignment in backward)
             main = torch.cuda.current_stream()
             tower = ops.aux_stream("tower", feat_embed.device)
-            tower.wait_stream(main)
+            forked = ops.stream_wait(tower, main)
             with torch.cuda.stream(tower):
                 cross_output = self.cross_net(feat_embed)
             dnn_output = self.parallel_dnn(feat_embed)
-            main.wait_stream(tower)
-            if tower is not main:
+            ops.stream_wait(main, tower)
+            if forked:
                 feat_embed.record_stream(tower)
                 cross_output.record_stream(main)
             final_output = torch.cat([cross_output, dnn_output], dim=-1)

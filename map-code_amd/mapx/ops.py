@@ -97,6 +97,16 @@ def aux_stream(name, device):
     return st
 
 
+def stream_wait(waiter, waited):
+    """waiter.wait_stream(waited), skipped when both are the same HIP stream (a self-wait is a
+    no-op when run eagerly, but inside a stream capture it hands hipStreamEndCapture a node that
+    depends on itself)."""
+    if waiter.cuda_stream != waited.cuda_stream:
+        waiter.wait_stream(waited)
+        return True
+    return False
+
+
 # --------------------------------------------------------------------------- deferred sums
 # Split-K slabs (weight gradients) and row-chunk partials (bias gradients) of a backward pass
 # are summed by ONE kernel launch right before their consumer (optimizer / gradient exchange)
