@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 10
+#define MAPX_ABI_VERSION 11
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -201,6 +201,13 @@ int mapx_relu_mask(const float* dy, const float* y, int64_t n, float* out, hipSt
 size_t mapx_bce_workspace_bytes(void);
 int mapx_bce_with_logits(const float* logits, const float* labels, int64_t n, float* dlogits_opt,
                          float* out3, void* ws, size_t ws_bytes, hipStream_t stream);
+/* Eval metrics on the device (replaces trainer.py:189-194: host lists + sklearn roc_auc_score /
+ * log_loss): out6 (device, f64) = {ROC-AUC with ties on the fp32 sigmoid, log-loss with sklearn's
+ * [eps, 1-eps] clip, mean logit, mean probability, #positives, #negatives}.  AUC is NaN when
+ * only one class is present (sklearn raises ValueError; the host wrapper does too). */
+size_t mapx_eval_metrics_workspace_bytes(int64_t n);
+int mapx_eval_metrics(const float* logits, const float* labels, int64_t n, double* out6, void* ws,
+                      size_t ws_bytes, hipStream_t stream);
 /* trainer.py:217-232 (MFP, sampling_method="randint"): masked_index_in NULL -> Philox. */
 int mapx_dynamic_mask_mfp(const int64_t* ids, int64_t B, int F, int L,
                           const int64_t* masked_index_in, uint64_t seed, uint64_t offset,

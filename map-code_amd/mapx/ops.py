@@ -523,6 +523,25 @@ def bce_with_logits(logits, labels, want_grad=True):
     return out3, dl
 
 
+def eval_metrics(logits, labels):
+    """ROC-AUC / log-loss / mean logit / mean probability of an eval pass, computed on the device
+    (reference trainer.py:189-199 uses sklearn on host lists).  One host read of 6 doubles.
+    -> dict(auc, logloss, avg_logits, avg_probs, positives, negatives)"""
+    require_gpu(logits, labels)
+    logits = logits.contiguous().view(-1).float()
+    labels = labels.contiguous().view(-1).float()
+    n = logits.numel()
+    if labels.numel() != n:
+        raise ValueError(f"eval_metrics: {n} logits but {labels.numel()} labels")
+    out = torch.empty(6, dtype=torch.float64, device=logits.device)
+    ws = scratch(lib.mapx_eval_metrics_workspace_bytes(n), logits.device)
+    check(lib.mapx_eval_metrics(ptr(logits), ptr(labels), n, ptr(out), ptr(ws), ws.numel(), stream()))
+    auc, ll, ml, mp, npos, nneg = out.tolist()
+    if npos == 0 or nneg == 0:                     # sklearn.metrics.roc_auc_score's behaviour
+        raise ValueError("Only one class present in y_true. ROC AUC score is not defined in that case.")
+    return dict(auc=auc, logloss=ll, avg_logits=ml, avg_probs=mp, positives=int(npos), negatives=int(nneg))
+
+
 def dynamic_mask_mfp(ids, L, masked_index=None, seed=0, offset=0, offset_dev=None):
     """-> (masked ids [B,F], labels [B,L], masked_index [B,L])  (trainer.py:217-232)."""
     require_gpu(ids)

@@ -327,7 +327,6 @@ class Trainer:
 
     # ------------------------------------------------------------------ CTR (scratch / finetune)
     def train(self):
-        from sklearn.metrics import roc_auc_score
         train = self._begin("training")
         self._patience, self._stop_training = 0, False
         B = self.args.per_gpu_train_batch_size
@@ -342,9 +341,10 @@ class Trainer:
                 win_logits.append(logits.clone())
                 win_labels.append(Y)
                 if self.global_step % self.args.logging_steps == 0:
-                    probs = torch.sigmoid(torch.cat(win_logits)).cpu().numpy()
-                    labels = torch.cat(win_labels).cpu().numpy()
-                    auc = roc_auc_score(np.int32(labels), probs) if 0 < labels.sum() < len(labels) else float("nan")
+                    try:
+                        auc = ops.eval_metrics(torch.cat(win_logits), torch.cat(win_labels))["auc"]
+                    except ValueError:                       # a window with one class only
+                        auc = float("nan")
                     _log = {"window_auc": auc, "window_loss": float(win_loss) / self.args.logging_steps}
                     logger.info(f"step = {self.global_step}, {_log}")
                     win_loss.zero_()
@@ -355,7 +355,6 @@ class Trainer:
         logger.info(str(self.eval_metrics))
 
     def eval(self, eval_dataset=None, test_eval=False):
-        from sklearn.metrics import log_loss, roc_auc_score
         ev = self._split(self.eval_dataset if eval_dataset is None else eval_dataset)
         logger.info("***** running TEST *****" if test_eval else "***** running eval *****")
         logger.info(f"  num examples = {ev.n}")
@@ -366,15 +365,14 @@ class Trainer:
         with torch.no_grad():
             for X, Y in ev.batches(self.args.per_gpu_eval_batch_size, False):
                 all_logits.append(self.model(input_ids=X, labels=Y)[1].view(-1))
-        preds = torch.cat(all_logits).cpu().numpy().astype("float64")
-        probs = 1.0 / (1.0 + np.exp(-preds))
-        label_ids = ev.Y.cpu().numpy()
-        auc = roc_auc_score(y_true=label_ids, y_score=probs)
-        ll = log_loss(y_true=label_ids, y_pred=probs)
+        # AUC / log-loss on the device over the fp32 sigmoid, ties included (csrc/metrics.hip):
+        # what sklearn's roc_auc_score / log_loss give the reference on its host copies
+        met = ops.eval_metrics(torch.cat(all_logits), ev.Y)
+        auc, ll = met["auc"], met["logloss"]
         self.eval_metrics.append([auc, ll])
         lr = self.scheduler.get_last_lr()[0] if self.optimizer is not None else float("nan")
-        _log = {"learning_rate": lr, "eval_auc": auc, "eval_loss": ll, "avg_logits": preds.mean(),
-                "avg_probs": probs.mean()}
+        _log = {"learning_rate": lr, "eval_auc": auc, "eval_loss": ll, "avg_logits": met["avg_logits"],
+                "avg_probs": met["avg_probs"]}
         logger.info(str(_log))
         if not test_eval:
             if auc > self.best_eval_auc:

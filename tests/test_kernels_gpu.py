@@ -558,3 +558,47 @@ def test_grouped_feat_encoder_matches_dense(ops, B, F, D):
                                atol=4e-6 * float((denc.view(B, -1).abs().t() @ final.abs().double()).max()) + 1e-6)
     if F > 30:
         assert float(_cpu(dw)[5 * P:6 * P].abs().max()) == 0.0       # unmasked field: exact zeros
+
+
+# ----------------------------------------------------------------------------- eval metrics
+@pytest.mark.parametrize("n,kind", [(1000, "smooth"), (50000, "ties"), (200001, "saturated"), (2, "smooth")])
+def test_eval_metrics_vs_sklearn(ops, n, kind):
+    """Device AUC / log-loss == sklearn on float64 copies of the fp32 sigmoid (reference
+    trainer.py:189-194), including heavy ties and saturated probabilities (p32 == 0 or 1)."""
+    from sklearn.metrics import log_loss, roc_auc_score
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=g) * 2.0
+    if kind == "ties":
+        x = (x * 4).round() / 4                                 # ~60 distinct scores
+    if kind == "saturated":
+        # far tails only (p32 == 1.0 exactly, or ~1e-22): in the band 14 < |x| < 17 one ulp of
+        # expf moves -log(1 - p32) by O(1), so log-loss parity there would test expf, not us
+        x = torch.where(x.abs() > 3.0, torch.sign(x) * 50.0, x)
+    y = (torch.rand(n, generator=g) < torch.sigmoid(0.5 * x)).float()
+    if kind == "saturated":                                     # confidently wrong rows: the clip matters
+        y = torch.where(torch.rand(n, generator=g) < 0.05, 1.0 - y, y)
+    if n == 2:
+        y = torch.tensor([0.0, 1.0])
+    got = ops.eval_metrics(x.to(DEV), y.to(DEV))
+    probs = torch.sigmoid(x).numpy().astype("float64")
+    assert got["positives"] == int(y.sum()) and got["negatives"] == n - int(y.sum())
+    np.testing.assert_allclose(got["auc"], roc_auc_score(y.numpy(), probs), rtol=0, atol=2e-7 if kind == "smooth" else 1e-6)
+    np.testing.assert_allclose(got["logloss"], log_loss(y.numpy(), probs), rtol=1e-5)
+    np.testing.assert_allclose(got["avg_logits"], x.double().mean().item(), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(got["avg_probs"], probs.mean(), rtol=1e-6)
+    # exact self-consistency: AUC from the device's own fp32 probabilities, by definition
+    p_dev = (1.0 / (1.0 + torch.exp(-x.to(DEV)))).cpu().double()
+    if n <= 50000:
+        pos, neg = p_dev[y > 0.5], p_dev[y <= 0.5]
+        u = (pos[:, None] > neg[None, :]).double().sum() + 0.5 * (pos[:, None] == neg[None, :]).double().sum()
+        want = float(u / (pos.numel() * neg.numel()))
+        # identical unless torch's GPU expf and the kernel's differ in the last bit somewhere
+        assert abs(got["auc"] - want) < 1e-7
+
+
+def test_eval_metrics_one_class_raises(ops):
+    x = torch.randn(100).to(DEV)
+    with pytest.raises(ValueError, match="Only one class"):
+        ops.eval_metrics(x, torch.ones(100).to(DEV))
+    with pytest.raises(ValueError):
+        ops.eval_metrics(x, torch.ones(99).to(DEV))
