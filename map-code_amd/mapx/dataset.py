@@ -38,9 +38,10 @@ def _read_table(data_dir, name):
     if os.path.exists(h5):
         try:
             import h5py
-        except ImportError as e:
-            raise ImportError(f"{h5} needs h5py, which is not installed; convert it once with "
-                              "np.savez(<name>.npz, feat_ids=..., labels=...)") from e
+        except ImportError:
+            from . import h5lite                      # libhdf5 through ctypes (h5py is not in the ROCm image)
+            t = h5lite.read_datasets(h5, ["feat_ids", "labels"])
+            return t["feat_ids"], t["labels"]
         with h5py.File(h5, "r") as f:
             return f["feat_ids"][:], f["labels"][:]
     raise FileNotFoundError(f"neither {npz} nor {h5} exists")

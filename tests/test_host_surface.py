@@ -136,6 +136,49 @@ def test_dataset_loader_and_feat_count(tmp_path):
     assert x.shape == (23,)
 
 
+def test_hdf5_tables_read_without_h5py(tmp_path):
+    """The reference's <name>.h5 (dataset.py:27-29) loads through libhdf5 + ctypes when h5py is
+    absent.  Fixture: a real HDF5 file written by the HDF5 C library (tests/golden/gen_h5_fixture.py):
+    contiguous int64 tables as proc_avazu.py writes them, one chunked+gzip and one big-endian set."""
+    import json
+    import pickle
+    import shutil
+    from mapx import h5lite
+    try:
+        h5lite.library()
+    except ImportError as e:
+        pytest.skip(str(e))
+    want = np.load(os.path.join(GOLD, "tiny_table_expected.npz"))
+    got = h5lite.read_datasets(os.path.join(GOLD, "tiny_table.h5"), list(want.files))
+    for k in want.files:
+        assert got[k].dtype == want[k].dtype and np.array_equal(got[k], want[k]), k
+    with pytest.raises(KeyError):
+        h5lite.read_datasets(os.path.join(GOLD, "tiny_table.h5"), ["absent"])
+    with pytest.raises(OSError):
+        h5lite.read_datasets(os.path.join(GOLD, "tiny_table_expected.npz"), ["feat_ids"])
+    # the loader itself, on a data_dir that only holds the .h5
+    from mapx.arguments import TrainingArguments
+    from mapx.dataset import BaseDataset
+    d = tmp_path / "tiny"
+    d.mkdir()
+    shutil.copy(os.path.join(GOLD, "tiny_table.h5"), d / "tiny.h5")
+    N, F = want["feat_ids"].shape
+    meta = dict(field_names=[f"C{i}" for i in range(F)], feat_map={str(i): i for i in range(1000)},
+                field_map={f"C{i}": i for i in range(F)})
+    (d / "tiny-meta.json").write_text(json.dumps(meta))
+    idx = np.arange(N)
+    with open(d / "split.pkl", "wb") as f:
+        pickle.dump(dict(train_index=idx[:48], valid_index=idx[48:56], test_index=idx[56:]), f)
+    try:
+        import h5py  # noqa: F401
+        pytest.skip("h5py present: the loader prefers it")
+    except ImportError:
+        pass
+    ds = BaseDataset(TrainingArguments(output_dir="o", data_dir=str(d), dataset_name="tiny", pretrain=True))
+    assert np.array_equal(ds.X["train"], want["feat_ids"][:48]) and np.array_equal(ds.Y["test"], want["labels"][56:])
+    assert float(ds.feat_count.sum()) == 48 * F
+
+
 def test_no_cpu_path():
     from mapx.arguments import TrainingArguments
     if torch.cuda.is_available():
