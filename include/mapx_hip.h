@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 11
+#define MAPX_ABI_VERSION 13
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -161,15 +161,15 @@ int mapx_sum_tasks(const mapx_sum_task* tasks_host, int ntasks, hipStream_t stre
 int mapx_colsum_chunks(void);
 /* Grouped feat_encoder (models.py:74-75; proj_size P = 32): only the L masked fields' P-blocks of
  * the encoder output are ever read, so targets are sorted by field and only those are computed.
- * mapx_enc_group_layout: from the segment plan over masked_index.flatten() (keys = field ids,
- *   V = F) build the padded slot layout: rowmap[cap_slots] (batch row or -1), hpos[T] (slot of
- *   target t), tile_group[cap_slots/128] (field of each 128-slot tile or -1), group_start[F+1].
- *   cap_slots = a multiple of 128 >= T + 127*F.
+ * mapx_enc_group_layout: from masked_index.flatten() (T = B*L field ids in [0, F), F <= 64; ids
+ *   outside are clamped) build, in one launch (stable counting sort in LDS), the padded slot
+ *   layout: rowmap[cap_slots] (batch row or -1), hpos[T] (slot of target t),
+ *   tile_group[cap_slots/128] (field of each 128-slot tile or -1), group_start[F+1].
+ *   Slots are ordered by field, then by target index.  cap_slots = a multiple of 128 >= T + 127*F.
  * mapx_enc_grouped_fwd: h_slots[slot, 0:32] = final[rowmap[slot], :] . W[f*32:(f+1)*32, :]^T + bias.
  * mapx_enc_grouped_dw:  dW[f*32 + p, :] = sum_{slot in group f} dh_slots[slot, p] * final[rowmap[slot], :]
  *   (all F*32 rows written; dh_slots must be zero in unused slots). */
-int mapx_enc_group_layout(const int32_t* perm, const int32_t* uniq, const int32_t* seg_start,
-                          const int32_t* n_uniq, int T, int L, int F, int cap_slots, int32_t* rowmap,
+int mapx_enc_group_layout(const int64_t* masked_index, int T, int L, int F, int cap_slots, int32_t* rowmap,
                           int32_t* hpos, int32_t* tile_group, int32_t* group_start, hipStream_t stream);
 int mapx_enc_grouped_fwd(const float* final_act, int64_t ld_final, int nrows, int K, const float* W,
                          int64_t ldw, const float* bias, const int32_t* rowmap,
@@ -186,11 +186,13 @@ int mapx_cross_bwd_pre(const float* g, const float* x0, const float* u, int64_t 
                        float* dx0, int accumulate, hipStream_t stream);
 
 /* The two elementwise backward steps fused with the bias-gradient column sum (one pass):
- * dz = y > 0 ? dy : 0, db = colsum(dz)  /  t = g*x0, dx0 (+)= g*u, db = colsum(t).  [M,N] dense. */
-int mapx_relu_mask_colsum(const float* dy, const float* y, int M, int N, float* dz, float* db, void* ws,
-                          size_t ws_bytes, hipStream_t stream);
-int mapx_cross_bwd_pre_colsum(const float* g, const float* x0, const float* u, int M, int N, float* t,
-                              float* dx0, int accumulate, float* db, void* ws, size_t ws_bytes,
+ * dz = y > 0 ? dy : 0, db = colsum(dz)  /  t = g*x0, dx0 (+)= g*u, db = colsum(t).  Outputs and x0, u
+ * are dense [M,N]; dy, y and g carry a leading dimension (column slices of the concatenated
+ * trunk output and of its gradient are read in place). */
+int mapx_relu_mask_colsum(const float* dy, int64_t ld_dy, const float* y, int64_t ld_y, int M, int N, float* dz,
+                          float* db, void* ws, size_t ws_bytes, hipStream_t stream);
+int mapx_cross_bwd_pre_colsum(const float* g, int64_t ld_g, const float* x0, const float* u, int M, int N,
+                              float* t, float* dx0, int accumulate, float* db, void* ws, size_t ws_bytes,
                               hipStream_t stream);
 /* ReLU backward: out = y > 0 ? dy : 0 (y = activated output of layers.py:178-185). */
 int mapx_relu_mask(const float* dy, const float* y, int64_t n, float* out, hipStream_t stream);

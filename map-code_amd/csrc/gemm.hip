@@ -519,54 +519,93 @@ __global__ void __launch_bounds__(256) gemm_grouped_kernel(GroupedArgs a) {
   }
 }
 
-// Padded by-field layout of the targets from the sorted plan over masked_index (keys = field id):
-// group u (field uniq[u], sorted positions seg_start[u]..seg_start[u+1]) gets ceil128(len) slots.
-__global__ void __launch_bounds__(256) enc_group_layout_kernel(
-    const int32_t* __restrict__ perm, const int32_t* __restrict__ uniq, const int32_t* __restrict__ seg_start,
-    const int32_t* __restrict__ n_uniq, int T, int L, int F, int cap_slots, int32_t* __restrict__ rowmap,
+// Padded by-field slot layout of the T = B*L targets, straight from masked_index (one block,
+// one launch; the targets' field ids are a key space of F <= 64 values, so a counting sort in
+// LDS replaces a general radix sort + run detection + layout = 9 launches).
+//   slots are ordered by field, inside a field by target index t (stable => the summation order
+//   of the grouped dW GEMM is fixed); every present field's group is padded to a multiple of 128.
+//   hpos[t] = slot of target t;  rowmap[slot] = batch row t / L, or -1 for padding;
+//   tile_group[slot / 128] = field of that 128-slot tile, or -1;  group_start[f], f = 0..F.
+constexpr int kLayoutThreads = 1024;
+constexpr int kLayoutMaxT = 96 * 1024;   // field ids of all targets cached in LDS as bytes
+__global__ void __launch_bounds__(kLayoutThreads) enc_group_layout_kernel(
+    const int64_t* __restrict__ masked_index, int T, int L, int F, int cap_slots, int32_t* __restrict__ rowmap,
     int32_t* __restrict__ hpos, int32_t* __restrict__ tile_group, int32_t* __restrict__ group_start) {
-  __shared__ int gstart[64 + 1];   // padded start of every present group (F <= 64)
-  __shared__ int gfield[64];
-  const int U = *n_uniq;
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    // per-field starts (absent fields: empty range)
-    int run = 0, u = 0;
-    for (int f = 0; f < F; ++f) {
-      group_start[f] = run;
-      if (u < U && uniq[u] == f) {
-        run += ((seg_start[u + 1] - seg_start[u] + 127) / 128) * 128;
-        ++u;
-      }
-    }
-    group_start[F] = run;
+  constexpr int NW = kLayoutThreads / 64;
+  __shared__ int wave_cnt[NW][64];     // targets of field f in wave w's chunk, then the wave's running offset
+  __shared__ int gstart[64 + 1];       // padded start of field f's group
+  extern __shared__ uint8_t fld[];     // [T]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rounds = (T + kLayoutThreads - 1) / kLayoutThreads;      // same for every wave
+  const int wbase = wave * rounds * 64;                              // wave w owns targets [wbase, wbase + rounds*64)
+  for (int i = threadIdx.x; i < NW * 64; i += kLayoutThreads) (&wave_cnt[0][0])[i] = 0;
+  for (int t = threadIdx.x; t < T; t += kLayoutThreads) {            // coalesced, all loads independent
+    int f = (int)masked_index[t];
+    fld[t] = (uint8_t)(f < 0 ? 0 : (f >= F ? F - 1 : f));
   }
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int u = 0; u < U; ++u) {
-      gstart[u] = run;
-      gfield[u] = uniq[u];
-      run += ((seg_start[u + 1] - seg_start[u] + 127) / 128) * 128;
-    }
-    gstart[U] = run;
+  for (int s = threadIdx.x; s < cap_slots; s += kLayoutThreads) rowmap[s] = -1;
+  __syncthreads();
+  for (int r = 0; r < rounds; ++r) {
+    const int t = wbase + r * 64 + lane;
+    if (t < T) atomicAdd(&wave_cnt[wave][fld[t]], 1);
   }
   __syncthreads();
-  const int used = gstart[U];
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
-  for (int s = tid; s < cap_slots; s += nth) {
-    // which group does slot s belong to, and is it a real entry?
-    int u = 0;
-    while (u + 1 <= U && gstart[u + 1] <= s && u < U) ++u;
-    int row = -1;
-    if (s < used) {
-      const int j = seg_start[u] + (s - gstart[u]);
-      if (j < seg_start[u + 1]) {
-        const int t = perm[j];
-        row = t / L;
-        hpos[t] = s;
-      }
+  if (threadIdx.x < 64) {              // thread f: exclusive prefix over the waves, field total
+    const int f = threadIdx.x;
+    int run = 0;
+    for (int w = 0; w < NW; ++w) {
+      const int c = wave_cnt[w][f];
+      wave_cnt[w][f] = run;
+      run += c;
     }
-    rowmap[s] = row;
-    if ((s & 127) == 0) tile_group[s >> 7] = s < used ? gfield[u] : -1;
+    gstart[f] = f < F ? (run + 127) / 128 * 128 : 0;                // padded length for now
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int f = 0; f < F; ++f) {
+      const int len = gstart[f];
+      gstart[f] = run;
+      group_start[f] = run;
+      run += len;
+    }
+    gstart[F] = run;
+    group_start[F] = run;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < cap_slots / 128; k += kLayoutThreads) {
+    int g = -1;
+    for (int f = 0; f < F; ++f)
+      if (gstart[f] <= k * 128 && k * 128 < gstart[f + 1]) g = f;
+    tile_group[k] = g;
+  }
+  // placement: a wave walks its chunk in target order; lanes of one round that share a field
+  // rank themselves by lane id, then the field's running offset advances by their number
+  for (int r = 0; r < rounds; ++r) {
+    const int t = wbase + r * 64 + lane;
+    const bool live = t < T;
+    const int f = live ? fld[t] : 0;
+    unsigned long long peers = __ballot(live);
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      const unsigned long long m = __ballot(live && ((f >> b) & 1));
+      peers &= ((f >> b) & 1) ? m : ~m;
+    }
+    const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+    // LDS operations of one wave execute in order: the next round's read sees this round's
+    // update without a hardware wait; only the compiler has to keep the order
+    int base = 0;
+    if (live) base = wave_cnt[wave][f];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (live) {
+      const int s = gstart[f] + base + rank;
+      hpos[t] = s;
+      rowmap[s] = t / L;
+      if (rank == 0) wave_cnt[wave][f] = base + __popcll(peers);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -664,11 +703,12 @@ __global__ void __launch_bounds__(256) cross_bwd_pre_kernel(const float* __restr
 //   OP 1 (cross layer):  t = g * x0 ; dx0 (+)= g * u              db = colsum(t)
 // Block = 64 columns x 4 row lanes over one of kColChunks row chunks; stage 2 adds the chunks.
 template <int OP>
-__global__ void __launch_bounds__(256) ew_colsum_kernel(const float* __restrict__ a, const float* __restrict__ b,
+__global__ void __launch_bounds__(256) ew_colsum_kernel(const float* __restrict__ a, int64_t lda,
+                                                        const float* __restrict__ b, int64_t ldb,
                                                         const float* __restrict__ c, int M, int N,
                                                         float* __restrict__ o1, float* __restrict__ o2,
                                                         int accumulate, float* __restrict__ part) {
-  // 64 lanes x float4 = 256 columns per block row; 4 row lanes; N % 4 == 0 (host-checked)
+  // 64 lanes x float4 = 256 columns per block row; 4 row lanes; N % 4 == 0, lda % 4 == 0 (host-checked)
   const int col = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
   const int rl = threadIdx.x >> 6;
   const int rows_per = (M + kColChunks - 1) / kColChunks;
@@ -679,8 +719,8 @@ __global__ void __launch_bounds__(256) ew_colsum_kernel(const float* __restrict_
 #pragma unroll 4
     for (int r = r0 + rl; r < r1; r += 4) {
       const int64_t i = ((int64_t)r * N + col) >> 2;
-      const float4 av = reinterpret_cast<const float4*>(a)[i];
-      const float4 bv = reinterpret_cast<const float4*>(b)[i];
+      const float4 av = reinterpret_cast<const float4*>(a)[((int64_t)r * lda + col) >> 2];   // a may be a column slice
+      const float4 bv = reinterpret_cast<const float4*>(b)[((int64_t)r * ldb + col) >> 2];
       if (OP == 0) {
         const float4 dz = make_float4(bv.x > 0.f ? av.x : 0.f, bv.y > 0.f ? av.y : 0.f,
                                       bv.z > 0.f ? av.z : 0.f, bv.w > 0.f ? av.w : 0.f);
@@ -807,17 +847,23 @@ extern "C" int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   return check_launch("gemm_f32");
 }
 
-extern "C" int mapx_enc_group_layout(const int32_t* perm, const int32_t* uniq, const int32_t* seg_start,
-                                     const int32_t* n_uniq, int T, int L, int F, int cap_slots,
+extern "C" int mapx_enc_group_layout(const int64_t* masked_index, int T, int L, int F, int cap_slots,
                                      int32_t* rowmap, int32_t* hpos, int32_t* tile_group,
                                      int32_t* group_start, hipStream_t stream) {
   using namespace mapx;
-  MAPX_REQUIRE(perm && uniq && seg_start && n_uniq && rowmap && hpos && tile_group && group_start,
-               "enc_group_layout: null pointer");
-  MAPX_REQUIRE(F >= 1 && F <= 64 && L >= 1 && T >= 0 && cap_slots % 128 == 0 && cap_slots >= T + 127 * 1,
-               "enc_group_layout: bad sizes (F <= 64, cap_slots multiple of 128)");
-  hipLaunchKernelGGL(enc_group_layout_kernel, dim3(grid_for(cap_slots, 256, 256)), dim3(256), 0, stream, perm,
-                     uniq, seg_start, n_uniq, T, L, F, cap_slots, rowmap, hpos, tile_group, group_start);
+  MAPX_REQUIRE(masked_index && rowmap && hpos && tile_group && group_start, "enc_group_layout: null pointer");
+  MAPX_REQUIRE(F >= 1 && F <= 64 && L >= 1 && T >= 0 && cap_slots % 128 == 0 && cap_slots >= T + 127 * F,
+               "enc_group_layout: bad sizes (F <= 64, cap_slots multiple of 128 and >= T + 127 F)");
+  MAPX_REQUIRE(T <= kLayoutMaxT, "enc_group_layout: at most %d targets per step", kLayoutMaxT);
+  const size_t dyn = ((size_t)T + 15) & ~(size_t)15;
+  static bool raised = false;
+  if (!raised) {       // above the 64 KB default of dynamic LDS
+    MAPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_group_layout_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLayoutMaxT));
+    raised = true;
+  }
+  hipLaunchKernelGGL(enc_group_layout_kernel, dim3(1), dim3(kLayoutThreads), dyn, stream, masked_index, T, L, F,
+                     cap_slots, rowmap, hpos, tile_group, group_start);
   return check_launch("enc_group_layout");
 }
 
@@ -887,35 +933,39 @@ extern "C" int mapx_colsum(const float* x, int64_t ld, int M, int N, float* out,
   return check_launch("colsum");
 }
 
-extern "C" int mapx_relu_mask_colsum(const float* dy, const float* y, int M, int N, float* dz, float* db,
+extern "C" int mapx_relu_mask_colsum(const float* dy, int64_t ld_dy, const float* y, int64_t ld_y, int M, int N,
+                                     float* dz, float* db,
                                       void* ws, size_t ws_bytes, hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(dy && y && dz && M >= 0 && N > 0, "relu_mask_colsum: bad arguments");
-  MAPX_REQUIRE(N % 4 == 0, "relu_mask_colsum: N %% 4 != 0");
+  MAPX_REQUIRE(N % 4 == 0 && ld_dy % 4 == 0 && ld_dy >= N && (uintptr_t)dy % 16 == 0 && ld_y % 4 == 0 &&
+                   ld_y >= N && (uintptr_t)y % 16 == 0,
+               "relu_mask_colsum: N, ld_dy, ld_y %% 4 != 0 or dy / y not 16-byte aligned");
   if (!ws || ws_bytes < mapx_colsum_workspace_bytes(N)) {
     set_error("relu_mask_colsum: workspace too small");
     return MAPX_EWORKSPACE;
   }
   float* part = static_cast<float*>(ws);
-  hipLaunchKernelGGL(ew_colsum_kernel<0>, dim3((N + 255) / 256, kColChunks), dim3(256), 0, stream, dy, y,
-                     (const float*)nullptr, M, N, dz, (float*)nullptr, 0, part);
+  hipLaunchKernelGGL(ew_colsum_kernel<0>, dim3((N + 255) / 256, kColChunks), dim3(256), 0, stream, dy, ld_dy, y,
+                     ld_y, (const float*)nullptr, M, N, dz, (float*)nullptr, 0, part);
   if (db) hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, db);
   return check_launch("relu_mask_colsum");
 }
 
-extern "C" int mapx_cross_bwd_pre_colsum(const float* g, const float* x0, const float* u, int M, int N,
+extern "C" int mapx_cross_bwd_pre_colsum(const float* g, int64_t ld_g, const float* x0, const float* u, int M, int N,
                                          float* t, float* dx0, int accumulate, float* db, void* ws,
                                          size_t ws_bytes, hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(g && x0 && u && t && dx0 && M >= 0 && N > 0, "cross_bwd_pre_colsum: bad arguments");
-  MAPX_REQUIRE(N % 4 == 0, "cross_bwd_pre_colsum: N %% 4 != 0");
+  MAPX_REQUIRE(N % 4 == 0 && ld_g % 4 == 0 && ld_g >= N && (uintptr_t)g % 16 == 0,
+               "cross_bwd_pre_colsum: N, ld_g %% 4 != 0 or g not 16-byte aligned");
   if (!ws || ws_bytes < mapx_colsum_workspace_bytes(N)) {
     set_error("cross_bwd_pre_colsum: workspace too small");
     return MAPX_EWORKSPACE;
   }
   float* part = static_cast<float*>(ws);
-  hipLaunchKernelGGL(ew_colsum_kernel<1>, dim3((N + 255) / 256, kColChunks), dim3(256), 0, stream, g, x0, u, M,
-                     N, t, dx0, accumulate, part);
+  hipLaunchKernelGGL(ew_colsum_kernel<1>, dim3((N + 255) / 256, kColChunks), dim3(256), 0, stream, g, ld_g, x0,
+                     (int64_t)N, u, M, N, t, dx0, accumulate, part);
   if (db) hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, db);
   return check_launch("cross_bwd_pre_colsum");
 }

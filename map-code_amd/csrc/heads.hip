@@ -54,9 +54,11 @@ __global__ void bce_finalize_kernel(const float* __restrict__ part, int nblocks,
   if (threadIdx.x == 0) { out[0] = a * inv_n; out[1] = b * inv_n; out[2] = c * inv_n; }
 }
 
-// MFP branch of dynamic_mask (trainer.py:224-232): one thread per row.
+// MFP branch of dynamic_mask (trainer.py:224-232).  A block owns kMaskRows rows: all threads
+// copy them (coalesced), then one thread per row draws / applies its L masks.
 //   masked_index[b,l] ~ U{0..F-1} with replacement (sampling_method == "randint")
 //   labels[b,l] = ids[b, masked_index[b,l]];  ids_out = ids with those fields set to 3
+constexpr int kMaskRows = 32;
 __global__ void __launch_bounds__(256) mask_mfp_kernel(const int64_t* __restrict__ ids, int64_t B,
                                                        int F, int L,
                                                        const int64_t* __restrict__ mi_in,
@@ -66,12 +68,13 @@ __global__ void __launch_bounds__(256) mask_mfp_kernel(const int64_t* __restrict
                                                        int64_t* __restrict__ labels,
                                                        int64_t* __restrict__ mi_out) {
   if (offset_dev) offset += (uint64_t)(uint32_t)*offset_dev;   // graph-replay safe stream offset
-  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B;
-       b += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t* row = ids + b * F;
-    int64_t* orow = ids_out + b * F;
-    for (int f = 0; f < F; ++f) orow[f] = row[f];
-    for (int l = 0; l < L; ++l) {
+  for (int64_t b0 = (int64_t)blockIdx.x * kMaskRows; b0 < B; b0 += (int64_t)gridDim.x * kMaskRows) {
+    const int64_t rows = (B - b0) < kMaskRows ? (B - b0) : kMaskRows;
+    for (int64_t i = threadIdx.x; i < rows * F; i += blockDim.x) ids_out[b0 * F + i] = ids[b0 * F + i];
+    __threadfence_block();
+    __syncthreads();
+    for (int64_t w = threadIdx.x; w < rows * L; w += blockDim.x) {     // draws: one per thread
+      const int64_t b = b0 + w / L, l = w % L;
       int64_t f;
       if (mi_in) {
         f = mi_in[b * L + l];
@@ -80,9 +83,10 @@ __global__ void __launch_bounds__(256) mask_mfp_kernel(const int64_t* __restrict
         f = bounded(r.x, (uint32_t)F);
       }
       if (mi_out) mi_out[b * L + l] = f;
-      labels[b * L + l] = row[f];
-      orow[f] = 3;  // '<mask>'
+      labels[b * L + l] = ids[b * F + f];
+      ids_out[b * F + f] = 3;  // '<mask>' (duplicates of f write the same value)
     }
+    __syncthreads();
   }
 }
 
@@ -186,7 +190,7 @@ extern "C" int mapx_dynamic_mask_mfp(const int64_t* ids, int64_t B, int F, int L
   MAPX_REQUIRE(ids && ids_out && labels && B >= 0 && F > 0 && L >= 0, "dynamic_mask_mfp: bad arguments");
   MAPX_REQUIRE(ids != ids_out, "dynamic_mask_mfp: in-place masking is not supported");
   if (B == 0) return MAPX_OK;
-  hipLaunchKernelGGL(mask_mfp_kernel, dim3(grid_for(B, 256)), dim3(256), 0, stream, ids, B, F, L,
+  hipLaunchKernelGGL(mask_mfp_kernel, dim3(grid_for(B, kMaskRows)), dim3(256), 0, stream, ids, B, F, L,
                      masked_index_in, seed, offset, offset_dev, ids_out, labels, masked_index_out);
   return check_launch("dynamic_mask_mfp");
 }

@@ -11,7 +11,10 @@ from . import ops
 
 
 # ----------------------------------------------------------------------------- row tables
-def _side_stream(device):
+def _side_stream(device, table_name=""):
+    """All tables' plans share one side stream.  (One stream per table was tried: inside the
+    captured graph the embedding table's sort then ran at the very end of the step and the
+    optimizer waited 70 us for it.)"""
     return ops.aux_stream("plan", device)
 
 
@@ -34,32 +37,30 @@ class RowTable:
     def num_rows(self):
         return self.p0.shape[0]
 
-    def prepare(self, keys_i32, need_plan):
+    def prepare(self, keys_i32, need_plan, defer_plan=False):
         """Called by the forward pass with this step's row ids (repeats allowed).
         * stale rows among them are brought up to date on the current stream, straight from the
           raw id list (ownership by atomicCAS in the kernel): nothing on the critical path
           waits for a sort;
         * when gradients will be needed, the segment plan (sort + runs) is built on a side
-          stream, concurrently with the forward/backward GEMMs, and joined in backward."""
+          stream, concurrently with the forward/backward GEMMs, and joined in backward.  With
+          `defer_plan` the caller picks the fork point by calling start_plan() once the kernels
+          that must not queue behind the sort are enqueued (a captured graph keeps the first
+          forked branch on the parent's queue); backward starts it itself if nobody did."""
+        self.plan = PlanSlot(self, keys_i32) if need_plan else None      # fork point: keys are final
         if self.lazy is not None and self.lazy.stale:
             self.lazy.catch_up_raw(keys_i32)
-        self.plan = None
-        if need_plan:
-            main = torch.cuda.current_stream()
-            side = _side_stream(keys_i32.device)
-            forked = ops.stream_wait(side, main)
-            with torch.cuda.stream(side):
-                self.plan = ops.SegPlan(keys_i32, self.num_rows)
-            if forked:
-                keys_i32.record_stream(side)
-                for t in self.plan.tensors():
-                    t.record_stream(main)
+        if need_plan and not defer_plan:
+            self.plan.start()
         return self.plan
 
-    @staticmethod
-    def join_plan(device):
-        """Make the current stream wait for the plans being built on the side stream."""
-        ops.stream_wait(torch.cuda.current_stream(), _side_stream(device))
+    def start_plan(self):
+        if self.plan is not None:
+            self.plan.start()
+
+    def join_plan(self, device):
+        """Make the current stream wait for the plan being built on this table's side stream."""
+        ops.stream_wait(torch.cuda.current_stream(), _side_stream(device, self.name))
 
     def dense_grad(self):
         """Reference-layout dense gradients [(V,W), (V,1)|None] from the sparse ones (tests)."""
@@ -71,6 +72,42 @@ class RowTable:
         if self.p1 is not None:
             g1 = torch.zeros_like(self.p1).index_copy_(0, uniq, r1[:U].unsqueeze(1))
         return g0, g1
+
+
+class PlanSlot:
+    """This step's segment plan of one table: created by prepare(), filled by start() on the
+    side stream, read (after join_plan) by the backward kernels through get().
+
+    The sort depends on the key list only, so the slot remembers the point where the keys
+    became final (an event) and start() forks from THAT point whenever it is called.  Callers
+    call start() late — after the kernels of the critical chain are enqueued — because a
+    captured hipGraph keeps the first-captured successor of a node on the node's own queue and
+    makes the later ones wait on another queue (measured: a sort chain captured first delayed
+    the trunk's first GEMM by 150 us)."""
+
+    def __init__(self, table, keys_i32):
+        self.table, self.keys, self.value = table, keys_i32, None
+        self.origin = torch.cuda.current_stream()
+        self.ready = ops.record_event()
+
+    def start(self):
+        if self.value is not None:
+            return
+        keys, self.keys = self.keys, None
+        side = _side_stream(keys.device, self.table.name)
+        forked = ops.stream_wait_event(side, self.ready, self.origin)
+        with torch.cuda.stream(side):
+            self.value = ops.SegPlan(keys, self.table.num_rows)
+        if forked:
+            keys.record_stream(side)
+            for t in self.value.tensors():
+                t.record_stream(self.origin)
+
+    def get(self):
+        """The plan, usable on the current stream."""
+        self.start()
+        self.table.join_plan(self.value.uniq.device)
+        return self.value
 
 
 class TableWeight(nn.Module):
@@ -95,9 +132,9 @@ class _Gather(Function):
     def backward(ctx, g):
         if ctx.plan is None:
             raise RuntimeError("embedding backward without a segment plan")
-        RowTable.join_plan(g.device)
+        plan = ctx.plan.get()
         g = g.contiguous().view(-1, ctx.width)
-        ctx.table.sparse_grad = (ctx.plan, ops.seg_reduce_rows(ctx.plan, g, ctx.width), None)
+        ctx.table.sparse_grad = (plan, ops.seg_reduce_rows(plan, g, ctx.width), None)
         return None, None, None
 
 
@@ -116,6 +153,7 @@ class Embeddings(nn.Module):
             self.embedding.weight.normal_(0.0, std)
         self.table = RowTable("embed.embedding", self.embedding.weight)
         self.validate_ids = False
+        self.defer_plan = False     # the owning model calls table.start_plan() at its chosen fork point
 
     def forward(self, input_ids):
         w = self.embedding.weight
@@ -123,7 +161,7 @@ class Embeddings(nn.Module):
         keys = ops.ids_to_i32(input_ids, w.shape[0], validate=self.validate_ids) \
             if (need_grad or self.table.lazy is not None) else None
         if keys is not None:
-            self.table.prepare(keys, need_grad)
+            self.table.prepare(keys, need_grad, defer_plan=self.defer_plan)
         return _Gather.apply(w, input_ids, self.table)
 
 
@@ -149,9 +187,9 @@ def _weight_grads(ctx, dz, x, sw, sb, need=None):
 
 class _Linear(Function):
     @staticmethod
-    def forward(ctx, x, w, b, relu):
+    def forward(ctx, x, w, b, relu, out=None):
         x = x.contiguous()
-        y = ops.linear_fwd(x, w, b, relu=relu)
+        y = ops.linear_fwd(x, w, b, relu=relu, out=out)
         ctx.relu = relu
         ctx.slots = (_grad_slot(w), _grad_slot(b))
         ctx.save_for_backward(x, w, y if relu else None)
@@ -162,14 +200,14 @@ class _Linear(Function):
         x, w, y = ctx.saved_tensors
         sw, sb = ctx.slots
         if ctx.relu and gy.shape[1] % 4 == 0:      # ReLU mask and bias gradient in one pass over dY
-            dz, db = ops.relu_mask_colsum(gy.contiguous(), y, db=sb, defer=True)
+            dz, db = ops.relu_mask_colsum(gy, y, db=sb, defer=True)      # gy may be a slice of d(concat)
             dw = ops.linear_bwd_weight(dz, x, out=sw, defer=True) if ctx.needs_input_grad[1] else None
             dw, db = (None if sw is not None else dw), (None if sb is not None else db)
         else:
-            dz = ops.relu_mask(gy.contiguous(), y) if ctx.relu else gy.contiguous()
+            dz = ops.relu_mask(gy.contiguous(), y.contiguous()) if ctx.relu else gy.contiguous()
             dw, db = _weight_grads(ctx, dz, x, sw, sb)
         dx = ops.linear_bwd_input(dz, w) if ctx.needs_input_grad[0] else None
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 class HipLinear(nn.Module):
@@ -186,8 +224,9 @@ class HipLinear(nn.Module):
             self.weight.uniform_(-bound, bound)
             self.bias.uniform_(-bound, bound)
 
-    def forward(self, x):
-        return _Linear.apply(x, self.weight, self.bias, self.relu)
+    def forward(self, x, out=None):
+        """`out`: optional pre-allocated destination (ops.alias_cols of a wider buffer)."""
+        return _Linear.apply(x, self.weight, self.bias, self.relu, out)
 
 
 class MLPBlock(nn.Module):
@@ -206,17 +245,18 @@ class MLPBlock(nn.Module):
             self.dnn[str(3 * i)] = HipLinear(input_dim, hidden_size, relu=True)
             input_dim = hidden_size
 
-    def forward(self, x):
-        for layer in self.dnn.values():
-            x = layer(x)
+    def forward(self, x, out=None):
+        layers = list(self.dnn.values())
+        for i, layer in enumerate(layers):
+            x = layer(x, out=out if i == len(layers) - 1 else None)
         return x
 
 
 class _CrossLayer(Function):
     @staticmethod
-    def forward(ctx, x0, xi, w, b):
+    def forward(ctx, x0, xi, w, b, out=None):
         x0, xi = x0.contiguous(), xi.contiguous()
-        y, u = ops.cross_layer_fwd(x0, xi, w, b)
+        y, u = ops.cross_layer_fwd(x0, xi, w, b, out=out)
         ctx.slots = (_grad_slot(w), _grad_slot(b))
         ctx.save_for_backward(x0, xi, w, u)
         return y
@@ -224,12 +264,13 @@ class _CrossLayer(Function):
     @staticmethod
     def backward(ctx, g):
         x0, xi, w, u = ctx.saved_tensors
-        g = g.contiguous()
+        if not (ops.row_sliceable(g) and g.shape[1] % 4 == 0):
+            g = g.contiguous()                   # else read in place: a slice of d(concat) costs no copy
         sw, sb = ctx.slots
         t, dx0, db = ops.cross_bwd_pre_colsum(g, x0, u, db=sb, defer=True)   # t = g*x0, dx0 = g*u, colsum(t)
         dxi = ops.linear_bwd_input(t, w, add=g)                              # g + t W
         dw = ops.linear_bwd_weight(t, xi, out=sw, defer=True)                # t^T xi
-        return dx0, dxi, (None if sw is not None else dw), (None if sb is not None else db)
+        return dx0, dxi, (None if sw is not None else dw), (None if sb is not None else db), None
 
 
 class CrossNetV2(nn.Module):
@@ -241,11 +282,25 @@ class CrossNetV2(nn.Module):
         self.num_layers = num_cross_layers
         self.cross_layers = nn.ModuleList(HipLinear(input_dim, input_dim) for _ in range(num_cross_layers))
 
-    def forward(self, x0):
+    def forward(self, x0, out=None):
         xi = x0
-        for layer in self.cross_layers:
-            xi = _CrossLayer.apply(x0, xi, layer.weight, layer.bias)
+        for i, layer in enumerate(self.cross_layers):
+            xi = _CrossLayer.apply(x0, xi, layer.weight, layer.bias, out if i == self.num_layers - 1 else None)
         return xi
+
+
+class _JoinColumns(Function):
+    """torch.cat([a, b], dim=1) when a and b were already written into their column ranges of
+    `buf` (ops.alias_cols): no copy forward, two slices backward."""
+
+    @staticmethod
+    def forward(ctx, a, b, buf):
+        ctx.split = a.shape[1]
+        return buf
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :ctx.split], g[:, ctx.split:], None
 
 
 class _Bce(Function):

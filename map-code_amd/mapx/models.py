@@ -9,7 +9,7 @@ from torch import nn
 
 from . import ops
 from .arguments import Config
-from .layers import CrossNetV2, Embeddings, HipLinear, MLPBlock, bce_with_logits
+from .layers import _JoinColumns, CrossNetV2, Embeddings, HipLinear, MLPBlock, bce_with_logits
 from .nce import IndexLinear
 
 logger = logging.getLogger(__name__)
@@ -132,6 +132,7 @@ class DCNV2(BaseModel):
     def __init__(self, config: Config):
         super().__init__(model_name="DCNV2", config=config)
         self.embed = Embeddings(config)
+        self.embed.defer_plan = True                 # forward() picks the fork point of the sort
         input_dim = config.num_fields * config.embed_size
         self.cross_net = CrossNetV2(input_dim, config.num_cross_layers)
         final_dim = input_dim
@@ -149,22 +150,31 @@ class DCNV2(BaseModel):
     def forward(self, input_ids, labels=None, masked_index=None, noise_samples=None):
         feat_embed = self.embed(input_ids).flatten(start_dim=1)
         if self.config.num_hidden_layers > 0:
-            # the two towers are independent: the cross tower's small GEMMs (D x D) run on a
-            # second stream and fill the tails of the deep tower's big ones (autograd replays
-            # the same stream assignment in backward)
+            # Three independent chains leave the gather: the cross tower (small D x D GEMMs on a
+            # second stream that fill the tails of the deep tower's big ones; autograd replays the
+            # same stream assignment in backward), the deep tower (main stream) and the sort for
+            # the embedding gradient's segment plan.  The sort is enqueued LAST but forks from the
+            # event where its keys were final: a captured hipGraph keeps the first-captured
+            # successor of a node on the node's queue, and a chain of tiny kernels there starves
+            # the other queues (measured: the trunk's first GEMM started 150 us late).
             main = torch.cuda.current_stream()
             tower = ops.aux_stream("tower", feat_embed.device)
             forked = ops.stream_wait(tower, main)
+            # both towers write their last layer straight into the concatenated buffer
+            D, H = feat_embed.shape[1], self.config.hidden_size
+            final_buf = torch.empty(feat_embed.shape[0], D + H, dtype=torch.float32, device=feat_embed.device)
             with torch.cuda.stream(tower):
-                cross_output = self.cross_net(feat_embed)
-            dnn_output = self.parallel_dnn(feat_embed)
+                cross_output = self.cross_net(feat_embed, out=ops.alias_cols(final_buf, 0, D))
+            dnn_output = self.parallel_dnn(feat_embed, out=ops.alias_cols(final_buf, D, H))
+            self.embed.table.start_plan()
             ops.stream_wait(main, tower)
             if forked:
                 feat_embed.record_stream(tower)
-                cross_output.record_stream(main)
-            final_output = torch.cat([cross_output, dnn_output], dim=-1)
+                final_buf.record_stream(tower)
+            final_output = _JoinColumns.apply(cross_output, dnn_output, final_buf)
         else:
             final_output = self.cross_net(feat_embed)
+            self.embed.table.start_plan()
         if self.config.pretrain:
             return self.get_outputs(final_output, labels, masked_index, noise_samples=noise_samples)
         return self.get_outputs(self.fc_out(final_output), labels)

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmapx_hip.so")
 
-MAPX_ABI_VERSION = 11
+MAPX_ABI_VERSION = 13
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_CROSS, EPI_ADD, EPI_RELU_MASK = range(6)
 
 _p, _i, _i64, _u64, _f, _d, _sz = (C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double,
@@ -42,7 +42,7 @@ SIGNATURES = {
     "mapx_gemm_f32": (_i, [_i, _i, _i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _i, _p, _p, _i64, _p,
                            _i64, _p, _i64, _i, _i, _p, _sz, _p, _p]),
     "mapx_sum_tasks": (_i, [_p, _i, _p]),
-    "mapx_enc_group_layout": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "mapx_enc_group_layout": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "mapx_enc_grouped_fwd": (_i, [_p, _i64, _i, _i, _p, _i64, _p, _p, _p, _i, _p, _p]),
     "mapx_enc_grouped_dw": (_i, [_p, _p, _i64, _i, _i, _p, _p, _i, _p, _i64, _p]),
     "mapx_colsum_chunks": (_i, []),
@@ -50,8 +50,8 @@ SIGNATURES = {
     "mapx_colsum": (_i, [_p, _i64, _i, _i, _p, _p, _sz, _p]),
     "mapx_cross_bwd_pre": (_i, [_p, _p, _p, _i64, _p, _p, _i, _p]),
     "mapx_relu_mask": (_i, [_p, _p, _i64, _p, _p]),
-    "mapx_relu_mask_colsum": (_i, [_p, _p, _i, _i, _p, _p, _p, _sz, _p]),
-    "mapx_cross_bwd_pre_colsum": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _p, _p, _sz, _p]),
+    "mapx_relu_mask_colsum": (_i, [_p, _i64, _p, _i64, _i, _i, _p, _p, _p, _sz, _p]),
+    "mapx_cross_bwd_pre_colsum": (_i, [_p, _i64, _p, _p, _i, _i, _p, _p, _i, _p, _p, _sz, _p]),
     "mapx_bce_workspace_bytes": (_sz, []),
     "mapx_bce_with_logits": (_i, [_p, _p, _i64, _p, _p, _p, _sz, _p]),
     "mapx_eval_metrics_workspace_bytes": (_sz, [_i64]),

@@ -74,10 +74,10 @@ class _NceLoss(Function):
         denc = ops.nce_scatter_dh(dh, mi, ctx.F, ctx.P, gscale=gl)
         if ctx.plan is None:
             raise RuntimeError("NCE backward without a segment plan")
-        RowTable.join_plan(dlogit.device)
+        plan = ctx.plan.get()
         ops.scale_(dlogit, gl)
-        ge, gb = ops.nce_table_grad(ctx.plan, dlogit, h, ctx.K, ctx.P)
-        ctx.crit.table.sparse_grad = (ctx.plan, ge, gb)
+        ge, gb = ops.nce_table_grad(plan, dlogit, h, ctx.K, ctx.P)
+        ctx.crit.table.sparse_grad = (plan, ge, gb)
         return denc, None, None, None, None, None, None, None, None, None
 
 
@@ -87,9 +87,9 @@ class _EncNceLoss(Function):
     Backward: dX through the dense scattered d_enc (unchanged), dW through the grouped GEMM."""
 
     @staticmethod
-    def forward(ctx, final, w_enc, b_enc, emb_w, bias_w, logq, masked_index, idx, crit, F, P, want_logits):
+    def forward(ctx, final, w_enc, b_enc, emb_w, bias_w, logq, masked_index, idx, crit, F, P, want_logits,
+                groups):
         final = final.contiguous()
-        groups = ops.EncGroups(masked_index, F)
         h_slots = ops.enc_grouped_fwd(final, w_enc, b_enc, groups)
         dh_slots = torch.zeros(groups.cap, P, dtype=torch.float32, device=final.device)
         o = ops.nce_fwd(h_slots, masked_index, idx, emb_w, bias_w.view(-1), logq, F, P,
@@ -109,17 +109,19 @@ class _EncNceLoss(Function):
         gl = gl.contiguous().float()
         denc = ops.nce_scatter_dh(dh, mi, ctx.F, ctx.P, gscale=gl)          # dense [B, F*P]
         dfinal = ops.linear_bwd_input(denc, w_enc) if ctx.needs_input_grad[0] else None
+        if ctx.plan is not None:
+            ctx.plan.start()         # sort of the sampled ids: forks from the draw, enqueued behind the dX GEMM
         ops.scale_(dh_slots, gl)
         dw = ops.enc_grouped_dw(dh_slots, final, ctx.groups, out=sw)
         db = ops.colsum(denc, out=sb)
         if ctx.plan is None:
             raise RuntimeError("NCE backward without a segment plan")
-        RowTable.join_plan(dlogit.device)
+        plan = ctx.plan.get()
         ops.scale_(dlogit, gl)
-        ge, gb = ops.nce_table_grad(ctx.plan, dlogit, h, ctx.K, ctx.P)
-        ctx.crit.table.sparse_grad = (ctx.plan, ge, gb)
+        ge, gb = ops.nce_table_grad(plan, dlogit, h, ctx.K, ctx.P)
+        ctx.crit.table.sparse_grad = (plan, ge, gb)
         return (dfinal, None if sw is not None else dw, None if sb is not None else db,
-                None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None)
 
 
 class IndexLinear(nn.Module):
@@ -184,7 +186,7 @@ class IndexLinear(nn.Module):
         else:
             idx = self.get_noise_index(target)
         need_grad = torch.is_grad_enabled() and self.emb.weight.requires_grad
-        self.table.prepare(idx.view(-1), need_grad)
+        self.table.prepare(idx.view(-1), need_grad, defer_plan=True)
         loss, acc, logits = _NceLoss.apply(enc, self.emb.weight, self.bias.weight, self.logprob_noise,
                                            masked_index, idx, self, F, P, self.return_logits)
         self.last_acc = acc
@@ -195,7 +197,7 @@ class IndexLinear(nn.Module):
     def supports_grouped_encoder(self):
         return self.proj_size == 32 and self.noise_ratio + 1 <= 32
 
-    def forward_with_encoder(self, target, final, encoder, masked_index, noise_samples=None):
+    def forward_with_encoder(self, target, final, encoder, masked_index, noise_samples=None, groups=None):
         """The MFP head from the trunk output: `encoder` (feat_encoder) is applied only to the
         field blocks that `masked_index` selects.  Same returns as forward()."""
         B, L = target.shape
@@ -206,10 +208,12 @@ class IndexLinear(nn.Module):
         else:
             idx = self.get_noise_index(target)
         need_grad = torch.is_grad_enabled() and self.emb.weight.requires_grad
-        self.table.prepare(idx.view(-1), need_grad)
+        self.table.prepare(idx.view(-1), need_grad, defer_plan=True)
+        if groups is None:
+            groups = ops.EncGroups(masked_index, F)       # one launch: counting sort of the targets by field
         loss, acc, logits = _EncNceLoss.apply(final, encoder.weight, encoder.bias, self.emb.weight,
                                               self.bias.weight, self.logprob_noise, masked_index, idx, self,
-                                              F, P, self.return_logits)
+                                              F, P, self.return_logits, groups)
         self.last_acc = acc
         if self.return_logits:
             logits = logits.view(B, L, -1)

@@ -107,6 +107,22 @@ def stream_wait(waiter, waited):
     return False
 
 
+def record_event():
+    """An event at the current tail of the current stream: a fork point another stream can be
+    made to wait on later (stream_wait_event), after more work has been enqueued here."""
+    ev = torch.cuda.Event()
+    ev.record()
+    return ev
+
+
+def stream_wait_event(waiter, event, origin):
+    """waiter.wait_event(event) unless waiter is the stream the event was recorded on."""
+    if waiter.cuda_stream != origin.cuda_stream:
+        waiter.wait_event(event)
+        return True
+    return False
+
+
 # --------------------------------------------------------------------------- deferred sums
 # Split-K slabs (weight gradients) and row-chunk partials (bias gradients) of a backward pass
 # are summed by ONE kernel launch right before their consumer (optimizer / gradient exchange)
@@ -290,15 +306,21 @@ class EncGroups:
         T, dev = B * L, masked_index.device
         self.T, self.L, self.F = T, L, F
         self.cap = (T + 127 * F + 127) // 128 * 128
-        plan = SegPlan(ids_to_i32(masked_index, F), F)
+        masked_index = masked_index.contiguous()
         i32 = dict(dtype=torch.int32, device=dev)
         self.rowmap = torch.empty(self.cap, **i32)
         self.hpos = torch.empty(T, **i32)
         self.tile_group = torch.empty(self.cap // 128, **i32)
         self.group_start = torch.empty(F + 1, **i32)
-        check(lib.mapx_enc_group_layout(ptr(plan.perm), ptr(plan.uniq), ptr(plan.seg_start), ptr(plan.n_uniq),
-                                        T, L, F, self.cap, ptr(self.rowmap), ptr(self.hpos),
+        check(lib.mapx_enc_group_layout(ptr(masked_index), T, L, F, self.cap, ptr(self.rowmap), ptr(self.hpos),
                                         ptr(self.tile_group), ptr(self.group_start), stream()))
+
+
+def _enc_groups_tensors(self):
+    return (self.rowmap, self.hpos, self.tile_group, self.group_start)
+
+
+EncGroups.tensors = _enc_groups_tensors
 
 
 def enc_grouped_fwd(final, w, b, groups):
@@ -470,33 +492,54 @@ def cross_bwd_pre(g, x0, u, dx0=None):
     return t, dx0
 
 
+def alias_cols(buf, col0, ncols):
+    """A tensor over columns [col0, col0+ncols) of the 2-D buffer `buf` that shares its memory but
+    is NOT an autograd view of it: kernels write a layer's output straight into its slot of a
+    concatenated buffer, and autograd's view+in-place bookkeeping never sees a relationship."""
+    return torch.empty(0, dtype=buf.dtype, device=buf.device).set_(
+        buf.untyped_storage(), buf.storage_offset() + col0, (buf.shape[0], ncols), (buf.stride(0), 1))
+
+
+def row_sliceable(x):
+    """True if x [M,N] can be read in place by the float4 row kernels: unit column stride,
+    16-byte aligned rows (a column slice of a wider buffer qualifies: no .contiguous() copy)."""
+    return x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 \
+        and x.stride(0) >= x.shape[1]
+
+
 def relu_mask_colsum(dy, y, db=None, defer=False):
-    """-> (dz = y > 0 ? dy : 0, db = colsum(dz)) in one pass."""
+    """-> (dz = y > 0 ? dy : 0, db = colsum(dz)) in one pass.  dy may be a column slice."""
+    if not row_sliceable(dy):
+        dy = dy.contiguous()
+    if not row_sliceable(y):
+        y = y.contiguous()
     M, Nn = dy.shape
-    dz = torch.empty_like(dy)
+    dz = torch.empty(M, Nn, dtype=torch.float32, device=dy.device)
     defer = DEFER and defer and db is not None
     if db is None:
         db = torch.empty(Nn, dtype=torch.float32, device=dy.device)
     ws = _partials(Nn, dy.device, defer)
-    check(lib.mapx_relu_mask_colsum(ptr(dy), ptr(y), M, Nn, ptr(dz), None if defer else ptr(db), ptr(ws),
-                                    ws.numel(), stream()))
+    check(lib.mapx_relu_mask_colsum(dy.data_ptr(), dy.stride(0), y.data_ptr(), y.stride(0), M, Nn, ptr(dz),
+                                    None if defer else ptr(db), ptr(ws), ws.numel(), stream()))
     if defer:
         defer_sum(db, ws.view(torch.float32), Nn, COLSUM_CHUNKS, Nn)
     return dz, db
 
 
 def cross_bwd_pre_colsum(g, x0, u, dx0=None, db=None, defer=False):
-    """-> (t = g*x0, dx0 (+)= g*u, db = colsum(t)) in one pass."""
+    """-> (t = g*x0, dx0 (+)= g*u, db = colsum(t)) in one pass.  g may be a column slice."""
+    if not row_sliceable(g):
+        g = g.contiguous()
     M, Nn = g.shape
-    t = torch.empty_like(g)
+    t = torch.empty(M, Nn, dtype=torch.float32, device=g.device)
     acc = dx0 is not None
     if dx0 is None:
-        dx0 = torch.empty_like(g)
+        dx0 = torch.empty(M, Nn, dtype=torch.float32, device=g.device)
     defer = DEFER and defer and db is not None
     if db is None:
         db = torch.empty(Nn, dtype=torch.float32, device=g.device)
     ws = _partials(Nn, g.device, defer)
-    check(lib.mapx_cross_bwd_pre_colsum(ptr(g), ptr(x0), ptr(u), M, Nn, ptr(t), ptr(dx0), int(acc),
+    check(lib.mapx_cross_bwd_pre_colsum(g.data_ptr(), g.stride(0), ptr(x0), ptr(u), M, Nn, ptr(t), ptr(dx0), int(acc),
                                         None if defer else ptr(db), ptr(ws), ws.numel(), stream()))
     if defer:
         defer_sum(db, ws.view(torch.float32), Nn, COLSUM_CHUNKS, Nn)

@@ -50,8 +50,11 @@ def _skewed_keys(n, V, seed):
 
 @pytest.mark.parametrize("n,V,W", [(1, 50, 16), (31, 50, 16), (32, 50, 16), (33, 7, 16),
                                    (5000, 1000, 16), (94208, 9449445, 16), (70001, 300, 32),
-                                   (4097, 5, 64), (2000, 100, 4)])
+                                   (4097, 5, 64), (2000, 100, 4), (131072, 70000, 4), (131073, 70000, 4),
+                                   (638976, 9449445, 4)])
 def test_seg_plan_and_reduce_rows(ops, n, V, W):
+    """The plan must be THE stable sort of the keys (perm == torch's stable argsort), with runs,
+    ranks and unique keys consistent with it."""
     keys = _skewed_keys(n, V, n)
     src = torch.randn(n, W, generator=torch.Generator().manual_seed(1))
     plan = ops.SegPlan(keys.to(torch.int32).to(DEV), V)
@@ -61,6 +64,10 @@ def test_seg_plan_and_reduce_rows(ops, n, V, W):
     assert torch.equal(_cpu(plan.uniq[:U]).long(), uniq_ref)
     sk = _cpu(plan.sorted_keys[:n]).long()
     assert torch.equal(sk, keys[_cpu(plan.perm[:n]).long()]) and bool((sk[1:] >= sk[:-1]).all())
+    assert torch.equal(_cpu(plan.perm[:n]).long(), torch.sort(keys, stable=True).indices)
+    starts = _cpu(plan.seg_start[:U + 1]).long()
+    assert int(starts[U]) == n and torch.equal(sk[starts[:U]], uniq_ref)
+    assert torch.equal(_cpu(plan.rank[:n]).long() - 1, inv[_cpu(plan.perm[:n]).long()])
     out = ops.seg_reduce_rows(plan, src.to(DEV), W)
     ref = torch.zeros(U, W, dtype=torch.float64).index_add_(0, inv, src.double())
     scale = torch.zeros(U, W, dtype=torch.float64).index_add_(0, inv, src.double().abs())
