@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 13
+#define MAPX_ABI_VERSION 14
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -166,14 +166,17 @@ int mapx_colsum_chunks(void);
  *   layout: rowmap[cap_slots] (batch row or -1), hpos[T] (slot of target t),
  *   tile_group[cap_slots/128] (field of each 128-slot tile or -1), group_start[F+1].
  *   Slots are ordered by field, then by target index.  cap_slots = a multiple of 128 >= T + 127*F.
- * mapx_enc_grouped_fwd: h_slots[slot, 0:32] = final[rowmap[slot], :] . W[f*32:(f+1)*32, :]^T + bias.
+ * mapx_enc_grouped_fwd: h_slots[slot, 0:32] = final[rowmap[slot], :] . W[f*32:(f+1)*32, :]^T + bias;
+ *   zero_slots_opt (may be NULL): a second [cap_slots, 32] buffer to clear in the same launch
+ *   (the slot-ordered dL/dh that mapx_nce_fwd fills and mapx_enc_grouped_dw reads).
  * mapx_enc_grouped_dw:  dW[f*32 + p, :] = sum_{slot in group f} dh_slots[slot, p] * final[rowmap[slot], :]
  *   (all F*32 rows written; dh_slots must be zero in unused slots). */
 int mapx_enc_group_layout(const int64_t* masked_index, int T, int L, int F, int cap_slots, int32_t* rowmap,
                           int32_t* hpos, int32_t* tile_group, int32_t* group_start, hipStream_t stream);
 int mapx_enc_grouped_fwd(const float* final_act, int64_t ld_final, int nrows, int K, const float* W,
                          int64_t ldw, const float* bias, const int32_t* rowmap,
-                         const int32_t* tile_group, int cap_slots, float* h_slots, hipStream_t stream);
+                         const int32_t* tile_group, int cap_slots, float* h_slots, float* zero_slots_opt,
+                         hipStream_t stream);
 int mapx_enc_grouped_dw(const float* dh_slots, const float* final_act, int64_t ld_final, int nrows, int N,
                         const int32_t* rowmap, const int32_t* group_start, int F, float* dW, int64_t ldw,
                         hipStream_t stream);

@@ -370,6 +370,7 @@ struct GroupedArgs {
   const int32_t* tile_group;         // FWD: [slots/128] field of the tile, -1 = unused
   const int32_t* group_start;        // DW: [F+1] first slot of each field's group (multiples of 128)
   int K, N, nrows;                   // FWD: K = D+H;  DW: N = D+H;  nrows = B (bounds of rowmap values)
+  float* zero_out;                   // FWD, optional: [slots, 32] buffer cleared tile by tile (dh_slots)
 };
 
 template <bool DW>
@@ -391,6 +392,10 @@ __global__ void __launch_bounds__(256) gemm_grouped_kernel(GroupedArgs a) {
     kend = a.group_start[f + 1];
     n0 = blockIdx.x * BN;
   } else {
+    if (a.zero_out) {                // saves the separate fill launch of the slot-ordered dL/dh buffer
+      float4* z = reinterpret_cast<float4*>(a.zero_out + (int64_t)blockIdx.x * BM * 32);
+      for (int i = threadIdx.x; i < BM * 32 / 4; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     f = a.tile_group[blockIdx.x];
     if (f < 0) return;               // capacity tile beyond the used slots
     slot0 = blockIdx.x * BM;
@@ -870,7 +875,7 @@ extern "C" int mapx_enc_group_layout(const int64_t* masked_index, int T, int L, 
 extern "C" int mapx_enc_grouped_fwd(const float* final_act, int64_t ld_final, int nrows, int K, const float* W,
                                     int64_t ldw, const float* bias, const int32_t* rowmap,
                                     const int32_t* tile_group, int cap_slots, float* h_slots,
-                                    hipStream_t stream) {
+                                    float* zero_slots_opt, hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(final_act && W && bias && rowmap && tile_group && h_slots, "enc_grouped_fwd: null pointer");
   MAPX_REQUIRE(K % 4 == 0 && ld_final % 4 == 0 && ldw % 4 == 0 && cap_slots % 128 == 0,
@@ -878,6 +883,7 @@ extern "C" int mapx_enc_grouped_fwd(const float* final_act, int64_t ld_final, in
   GroupedArgs g{};
   g.A = final_act; g.lda = ld_final; g.B = W; g.ldb = ldw; g.C = h_slots; g.ldc = 32; g.bias = bias;
   g.rowmap = rowmap; g.tile_group = tile_group; g.K = K; g.N = 32; g.nrows = nrows;
+  g.zero_out = zero_slots_opt;
   hipLaunchKernelGGL(gemm_grouped_kernel<false>, dim3(cap_slots / 128), dim3(256), 0, stream, g);
   return check_launch("enc_grouped_fwd");
 }

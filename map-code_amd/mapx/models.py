@@ -54,7 +54,8 @@ class BaseModel(nn.Module):
             logger.info(f"  {key} = {getattr(self.config, key)}")
 
     # ------------------------------------------------------------------ heads
-    def get_outputs(self, inputs, labels=None, masked_index=None, is_pretrain=None, noise_samples=None):
+    def get_outputs(self, inputs, labels=None, masked_index=None, is_pretrain=None, noise_samples=None,
+                    groups=None):
         """MFP -> (loss, #signals, #targets ranked first)            (models.py:71-78)
         RFD -> (loss, #signals, accuracy, positive ratio)            (models.py:79-85)
         CTR -> (loss, logits) or (logits,)                           (models.py:88-93)
@@ -67,7 +68,8 @@ class BaseModel(nn.Module):
                 if GROUPED_ENCODER and crit.supports_grouped_encoder() and inputs.shape[1] % 4 == 0:
                     # only the L masked fields' blocks of feat_encoder are computed (26 %)
                     loss, _logits, _idx = crit.forward_with_encoder(labels, inputs, self.feat_encoder,
-                                                                    masked_index, noise_samples=noise_samples)
+                                                                    masked_index, noise_samples=noise_samples,
+                                                                    groups=groups)
                 else:
                     enc = self.feat_encoder(inputs)
                     loss, _logits, _idx = crit(labels, enc, masked_index=masked_index,
@@ -147,7 +149,13 @@ class DCNV2(BaseModel):
         else:
             self.fc_out = HipLinear(final_dim, 1)
 
+    def _grouped_head(self, masked_index):
+        return (self.config.pretrain and self.config.pt_type == "MFP" and masked_index is not None
+                and GROUPED_ENCODER and self.mfp_criterion.supports_grouped_encoder()
+                and self.feat_encoder.in_features % 4 == 0)
+
     def forward(self, input_ids, labels=None, masked_index=None, noise_samples=None):
+        groups = None
         feat_embed = self.embed(input_ids).flatten(start_dim=1)
         if self.config.num_hidden_layers > 0:
             # Three independent chains leave the gather: the cross tower (small D x D GEMMs on a
@@ -164,6 +172,10 @@ class DCNV2(BaseModel):
             D, H = feat_embed.shape[1], self.config.hidden_size
             final_buf = torch.empty(feat_embed.shape[0], D + H, dtype=torch.float32, device=feat_embed.device)
             with torch.cuda.stream(tower):
+                if self._grouped_head(masked_index):
+                    # the cross tower has ~70 us of slack against the deep one: the slot layout of
+                    # the grouped encoder (one single-workgroup launch) rides on its stream
+                    groups = ops.EncGroups(masked_index, self.config.num_fields)
                 cross_output = self.cross_net(feat_embed, out=ops.alias_cols(final_buf, 0, D))
             dnn_output = self.parallel_dnn(feat_embed, out=ops.alias_cols(final_buf, D, H))
             self.embed.table.start_plan()
@@ -171,10 +183,14 @@ class DCNV2(BaseModel):
             if forked:
                 feat_embed.record_stream(tower)
                 final_buf.record_stream(tower)
+                if groups is not None:
+                    masked_index.record_stream(tower)
+                    for t in groups.tensors():
+                        t.record_stream(main)
             final_output = _JoinColumns.apply(cross_output, dnn_output, final_buf)
         else:
             final_output = self.cross_net(feat_embed)
             self.embed.table.start_plan()
         if self.config.pretrain:
-            return self.get_outputs(final_output, labels, masked_index, noise_samples=noise_samples)
+            return self.get_outputs(final_output, labels, masked_index, noise_samples=noise_samples, groups=groups)
         return self.get_outputs(self.fc_out(final_output), labels)

@@ -90,8 +90,8 @@ class _EncNceLoss(Function):
     def forward(ctx, final, w_enc, b_enc, emb_w, bias_w, logq, masked_index, idx, crit, F, P, want_logits,
                 groups):
         final = final.contiguous()
-        h_slots = ops.enc_grouped_fwd(final, w_enc, b_enc, groups)
-        dh_slots = torch.zeros(groups.cap, P, dtype=torch.float32, device=final.device)
+        dh_slots = torch.empty(groups.cap, P, dtype=torch.float32, device=final.device)
+        h_slots = ops.enc_grouped_fwd(final, w_enc, b_enc, groups, zero_slots=dh_slots)
         o = ops.nce_fwd(h_slots, masked_index, idx, emb_w, bias_w.view(-1), logq, F, P,
                         want_logits=want_logits, hpos=groups.hpos, dh_slots=dh_slots)
         ctx.crit, ctx.F, ctx.P, ctx.K, ctx.groups = crit, F, P, idx.shape[1] - 1, groups

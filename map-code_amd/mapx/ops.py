@@ -323,14 +323,15 @@ def _enc_groups_tensors(self):
 EncGroups.tensors = _enc_groups_tensors
 
 
-def enc_grouped_fwd(final, w, b, groups):
-    """h_slots [cap, 32]: the masked fields' encoder blocks only (26 % of the dense GEMM)."""
+def enc_grouped_fwd(final, w, b, groups, zero_slots=None):
+    """h_slots [cap, 32]: the masked fields' encoder blocks only (26 % of the dense GEMM).
+    zero_slots: a [cap, 32] buffer cleared by the same launch."""
     require_gpu(final, w, b)
     h = torch.empty(groups.cap, 32, dtype=torch.float32, device=final.device)
     with _timed("gemm_enc_grouped_fwd", 2.0 * groups.T * 32 * final.shape[1]):
         check(lib.mapx_enc_grouped_fwd(final.data_ptr(), final.stride(0), final.shape[0], final.shape[1],
                                        ptr(w), w.stride(0), ptr(b), ptr(groups.rowmap), ptr(groups.tile_group),
-                                       groups.cap, ptr(h), stream()))
+                                       groups.cap, ptr(h), ptr(zero_slots), stream()))
     return h
 
 
