@@ -191,7 +191,8 @@ int mapx_cross_bwd_pre(const float* g, const float* x0, const float* u, int64_t 
 /* The two elementwise backward steps fused with the bias-gradient column sum (one pass):
  * dz = y > 0 ? dy : 0, db = colsum(dz)  /  t = g*x0, dx0 (+)= g*u, db = colsum(t).  Outputs and x0, u
  * are dense [M,N]; dy, y and g carry a leading dimension (column slices of the concatenated
- * trunk output and of its gradient are read in place). */
+ * trunk output and of its gradient are read in place).  cross: `accumulate` bit 0 adds to the dx0
+ * already stored, bit 1 adds g as well (layer 0, whose Xi is X0). */
 int mapx_relu_mask_colsum(const float* dy, int64_t ld_dy, const float* y, int64_t ld_y, int M, int N, float* dz,
                           float* db, void* ws, size_t ws_bytes, hipStream_t stream);
 int mapx_cross_bwd_pre_colsum(const float* g, int64_t ld_g, const float* x0, const float* u, int M, int N,

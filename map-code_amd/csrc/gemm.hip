@@ -705,7 +705,8 @@ __global__ void __launch_bounds__(256) cross_bwd_pre_kernel(const float* __restr
 // Elementwise backward steps fused with the bias-gradient column sum (one pass over the
 // data instead of elementwise kernel + colsum stage 1):
 //   OP 0 (ReLU layer):   dz = y > 0 ? dy : 0                      db = colsum(dz)
-//   OP 1 (cross layer):  t = g * x0 ; dx0 (+)= g * u              db = colsum(t)
+//   OP 1 (cross layer):  t = g * x0 ; dx0 (+)= g * u (+ g)        db = colsum(t)
+//                        accumulate bit 0: add to the dx0 already there; bit 1: also add g
 // Block = 64 columns x 4 row lanes over one of kColChunks row chunks; stage 2 adds the chunks.
 template <int OP>
 __global__ void __launch_bounds__(256) ew_colsum_kernel(const float* __restrict__ a, int64_t lda,
@@ -735,9 +736,12 @@ __global__ void __launch_bounds__(256) ew_colsum_kernel(const float* __restrict_
         const float4 cv = reinterpret_cast<const float4*>(c)[i];
         const float4 t = make_float4(av.x * bv.x, av.y * bv.y, av.z * bv.z, av.w * bv.w);
         float4 d = make_float4(av.x * cv.x, av.y * cv.y, av.z * cv.z, av.w * cv.w);
-        if (accumulate) {
+        if (accumulate & 1) {
           const float4 o = reinterpret_cast<const float4*>(o2)[i];
           d.x += o.x; d.y += o.y; d.z += o.z; d.w += o.w;
+        }
+        if (accumulate & 2) {   // first cross layer: Xi IS X0, its gradient g joins the X0 total
+          d.x += av.x; d.y += av.y; d.z += av.z; d.w += av.w;
         }
         reinterpret_cast<float4*>(o1)[i] = t;
         reinterpret_cast<float4*>(o2)[i] = d;

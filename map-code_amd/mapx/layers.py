@@ -147,6 +147,9 @@ class Embeddings(nn.Module):
             raise NotImplementedError("embed_norm=True (LayerNorm on embeddings) is outside the DCNv2 scripts")
         if getattr(config, "embed_dropout_rate", 0.0) > 0:
             raise NotImplementedError("embed_dropout_rate > 0 is outside the DCNv2 scripts")
+        if config.embed_size % 4 != 0:
+            raise NotImplementedError("embed_size must be a multiple of 4 (16-byte rows for the gather, "
+                                      "segment-reduce and float4 elementwise kernels)")
         self.embedding = TableWeight(config.input_size, config.embed_size)
         std = math.sqrt(2.0 / float(config.num_fields + config.embed_size))
         with torch.no_grad():
@@ -252,25 +255,52 @@ class MLPBlock(nn.Module):
         return x
 
 
-class _CrossLayer(Function):
+class _CrossTower(Function):
+    """All cross layers in one autograd node: X_{i+1} = X_i + X_0 * (X_i W_i^T + b_i).
+    One node instead of one per layer lets backward keep a single running dL/dX0 inside the
+    kernels (cross_bwd_pre accumulates g*u_i, layer 0 also adds its g, the last dX GEMM adds the
+    total in its epilogue) — autograd would otherwise add the four contributions with four
+    elementwise launches at the very end of the step."""
+
     @staticmethod
-    def forward(ctx, x0, xi, w, b, out=None):
-        x0, xi = x0.contiguous(), xi.contiguous()
-        y, u = ops.cross_layer_fwd(x0, xi, w, b, out=out)
-        ctx.slots = (_grad_slot(w), _grad_slot(b))
-        ctx.save_for_backward(x0, xi, w, u)
-        return y
+    def forward(ctx, x0, out, *wb):
+        x0 = x0.contiguous()
+        n = len(wb) // 2
+        xi, xs, us = x0, [], []
+        for i in range(n):
+            xs.append(xi)
+            xi, u = ops.cross_layer_fwd(x0, xi, wb[2 * i], wb[2 * i + 1], out=out if i == n - 1 else None)
+            us.append(u)
+        ctx.n = n
+        ctx.slots = [(_grad_slot(wb[2 * i]), _grad_slot(wb[2 * i + 1])) for i in range(n)]
+        ctx.save_for_backward(x0, *xs[1:], *us, *wb[0::2])
+        return xi
 
     @staticmethod
     def backward(ctx, g):
-        x0, xi, w, u = ctx.saved_tensors
-        if not (ops.row_sliceable(g) and g.shape[1] % 4 == 0):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        x0 = saved[0]
+        xs = (x0,) + tuple(saved[1:n])
+        us = saved[n:2 * n]
+        ws = saved[2 * n:3 * n]
+        if not ops.row_sliceable(g):
             g = g.contiguous()                   # else read in place: a slice of d(concat) costs no copy
-        sw, sb = ctx.slots
-        t, dx0, db = ops.cross_bwd_pre_colsum(g, x0, u, db=sb, defer=True)   # t = g*x0, dx0 = g*u, colsum(t)
-        dxi = ops.linear_bwd_input(t, w, add=g)                              # g + t W
-        dw = ops.linear_bwd_weight(t, xi, out=sw, defer=True)                # t^T xi
-        return dx0, dxi, (None if sw is not None else dw), (None if sb is not None else db), None
+        grads = [None] * (2 * n)
+        dx0 = None
+        for i in range(n - 1, -1, -1):
+            sw, sb = ctx.slots[i]
+            first = i == 0
+            # width D = F * embed_size is a multiple of 4 (Embeddings enforces embed_size % 4 == 0)
+            t, dx0, db = ops.cross_bwd_pre_colsum(g, x0, us[i], dx0=dx0, db=sb, defer=True, plus_g=first)
+            dw = ops.linear_bwd_weight(t, xs[i], out=sw, defer=True)                # t^T X_i
+            if ctx.needs_input_grad[2 + 2 * i]:
+                grads[2 * i] = None if sw is not None else dw
+            if ctx.needs_input_grad[3 + 2 * i]:
+                grads[2 * i + 1] = None if sb is not None else db
+            # dL/dX_i = g + t W_i; for layer 0 that is part of dL/dX0 and g is already inside dx0
+            g = ops.linear_bwd_input(t, ws[i], add=dx0 if first else g)
+        return (g, None, *grads)
 
 
 class CrossNetV2(nn.Module):
@@ -283,10 +313,11 @@ class CrossNetV2(nn.Module):
         self.cross_layers = nn.ModuleList(HipLinear(input_dim, input_dim) for _ in range(num_cross_layers))
 
     def forward(self, x0, out=None):
-        xi = x0
-        for i, layer in enumerate(self.cross_layers):
-            xi = _CrossLayer.apply(x0, xi, layer.weight, layer.bias, out if i == self.num_layers - 1 else None)
-        return xi
+        """`out`: optional pre-allocated destination of the last layer (ops.alias_cols)."""
+        if self.num_layers == 0:
+            return x0
+        wb = [p for layer in self.cross_layers for p in (layer.weight, layer.bias)]
+        return _CrossTower.apply(x0, out, *wb)
 
 
 class _JoinColumns(Function):

@@ -170,14 +170,15 @@ class DCNV2(BaseModel):
             forked = ops.stream_wait(tower, main)
             # both towers write their last layer straight into the concatenated buffer
             D, H = feat_embed.shape[1], self.config.hidden_size
+            direct = self.config.num_cross_layers > 0
             final_buf = torch.empty(feat_embed.shape[0], D + H, dtype=torch.float32, device=feat_embed.device)
             with torch.cuda.stream(tower):
                 if self._grouped_head(masked_index):
                     # the cross tower has ~70 us of slack against the deep one: the slot layout of
                     # the grouped encoder (one single-workgroup launch) rides on its stream
                     groups = ops.EncGroups(masked_index, self.config.num_fields)
-                cross_output = self.cross_net(feat_embed, out=ops.alias_cols(final_buf, 0, D))
-            dnn_output = self.parallel_dnn(feat_embed, out=ops.alias_cols(final_buf, D, H))
+                cross_output = self.cross_net(feat_embed, out=ops.alias_cols(final_buf, 0, D) if direct else None)
+            dnn_output = self.parallel_dnn(feat_embed, out=ops.alias_cols(final_buf, D, H) if direct else None)
             self.embed.table.start_plan()
             ops.stream_wait(main, tower)
             if forked:
@@ -187,7 +188,8 @@ class DCNV2(BaseModel):
                     masked_index.record_stream(tower)
                     for t in groups.tensors():
                         t.record_stream(main)
-            final_output = _JoinColumns.apply(cross_output, dnn_output, final_buf)
+            final_output = _JoinColumns.apply(cross_output, dnn_output, final_buf) if direct \
+                else torch.cat([cross_output, dnn_output], dim=-1)
         else:
             final_output = self.cross_net(feat_embed)
             self.embed.table.start_plan()

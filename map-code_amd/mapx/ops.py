@@ -527,8 +527,8 @@ def relu_mask_colsum(dy, y, db=None, defer=False):
     return dz, db
 
 
-def cross_bwd_pre_colsum(g, x0, u, dx0=None, db=None, defer=False):
-    """-> (t = g*x0, dx0 (+)= g*u, db = colsum(t)) in one pass.  g may be a column slice."""
+def cross_bwd_pre_colsum(g, x0, u, dx0=None, db=None, defer=False, plus_g=False):
+    """-> (t = g*x0, dx0 (+)= g*u (+ g if plus_g), db = colsum(t)) in one pass.  g may be a column slice."""
     if not row_sliceable(g):
         g = g.contiguous()
     M, Nn = g.shape
@@ -540,7 +540,8 @@ def cross_bwd_pre_colsum(g, x0, u, dx0=None, db=None, defer=False):
     if db is None:
         db = torch.empty(Nn, dtype=torch.float32, device=g.device)
     ws = _partials(Nn, g.device, defer)
-    check(lib.mapx_cross_bwd_pre_colsum(g.data_ptr(), g.stride(0), ptr(x0), ptr(u), M, Nn, ptr(t), ptr(dx0), int(acc),
+    check(lib.mapx_cross_bwd_pre_colsum(g.data_ptr(), g.stride(0), ptr(x0), ptr(u), M, Nn, ptr(t), ptr(dx0),
+                                        int(acc) | (2 if plus_g else 0),
                                         None if defer else ptr(db), ptr(ws), ws.numel(), stream()))
     if defer:
         defer_sum(db, ws.view(torch.float32), Nn, COLSUM_CHUNKS, Nn)

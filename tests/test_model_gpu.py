@@ -192,3 +192,34 @@ def test_unknown_backbones_raise_like_the_reference():
         c.model_name = name
         with pytest.raises(NotImplementedError):
             BaseModel.from_config(c)
+
+
+@pytest.mark.parametrize("E,NC", [(4, 2), (16, 1), (16, 0)])
+def test_cross_tower_depths_vs_oracle(E, NC):
+    """Narrow rows, a hidden width that is not a multiple of 4, and 0 / 1 / 2 cross layers:
+    forward and every gradient of the DCNv2 trunk + CTR head against the oracle."""
+    from mapx.models import BaseModel
+    from oracle import ref_model as R
+    from util import make_config
+    cfg = dict(F=5, V=300, E=E, H=10, NL=2, NC=NC, P=32, K=5)
+    torch.manual_seed(3)
+    model = BaseModel.from_config(make_config(cfg, "CTR", None)).to(DEV)
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, cfg["V"], (9, cfg["F"]), generator=g)
+    y = torch.randint(0, 2, (9,), generator=g)
+    loss, logits = model(input_ids=ids.to(DEV), labels=y.to(DEV))
+    loss.backward()
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()
+              if v.dtype.is_floating_point}
+    fin = R.trunk(params, ids, NC, cfg["NL"])
+    loss_ref, logits_ref = R.ctr_head(params, fin, y)
+    loss_ref.backward()
+    np.testing.assert_allclose(logits.detach().cpu().numpy().ravel(), logits_ref.detach().numpy().ravel(),
+                               rtol=1e-5, atol=1e-6)
+    from mapx.optim import decays  # noqa: F401  (import check only)
+    for name, p in model.named_parameters():
+        if name == "embed.embedding.weight":
+            got = model.embed.table.dense_grad()[0].cpu()
+        else:
+            got = p.grad.cpu()
+        np.testing.assert_allclose(got.numpy(), params[name].grad.numpy(), rtol=2e-5, atol=2e-6, err_msg=name)
