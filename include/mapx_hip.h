@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 14
+#define MAPX_ABI_VERSION 15
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -58,7 +58,10 @@ int mapx_ids_to_i32(const int64_t* ids, int64_t n, int64_t V, int32_t* out, int*
  * reduce-by-key.  mapx_seg_plan sorts n keys and describes the runs of equal keys:
  *   sorted_keys[n], perm[n] (sorted position -> original position), rank[n] (1-based run
  *   id), uniq[<=n] (key of each run), seg_start[<=n+1] (first sorted position of each run,
- *   closed by n), n_uniq[1].  All int32 device arrays of capacity n (seg_start: n+1). */
+ *   closed by n), n_uniq[2] = {number of runs, 0}.  All int32 device arrays of capacity n
+ *   (seg_start: n+1).  n_uniq[1] is a counter left at zero for the ONE segment reduction that
+ *   consumes the plan (pass &n_uniq[1] as zeroed_counter_opt there and it needs no memset launch;
+ *   pass NULL on any later reduction over the same plan). */
 size_t mapx_seg_plan_workspace_bytes(int64_t n, int64_t V);
 int mapx_seg_plan(const int32_t* keys, int64_t n, int64_t V, void* ws, size_t ws_bytes,
                   int32_t* sorted_keys, int32_t* perm, int32_t* rank, int32_t* uniq,
@@ -69,7 +72,7 @@ int mapx_seg_plan(const int32_t* keys, int64_t n, int64_t V, void* ws, size_t ws
 size_t mapx_seg_reduce_workspace_bytes(int64_t n, int W);
 int mapx_seg_reduce_rows(int64_t n, const int32_t* perm, const int32_t* rank,
                          const int32_t* seg_start, const float* src, int W, float* out, void* ws,
-                         size_t ws_bytes, hipStream_t stream);
+                         size_t ws_bytes, int32_t* zeroed_counter_opt, hipStream_t stream);
 
 /* ------------------------------------------------------------------ NCE sampler (a7, a8)
  * nce/alias_multinomial.py:39-72: Walker table from the renormalised noise probabilities,
@@ -96,7 +99,8 @@ int mapx_nce_pack_idx(const int64_t* targets, const int64_t* noise, int64_t T, i
  *   emb [V,P], bias [V], logq [V] (= logprob_noise).
  * Outputs: h_out [B*L,P] (gathered hidden), dlogit [B*L,K+1] = dLoss/dlogit (mean over
  * B*L folded in), dh [B*L,P] = dLoss/dh, logits_opt [B*L,K+1] or NULL (the reference's
- * `logits`, i.e. score - ln V), loss_out[1] (mean), acc_out[1] (# targets ranked first).
+ * `logits`, i.e. score - ln V), loss_out[2] = {mean loss, fraction of targets ranked first},
+ * acc_out[1] (# targets ranked first).
  * hpos_opt != NULL (grouped encoder, P = 32): `enc` is h_slots [slots, P] and target t reads
  * slot hpos_opt[t]; dh_slots_opt then also receives dh at the slot (for mapx_enc_grouped_dw). */
 size_t mapx_nce_fwd_workspace_bytes(void);
@@ -114,8 +118,8 @@ int mapx_nce_scatter_dh(const float* dh, const int64_t* masked_index, const floa
 size_t mapx_nce_table_grad_workspace_bytes(int64_t n, int P);
 int mapx_nce_table_grad(int64_t n, const int32_t* perm, const int32_t* rank,
                         const int32_t* seg_start, const float* dlogit, const float* h, int K,
-                        int P, float* out_emb, float* out_bias, void* ws, size_t ws_bytes,
-                        hipStream_t stream);
+                        int P, const float* gscale_opt, float* out_emb, float* out_bias, void* ws,
+                        size_t ws_bytes, int32_t* zeroed_counter_opt, hipStream_t stream);
 int mapx_scale_inplace(float* x, int64_t n, const float* g, hipStream_t stream);
 
 /* ------------------------------------------------------------------ dense trunk (a4, a5, a6, a11, a12)
@@ -170,7 +174,7 @@ int mapx_colsum_chunks(void);
  *   zero_slots_opt (may be NULL): a second [cap_slots, 32] buffer to clear in the same launch
  *   (the slot-ordered dL/dh that mapx_nce_fwd fills and mapx_enc_grouped_dw reads).
  * mapx_enc_grouped_dw:  dW[f*32 + p, :] = sum_{slot in group f} dh_slots[slot, p] * final[rowmap[slot], :]
- *   (all F*32 rows written; dh_slots must be zero in unused slots). */
+ *   (all F*32 rows written; dh_slots must be zero in unused slots), times *gscale_opt if given. */
 int mapx_enc_group_layout(const int64_t* masked_index, int T, int L, int F, int cap_slots, int32_t* rowmap,
                           int32_t* hpos, int32_t* tile_group, int32_t* group_start, hipStream_t stream);
 int mapx_enc_grouped_fwd(const float* final_act, int64_t ld_final, int nrows, int K, const float* W,
@@ -178,8 +182,8 @@ int mapx_enc_grouped_fwd(const float* final_act, int64_t ld_final, int nrows, in
                          const int32_t* tile_group, int cap_slots, float* h_slots, float* zero_slots_opt,
                          hipStream_t stream);
 int mapx_enc_grouped_dw(const float* dh_slots, const float* final_act, int64_t ld_final, int nrows, int N,
-                        const int32_t* rowmap, const int32_t* group_start, int F, float* dW, int64_t ldw,
-                        hipStream_t stream);
+                        const int32_t* rowmap, const int32_t* group_start, int F, const float* gscale_opt,
+                        float* dW, int64_t ldw, hipStream_t stream);
 /* out[n] = sum_m x[m*ld + n]  (bias gradients), deterministic two-stage. */
 size_t mapx_colsum_workspace_bytes(int N);
 int mapx_colsum(const float* x, int64_t ld, int M, int N, float* out, void* ws, size_t ws_bytes,

@@ -371,6 +371,7 @@ struct GroupedArgs {
   const int32_t* group_start;        // DW: [F+1] first slot of each field's group (multiples of 128)
   int K, N, nrows;                   // FWD: K = D+H;  DW: N = D+H;  nrows = B (bounds of rowmap values)
   float* zero_out;                   // FWD, optional: [slots, 32] buffer cleared tile by tile (dh_slots)
+  const float* gscale;               // DW, optional device scalar multiplied into the result
 };
 
 template <bool DW>
@@ -515,11 +516,12 @@ __global__ void __launch_bounds__(256) gemm_grouped_kernel(GroupedArgs a) {
   const int n = (DW ? n0 : 0) + bbase + l31;
   if (DW ? (n < a.N) : true) {
     const float bn = DW ? 0.f : a.bias[f * 32 + n];
+    const float gs = (DW && a.gscale) ? *a.gscale : 1.f;
     float* __restrict__ Cb = DW ? a.C + (int64_t)f * 32 * a.ldc : a.C + (int64_t)slot0 * a.ldc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = abase + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      Cb[(int64_t)m * a.ldc + n] = acc[r] + bn;
+      Cb[(int64_t)m * a.ldc + n] = DW ? acc[r] * gs : acc[r] + bn;
     }
   }
 }
@@ -894,13 +896,14 @@ extern "C" int mapx_enc_grouped_fwd(const float* final_act, int64_t ld_final, in
 
 extern "C" int mapx_enc_grouped_dw(const float* dh_slots, const float* final_act, int64_t ld_final, int nrows,
                                    int N, const int32_t* rowmap, const int32_t* group_start, int F,
-                                   float* dW, int64_t ldw, hipStream_t stream) {
+                                   const float* gscale_opt, float* dW, int64_t ldw, hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(dh_slots && final_act && rowmap && group_start && dW, "enc_grouped_dw: null pointer");
   MAPX_REQUIRE(N % 4 == 0 && ld_final % 4 == 0 && F >= 1, "enc_grouped_dw: N, ld %% 4 must be 0");
   GroupedArgs g{};
   g.A = dh_slots; g.lda = 32; g.B = final_act; g.ldb = ld_final; g.C = dW; g.ldc = ldw;
   g.rowmap = rowmap; g.group_start = group_start; g.K = 0; g.N = N; g.nrows = nrows;
+  g.gscale = gscale_opt;
   hipLaunchKernelGGL(gemm_grouped_kernel<true>, dim3((N + 127) / 128, F), dim3(256), 0, stream, g);
   return check_launch("enc_grouped_dw");
 }

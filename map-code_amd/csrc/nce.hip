@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(256) nce_fwd_kernel(
     int L, const int32_t* __restrict__ idx, int64_t T, int K1, const float* __restrict__ emb,
     const float* __restrict__ bias, const float* __restrict__ logq, float lnV, float lnK,
     float invT, float* __restrict__ h_out, float* __restrict__ dlogit, float* __restrict__ dh,
-    float* __restrict__ logits, float* __restrict__ loss_partial, int* __restrict__ acc_count) {
+    float* __restrict__ logits, float* __restrict__ loss_partial, int* __restrict__ acc_partial) {
   constexpr int P = LG * 4;
   constexpr int GPB = 256 / LG;  // targets per block pass
   const int sub = threadIdx.x % LG;
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256) nce_fwd_kernel(
     int a = 0;
     for (int i = 0; i < GPB; ++i) { l += sl[i]; a += sa[i]; }
     loss_partial[blockIdx.x] = l;
-    if (a) atomicAdd(acc_count, a);
+    acc_partial[blockIdx.x] = a;      // summed by the finalize kernel: no atomics, no zero-fill launch
   }
 }
 
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(256) nce_fwd_p32_kernel(
     int L, const int32_t* __restrict__ idx, int64_t T, int K1, const float* __restrict__ emb,
     const float* __restrict__ bias, const float* __restrict__ logq, float lnV, float lnK,
     float invT, float* __restrict__ h_out, float* __restrict__ dlogit, float* __restrict__ dh,
-    float* __restrict__ logits, float* __restrict__ loss_partial, int* __restrict__ acc_count,
+    float* __restrict__ logits, float* __restrict__ loss_partial, int* __restrict__ acc_partial,
     const int32_t* __restrict__ hpos, float* __restrict__ dh_slots) {
   constexpr int LG = 8, P = 32, GPB = 256 / LG, MAXB = 4;   // up to 32 rows per target
   const int lane = threadIdx.x & 63;
@@ -266,17 +266,26 @@ __global__ void __launch_bounds__(256) nce_fwd_p32_kernel(
     int a = 0;
     for (int i = 0; i < GPB; ++i) { l += sl[i]; a += sa[i]; }
     loss_partial[blockIdx.x] = l;
-    if (a) atomicAdd(acc_count, a);
+    acc_partial[blockIdx.x] = a;      // summed by the finalize kernel: no atomics, no zero-fill launch
   }
 }
 
-__global__ void nce_loss_finalize_kernel(const float* __restrict__ partial, int n, float invT,
-                                         float* __restrict__ loss) {
+__global__ void nce_loss_finalize_kernel(const float* __restrict__ partial, const int32_t* __restrict__ acc_partial,
+                                         int n, float invT, float* __restrict__ loss, int32_t* __restrict__ acc) {
   // single wave, fixed order: lane i sums partial[i], partial[i+64], ...; then butterfly
   float v = 0.f;
-  for (int i = threadIdx.x; i < n; i += kWave) v += partial[i];
+  int a = 0;
+  for (int i = threadIdx.x; i < n; i += kWave) {
+    v += partial[i];
+    a += acc_partial[i];
+  }
   v = group_sum<kWave>(v);
-  if (threadIdx.x == 0) *loss = v * invT;
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+  if (threadIdx.x == 0) {
+    loss[0] = v * invT;
+    loss[1] = (float)a * invT;      // fraction of targets ranked first (the trainers log this)
+    *acc = a;
+  }
 }
 
 // d enc[b, f*P + p] = g * sum_{l : masked_index[b,l] == f} dh[b,l,p]   (backward of the
@@ -345,7 +354,7 @@ extern "C" int mapx_nce_pack_idx(const int64_t* targets, const int64_t* noise, i
   return mapx::check_launch("nce_pack_idx");
 }
 
-extern "C" size_t mapx_nce_fwd_workspace_bytes(void) { return mapx::kNceBlocks * sizeof(float); }
+extern "C" size_t mapx_nce_fwd_workspace_bytes(void) { return mapx::kNceBlocks * (sizeof(float) + sizeof(int32_t)); }
 
 extern "C" int mapx_nce_fwd(const float* enc, int64_t B, int L, int F, int P,
                             const int64_t* masked_index, const int32_t* idx, int K,
@@ -366,21 +375,22 @@ extern "C" int mapx_nce_fwd(const float* enc, int64_t B, int L, int F, int P,
     return MAPX_EWORKSPACE;
   }
   const int64_t T = B * L;
-  MAPX_HIP(hipMemsetAsync(acc_out, 0, sizeof(int32_t), stream));
   if (T == 0) {
-    MAPX_HIP(hipMemsetAsync(loss_out, 0, sizeof(float), stream));
+    MAPX_HIP(hipMemsetAsync(acc_out, 0, sizeof(int32_t), stream));
+    MAPX_HIP(hipMemsetAsync(loss_out, 0, 2 * sizeof(float), stream));
     return MAPX_OK;
   }
   const int LG = P / 4, GPB = 256 / LG;
   int grid = (int)mapx::ceil_div(T, GPB);
   if (grid > mapx::kNceBlocks) grid = mapx::kNceBlocks;
   float* partial = static_cast<float*>(ws);
+  int32_t* acc_partial = reinterpret_cast<int32_t*>(partial + mapx::kNceBlocks);
   const float lnV = (float)log((double)V), lnK = (float)log((double)K), invT = 1.0f / (float)T;
   const int64_t enc_stride = (int64_t)F * P;
 #define MAPX_NCE(LG_)                                                                           \
   hipLaunchKernelGGL(mapx::nce_fwd_kernel<LG_>, dim3(grid), dim3(256), 0, stream, enc,          \
                      enc_stride, masked_index, L, idx, T, K + 1, emb, bias, logq, lnV, lnK,     \
-                     invT, h_out, dlogit, dh, logits_opt, partial, acc_out)
+                     invT, h_out, dlogit, dh, logits_opt, partial, acc_partial)
   switch (LG) {
     case 2: MAPX_NCE(2); break;
     case 4: MAPX_NCE(4); break;
@@ -388,7 +398,7 @@ extern "C" int mapx_nce_fwd(const float* enc, int64_t B, int L, int F, int P,
       if (K + 1 <= 32)
         hipLaunchKernelGGL(mapx::nce_fwd_p32_kernel, dim3(grid), dim3(256), 0, stream, enc, enc_stride,
                            masked_index, L, idx, T, K + 1, emb, bias, logq, lnV, lnK, invT, h_out, dlogit,
-                           dh, logits_opt, partial, acc_out, hpos_opt, dh_slots_opt);
+                           dh, logits_opt, partial, acc_partial, hpos_opt, dh_slots_opt);
       else
         MAPX_NCE(8);
       break;
@@ -396,8 +406,8 @@ extern "C" int mapx_nce_fwd(const float* enc, int64_t B, int L, int F, int P,
     default: MAPX_NCE(32); break;
   }
 #undef MAPX_NCE
-  hipLaunchKernelGGL(mapx::nce_loss_finalize_kernel, dim3(1), dim3(64), 0, stream, partial, grid,
-                     invT, loss_out);
+  hipLaunchKernelGGL(mapx::nce_loss_finalize_kernel, dim3(1), dim3(64), 0, stream, partial,
+                     acc_partial, grid, invT, loss_out, acc_out);
   return mapx::check_launch("nce_fwd");
 }
 
@@ -419,15 +429,15 @@ extern "C" size_t mapx_nce_table_grad_workspace_bytes(int64_t n, int P) {
 // built over idx.flatten() (n = T*(K+1) keys).
 extern "C" int mapx_nce_table_grad(int64_t n, const int32_t* perm, const int32_t* rank,
                                    const int32_t* seg_start, const float* dlogit, const float* h,
-                                   int K, int P, float* out_emb, float* out_bias, void* ws,
-                                   size_t ws_bytes, hipStream_t stream) {
+                                   int K, int P, const float* gscale_opt, float* out_emb, float* out_bias,
+                                   void* ws, size_t ws_bytes, int32_t* zeroed_counter_opt, hipStream_t stream) {
   MAPX_REQUIRE(n >= 0, "nce_table_grad: n < 0");
   if (n == 0) return MAPX_OK;
   MAPX_REQUIRE(perm && rank && seg_start && dlogit && h && out_emb && out_bias,
                "nce_table_grad: null pointer");
   mapx::SegPlanView pl{n, perm, rank, seg_start};
-  mapx::NceContrib c{dlogit, h, K + 1, P};
-  return mapx::seg_reduce_launch<true>(pl, c, P, out_emb, out_bias, ws, ws_bytes, stream,
+  mapx::NceContrib c{dlogit, h, K + 1, P, gscale_opt};
+  return mapx::seg_reduce_launch<true>(pl, c, P, out_emb, out_bias, ws, ws_bytes, zeroed_counter_opt, stream,
                                        "nce_table_grad");
 }
 

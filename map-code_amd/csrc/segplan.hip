@@ -37,7 +37,8 @@ __global__ void __launch_bounds__(256) seg_mark_kernel(const int32_t* __restrict
       seg_start[r - 1] = (int32_t)j;
     }
     if (j == n - 1) {
-      *n_uniq = r;
+      n_uniq[0] = r;
+      n_uniq[1] = 0;      // owner counter of the one segment reduction that will use this plan
       seg_start[r] = (int32_t)n;
     }
   }
@@ -126,7 +127,7 @@ extern "C" int mapx_seg_plan(const int32_t* keys, int64_t n, int64_t V, void* ws
   MAPX_REQUIRE(n >= 0 && n < (1LL << 31) && V > 0 && V < (1LL << 31), "seg_plan: bad sizes");
   MAPX_REQUIRE(n_uniq && seg_start, "seg_plan: null output");
   if (n == 0) {
-    MAPX_HIP(hipMemsetAsync(n_uniq, 0, sizeof(int32_t), stream));
+    MAPX_HIP(hipMemsetAsync(n_uniq, 0, 2 * sizeof(int32_t), stream));
     MAPX_HIP(hipMemsetAsync(seg_start, 0, sizeof(int32_t), stream));
     return MAPX_OK;
   }
@@ -191,7 +192,7 @@ extern "C" size_t mapx_seg_reduce_workspace_bytes(int64_t n, int W) {
 
 extern "C" int mapx_seg_reduce_rows(int64_t n, const int32_t* perm, const int32_t* rank,
                                     const int32_t* seg_start, const float* src, int W, float* out,
-                                    void* ws, size_t ws_bytes, hipStream_t stream) {
+                                    void* ws, size_t ws_bytes, int32_t* zeroed_counter_opt, hipStream_t stream) {
   MAPX_REQUIRE(n >= 0, "seg_reduce_rows: n < 0");
   if (n == 0) return MAPX_OK;
   MAPX_REQUIRE(perm && rank && seg_start && src && out, "seg_reduce_rows: null pointer");
@@ -199,6 +200,6 @@ extern "C" int mapx_seg_reduce_rows(int64_t n, const int32_t* perm, const int32_
                "seg_reduce_rows: pointers must be 16-byte aligned");
   mapx::SegPlanView pl{n, perm, rank, seg_start};
   mapx::RowsContrib c{src, W};
-  return mapx::seg_reduce_launch<false>(pl, c, W, out, nullptr, ws, ws_bytes, stream,
+  return mapx::seg_reduce_launch<false>(pl, c, W, out, nullptr, ws, ws_bytes, zeroed_counter_opt, stream,
                                         "seg_reduce_rows");
 }

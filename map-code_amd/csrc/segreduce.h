@@ -47,8 +47,9 @@ struct NceContrib {
   const float* dlogit;  // [T*(K+1)]
   const float* h;       // [T, P]
   int K1, P;
+  const float* gscale;  // optional device scalar: incoming gradient of the loss (dlogit is per unit loss)
   __device__ inline float4 operator()(int32_t p, int sub, float& extra) const {
-    const float d = dlogit[p];
+    const float d = gscale ? dlogit[p] * *gscale : dlogit[p];
     const int t = p / K1;
     float4 v = *reinterpret_cast<const float4*>(h + (int64_t)t * P + 4 * sub);
     extra = d;
@@ -229,7 +230,7 @@ inline size_t seg_reduce_partial_bytes(int64_t n, int W, bool extra) {
 
 template <bool EXTRA, class Contrib>
 int seg_reduce_launch(const SegPlanView& pl, const Contrib& contrib, int W, float* out,
-                      float* out_extra, void* ws, size_t ws_bytes, hipStream_t stream,
+                      float* out_extra, void* ws, size_t ws_bytes, int32_t* zeroed_counter, hipStream_t stream,
                       const char* what) {
   if (pl.n == 0) return MAPX_OK;
   MAPX_REQUIRE(W % 4 == 0 && W >= 4 && W <= 256, "%s: row width %d must be a multiple of 4", what, W);
@@ -244,7 +245,9 @@ int seg_reduce_launch(const SegPlanView& pl, const Contrib& contrib, int W, floa
   float* part_tail = part_head + nchunks * WS;
   int32_t* n_owners = reinterpret_cast<int32_t*>(part_tail + nchunks * WS);
   int32_t* owners = n_owners + 16;
-  if (hipMemsetAsync(n_owners, 0, sizeof(int32_t), stream) != hipSuccess) {
+  if (zeroed_counter) {
+    n_owners = zeroed_counter;       // the plan's own counter, zeroed when the plan was built: no memset launch
+  } else if (hipMemsetAsync(n_owners, 0, sizeof(int32_t), stream) != hipSuccess) {
     set_error("%s: memset failed", what);
     return MAPX_EHIP;
   }

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmapx_hip.so")
 
-MAPX_ABI_VERSION = 14
+MAPX_ABI_VERSION = 15
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_CROSS, EPI_ADD, EPI_RELU_MASK = range(6)
 
 _p, _i, _i64, _u64, _f, _d, _sz = (C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double,
@@ -26,7 +26,7 @@ SIGNATURES = {
     "mapx_seg_plan_workspace_bytes": (_sz, [_i64, _i64]),
     "mapx_seg_plan": (_i, [_p, _i64, _i64, _p, _sz, _p, _p, _p, _p, _p, _p, _p]),
     "mapx_seg_reduce_workspace_bytes": (_sz, [_i64, _i]),
-    "mapx_seg_reduce_rows": (_i, [_i64, _p, _p, _p, _p, _i, _p, _p, _sz, _p]),
+    "mapx_seg_reduce_rows": (_i, [_i64, _p, _p, _p, _p, _i, _p, _p, _sz, _p, _p]),
     "mapx_alias_build_host": (_i, [_p, _i64, _p, _p]),
     "mapx_alias_pack": (_i, [_p, _p, _i64, _p, _p]),
     "mapx_alias_draw": (_i, [_p, _i64, _p, _i64, _i, _u64, _u64, _p, _p, _p]),
@@ -36,7 +36,7 @@ SIGNATURES = {
                           _p, _p, _sz, _p, _p, _p]),
     "mapx_nce_scatter_dh": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p, _p]),
     "mapx_nce_table_grad_workspace_bytes": (_sz, [_i64, _i]),
-    "mapx_nce_table_grad": (_i, [_i64, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _sz, _p]),
+    "mapx_nce_table_grad": (_i, [_i64, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _sz, _p, _p]),
     "mapx_scale_inplace": (_i, [_p, _i64, _p, _p]),
     "mapx_gemm_splitk_workspace_bytes": (_sz, [_i, _i, _i]),
     "mapx_gemm_f32": (_i, [_i, _i, _i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _i, _p, _p, _i64, _p,
@@ -44,7 +44,7 @@ SIGNATURES = {
     "mapx_sum_tasks": (_i, [_p, _i, _p]),
     "mapx_enc_group_layout": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "mapx_enc_grouped_fwd": (_i, [_p, _i64, _i, _i, _p, _i64, _p, _p, _p, _i, _p, _p, _p]),
-    "mapx_enc_grouped_dw": (_i, [_p, _p, _i64, _i, _i, _p, _p, _i, _p, _i64, _p]),
+    "mapx_enc_grouped_dw": (_i, [_p, _p, _i64, _i, _i, _p, _p, _i, _p, _p, _i64, _p]),
     "mapx_colsum_chunks": (_i, []),
     "mapx_colsum_workspace_bytes": (_sz, [_i]),
     "mapx_colsum": (_i, [_p, _i64, _i, _i, _p, _p, _sz, _p]),

@@ -65,7 +65,8 @@ class _NceLoss(Function):
         ctx.save_for_backward(o["dlogit"], o["dh"], o["h"], masked_index)
         logits = o["logits"] if want_logits else torch.empty(0, device=enc.device)
         ctx.mark_non_differentiable(o["acc"], logits)
-        return o["loss"].view(()), o["acc"].view(()), logits
+        ctx.crit.last_acc_ratio = o["loss"][1]      # device float, same launch as the loss
+        return o["loss"][0], o["acc"].view(()), logits
 
     @staticmethod
     def backward(ctx, gl, _a, _l):
@@ -75,8 +76,7 @@ class _NceLoss(Function):
         if ctx.plan is None:
             raise RuntimeError("NCE backward without a segment plan")
         plan = ctx.plan.get()
-        ops.scale_(dlogit, gl)
-        ge, gb = ops.nce_table_grad(plan, dlogit, h, ctx.K, ctx.P)
+        ge, gb = ops.nce_table_grad(plan, dlogit, h, ctx.K, ctx.P, gscale=gl)
         ctx.crit.table.sparse_grad = (plan, ge, gb)
         return denc, None, None, None, None, None, None, None, None, None
 
@@ -100,7 +100,8 @@ class _EncNceLoss(Function):
         ctx.save_for_backward(final, w_enc, o["dlogit"], o["dh"], o["h"], masked_index, dh_slots)
         logits = o["logits"] if want_logits else torch.empty(0, device=final.device)
         ctx.mark_non_differentiable(o["acc"], logits)
-        return o["loss"].view(()), o["acc"].view(()), logits
+        ctx.crit.last_acc_ratio = o["loss"][1]      # device float, same launch as the loss
+        return o["loss"][0], o["acc"].view(()), logits
 
     @staticmethod
     def backward(ctx, gl, _a, _l):
@@ -111,14 +112,12 @@ class _EncNceLoss(Function):
         dfinal = ops.linear_bwd_input(denc, w_enc) if ctx.needs_input_grad[0] else None
         if ctx.plan is not None:
             ctx.plan.start()         # sort of the sampled ids: forks from the draw, enqueued behind the dX GEMM
-        ops.scale_(dh_slots, gl)
-        dw = ops.enc_grouped_dw(dh_slots, final, ctx.groups, out=sw)
+        dw = ops.enc_grouped_dw(dh_slots, final, ctx.groups, out=sw, gscale=gl)
         db = ops.colsum(denc, out=sb)
         if ctx.plan is None:
             raise RuntimeError("NCE backward without a segment plan")
         plan = ctx.plan.get()
-        ops.scale_(dlogit, gl)
-        ge, gb = ops.nce_table_grad(plan, dlogit, h, ctx.K, ctx.P)
+        ge, gb = ops.nce_table_grad(plan, dlogit, h, ctx.K, ctx.P, gscale=gl)
         ctx.crit.table.sparse_grad = (plan, ge, gb)
         return (dfinal, None if sw is not None else dw, None if sb is not None else db,
                 None, None, None, None, None, None, None, None, None, None)

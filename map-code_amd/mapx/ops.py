@@ -204,7 +204,8 @@ class SegPlan:
         self.rank = torch.empty(max(n, 1), **i32)
         self.uniq = torch.empty(max(n, 1), **i32)
         self.seg_start = torch.empty(n + 1, **i32)
-        self.n_uniq = torch.empty(1, **i32)
+        self.n_uniq = torch.empty(2, **i32)         # [number of runs, owner counter (zeroed by the plan)]
+        self._counter_fresh = n > 0
         nb = lib.mapx_seg_plan_workspace_bytes(n, V)
         ws = scratch(nb, dev)
         with _timed("seg_plan", n * 4.0):
@@ -217,7 +218,14 @@ class SegPlan:
 
     def count(self):
         """Number of unique keys (host sync)."""
-        return int(self.n_uniq.item())
+        return int(self.n_uniq[0].item())
+
+    def take_counter(self):
+        """Address of the plan's zeroed owner counter for its first segment reduction, None after."""
+        if not self._counter_fresh:
+            return None
+        self._counter_fresh = False
+        return self.n_uniq.data_ptr() + 4
 
 
 def seg_reduce_rows(plan, src, W):
@@ -228,7 +236,8 @@ def seg_reduce_rows(plan, src, W):
     ws = scratch(nb, src.device)
     with _timed("seg_reduce_rows", plan.n * (4.0 * W + 8)):
         check(lib.mapx_seg_reduce_rows(plan.n, ptr(plan.perm), ptr(plan.rank), ptr(plan.seg_start),
-                                       ptr(src), W, ptr(out), ptr(ws), ws.numel(), stream()))
+                                       ptr(src), W, ptr(out), ptr(ws), ws.numel(), plan.take_counter(),
+                                       stream()))
     return out
 
 
@@ -275,7 +284,7 @@ def nce_pack_idx(targets, noise, V, validate=False):
 
 
 def nce_fwd(enc, masked_index, idx, emb, bias, logq, F, P, want_logits=False, hpos=None, dh_slots=None):
-    """-> dict(loss [1], acc [1] i32, h [T,P], dlogit [T,K+1], dh [T,P], logits or None).
+    """-> dict(loss [2] = {mean loss, accuracy}, acc [1] i32, h [T,P], dlogit [T,K+1], dh [T,P], logits or None).
     hpos (grouped encoder): `enc` is h_slots [slots,P]; dh_slots receives dh at the slots too."""
     require_gpu(enc, masked_index, idx, emb, bias, logq)
     B, L = masked_index.shape
@@ -283,7 +292,7 @@ def nce_fwd(enc, masked_index, idx, emb, bias, logq, F, P, want_logits=False, hp
     assert T == B * L and (hpos is not None or enc.shape == (B, F * P))
     dev = enc.device
     f32 = dict(dtype=torch.float32, device=dev)
-    out = dict(loss=torch.empty(1, **f32), acc=torch.empty(1, dtype=torch.int32, device=dev),
+    out = dict(loss=torch.empty(2, **f32), acc=torch.empty(1, dtype=torch.int32, device=dev),
                h=torch.empty(T, P, **f32), dlogit=torch.empty(T, K1, **f32),
                dh=torch.empty(T, P, **f32),
                logits=torch.empty(T, K1, **f32) if want_logits else None)
@@ -335,16 +344,17 @@ def enc_grouped_fwd(final, w, b, groups, zero_slots=None):
     return h
 
 
-def enc_grouped_dw(dh_slots, final, groups, out=None):
-    """dW [F*32, D+H] of feat_encoder from the slot-ordered dh (every row written)."""
+def enc_grouped_dw(dh_slots, final, groups, out=None, gscale=None):
+    """dW [F*32, D+H] of feat_encoder from the slot-ordered dh (every row written), times the
+    device scalar `gscale` if given."""
     require_gpu(dh_slots, final)
     Nn = final.shape[1]
     if out is None:
         out = torch.empty(groups.F * 32, Nn, dtype=torch.float32, device=final.device)
     with _timed("gemm_enc_grouped_dw", 2.0 * groups.T * 32 * Nn):
         check(lib.mapx_enc_grouped_dw(ptr(dh_slots), final.data_ptr(), final.stride(0), final.shape[0], Nn,
-                                      ptr(groups.rowmap), ptr(groups.group_start), groups.F, ptr(out),
-                                      out.stride(0), stream()))
+                                      ptr(groups.rowmap), ptr(groups.group_start), groups.F, ptr(gscale),
+                                      ptr(out), out.stride(0), stream()))
     return out
 
 
@@ -357,8 +367,9 @@ def nce_scatter_dh(dh, masked_index, F, P, gscale=None):
     return denc
 
 
-def nce_table_grad(plan, dlogit, h, K, P):
-    """-> (emb grad rows [cap,P], bias grad rows [cap]) for plan.uniq."""
+def nce_table_grad(plan, dlogit, h, K, P, gscale=None):
+    """-> (emb grad rows [cap,P], bias grad rows [cap]) for plan.uniq; dlogit is multiplied by the
+    device scalar `gscale` (incoming gradient of the loss) on the fly."""
     dev = dlogit.device
     out_emb = torch.empty(max(plan.n, 1), P, dtype=torch.float32, device=dev)
     out_bias = torch.empty(max(plan.n, 1), dtype=torch.float32, device=dev)
@@ -366,8 +377,8 @@ def nce_table_grad(plan, dlogit, h, K, P):
     ws = scratch(nb, dev)
     with _timed("nce_table_grad", plan.n * (4.0 * P + 4)):
         check(lib.mapx_nce_table_grad(plan.n, ptr(plan.perm), ptr(plan.rank), ptr(plan.seg_start),
-                                      ptr(dlogit), ptr(h), K, P, ptr(out_emb), ptr(out_bias), ptr(ws),
-                                      ws.numel(), stream()))
+                                      ptr(dlogit), ptr(h), K, P, ptr(gscale), ptr(out_emb), ptr(out_bias),
+                                      ptr(ws), ws.numel(), plan.take_counter(), stream()))
     return out_emb, out_bias
 
 

@@ -119,6 +119,7 @@ class Trainer:
         t_total = int(steps_per_epoch * self.args.num_train_epochs)
         t_warmup = int(t_total * self.args.warmup_ratio)
         self.model.to(self.device)
+        self._one = torch.ones((), device=self.device)       # dLoss/dLoss, allocated once (no fill launch per step)
         self.optimizer = self.get_optimizer(t_total, t_warmup)
         self.scheduler = self.optimizer                      # get_last_lr() lives there
         if hasattr(self.model, "mfp_criterion"):
@@ -145,20 +146,20 @@ class Trainer:
     def _mfp_step(self, X, Y):
         inputs = self.dynamic_mask({"input_ids": X, "labels": Y}, self.args.sampling_method)
         loss, count, acc = self.model(**inputs)
-        loss.backward()
+        loss.backward(self._one.view(loss.shape))
         self._optimizer_step()
-        return loss.detach(), acc.float() / count
+        return loss.detach(), self.model.mfp_criterion.last_acc_ratio      # = acc / count, from the loss kernel
 
     def _rfd_step(self, X, Y):
         inputs = self.dynamic_mask({"input_ids": X, "labels": Y}, self.args.sampling_method)
         loss, count, acc, pos_ratio = self.model(**inputs)
-        loss.backward()
+        loss.backward(self._one.view(loss.shape))
         self._optimizer_step()
         return loss.detach(), acc
 
     def _ctr_step(self, X, Y):
         loss, logits = self.model(input_ids=X, labels=Y)
-        loss.backward()
+        loss.backward(self._one.view(loss.shape))
         self._optimizer_step()
         return loss.detach(), logits.detach().view(-1)
 

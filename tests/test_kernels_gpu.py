@@ -151,8 +151,9 @@ def test_nce_fwd_and_grads_vs_oracle(ops, B, F, P, K, V):
     # tolerance: fp32 1e-5 relative (north star), logits have |s| ~ 1..10
     np.testing.assert_allclose(_cpu(o["logits"]).view(B, L, K + 1).numpy(),
                                logits_ref.detach().numpy(), rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(float(o["loss"]), float(loss_ref), rtol=1e-5)
+    np.testing.assert_allclose(float(o["loss"][0]), float(loss_ref), rtol=1e-5)
     assert int(o["acc"]) == acc_ref
+    np.testing.assert_allclose(float(o["loss"][1]), acc_ref / (B * L), rtol=1e-6)   # accuracy, same launch
     denc = ops.nce_scatter_dh(o["dh"], mi.to(DEV), F, P)
     np.testing.assert_allclose(_cpu(denc).numpy(), enc.grad.numpy(), rtol=1e-4, atol=1e-7)
     plan = ops.SegPlan(idx.view(-1), V)
