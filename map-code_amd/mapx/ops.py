@@ -131,8 +131,10 @@ _deferred = []
 COLSUM_CHUNKS = lib.mapx_colsum_chunks()
 
 
-# measured on MI355X inside the full step: deferring is 2 % SLOWER (1.71 vs 1.68 ms) — the tiny sums
-# run in the shadow of side-stream work and read L2-hot slabs — so it is off by default.
+# measured on MI355X inside the full step: deferring is 2-3 % SLOWER (1.56 vs 1.52 ms) — by then the
+# slabs have left L2 and one launch has few blocks — so it is off by default.  Sending each layer's
+# sums to a side stream instead was far worse (1.78 vs 1.45 ms): inside the captured graph every
+# extra parallel branch of tiny kernels disturbs the queue assignment of the GEMM chains.
 DEFER = os.environ.get("MAPX_DEFER", "0") == "1"
 
 
