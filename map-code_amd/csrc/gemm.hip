@@ -161,37 +161,76 @@ struct Operand {
   }
 };
 
-template <int EPI>
-__device__ inline void epilogue_store(const GemmArgs& a, float* __restrict__ C, int m, int n,
-                                      float acc, float bn) {
-  float v = acc + bn;
-  if (EPI == MAPX_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-  if (EPI == MAPX_EPI_BIAS_CROSS) {
-    a.out2[(int64_t)m * a.ldo2 + n] = v;
-    v = a.aux1[(int64_t)m * a.ld1 + n] + a.aux2[(int64_t)m * a.ld2 + n] * v;
-  }
-  if (EPI == MAPX_EPI_ADD) v += a.aux1[(int64_t)m * a.ld1 + n];
-  if (EPI == MAPX_EPI_RELU_MASK) v = a.aux1[(int64_t)m * a.ld1 + n] > 0.f ? v : 0.f;
-  C[(int64_t)m * a.ldc + n] = v;
-}
-
 // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-template <int EPI, int WMT, int WNT>
-__device__ inline void epilogue(const GemmArgs& a, float* __restrict__ C, f32x16 (&acc)[WMT][WNT],
-                                int mbase, int nbase, int l31, int kh) {
-#pragma unroll
-  for (int i = 0; i < WMT; ++i) {
+// Element (i, j, r) of a wave's accumulators sits at row mrow + ROW(r), column n of the output,
+// ROW(r) = (r&3) + 8*(r>>2): all addresses are `base + 32-bit element offset` with offsets that
+// differ by compile-time multiples of the leading dimension (host-checked: every operand spans
+// < 2^31 elements), so an element costs one add and one store instead of a 64-bit multiply.
+// Control flow is kept out of the element loops — one lane-mask test per 32-column group, one
+// wave-uniform test per 32-row band (ROWS_OK) — because every conditional block between a
+// load and its use makes the compiler fall back to `s_waitcnt vmcnt(0)` in front of each store,
+// which drains the previous store first: 64 serialised stores cost 4 us per launch.
+// Per band the auxiliary operands of all elements are fetched first, the stores follow.
+template <int EPI, int WMT, int WNT, bool ROWS_OK>
+__device__ inline void epilogue_band(const GemmArgs& a, float* __restrict__ C, f32x16 (&acc)[WMT][WNT],
+                                     const float (&bias_r)[WNT], int i, uint32_t mrow, int nbase, int l31) {
+  constexpr bool kAux1 = EPI == MAPX_EPI_BIAS_CROSS || EPI == MAPX_EPI_ADD || EPI == MAPX_EPI_RELU_MASK;
+  constexpr bool kAux2 = EPI == MAPX_EPI_BIAS_CROSS;
+  const float* __restrict__ aux1 = a.aux1;
+  const float* __restrict__ aux2 = a.aux2;
+  float* __restrict__ out2 = a.out2;
+  const uint32_t ldc = (uint32_t)a.ldc, ld1 = (uint32_t)a.ld1, ld2 = (uint32_t)a.ld2, ldo = (uint32_t)a.ldo2;
+#define MAPX_ROW(r) ((uint32_t)(((r) & 3) + 8 * ((r) >> 2)))
+  float x1[WNT][16], x2[WNT][16];
+  if (kAux1) {
 #pragma unroll
     for (int j = 0; j < WNT; ++j) {
-      const int n = nbase + 32 * j + l31;
-      if (n >= a.N) continue;
-      const float bn = (EPI >= MAPX_EPI_BIAS && EPI <= MAPX_EPI_BIAS_CROSS) ? a.bias[n] : 0.f;
+      // clamped, always-valid addresses: the loads carry no predicate (values of dead lanes are unused)
+      uint32_t n = (uint32_t)(nbase + 32 * j + l31);
+      n = (int)n < a.N ? n : (uint32_t)(a.N - 1);
+      const uint32_t o1 = mrow * ld1 + n, o2 = mrow * ld2 + n;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = mbase + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (m < a.M) epilogue_store<EPI>(a, C, m, n, acc[i][j][r], bn);
+        const uint32_t dr = ROWS_OK ? MAPX_ROW(r) : ((int)(mrow + MAPX_ROW(r)) < a.M ? MAPX_ROW(r) : 0u);
+        x1[j][r] = aux1[o1 + dr * ld1];
+        if (kAux2) x2[j][r] = aux2[o2 + dr * ld2];
       }
     }
+  }
+#pragma unroll
+  for (int j = 0; j < WNT; ++j) {
+    const uint32_t n = (uint32_t)(nbase + 32 * j + l31);
+    if ((int)n < a.N) {
+      const uint32_t oc = mrow * ldc + n, oo = mrow * ldo + n;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[i][j][r];
+        if (EPI >= MAPX_EPI_BIAS && EPI <= MAPX_EPI_BIAS_CROSS) v += bias_r[j];
+        if (EPI == MAPX_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+        float u = v;
+        if (EPI == MAPX_EPI_BIAS_CROSS) v = x1[j][r] + x2[j][r] * v;
+        if (EPI == MAPX_EPI_ADD) v += x1[j][r];
+        if (EPI == MAPX_EPI_RELU_MASK) v = x1[j][r] > 0.f ? v : 0.f;
+        if (ROWS_OK || (int)(mrow + MAPX_ROW(r)) < a.M) {
+          if (EPI == MAPX_EPI_BIAS_CROSS) out2[oo + MAPX_ROW(r) * ldo] = u;
+          C[oc + MAPX_ROW(r) * ldc] = v;
+        }
+      }
+    }
+  }
+#undef MAPX_ROW
+}
+
+template <int EPI, int WMT, int WNT>
+__device__ inline void epilogue(const GemmArgs& a, float* __restrict__ C, f32x16 (&acc)[WMT][WNT],
+                                const float (&bias_r)[WNT], int mbase, int nbase, int l31, int kh) {
+#pragma unroll
+  for (int i = 0; i < WMT; ++i) {
+    const uint32_t mrow = (uint32_t)(mbase + 32 * i + 4 * kh);
+    if (mbase + 32 * i + 32 <= a.M)      // wave-uniform: the whole 32-row band is inside the matrix
+      epilogue_band<EPI, WMT, WNT, true>(a, C, acc, bias_r, i, mrow, nbase, l31);
+    else if (mbase + 32 * i < a.M)
+      epilogue_band<EPI, WMT, WNT, false>(a, C, acc, bias_r, i, mrow, nbase, l31);
   }
 }
 
@@ -228,6 +267,14 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs a) {
     for (int j = 0; j < WNT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // bias of this lane's output columns, fetched now so that its latency hides behind the K loop
+  float bias_r[WNT];
+#pragma unroll
+  for (int j = 0; j < WNT; ++j) {
+    const int n = n0 + bbase + 32 * j + l31;
+    bias_r[j] = (a.epi >= MAPX_EPI_BIAS && a.epi <= MAPX_EPI_BIAS_CROSS && n < a.N) ? a.bias[n] : 0.f;
+  }
 
   // Two register sets per operand: set (t & 1) carries tile t from its global load (issued during
   // K-step t-2) to its LDS store (during K-step t-1).  Loads and stores are cut into per-k-group
@@ -338,13 +385,18 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs a) {
 #undef MAPX_STORE_SLICE
 
   const int mbase = m0 + abase, nbase = n0 + bbase;
+  // The bias registers were loaded before the K loop; passing them through an ALU move here
+  // retires that load for the compiler's wait-count bookkeeping (otherwise it re-waits, with
+  // vmcnt(0), in front of every store of the epilogue).
+#pragma unroll
+  for (int j = 0; j < WNT; ++j) asm volatile("v_mov_b32 %0, %1" : "=v"(bias_r[j]) : "v"(bias_r[j]));
   switch (a.epi) {
-    case MAPX_EPI_BIAS: epilogue<MAPX_EPI_BIAS>(a, C, acc, mbase, nbase, l31, kh); break;
-    case MAPX_EPI_BIAS_RELU: epilogue<MAPX_EPI_BIAS_RELU>(a, C, acc, mbase, nbase, l31, kh); break;
-    case MAPX_EPI_BIAS_CROSS: epilogue<MAPX_EPI_BIAS_CROSS>(a, C, acc, mbase, nbase, l31, kh); break;
-    case MAPX_EPI_ADD: epilogue<MAPX_EPI_ADD>(a, C, acc, mbase, nbase, l31, kh); break;
-    case MAPX_EPI_RELU_MASK: epilogue<MAPX_EPI_RELU_MASK>(a, C, acc, mbase, nbase, l31, kh); break;
-    default: epilogue<MAPX_EPI_NONE>(a, C, acc, mbase, nbase, l31, kh); break;
+    case MAPX_EPI_BIAS: epilogue<MAPX_EPI_BIAS>(a, C, acc, bias_r, mbase, nbase, l31, kh); break;
+    case MAPX_EPI_BIAS_RELU: epilogue<MAPX_EPI_BIAS_RELU>(a, C, acc, bias_r, mbase, nbase, l31, kh); break;
+    case MAPX_EPI_BIAS_CROSS: epilogue<MAPX_EPI_BIAS_CROSS>(a, C, acc, bias_r, mbase, nbase, l31, kh); break;
+    case MAPX_EPI_ADD: epilogue<MAPX_EPI_ADD>(a, C, acc, bias_r, mbase, nbase, l31, kh); break;
+    case MAPX_EPI_RELU_MASK: epilogue<MAPX_EPI_RELU_MASK>(a, C, acc, bias_r, mbase, nbase, l31, kh); break;
+    default: epilogue<MAPX_EPI_NONE>(a, C, acc, bias_r, mbase, nbase, l31, kh); break;
   }
 }
 
@@ -807,6 +859,11 @@ extern "C" int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   MAPX_REQUIRE(A && B && C, "gemm_f32: null operand");
   MAPX_REQUIRE(!(a_kc == 0 && b_kc != 0), "gemm_f32: layout (A m-contiguous, B k-contiguous) unused");
   MAPX_REQUIRE(epi >= MAPX_EPI_NONE && epi <= MAPX_EPI_RELU_MASK, "gemm_f32: bad epilogue %d", epi);
+  {   // the epilogue addresses every output / auxiliary operand with 32-bit element offsets
+    const int64_t lim = (int64_t)1 << 31, rows = M > 0 ? M : 1;
+    MAPX_REQUIRE(rows * ldc < lim && rows * ld1 < lim && rows * ld2 < lim && rows * ldo2 < lim,
+                 "gemm_f32: an output or auxiliary operand spans 2^31 elements or more");
+  }
   if (epi >= MAPX_EPI_BIAS && epi <= MAPX_EPI_BIAS_CROSS) MAPX_REQUIRE(bias, "gemm_f32: bias missing");
   if (epi == MAPX_EPI_BIAS_CROSS) MAPX_REQUIRE(aux1 && aux2 && out2, "gemm_f32: cross operands missing");
   if (epi == MAPX_EPI_ADD || epi == MAPX_EPI_RELU_MASK) MAPX_REQUIRE(aux1, "gemm_f32: aux missing");
