@@ -9,7 +9,8 @@ forward/backward on its own `per_gpu_train_batch_size` rows with its own masks/n
   * dense gradients: ONE all-reduce(sum) per flat group (~15 MB fp32 at Avazu-MFP), / world;
   * table gradients: each rank's deduplicated (row id, gradient row) list is all-gathered
     (padded to the largest rank's count with zero rows on id 0), merged by the same
-    deterministic reduce-by-key as the local gradient (csrc/segreduce.h), / world.
+    deterministic reduce-by-key as the local gradient (csrc/segreduce.h), / world.  The
+    largest counts of all tables travel in one MAX all-reduce: one host sync per step.
 
 Every replica then applies the identical update, so replicas stay bit-identical without
 ever broadcasting parameters.  The merge is injectable (`merge_fn`) so that the exchange
@@ -43,21 +44,24 @@ def allreduce_mean_(flat):
     return flat
 
 
-def gather_sparse(uniq, rows, count):
-    """All-gather every rank's first `count` (id, row) pairs.
-    -> (keys int32 [world*maxc], rows f32 [world*maxc, W]); padding = id 0 with a zero row."""
+def max_counts(counts_dev):
+    """Element-wise MAX over ranks of a small int64 device vector -> Python list (ONE host sync
+    per step for all tables together)."""
+    cs = _staged(counts_dev.clone())
+    dist.all_reduce(cs, op=dist.ReduceOp.MAX)
+    return [max(1, int(c)) for c in cs.tolist()]
+
+
+def gather_sparse(uniq, rows, n_uniq_dev, maxc):
+    """All-gather every rank's first n_uniq (id, row) pairs, padded to `maxc` (the largest count
+    over ranks) with zero rows on id 0; the local count stays on the device (a mask, no sync).
+    -> (keys int32 [world*maxc], rows f32 [world*maxc, W])."""
     w = world()
     dev = rows.device
-    counts = torch.zeros(w, dtype=torch.int64)
-    counts[rank()] = count
-    cs = counts.to(dev) if dist.get_backend() != "gloo" else counts
-    dist.all_reduce(cs, op=dist.ReduceOp.SUM)
-    maxc = max(1, int(cs.max()))
     W = rows.shape[1]
-    k_loc = torch.zeros(maxc, dtype=torch.int32, device=dev)
-    r_loc = torch.zeros(maxc, W, dtype=torch.float32, device=dev)
-    k_loc[:count] = uniq[:count]
-    r_loc[:count] = rows[:count]
+    live = torch.arange(maxc, device=dev) < n_uniq_dev
+    k_loc = torch.where(live, uniq[:maxc], torch.zeros((), dtype=uniq.dtype, device=dev))
+    r_loc = torch.where(live.unsqueeze(1), rows[:maxc], torch.zeros((), dtype=rows.dtype, device=dev))
     k_all = torch.empty(w * maxc, dtype=torch.int32, device=_staged(k_loc).device)
     r_all = torch.empty(w * maxc, W, dtype=torch.float32, device=_staged(r_loc).device)
     dist.all_gather_into_tensor(k_all, _staged(k_loc))
@@ -72,12 +76,9 @@ def hip_merge(keys, rows, num_rows):
     return plan, ops.seg_reduce_rows(plan, rows, rows.shape[1])
 
 
-def sync_table_grad(table, merge_fn=hip_merge):
+def sync_table_grad(table, maxc, merge_fn=hip_merge):
     """Replace table.sparse_grad by the mean over ranks of all ranks' sparse gradients."""
-    if world() == 1 or table.sparse_grad is None:
-        return
     plan, r0, r1 = table.sparse_grad
-    count = plan.count()
     W0 = r0.shape[1]
     if r1 is not None:                      # ride the scalar-per-row gradient in 4 extra columns
         packed = torch.zeros(r0.shape[0], W0 + 4, dtype=torch.float32, device=r0.device)
@@ -85,7 +86,11 @@ def sync_table_grad(table, merge_fn=hip_merge):
         packed[:, W0] = r1
     else:
         packed = r0
-    keys, rows = gather_sparse(plan.uniq, packed, count)
+    if packed.shape[0] < maxc:              # capacity = this rank's key count; another rank may hold more
+        packed = torch.cat([packed, packed.new_zeros(maxc - packed.shape[0], packed.shape[1])])
+    uniq = plan.uniq if plan.uniq.shape[0] >= maxc else torch.cat(
+        [plan.uniq, plan.uniq.new_zeros(maxc - plan.uniq.shape[0])])
+    keys, rows = gather_sparse(uniq, packed, plan.n_uniq[0], maxc)
     mplan, merged = merge_fn(keys, rows, table.num_rows)
     merged = merged / world()
     if r1 is not None:
@@ -102,8 +107,12 @@ def sync_gradients(optimizer, merge_fn=hip_merge):
     ops.flush_deferred()                # dense gradients must be final before the all-reduce
     for g in optimizer.groups:
         allreduce_mean_(g["g"])
-    for t in optimizer.tables:
-        sync_table_grad(t.table, merge_fn)
+    tabs = [t.table for t in optimizer.tables if t.table.sparse_grad is not None]
+    if not tabs:
+        return
+    counts = torch.stack([tb.sparse_grad[0].n_uniq[0] for tb in tabs]).to(torch.int64)
+    for tb, maxc in zip(tabs, max_counts(counts)):
+        sync_table_grad(tb, maxc, merge_fn)
 
 
 def barrier():

@@ -80,6 +80,32 @@ class GraphedStep:
         return self.out
 
 
+class GraphedBackward:
+    """Data-parallel steps: mask -> forward -> backward captured in a hipGraph, the gradient
+    exchange (host-side sizes) and the optimizer run eagerly after each replay.  The graph leaves
+    the dense gradients in the optimizer's flat buffers and the tables' sparse gradients in
+    buffers of fixed address; the Python references to them (cleared by optimizer.step()) are
+    put back after every replay."""
+
+    def __init__(self, trainer, fwd_bwd_fn, X, Y):
+        self.trainer = trainer
+        self.X, self.Y = X.clone(), Y.clone()
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = fwd_bwd_fn(self.X, self.Y)
+        self.sparse = [t.table.sparse_grad for t in trainer.optimizer.tables]
+
+    def __call__(self, X, Y):
+        self.X.copy_(X)
+        self.Y.copy_(Y)
+        self.graph.replay()
+        for t, sg in zip(self.trainer.optimizer.tables, self.sparse):
+            t.table.sparse_grad = sg
+        self.trainer._optimizer_step()
+        return self.out
+
+
 class Trainer:
     def __init__(self, model, model_config, training_args, train_dataset, eval_dataset):
         self.model, self.model_config, self.args = model, model_config, training_args
@@ -143,35 +169,49 @@ class Trainer:
         self.optimizer.step()                                # + scheduler.step() + zero_grad()
         self.global_step += 1
 
-    def _mfp_step(self, X, Y):
+    # forward + backward of one step (what a data-parallel graph captures); *_step adds the
+    # gradient exchange, the optimizer and the schedule
+    def _mfp_fwd_bwd(self, X, Y):
         inputs = self.dynamic_mask({"input_ids": X, "labels": Y}, self.args.sampling_method)
         loss, count, acc = self.model(**inputs)
         loss.backward(self._one.view(loss.shape))
-        self._optimizer_step()
         return loss.detach(), self.model.mfp_criterion.last_acc_ratio      # = acc / count, from the loss kernel
 
-    def _rfd_step(self, X, Y):
+    def _rfd_fwd_bwd(self, X, Y):
         inputs = self.dynamic_mask({"input_ids": X, "labels": Y}, self.args.sampling_method)
         loss, count, acc, pos_ratio = self.model(**inputs)
         loss.backward(self._one.view(loss.shape))
-        self._optimizer_step()
         return loss.detach(), acc
 
-    def _ctr_step(self, X, Y):
+    def _ctr_fwd_bwd(self, X, Y):
         loss, logits = self.model(input_ids=X, labels=Y)
         loss.backward(self._one.view(loss.shape))
-        self._optimizer_step()
         return loss.detach(), logits.detach().view(-1)
+
+    def _mfp_step(self, X, Y):
+        out = self._mfp_fwd_bwd(X, Y)
+        self._optimizer_step()
+        return out
+
+    def _rfd_step(self, X, Y):
+        out = self._rfd_fwd_bwd(X, Y)
+        self._optimizer_step()
+        return out
+
+    def _ctr_step(self, X, Y):
+        out = self._ctr_fwd_bwd(X, Y)
+        self._optimizer_step()
+        return out
 
     GRAPH_AFTER = 3      # eager steps per (kind, shape) before capture (allocator / workspace warm-up)
 
     def run_step(self, kind, X, Y):
-        """One training step.  Full-size single-GPU batches run from a captured hipGraph after a
-        few eager steps; ragged batches, multi-GPU steps (host-side exchange sizes), gradient
-        clipping and host-side mask sampling ("normal") stay eager."""
+        """One training step.  Full-size batches run from a captured hipGraph after a few eager
+        steps: the whole step on one GPU; mask + forward + backward when a gradient exchange
+        (N > 1) or gradient clipping needs host-side decisions before the optimizer.  Ragged
+        batches and host-side mask sampling ("normal") stay eager."""
         fn = {"mfp": self._mfp_step, "rfd": self._rfd_step, "ctr": self._ctr_step}[kind]
-        graphable = (self.use_graph and self.world == 1 and self.optimizer.max_grad_norm <= 0
-                     and X.shape[0] == self.args.per_gpu_train_batch_size
+        graphable = (self.use_graph and X.shape[0] == self.args.per_gpu_train_batch_size
                      and (kind == "ctr" or self.args.sampling_method == "randint"))
         if not graphable:
             return fn(X, Y)
@@ -181,7 +221,12 @@ class Trainer:
             if g < self.GRAPH_AFTER:
                 self._graphs[key] = g + 1
                 return fn(X, Y)
-            g = self._graphs[key] = GraphedStep(self, fn, X, Y)
+            if self.world == 1 and self.optimizer.max_grad_norm <= 0:
+                g = GraphedStep(self, fn, X, Y)
+            else:   # exchange sizes / the clipping norm are host decisions: graph up to the gradients
+                half = {"mfp": self._mfp_fwd_bwd, "rfd": self._rfd_fwd_bwd, "ctr": self._ctr_fwd_bwd}[kind]
+                g = GraphedBackward(self, half, X, Y)
+            self._graphs[key] = g
         return g(X, Y)
 
     # ------------------------------------------------------------------ masking (a1, a2)

@@ -47,8 +47,9 @@ def _local_grad(rank, V, W, with_bias):
     g = torch.Generator().manual_seed(100 + rank)
     n = 5 + 3 * rank                                   # ranks hold different counts
     uniq = torch.randperm(V, generator=g)[:n].sort().values
-    r0 = torch.randn(n + 4, W, generator=g)            # capacity > count: tail is garbage
-    r1 = torch.randn(n + 4, generator=g) if with_bias else None
+    cap = n + 1 + 3 * rank                             # capacity > count: tail is garbage; rank 0's
+    r0 = torch.randn(cap, W, generator=g)              # capacity (6) is below rank 1's count (8)
+    r1 = torch.randn(cap, generator=g) if with_bias else None
     return uniq, n, r0, r1
 
 
@@ -59,8 +60,10 @@ def _worker(rank, world, port, V, W, with_bias, out):
     from mapx import parallel
     uniq, n, r0, r1 = _local_grad(rank, V, W, with_bias)
     table = _Table(V, W, with_bias)
-    table.sparse_grad = (_Plan(uniq, n + 4), r0, r1)
-    parallel.sync_table_grad(table, merge_fn=_torch_merge)
+    table.sparse_grad = (_Plan(uniq, r0.shape[0]), r0, r1)
+    (maxc,) = parallel.max_counts(table.sparse_grad[0].n_uniq[:1].to(torch.int64))
+    assert maxc == 5 + 3 * (world - 1)                 # the largest rank's count, known to everyone
+    parallel.sync_table_grad(table, maxc, merge_fn=_torch_merge)
     plan, m0, m1 = table.sparse_grad
     U = plan.count()
     dense0 = torch.zeros(V, W).index_add_(0, plan.uniq[:U].long(), m0[:U])

@@ -229,9 +229,12 @@ def test_data_parallel_two_ranks_equal_single_process(tmp_path):
         np.testing.assert_allclose(b0[k].numpy(), a[k].numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
 
 
-def test_graph_replay_equals_eager_bitwise():
+@pytest.mark.parametrize("max_grad_norm", [0.0, 0.5])
+def test_graph_replay_equals_eager_bitwise(max_grad_norm):
     """The captured-hipGraph step and the eager step draw the same Philox streams (device-side
-    counter) and run the same kernels: identical parameters after two epochs, bit for bit."""
+    counter) and run the same kernels: identical parameters after two epochs, bit for bit.
+    With gradient clipping (as with N > 1) only mask + forward + backward are captured and the
+    rest of the step runs eagerly after each replay (trainer.GraphedBackward)."""
     from mapx.arguments import TrainingArguments
     from mapx.dataset import OurDataset, synth_table
     from mapx.models import BaseModel
@@ -248,7 +251,8 @@ def test_graph_replay_equals_eager_bitwise():
         targs = TrainingArguments(output_dir="/tmp/mapx_graph_test", per_gpu_train_batch_size=512,
                                   per_gpu_eval_batch_size=512, learning_rate=1e-3, lr_sched="cosine",
                                   weight_decay=5e-2, num_train_epochs=2, pretrain=True, pt_type="MFP",
-                                  sampling_method="randint", mask_ratio=0.3, logging_steps=7, seed=11)
+                                  sampling_method="randint", mask_ratio=0.3, logging_steps=7, seed=11,
+                                  max_grad_norm=max_grad_norm)
         targs._device = torch.device(DEV)
         os.makedirs(targs.output_dir, exist_ok=True)
         ds = OurDataset(ids, labels)
@@ -257,6 +261,9 @@ def test_graph_replay_equals_eager_bitwise():
         tr.MFP_pretrain()
         assert tr.global_step == 2 * 10
         assert (len(tr._graphs) == 1 and not isinstance(next(iter(tr._graphs.values())), int)) == use_graph
+        if use_graph:
+            kind = type(next(iter(tr._graphs.values()))).__name__
+            assert kind == ("GraphedBackward" if max_grad_norm > 0 else "GraphedStep")
         out.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
     for k in out[0]:
         assert torch.equal(out[0][k], out[1][k]), k
