@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 15
+#define MAPX_ABI_VERSION 16
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -73,6 +73,25 @@ size_t mapx_seg_reduce_workspace_bytes(int64_t n, int W);
 int mapx_seg_reduce_rows(int64_t n, const int32_t* perm, const int32_t* rank,
                          const int32_t* seg_start, const float* src, int W, float* out, void* ws,
                          size_t ws_bytes, int32_t* zeroed_counter_opt, hipStream_t stream);
+
+/* Same with one extra scalar per run: out_extra[u] = sum_{j in run u} extra[perm[j] / group].
+ * DeepFM: the LR weight w[V,1] (models.py:134) is read with the embedding's ids,
+ * so its gradient dL/dlr[b], shared by the F positions of row b (group = F), is reduced with the
+ * embedding rows.  Workspace: mapx_seg_reduce_workspace_bytes(n, W). */
+int mapx_seg_reduce_rows_extra(int64_t n, const int32_t* perm, const int32_t* rank,
+                               const int32_t* seg_start, const float* src, int W, const float* extra,
+                               int group, float* out, float* out_extra, void* ws, size_t ws_bytes,
+                               int32_t* zeroed_counter_opt, hipStream_t stream);
+
+/* ------------------------------------------------------------------ DeepFM terms
+ * LR  (models.py:129-143): out[b] = sum_f w[ids[b,f]]  (bias added by the caller).
+ * FM  (layers.py:123-131, 'product_sum'): out[b] = 0.5 sum_e((sum_f x)^2 - sum_f x^2), s[b,e] = sum_f x;
+ *     backward dx[b,f,e] = g[b] (s[b,e] - x[b,f,e]).  x [B,F,E] dense, E in {4,8,16,32,64}. */
+int mapx_lr_sum_fwd(const int64_t* ids, int64_t B, int F, const float* w, int64_t V, float* out,
+                    int* err_flag, hipStream_t stream);
+int mapx_fm_fwd(const float* x, int64_t B, int F, int E, float* out, float* s, hipStream_t stream);
+int mapx_fm_bwd(const float* g, const float* s, const float* x, int64_t B, int F, int E, float* dx,
+                hipStream_t stream);
 
 /* ------------------------------------------------------------------ NCE sampler (a7, a8)
  * nce/alias_multinomial.py:39-72: Walker table from the renormalised noise probabilities,

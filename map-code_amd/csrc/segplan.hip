@@ -203,3 +203,22 @@ extern "C" int mapx_seg_reduce_rows(int64_t n, const int32_t* perm, const int32_
   return mapx::seg_reduce_launch<false>(pl, c, W, out, nullptr, ws, ws_bytes, zeroed_counter_opt, stream,
                                         "seg_reduce_rows");
 }
+
+// Same reduction with an extra scalar per run: out_extra[u] = sum over the run of
+// extra[position / group] (DeepFM: the LR weight shares the embedding's ids, its gradient
+// dL/dlr[b] is common to the F positions of batch row b).
+extern "C" int mapx_seg_reduce_rows_extra(int64_t n, const int32_t* perm, const int32_t* rank,
+                                          const int32_t* seg_start, const float* src, int W,
+                                          const float* extra, int group, float* out, float* out_extra,
+                                          void* ws, size_t ws_bytes, int32_t* zeroed_counter_opt,
+                                          hipStream_t stream) {
+  MAPX_REQUIRE(n >= 0 && group >= 1, "seg_reduce_rows_extra: bad sizes");
+  if (n == 0) return MAPX_OK;
+  MAPX_REQUIRE(perm && rank && seg_start && src && extra && out && out_extra, "seg_reduce_rows_extra: null pointer");
+  MAPX_REQUIRE(((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)ws % 16 == 0),
+               "seg_reduce_rows_extra: pointers must be 16-byte aligned");
+  mapx::SegPlanView pl{n, perm, rank, seg_start};
+  mapx::RowsExtraContrib c{src, W, extra, group};
+  return mapx::seg_reduce_launch<true>(pl, c, W, out, out_extra, ws, ws_bytes, zeroed_counter_opt, stream,
+                                       "seg_reduce_rows_extra");
+}

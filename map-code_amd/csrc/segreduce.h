@@ -43,6 +43,19 @@ struct RowsContrib {
 // NCE output-table gradient, never materialised per (target, sample) pair:
 // d emb[idx[t,j]] += dlogit[t,j] * h[t,:]   d bias[idx[t,j]] += dlogit[t,j]
 // (backward of reference nce/index_linear.py:99-102; p = t*(K+1)+j)
+// Rows plus one scalar per GROUP of consecutive positions: embedding gradient rows dL/dX[b,f,:]
+// together with the LR gradient dL/dlr[b] that every field of row b shares (group = F).
+struct RowsExtraContrib {
+  const float* src;    // [n, W]
+  int W;
+  const float* extra;  // [n / group]
+  int group;
+  __device__ inline float4 operator()(int32_t p, int sub, float& ex) const {
+    ex = extra[p / group];
+    return *reinterpret_cast<const float4*>(src + (int64_t)p * W + 4 * sub);
+  }
+};
+
 struct NceContrib {
   const float* dlogit;  // [T*(K+1)]
   const float* h;       // [T, P]

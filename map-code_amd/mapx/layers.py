@@ -138,6 +138,48 @@ class _Gather(Function):
         return None, None, None
 
 
+class _GatherLinear(Function):
+    """Embedding rows [B,F,E] and the LR term sum_f w[id] [B] from one id matrix; backward reduces
+    both gradients with the table's one segment plan (rows + a scalar per batch row)."""
+
+    @staticmethod
+    def forward(ctx, weight, lin_weight, ids, table):
+        ctx.table, ctx.plan, ctx.width, ctx.F = table, table.plan, weight.shape[1], ids.shape[1]
+        x = ops.emb_gather(ids, weight)
+        lr = ops.lr_sum(ids, lin_weight.view(-1))
+        return x, lr
+
+    @staticmethod
+    def backward(ctx, gx, glr):
+        if ctx.plan is None:
+            raise RuntimeError("embedding backward without a segment plan")
+        plan = ctx.plan.get()
+        gx = gx.contiguous().view(-1, ctx.width)
+        rows0, rows1 = ops.seg_reduce_rows_extra(plan, gx, ctx.width, glr.contiguous().view(-1), ctx.F)
+        ctx.table.sparse_grad = (plan, rows0, rows1)
+        return None, None, None, None
+
+
+class _FmProductSum(Function):
+    """InnerProductLayer(output='product_sum') (reference layers.py:123-131) on [B,F,E] -> [B,1]."""
+
+    @staticmethod
+    def forward(ctx, x3):
+        x3 = x3.contiguous()
+        out, s = ops.fm_fwd(x3)
+        ctx.save_for_backward(x3, s)
+        return out.view(-1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        x3, s = ctx.saved_tensors
+        return ops.fm_bwd(g.contiguous().view(-1), s, x3)
+
+
+def fm_product_sum(x3):
+    return _FmProductSum.apply(x3)
+
+
 class Embeddings(nn.Module):
     """One shared id space over all fields (reference layers.py:83-102)."""
 
@@ -166,6 +208,20 @@ class Embeddings(nn.Module):
         if keys is not None:
             self.table.prepare(keys, need_grad, defer_plan=self.defer_plan)
         return _Gather.apply(w, input_ids, self.table)
+
+    def forward_with_linear(self, input_ids, lin_weight):
+        """-> (embeddings [B,F,E], sum_f lin_weight[id] [B]).  `lin_weight` [V,1] must be the
+        table's secondary parameter (RowTable p1): both are read with the same ids, kept current
+        by the same lazy optimizer state and get their gradients from one segment reduction."""
+        if self.table.p1 is not lin_weight:
+            raise ValueError("lin_weight must be the secondary parameter of this embedding's RowTable")
+        w = self.embedding.weight
+        need_grad = torch.is_grad_enabled() and w.requires_grad
+        keys = ops.ids_to_i32(input_ids, w.shape[0], validate=self.validate_ids) \
+            if (need_grad or self.table.lazy is not None) else None
+        if keys is not None:
+            self.table.prepare(keys, need_grad, defer_plan=self.defer_plan)
+        return _GatherLinear.apply(w, lin_weight, input_ids, self.table)
 
 
 # ----------------------------------------------------------------------------- dense layers

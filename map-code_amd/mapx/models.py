@@ -9,13 +9,14 @@ from torch import nn
 
 from . import ops
 from .arguments import Config
-from .layers import _JoinColumns, CrossNetV2, Embeddings, HipLinear, MLPBlock, bce_with_logits
+from .layers import (_JoinColumns, CrossNetV2, Embeddings, HipLinear, MLPBlock, RowTable, TableWeight,
+                     bce_with_logits, fm_product_sum)
 from .nce import IndexLinear
 
 logger = logging.getLogger(__name__)
 GROUPED_ENCODER = os.environ.get("MAPX_GROUPED_ENC", "1") == "1"
 
-_OTHER_BACKBONES = ("dnn", "autoint", "trans", "fignn", "fgcnn", "deepfm", "xdeepfm")
+_OTHER_BACKBONES = ("autoint", "trans", "fignn", "fgcnn", "xdeepfm")
 
 
 class _RfdPredictor(nn.ModuleDict):
@@ -42,10 +43,14 @@ class BaseModel(nn.Module):
         name = config.model_name.lower()
         if name == "dcnv2":
             return DCNV2(config)
+        if name == "dnn":
+            return DNN(config)
+        if name == "deepfm":
+            return DeepFM(config)
         if name in _OTHER_BACKBONES:
             raise NotImplementedError(
-                f"{config.model_name}: only the DCNv2 backbone is built in mapx (SURVEY §8: the "
-                "other backbones are out of the hot-path scope)")
+                f"{config.model_name}: mapx builds the DCNv2 hot path and, of the other backbones "
+                "(SURVEY §8 f4), DNN and DeepFM")
         raise NotImplementedError(config.model_name)
 
     def validate_model_config(self):
@@ -196,3 +201,87 @@ class DCNV2(BaseModel):
         if self.config.pretrain:
             return self.get_outputs(final_output, labels, masked_index, noise_samples=noise_samples, groups=groups)
         return self.get_outputs(self.fc_out(final_output), labels)
+
+
+class DNN(BaseModel):
+    """Embeddings -> MLP -> head (reference models.py:164-193).  Same heads, tables and optimizer
+    path as DCNV2; only the trunk differs."""
+    used_params = ["embed_size", "hidden_size", "num_hidden_layers", "hidden_dropout_rate", "hidden_act"]
+
+    def __init__(self, config: Config):
+        super().__init__(model_name="DNN", config=config)
+        self.embed = Embeddings(config)
+        self.embed.defer_plan = True
+        self.dnn = MLPBlock(input_dim=config.embed_size * config.num_fields, hidden_size=config.hidden_size,
+                            num_hidden_layers=config.num_hidden_layers,
+                            hidden_dropout_rate=config.hidden_dropout_rate, hidden_act=config.hidden_act)
+        if config.pretrain:
+            self.create_pretraining_predictor(config.hidden_size)
+        else:
+            self.fc_out = HipLinear(config.hidden_size, 1)
+
+    def forward(self, input_ids, labels=None, masked_index=None, noise_samples=None):
+        feat_embed = self.embed(input_ids).flatten(start_dim=1)
+        nn_output = self.dnn(feat_embed)
+        self.embed.table.start_plan()        # the sort forks from the ids, enqueued behind the trunk
+        if self.config.pretrain:
+            return self.get_outputs(nn_output, labels, masked_index, noise_samples=noise_samples)
+        return self.get_outputs(self.fc_out(nn_output), labels)
+
+
+class LR(nn.Module):
+    """First-order term (reference models.py:129-143): `embed_w` [V,1] + `bias` [1].  In DeepFM the
+    weight is the secondary parameter of the embedding's RowTable (same ids, one gradient plan);
+    the reference initialises it like any nn.Embedding, N(0, 1)."""
+
+    def __init__(self, config: Config):
+        super().__init__()
+        self.embed_w = TableWeight(config.input_size, 1)
+        with torch.no_grad():
+            self.embed_w.weight.normal_(0.0, 1.0)
+        self.bias = nn.Parameter(torch.zeros(1))
+
+
+class _InnerProductBuffers(nn.Module):
+    """The reference's InnerProductLayer keeps three index tensors as frozen Parameters
+    (layers.py:116-121); they appear in its state_dict, so they do here (as buffers)."""
+
+    def __init__(self, num_fields):
+        super().__init__()
+        iu = torch.triu_indices(num_fields, num_fields, offset=1)
+        self.register_buffer("field_p", iu[0].clone())
+        self.register_buffer("field_q", iu[1].clone())
+        self.register_buffer("upper_triangle_mask",
+                             torch.triu(torch.ones(num_fields, num_fields), 1).bool())
+
+
+class DeepFM(BaseModel):
+    """LR + FM(product_sum) + MLP (reference models.py:196-233).  Pretraining feeds
+    cat([dnn_vec, lr + fm]) [B, H+1] to the MFP / RFD heads; CTR sums the three logits."""
+    used_params = ["embed_size", "hidden_size", "num_hidden_layers", "hidden_dropout_rate", "hidden_act"]
+
+    def __init__(self, config: Config):
+        super().__init__(model_name="DeepFM", config=config)
+        self.embed = Embeddings(config)
+        self.embed.defer_plan = True
+        self.lr_layer = LR(config)
+        # one row table for both [V,*] parameters read with input_ids
+        self.embed.table = RowTable("embed.embedding", self.embed.embedding.weight, self.lr_layer.embed_w.weight)
+        self.dnn = MLPBlock(input_dim=config.num_fields * config.embed_size, hidden_size=config.hidden_size,
+                            num_hidden_layers=config.num_hidden_layers,
+                            hidden_dropout_rate=config.hidden_dropout_rate, hidden_act=config.hidden_act)
+        self.ip_layer = _InnerProductBuffers(config.num_fields)
+        if config.pretrain:
+            self.create_pretraining_predictor(config.hidden_size + 1)
+        else:
+            self.dnn_fc_out = HipLinear(config.hidden_size, 1)
+
+    def forward(self, input_ids, labels=None, masked_index=None, noise_samples=None):
+        x3, lr = self.embed.forward_with_linear(input_ids, self.lr_layer.embed_w.weight)
+        dnn_vec = self.dnn(x3.flatten(start_dim=1))
+        self.embed.table.start_plan()
+        lr_fm = lr.view(-1, 1) + self.lr_layer.bias + fm_product_sum(x3)
+        if self.config.pretrain:
+            final_vec = torch.cat([dnn_vec, lr_fm], dim=1)
+            return self.get_outputs(final_vec, labels, masked_index, noise_samples=noise_samples)
+        return self.get_outputs(self.dnn_fc_out(dnn_vec) + lr_fm, labels)

@@ -246,6 +246,52 @@ def seg_reduce_rows(plan, src, W):
     return out
 
 
+def seg_reduce_rows_extra(plan, src, W, extra, group):
+    """-> (rows [cap,W], scalars [cap]): the row reduction of seg_reduce_rows plus, per unique key,
+    the sum of extra[position // group] (DeepFM's LR weight gradient rides with the embedding's)."""
+    require_gpu(src, extra)
+    out = torch.empty(max(plan.n, 1), W, dtype=torch.float32, device=src.device)
+    out1 = torch.empty(max(plan.n, 1), dtype=torch.float32, device=src.device)
+    ws = scratch(lib.mapx_seg_reduce_workspace_bytes(plan.n, W), src.device)
+    with _timed("seg_reduce_rows", plan.n * (4.0 * W + 12)):
+        check(lib.mapx_seg_reduce_rows_extra(plan.n, ptr(plan.perm), ptr(plan.rank), ptr(plan.seg_start),
+                                             ptr(src), W, ptr(extra), group, ptr(out), ptr(out1), ptr(ws),
+                                             ws.numel(), plan.take_counter(), stream()))
+    return out, out1
+
+
+# --------------------------------------------------------------------------- DeepFM terms
+def lr_sum(ids, w, validate=False):
+    """out[b] = sum_f w[ids[b,f]]   (reference models.py:137-140, before the bias)."""
+    require_gpu(ids, w)
+    ids = ids.contiguous()
+    B, F = ids.shape
+    out = torch.empty(B, dtype=torch.float32, device=ids.device)
+    err = _err_flag(ids.device) if validate else None
+    check(lib.mapx_lr_sum_fwd(ptr(ids), B, F, ptr(w), w.numel(), ptr(out), ptr(err), stream()))
+    if validate and int(err):
+        raise IndexError("index out of range in self")
+    return out
+
+
+def fm_fwd(x3):
+    """x3 [B,F,E] -> (fm [B], s [B,E] = sum over fields, kept for backward)   (layers.py:123-131)."""
+    require_gpu(x3)
+    x3 = x3.contiguous()
+    B, F, E = x3.shape
+    out = torch.empty(B, dtype=torch.float32, device=x3.device)
+    s = torch.empty(B, E, dtype=torch.float32, device=x3.device)
+    check(lib.mapx_fm_fwd(ptr(x3), B, F, E, ptr(out), ptr(s), stream()))
+    return out, s
+
+
+def fm_bwd(g, s, x3):
+    B, F, E = x3.shape
+    dx = torch.empty_like(x3)
+    check(lib.mapx_fm_bwd(ptr(g.contiguous()), ptr(s), ptr(x3), B, F, E, ptr(dx), stream()))
+    return dx
+
+
 # --------------------------------------------------------------------------- NCE
 def alias_build(probs_cpu):
     """Host Walker table, bit-identical to the reference's (alias_multinomial.py:39-72)."""

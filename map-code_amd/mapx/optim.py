@@ -111,6 +111,7 @@ class MapxOptimizer:
         self.steps_done = 0
         table_ids = model.table_parameter_ids()
         named = [(n, p) for n, p in model.named_parameters() if id(p) not in table_ids and p.requires_grad]
+        self.dense_params = [p for _, p in named]
         self.groups = []
         for wd, members in ((self.wd, [(n, p) for n, p in named if decays(n)]),
                             (0.0, [(n, p) for n, p in named if not decays(n)])):
@@ -160,7 +161,16 @@ class MapxOptimizer:
                 if r1 is not None:
                     r1.mul_(coef)
 
+    def collect_torch_grads(self):
+        """Parameters that a model uses through plain torch ops (e.g. DeepFM's one-element LR bias)
+        get their gradient in `.grad`, not in the flat buffer the fused kernels write: move it."""
+        for p in self.dense_params:
+            if p.grad is not None:
+                p._mapx_grad.copy_(p.grad)
+                p.grad = None
+
     def step(self):
+        self.collect_torch_grads()
         ops.flush_deferred()            # split-K slabs / colsum partials of this backward pass
         if self.max_grad_norm > 0:
             self.clip_grad_norm_()

@@ -104,6 +104,7 @@ def sync_gradients(optimizer, merge_fn=hip_merge):
     if world() == 1:
         return
     from . import ops
+    optimizer.collect_torch_grads()
     ops.flush_deferred()                # dense gradients must be final before the all-reduce
     for g in optimizer.groups:
         allreduce_mean_(g["g"])

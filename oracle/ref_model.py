@@ -15,6 +15,7 @@ Reference sites restated (paths under /root/reference/code):
   cross            layers.py:197-201    Xi+1 = Xi + X0 * (W_i Xi + b_i)
   dnn              layers.py:173-188    [Linear, ReLU, Dropout(p=0)] x NL
   trunk            models.py:306-314    cat(cross, dnn)
+  DNN / DeepFM     models.py:164-233, 129-143 (LR), layers.py:123-131 (FM product_sum)
   mfp head         models.py:71-78, nce/nce_loss.py:79-144,158-173,201-230,
                    nce/index_linear.py:68-106
   rfd head         models.py:79-85,119-124
@@ -48,10 +49,10 @@ def cross(params, x0, num_cross):
     return xi
 
 
-def dnn(params, x, num_hidden):
+def dnn(params, x, num_hidden, tower="parallel_dnn"):
     for i in range(num_hidden):
-        w = params[f"parallel_dnn.dnn.{3 * i}.weight"]
-        b = params[f"parallel_dnn.dnn.{3 * i}.bias"]
+        w = params[f"{tower}.dnn.{3 * i}.weight"]
+        b = params[f"{tower}.dnn.{3 * i}.bias"]
         x = torch.relu(x @ w.t() + b)
     return x
 
@@ -62,6 +63,52 @@ def trunk(params, ids, num_cross, num_hidden):
     if num_hidden > 0:
         return torch.cat([c, dnn(params, x0, num_hidden)], dim=-1)
     return c
+
+
+# The other backbones of SURVEY §8(f4); their heads are the functions below, unchanged.
+def trunk_dnn(params, ids, num_hidden):
+    """DNN (models.py:164-193): the MLP over the flattened embeddings feeds the heads / fc_out."""
+    return dnn(params, embed(params, ids), num_hidden, tower="dnn")
+
+
+def lr_logit(params, ids):
+    """LR (models.py:129-143): sum over the fields of a scalar weight per feature id, + bias -> [B,1]."""
+    return params["lr_layer.embed_w.weight"][ids].sum(dim=1) + params["lr_layer.bias"]
+
+
+def fm_product_sum(x3):
+    """InnerProductLayer(output='product_sum') (layers.py:123-131) on [B,F,E] -> [B,1]."""
+    return (0.5 * (x3.sum(dim=1) ** 2 - (x3 ** 2).sum(dim=1))).sum(dim=-1, keepdim=True)
+
+
+def trunk_deepfm(params, ids, num_hidden):
+    """DeepFM (models.py:196-233) -> (dnn_vec [B,H], lr + fm [B,1]).  Pretraining feeds
+    cat([dnn_vec, lr_fm]) to the heads; CTR adds lr_fm to dnn_fc_out(dnn_vec)."""
+    x3 = params["embed.embedding.weight"][ids]
+    return dnn(params, x3.flatten(1), num_hidden, tower="dnn"), lr_logit(params, ids) + fm_product_sum(x3)
+
+
+def final_of(backbone, params, ids, num_cross, num_hidden):
+    """The vector the pretraining heads see, per backbone."""
+    if backbone == "DCNv2":
+        return trunk(params, ids, num_cross, num_hidden)
+    if backbone == "DNN":
+        return trunk_dnn(params, ids, num_hidden)
+    if backbone == "DeepFM":
+        return torch.cat(trunk_deepfm(params, ids, num_hidden), dim=1)
+    raise NotImplementedError(backbone)
+
+
+def ctr_logits_of(backbone, params, ids, num_cross, num_hidden):
+    """CTR logits [B,1] per backbone (models.py:189-190, 228-231, 319)."""
+    if backbone == "DCNv2":
+        return ctr_head(params, trunk(params, ids, num_cross, num_hidden))[0]
+    if backbone == "DNN":
+        return ctr_head(params, trunk_dnn(params, ids, num_hidden))[0]
+    if backbone == "DeepFM":
+        vec, lr_fm = trunk_deepfm(params, ids, num_hidden)
+        return vec @ params["dnn_fc_out.weight"].t() + params["dnn_fc_out.bias"] + lr_fm
+    raise NotImplementedError(backbone)
 
 
 # ----------------------------------------------------------------------------- heads

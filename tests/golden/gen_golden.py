@@ -39,9 +39,9 @@ def import_reference():
     return arguments, models
 
 
-def ref_config(arguments, cfg, mode, feat_count, data_dir):
+def ref_config(arguments, cfg, mode, feat_count, data_dir, backbone="DCNv2"):
     d = dict(
-        model_name="DCNv2", data_dir=data_dir, input_size=cfg["V"], num_fields=cfg["F"],
+        model_name=backbone, data_dir=data_dir, input_size=cfg["V"], num_fields=cfg["F"],
         embed_size=cfg["E"], embed_dropout_rate=0.0, embed_norm=False, layer_norm_eps=1e-12,
         hidden_size=cfg["H"], num_hidden_layers=cfg["NL"], hidden_act="relu",
         hidden_dropout_rate=0.0, num_cross_layers=cfg["NC"], pt_neg_num=cfg["K"],
@@ -56,13 +56,21 @@ def put(store, prefix, name, arr):
         store[f"{prefix}/{name}/{k}"] = v
 
 
-def run_case(arguments, models, case, cfg, mode, outdir):
+def trunk_of(model, backbone, emb3):
+    """The backbone's representation that feeds the heads, from the embedded input [B,F,E]."""
+    flat = emb3.flatten(1)
+    if backbone == "DCNv2":
+        return torch.cat([model.cross_net(flat), model.parallel_dnn(flat)], -1)
+    return model.dnn(flat)      # DNN; DeepFM's pretrain vector also appends lr + fm (not needed below)
+
+
+def run_case(arguments, models, case, cfg, mode, outdir, backbone="DCNv2"):
     torch.manual_seed(0)
     inp = pg.make_inputs(case, cfg)
-    params = pg.make_params(case, cfg, mode)
+    params = pg.make_params(case, cfg, mode, backbone)
     store = {}
     with tempfile.TemporaryDirectory() as tmp:      # alias_self_*.h5 cache goes here
-        config = ref_config(arguments, cfg, mode, inp["feat_count"], tmp)
+        config = ref_config(arguments, cfg, mode, inp["feat_count"], tmp, backbone)
         model = models.BaseModel.from_config(config)
     sd = model.state_dict()
     manifest = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()}
@@ -77,11 +85,12 @@ def run_case(arguments, models, case, cfg, mode, outdir):
         store["nce/emb_init_absmax"] = np.float64(crit.emb.weight.detach().abs().max())
     store["init/embed_std"] = np.float64(model.embed.embedding.weight.detach().std())
     # overwrite every parameter with the reproducible numpy ones
-    with torch.no_grad():
-        for k, p in model.named_parameters():
+    trainable = {k: p for k, p in model.named_parameters() if p.requires_grad}   # (DeepFM's ip_layer keeps
+    with torch.no_grad():                                                        # index tensors as frozen Parameters)
+        for k, p in trainable.items():
             assert tuple(p.shape) == params[k].shape, (k, p.shape, params[k].shape)
             p.copy_(torch.from_numpy(params[k]))
-    assert set(params) == {k for k, _ in model.named_parameters()}
+    assert set(params) == set(trainable)
     model.train()
     ids = torch.from_numpy(inp["input_ids"])
     mi = torch.from_numpy(inp["masked_index"])
@@ -118,10 +127,9 @@ def run_case(arguments, models, case, cfg, mode, outdir):
         store["out/count"] = np.int64(count)
         store["out/acc"] = acc.detach().numpy()
         store["out/pos_ratio"] = pos_ratio.detach().numpy()
-        with torch.no_grad():
-            emb = model.embed(ids_in).flatten(1)
-            fin = torch.cat([model.cross_net(emb), model.parallel_dnn(emb)], -1)
-            store["out/logits"] = model.pred_rfd(fin).numpy()
+        if backbone != "DeepFM":
+            with torch.no_grad():
+                store["out/logits"] = model.pred_rfd(trunk_of(model, backbone, model.embed(ids_in))).numpy()
     else:
         y = torch.from_numpy(inp["y"])
         loss, logits = model(input_ids=ids, labels=y)
@@ -129,13 +137,18 @@ def run_case(arguments, models, case, cfg, mode, outdir):
         with torch.no_grad():   # intermediate activations for per-kernel unit tests
             emb = model.embed(ids).flatten(1)
             store["mid/embed_flat"] = emb.numpy()
-            store["mid/cross_out"] = model.cross_net(emb).numpy()
-            store["mid/dnn_out"] = model.parallel_dnn(emb).numpy()
+            if backbone == "DCNv2":
+                store["mid/cross_out"] = model.cross_net(emb).numpy()
+                store["mid/dnn_out"] = model.parallel_dnn(emb).numpy()
+            if backbone == "DeepFM":
+                store["mid/lr"] = model.lr_layer(ids)[0].numpy()
+                store["mid/fm"] = model.ip_layer(model.embed(ids)).numpy()
     loss.backward()
     store["out/loss"] = loss.detach().numpy()
-    for k, p in model.named_parameters():
+    for k, p in trainable.items():
         put(store, "grad", k, p.grad.numpy())
-    np.savez_compressed(os.path.join(outdir, f"{case}_{mode}.npz"), **store)
+    suffix = "" if backbone == "DCNv2" else f"_{backbone}"
+    np.savez_compressed(os.path.join(outdir, f"{case}_{mode}{suffix}.npz"), **store)
     return manifest
 
 
@@ -167,6 +180,12 @@ def main():
         for mode in ("MFP", "RFD", "CTR"):
             manifests[f"{case}_{mode}"] = run_case(arguments, models, case, cfg, mode, HERE)
             print("wrote", case, mode)
+    case = "B_f25_b64"                       # the other backbones: one case each
+    for backbone in pg.BACKBONES[1:]:
+        for mode in ("MFP", "RFD", "CTR"):
+            manifests[f"{case}_{mode}_{backbone}"] = run_case(arguments, models, case, pg.CASES[case], mode, HERE,
+                                                              backbone)
+            print("wrote", case, mode, backbone)
     with open(os.path.join(HERE, "state_dict_manifest.json"), "w") as f:
         json.dump(manifests, f, indent=1, sort_keys=True)
     # flag surface (names + defaults) of the two argument dataclasses -> json

@@ -64,21 +64,37 @@ def make_param(case, name, shape, scale):
     return (_rng(case, "param", name).standard_normal(shape) * scale).astype(np.float32)
 
 
-def param_shapes(cfg, mode):
-    """state_dict key -> (shape, init scale) for DCNv2 in `mode` in {MFP, RFD, CTR}.
-    Key layout = SURVEY §8(b) checkpoint manifest."""
+BACKBONES = ("DCNv2", "DNN", "DeepFM")      # DNN / DeepFM: SURVEY §8(f4), fixtures for case B only
+
+
+def param_shapes(cfg, mode, backbone="DCNv2"):
+    """state_dict key of every TRAINABLE parameter -> (shape, init scale) for `backbone` in `mode`
+    in {MFP, RFD, CTR}.  Key layout = SURVEY §8(b) checkpoint manifest (DCNv2) and the reference
+    modules' attribute names (models.py:164-233) for DNN / DeepFM."""
     F, V, E, H, NL, NC, P = (cfg[k] for k in ("F", "V", "E", "H", "NL", "NC", "P"))
     D = F * E
     out = {"embed.embedding.weight": ((V, E), (2.0 / (F + E)) ** 0.5)}
-    for i in range(NC):
-        out[f"cross_net.cross_layers.{i}.weight"] = ((D, D), D ** -0.5)
-        out[f"cross_net.cross_layers.{i}.bias"] = ((D,), 0.1)
+    if backbone == "DCNv2":
+        for i in range(NC):
+            out[f"cross_net.cross_layers.{i}.weight"] = ((D, D), D ** -0.5)
+            out[f"cross_net.cross_layers.{i}.bias"] = ((D,), 0.1)
+    elif backbone == "DeepFM":
+        out["lr_layer.embed_w.weight"] = ((V, 1), 0.3)
+        out["lr_layer.bias"] = ((1,), 0.1)
+    elif backbone != "DNN":
+        raise ValueError(backbone)
+    tower = "parallel_dnn" if backbone == "DCNv2" else "dnn"
     d_in = D
     for i in range(NL):
-        out[f"parallel_dnn.dnn.{3 * i}.weight"] = ((H, d_in), d_in ** -0.5)
-        out[f"parallel_dnn.dnn.{3 * i}.bias"] = ((H,), 0.1)
+        out[f"{tower}.dnn.{3 * i}.weight"] = ((H, d_in), d_in ** -0.5)
+        out[f"{tower}.dnn.{3 * i}.bias"] = ((H,), 0.1)
         d_in = H
-    Dfin = D + (H if NL > 0 else 0)
+    Dfin = {"DCNv2": D + (H if NL > 0 else 0), "DNN": H, "DeepFM": H + 1}[backbone]
+    if mode == "CTR" and backbone != "DCNv2":
+        head = "fc_out" if backbone == "DNN" else "dnn_fc_out"       # models.py:180, 212: Linear(H, 1)
+        out[f"{head}.weight"] = ((1, H), H ** -0.5)
+        out[f"{head}.bias"] = ((1,), 0.1)
+        return out
     if mode == "MFP":
         out["feat_encoder.weight"] = ((F * P, Dfin), Dfin ** -0.5)
         out["feat_encoder.bias"] = ((F * P,), 0.1)
@@ -97,8 +113,8 @@ def param_shapes(cfg, mode):
     return out
 
 
-def make_params(case, cfg, mode):
-    return {k: make_param(case, k, shp, sc) for k, (shp, sc) in param_shapes(cfg, mode).items()}
+def make_params(case, cfg, mode, backbone="DCNv2"):
+    return {k: make_param(case, k, shp, sc) for k, (shp, sc) in param_shapes(cfg, mode, backbone).items()}
 
 
 def digest(name, g):

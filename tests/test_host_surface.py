@@ -57,14 +57,15 @@ def test_config_json_round_trip(tmp_path):
 
 
 @pytest.mark.parametrize("mode", ["MFP", "RFD", "CTR"])
-@pytest.mark.parametrize("case", list(pg.CASES))
-def test_state_dict_layout_matches_reference(case, mode):
+@pytest.mark.parametrize("case,backbone", [(c, "DCNv2") for c in pg.CASES] + [("B_f25_b64", b) for b in pg.BACKBONES[1:]])
+def test_state_dict_layout_matches_reference(case, backbone, mode):
     from mapx.models import BaseModel
     cfg = pg.CASES[case]
     inp = pg.make_inputs(case, cfg)
-    model = BaseModel.from_config(make_config(cfg, mode, inp["feat_count"]))
+    model = BaseModel.from_config(make_config(cfg, mode, inp["feat_count"], backbone=backbone))
     got = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in model.state_dict().items()}
-    gold = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))[f"{case}_{mode}"]
+    key = f"{case}_{mode}" if backbone == "DCNv2" else f"{case}_{mode}_{backbone}"
+    gold = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))[key]
     assert got == gold
 
 

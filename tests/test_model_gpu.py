@@ -12,6 +12,7 @@ from util import assert_digest, build_model, load_case, t
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 CASES = list(pg.CASES)
+OTHER = [("B_f25_b64", b) for b in pg.BACKBONES[1:]]      # DNN, DeepFM
 
 
 def _dense_named_grads(model):
@@ -187,7 +188,7 @@ def test_unknown_backbones_raise_like_the_reference():
     from mapx.models import BaseModel
     from util import make_config
     cfg = pg.CASES["A_f23_b7"]
-    for name in ("deepfm", "nonsense"):
+    for name in ("xdeepfm", "nonsense"):
         c = make_config(cfg, "CTR")
         c.model_name = name
         with pytest.raises(NotImplementedError):
@@ -223,3 +224,40 @@ def test_cross_tower_depths_vs_oracle(E, NC):
         else:
             got = p.grad.cpu()
         np.testing.assert_allclose(got.numpy(), params[name].grad.numpy(), rtol=2e-5, atol=2e-6, err_msg=name)
+
+
+# ----------------------------------------------------------------------------- other backbones (§8 f4)
+@pytest.mark.parametrize("case,backbone", OTHER)
+@pytest.mark.parametrize("mode", ["MFP", "RFD", "CTR"])
+def test_other_backbones_golden(case, backbone, mode):
+    """DNN / DeepFM through the same C-ABI kernels, heads and row tables vs golden vectors of the
+    reference's own classes (models.py:164-233): loss, outputs and every gradient (for DeepFM
+    including the LR weight rows, reduced together with the embedding rows)."""
+    from mapx import ops
+    cfg, z, inp, params = load_case(case, mode, backbone)
+    model = build_model(cfg, mode, params, inp["feat_count"] if mode == "MFP" else None, backbone=backbone)
+    ids, mi = t(inp["input_ids"], DEV), t(inp["masked_index"], DEV)
+    model.train()
+    if mode == "MFP":
+        masked, labels, _ = ops.dynamic_mask_mfp(ids, mi.shape[1], masked_index=mi)
+        loss, count, acc = model(input_ids=masked, labels=labels, masked_index=mi, noise_samples=t(inp["noise"], DEV))
+        assert count == int(z["out/count"]) and int(acc) == int(z["out/total_acc"])
+    elif mode == "RFD":
+        replaced, labels, _ = ops.dynamic_mask_rfd(ids, mi.shape[1], masked_index=mi,
+                                                   replace_feat=t(inp["replace_feat"], DEV))
+        loss, count, acc, pos = model(input_ids=replaced, labels=labels)
+        np.testing.assert_allclose(float(acc), float(z["out/acc"]), rtol=1e-6)
+        np.testing.assert_allclose(float(pos), float(z["out/pos_ratio"]), rtol=1e-6)
+    else:
+        loss, logits = model(input_ids=ids, labels=t(inp["y"], DEV))
+        np.testing.assert_allclose(logits.detach().cpu().numpy(), z["out/logits"], rtol=1e-5, atol=1e-5)
+        if backbone == "DeepFM":
+            x3, lr = model.embed.forward_with_linear(ids, model.lr_layer.embed_w.weight)
+            np.testing.assert_allclose((lr.view(-1, 1) + model.lr_layer.bias).detach().cpu().numpy(), z["mid/lr"],
+                                       rtol=1e-5, atol=1e-6)
+            from mapx.layers import fm_product_sum
+            # 0.5 * sum_e((sum_f x)^2 - sum_f x^2) cancels: absolute tolerance at the scale of its two terms
+            np.testing.assert_allclose(fm_product_sum(x3).detach().cpu().numpy(), z["mid/fm"], rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(float(loss.detach()), float(z["out/loss"]), rtol=1e-5)
+    loss.backward()
+    _check_grads(z, model)

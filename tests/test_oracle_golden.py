@@ -10,16 +10,16 @@ import paramgen as pg
 from oracle import ref_model as R
 from util import assert_digest, load_case, t
 
-CASES = list(pg.CASES)
+CASES = [(c, "DCNv2") for c in pg.CASES] + [("B_f25_b64", b) for b in pg.BACKBONES[1:]]   # (case, backbone)
 
 
 def _params(params, requires_grad=True):
     return {k: t(v).requires_grad_(requires_grad) for k, v in params.items()}
 
 
-@pytest.mark.parametrize("case", CASES)
-def test_mfp_matches_reference(case):
-    cfg, z, inp, params = load_case(case, "MFP")
+@pytest.mark.parametrize("case,backbone", CASES)
+def test_mfp_matches_reference(case, backbone):
+    cfg, z, inp, params = load_case(case, "MFP", backbone)
     P = _params(params)
     ids, mi = t(inp["input_ids"]), t(inp["masked_index"])
     masked, labels = R.dynamic_mask_mfp(ids, mi)
@@ -28,7 +28,7 @@ def test_mfp_matches_reference(case):
     logq, lnV, _ = R.nce_buffers(inp["feat_count"])
     np.testing.assert_allclose(logq.numpy(), z["nce/logprob_noise"], rtol=1e-6, atol=1e-6)
     assert lnV == pytest.approx(float(z["nce/norm_term"]))
-    final = R.trunk(P, masked, cfg["NC"], cfg["NL"])
+    final = R.final_of(backbone, P, masked, cfg["NC"], cfg["NL"])
     loss, logits, acc = R.mfp_head(P, final, labels, mi, t(inp["noise"]), logq,
                                    cfg["F"], cfg["P"], cfg["K"])
     np.testing.assert_allclose(loss.item(), float(z["out/loss"]), rtol=2e-6)
@@ -40,18 +40,19 @@ def test_mfp_matches_reference(case):
         assert_digest(z, "grad", k, p.grad.numpy())
 
 
-@pytest.mark.parametrize("case", CASES)
-def test_rfd_matches_reference(case):
-    cfg, z, inp, params = load_case(case, "RFD")
+@pytest.mark.parametrize("case,backbone", CASES)
+def test_rfd_matches_reference(case, backbone):
+    cfg, z, inp, params = load_case(case, "RFD", backbone)
     P = _params(params)
     ids, mi = t(inp["input_ids"]), t(inp["masked_index"])
     replaced, labels = R.dynamic_mask_rfd(ids, mi, t(inp["replace_feat"]))
     assert torch.equal(replaced, t(z["in/input_ids_replaced"]))
     assert torch.equal(labels, t(z["in/labels"]))
-    final = R.trunk(P, replaced, cfg["NC"], cfg["NL"])
+    final = R.final_of(backbone, P, replaced, cfg["NC"], cfg["NL"])
     loss, count, acc, pos, logits = R.rfd_head(P, final, labels)
     np.testing.assert_allclose(loss.item(), float(z["out/loss"]), rtol=2e-6)
-    np.testing.assert_allclose(logits.detach().numpy(), z["out/logits"], rtol=1e-5, atol=2e-6)
+    if "out/logits" in z.files:
+        np.testing.assert_allclose(logits.detach().numpy(), z["out/logits"], rtol=1e-5, atol=2e-6)
     assert count == int(z["out/count"])
     np.testing.assert_allclose(acc.item(), float(z["out/acc"]), rtol=1e-6)
     np.testing.assert_allclose(pos.item(), float(z["out/pos_ratio"]), rtol=1e-6)
@@ -60,19 +61,24 @@ def test_rfd_matches_reference(case):
         assert_digest(z, "grad", k, p.grad.numpy())
 
 
-@pytest.mark.parametrize("case", CASES)
-def test_ctr_matches_reference(case):
-    cfg, z, inp, params = load_case(case, "CTR")
+@pytest.mark.parametrize("case,backbone", CASES)
+def test_ctr_matches_reference(case, backbone):
+    cfg, z, inp, params = load_case(case, "CTR", backbone)
     P = _params(params)
     ids = t(inp["input_ids"])
     x0 = R.embed(P, ids)
     np.testing.assert_array_equal(x0.detach().numpy(), z["mid/embed_flat"])
-    np.testing.assert_allclose(R.cross(P, x0, cfg["NC"]).detach().numpy(), z["mid/cross_out"],
-                               rtol=1e-5, atol=2e-6)
-    np.testing.assert_allclose(R.dnn(P, x0, cfg["NL"]).detach().numpy(), z["mid/dnn_out"],
-                               rtol=1e-5, atol=2e-6)
-    final = R.trunk(P, ids, cfg["NC"], cfg["NL"])
-    loss, logits = R.ctr_head(P, final, t(inp["y"]))
+    if backbone == "DCNv2":
+        np.testing.assert_allclose(R.cross(P, x0, cfg["NC"]).detach().numpy(), z["mid/cross_out"],
+                                   rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(R.dnn(P, x0, cfg["NL"]).detach().numpy(), z["mid/dnn_out"],
+                                   rtol=1e-5, atol=2e-6)
+    if backbone == "DeepFM":
+        np.testing.assert_allclose(R.lr_logit(P, ids).detach().numpy(), z["mid/lr"], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(R.fm_product_sum(P["embed.embedding.weight"][ids]).detach().numpy(),
+                                   z["mid/fm"], rtol=1e-5, atol=2e-6)
+    logits = R.ctr_logits_of(backbone, P, ids, cfg["NC"], cfg["NL"])
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits.view(-1), t(inp["y"]).float())
     np.testing.assert_allclose(loss.item(), float(z["out/loss"]), rtol=2e-6)
     np.testing.assert_allclose(logits.detach().numpy(), z["out/logits"], rtol=1e-5, atol=2e-6)
     loss.backward()
@@ -80,7 +86,7 @@ def test_ctr_matches_reference(case):
         assert_digest(z, "grad", k, p.grad.numpy())
 
 
-@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("case", list(pg.CASES))
 def test_alias_table_and_bias_init(case):
     cfg, z, inp, _ = load_case(case, "MFP")
     logq, lnV, q = R.nce_buffers(inp["feat_count"])

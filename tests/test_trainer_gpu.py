@@ -42,7 +42,7 @@ def _step_inputs(case, cfg, step):
                 y=(r.random(B) < 0.3).astype(np.int64), feat_count=inp["feat_count"])
 
 
-def _oracle_loop(mode, cfg, params, steps, case, total, warmup, kind, lr0, wd):
+def _oracle_loop(mode, cfg, params, steps, case, total, warmup, kind, lr0, wd, backbone="DCNv2"):
     from oracle import ref_model as R
     P = {k: t(v).clone().requires_grad_(True) for k, v in params.items()}
     m = {k: torch.zeros_like(p) for k, p in P.items()}
@@ -54,13 +54,14 @@ def _oracle_loop(mode, cfg, params, steps, case, total, warmup, kind, lr0, wd):
         if mode == "MFP":
             logq, _, _ = R.nce_buffers(si["feat_count"])
             masked, labels = R.dynamic_mask_mfp(ids, t(si["mi"]))
-            fin = R.trunk(P, masked, cfg["NC"], cfg["NL"])
+            fin = R.final_of(backbone, P, masked, cfg["NC"], cfg["NL"])
             loss, _, _ = R.mfp_head(P, fin, labels, t(si["mi"]), t(si["noise"]), logq, cfg["F"], cfg["P"], cfg["K"])
         elif mode == "RFD":
             rep, labels = R.dynamic_mask_rfd(ids, t(si["mi"]), t(si["repl"]))
-            loss = R.rfd_head(P, R.trunk(P, rep, cfg["NC"], cfg["NL"]), labels)[0]
+            loss = R.rfd_head(P, R.final_of(backbone, P, rep, cfg["NC"], cfg["NL"]), labels)[0]
         else:
-            loss = R.ctr_head(P, R.trunk(P, ids, cfg["NC"], cfg["NL"]), t(si["y"]))[0]
+            logits = R.ctr_logits_of(backbone, P, ids, cfg["NC"], cfg["NL"])
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(logits.view(-1), t(si["y"]).float())
         loss.backward()
         losses.append(float(loss.detach()))
         lr = lr0 * R.lr_lambda(kind, s, total, warmup)
@@ -71,19 +72,23 @@ def _oracle_loop(mode, cfg, params, steps, case, total, warmup, kind, lr0, wd):
     return losses, {k: p.detach() for k, p in P.items()}
 
 
-@pytest.mark.parametrize("mode,kind,warm", [("MFP", "cosine", 0.2), ("RFD", "cosine", 0.0), ("CTR", "const", 0.0)])
-def test_training_trajectory_matches_reference_semantics(mode, kind, warm):
+@pytest.mark.parametrize("mode,kind,warm,backbone",
+                         [("MFP", "cosine", 0.2, "DCNv2"), ("RFD", "cosine", 0.0, "DCNv2"), ("CTR", "const", 0.0, "DCNv2"),
+                          ("MFP", "cosine", 0.0, "DNN"), ("CTR", "const", 0.0, "DNN"),
+                          ("MFP", "cosine", 0.2, "DeepFM"), ("RFD", "cosine", 0.0, "DeepFM"),
+                          ("CTR", "const", 0.0, "DeepFM")])
+def test_training_trajectory_matches_reference_semantics(mode, kind, warm, backbone):
     from mapx import ops
     from mapx.optim import MapxOptimizer
     case = "B_f25_b64"
     cfg = pg.CASES[case]
-    _, _, inp, params = load_case(case, mode)
+    _, _, inp, params = load_case(case, mode, backbone)
     steps, total = 8, 10
     warmup = int(total * warm)
     lr0, wd = 1e-3, 5e-2
-    ref_losses, ref_params = _oracle_loop(mode, cfg, params, steps, case, total, warmup, kind, lr0, wd)
+    ref_losses, ref_params = _oracle_loop(mode, cfg, params, steps, case, total, warmup, kind, lr0, wd, backbone)
 
-    model = build_model(cfg, mode, params, inp["feat_count"] if mode == "MFP" else None)
+    model = build_model(cfg, mode, params, inp["feat_count"] if mode == "MFP" else None, backbone=backbone)
     targs = _targs(lr_sched=kind, learning_rate=lr0, weight_decay=wd)
     opt = MapxOptimizer(model, targs, num_training_steps=total, num_warmup_steps=warmup, max_gap=3)
     model.train()
@@ -115,7 +120,7 @@ def test_training_trajectory_matches_reference_semantics(mode, kind, warm):
         model.eval()
         with torch.no_grad():
             (logits,) = model(input_ids=t(held["ids"], DEV))
-            ref_logits = R.ctr_head(ref_params, R.trunk(ref_params, t(held["ids"]), cfg["NC"], cfg["NL"]))[0]
+            ref_logits = R.ctr_logits_of(backbone, ref_params, t(held["ids"]), cfg["NC"], cfg["NL"])
         y = held["y"]
         auc = roc_auc_score(y, torch.sigmoid(logits.view(-1)).cpu().numpy())
         auc_ref = roc_auc_score(y, torch.sigmoid(ref_logits.view(-1)).numpy())
@@ -229,8 +234,8 @@ def test_data_parallel_two_ranks_equal_single_process(tmp_path):
         np.testing.assert_allclose(b0[k].numpy(), a[k].numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
 
 
-@pytest.mark.parametrize("max_grad_norm", [0.0, 0.5])
-def test_graph_replay_equals_eager_bitwise(max_grad_norm):
+@pytest.mark.parametrize("max_grad_norm,backbone", [(0.0, "DCNv2"), (0.5, "DCNv2"), (0.0, "DeepFM")])
+def test_graph_replay_equals_eager_bitwise(max_grad_norm, backbone):
     """The captured-hipGraph step and the eager step draw the same Philox streams (device-side
     counter) and run the same kernels: identical parameters after two epochs, bit for bit.
     With gradient clipping (as with N > 1) only mask + forward + backward are captured and the
@@ -246,7 +251,7 @@ def test_graph_replay_equals_eager_bitwise(max_grad_norm):
     out = []
     for use_graph in (True, False):
         torch.manual_seed(5)
-        config = make_config(cfg, "MFP", cnt)
+        config = make_config(cfg, "MFP", cnt, backbone=backbone)
         model = BaseModel.from_config(config)
         targs = TrainingArguments(output_dir="/tmp/mapx_graph_test", per_gpu_train_batch_size=512,
                                   per_gpu_eval_batch_size=512, learning_rate=1e-3, lr_sched="cosine",

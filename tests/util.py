@@ -10,11 +10,12 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 MODES = ("MFP", "RFD", "CTR")
 
 
-def load_case(case, mode):
+def load_case(case, mode, backbone="DCNv2"):
     cfg = pg.CASES[case]
-    z = np.load(os.path.join(GOLD, f"{case}_{mode}.npz"))
+    suffix = "" if backbone == "DCNv2" else f"_{backbone}"
+    z = np.load(os.path.join(GOLD, f"{case}_{mode}{suffix}.npz"))
     inp = pg.make_inputs(case, cfg)
-    params = pg.make_params(case, cfg, mode)
+    params = pg.make_params(case, cfg, mode, backbone)
     return cfg, z, inp, params
 
 
@@ -40,10 +41,10 @@ def assert_digest(z, prefix, name, got, rtol=2e-5, atol=1e-6):
                                    err_msg=f"{prefix}/{name}/{k}")
 
 
-def make_config(cfg, mode, feat_count=None, data_dir=None, seed=42):
+def make_config(cfg, mode, feat_count=None, data_dir=None, seed=42, backbone="DCNv2"):
     """mapx Config for a fixture case (the 11 runtime keys of reference run.py:50-61 + flags)."""
     from mapx.arguments import Config
-    return Config(model_name="DCNv2", data_dir=data_dir, input_size=cfg["V"], num_fields=cfg["F"],
+    return Config(model_name=backbone, data_dir=data_dir, input_size=cfg["V"], num_fields=cfg["F"],
                   embed_size=cfg["E"], embed_dropout_rate=0.0, embed_norm=False, layer_norm_eps=1e-12,
                   hidden_size=cfg["H"], num_hidden_layers=cfg["NL"], hidden_act="relu",
                   hidden_dropout_rate=0.0, num_cross_layers=cfg["NC"], pt_neg_num=cfg["K"],
@@ -53,10 +54,10 @@ def make_config(cfg, mode, feat_count=None, data_dir=None, seed=42):
                   device=None, n_gpu=1, idx_low=None, idx_high=None, feat_num_per_field=None, seed=seed)
 
 
-def build_model(cfg, mode, params, feat_count, device="cuda"):
-    """DCNV2 with the fixture's reproducible parameters loaded."""
+def build_model(cfg, mode, params, feat_count, device="cuda", backbone="DCNv2"):
+    """The backbone with the fixture's reproducible parameters loaded."""
     from mapx.models import BaseModel
-    model = BaseModel.from_config(make_config(cfg, mode, feat_count))
+    model = BaseModel.from_config(make_config(cfg, mode, feat_count, backbone=backbone))
     with torch.no_grad():
         sd = model.state_dict()
         for k, v in params.items():
