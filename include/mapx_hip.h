@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 16
+#define MAPX_ABI_VERSION 17
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -262,15 +262,19 @@ int mapx_step_advance(int32_t* done, hipStream_t stream);
  * last[V].  rows NULL: rows row_begin..row_begin+n_rows-1 (flush / sweep); else rows[i],
  * i < *n_rows_dev (or n_rows if NULL).  grad0 NULL: catch-up to *done only; else catch-up
  * then update *done+1 with grad0 [*, W0] (grad1 [*]) and last = *done+1.
- * aux [3][aux_len] f64 (device): prefix products prod_{i<s}(1 - lr_i*wd), beta1^n, beta2^n —
- * the closed-form tail of a replay once the Adam term can no longer move p (csrc/optim.hip).
+ * aux [aux_rows][aux_len] f64 (device), the host tables of the CLOSED-FORM replay of zero-gradient
+ * steps (csrc/optim.hip: replay_coef): row 0 prefix products P[s] = prod_{i<s}(1 - lr_i*wd), row 1
+ * beta1^n, row 2 beta2^n, rows 3..9 R_i[s] = a_s + q_i/(1 - lr_s*wd) R_i[s+1] (a_s = step size of
+ * update s+1, q_i = beta1 * beta2^(-(i+1)/2), i = 0..6), rows 10..16 the same with wd = 0.
+ * aux_rows = 17: a replay of any length is O(1) per element; aux_rows = 3: steps are replayed one
+ * by one while the Adam term can still move p, the rest from rows 0-2.
  * rows_may_repeat (catch-up only): rows[] is the raw id list of the batch; one lane group per
  * stale row wins an atomicCAS on last[row], so no sort is needed before the forward pass. */
 int mapx_table_adam(float* p0, float* m0, float* v0, int W0, float wd0, float* p1, float* m1,
                     float* v1, float wd1, int32_t* last, const int32_t* rows, int64_t row_begin,
                     int64_t n_rows, const int32_t* n_rows_dev, const float* grad0,
                     const float* grad1, const float* sched, int sched_len, const int32_t* done,
-                    const double* aux, int aux_len, double beta1, double beta2, double eps,
+                    const double* aux, int aux_len, int aux_rows, double beta1, double beta2, double eps,
                     int rows_may_repeat, hipStream_t stream);
 
 #ifdef __cplusplus

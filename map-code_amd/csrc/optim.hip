@@ -18,11 +18,12 @@
 // zero-gradient updates IN REGISTERS, with the same fp32 operations in the same order,
 // when the row is next needed (catch-up before the forward gather; again, as a no-op,
 // inside the gradient update) or when the table is flushed (checkpoint / eval).
-// A replay runs step by step only while the Adam term can still move p (|term| >= 2^-26 |p|,
-// about 150 steps after the row's last gradient); the remaining steps are pure geometric
-// decay (m *= b1, v *= b2, p *= 1 - lr_s*wd) and are applied in closed form from prefix
-// tables accumulated in fp64 (`aux`): p * prod(1 - lr_s*wd), m * b1^n, v * b2^n.  That last
-// part differs from the reference's n successive fp32 roundings by <= n * 2^-24 relative.
+// A replay of n zero-gradient steps is applied in CLOSED FORM, O(1) per element for any n (see
+// replay_coef below): host fp64 tables over the schedule give the decay product, b1^n, b2^n and
+// seven per-row coefficients of the accumulated Adam displacement.  It differs from the
+// reference's n successive fp32 roundings by <= n * 2^-24 relative (and from the same steps done
+// in fp64 by 2e-14).  Only gaps that run past the end of the tables (steps beyond the schedule)
+// are replayed step by step, with a closed-form tail once the Adam term can no longer move p.
 #include "../../include/mapx_hip.h"
 #include "common.h"
 
@@ -64,10 +65,75 @@ __device__ inline bool adam_elem_zero_grad(float& p, float& m, float& v, float s
 // Prefix tables for the closed-form tail of a replay (host fp64):
 //   aux[0*len + s] = prod_{i<s} (1 - lr_i * wd)   (wd = the optimizer's weight decay)
 //   aux[1*len + n] = beta1^n,  aux[2*len + n] = beta2^n
+//   aux[(3 + i) * len + s]          = R_i[s] with the optimizer's weight decay, i = 0..kJ
+//   aux[(3 + kJ + 1 + i) * len + s] = R_i[s] without decay                      (see replay_coef)
 struct ReplayAux {
   const double* t;
   int len;
+  int rows;          // 3: prefix tables only (iterative replay + closed-form tail); 3 + 2(kJ+1): full closed form
+  double rho;        // beta1 / sqrt(beta2)
+  double inv_beta;   // 1 / sqrt(beta2)
 };
+
+// ---------------------------------------------------------------------------------------------
+// Closed form of n zero-gradient AdamW steps (updates s+1 .. e, n = e - s) on one element:
+//     m_k = b1^k m,  v_k = b2^k v,   p_k = (p_{k-1} - a_u m_k / (sqrt(v_k) + eps)) (1 - d_u),  u = s+k-1
+// with a_u the step size and d_u = lr_u * wd of update u+1.  With r = sqrt(v), beta = sqrt(b2),
+// y = eps / (r + eps) and delta_k = beta^-k - 1 (<= 0.07 while rho^k matters):
+//     1 / (r beta^k + eps) = beta^-k / ((r + eps) (1 + y delta_k)) = beta^-k/(r+eps) * sum_j (-y delta_k)^j
+// so the total Adam displacement is   m / (r + eps) * sum_j (-y)^j T_j,   with per-ROW coefficients
+//     T_j = sum_k a_u rho^k delta_k^j D_k = sum_i C(j,i) (-1)^(j-i) Q_i,      rho = b1 / beta,
+//     Q_i = sum_k a_u (rho beta^-i)^k D_k = q_i [ (P_e / P_s) R_i[s] - q_i^n R_i[e] ],   q_i = rho beta^-i,
+// D_k = prod_{j >= u}^{e-1} (1 - d_j), P = prefix product of (1 - d), and the host fp64 table
+//     R_i[s] = a_s + q_i / (1 - d_s) * R_i[s+1]        (backward recurrence: every quantity is O(a), no
+// underflow and no cancellation however long the gap or the schedule).  kJ + 1 = 7 terms leave a
+// relative error < 0.07^7 = 8e-9 of the displacement for ANY eps/r; against step-by-step replay
+// in fp64 the closed form agrees to 2e-14 (tests: lazy == dense reference AdamW), which is 8
+// orders closer than the reference's own fp32 stepwise rounding.  Cost: O(1) per element instead
+// of up to ~150 replayed steps — the catch-up kernels become HBM-bound.
+constexpr int kJ = 6;
+struct ReplayCoef {
+  float fp, fm, fv;
+  float T[kJ + 1];
+};
+
+__device__ inline void replay_coef(int s, int e, const ReplayAux& ax, bool decayed, ReplayCoef& c) {
+  const int n = e - s;
+  const double* __restrict__ P = ax.t;
+  const double* __restrict__ R = ax.t + (size_t)(3 + (decayed ? 0 : kJ + 1)) * ax.len;
+  const double pr = decayed ? P[e] / P[s] : 1.0;
+  const double b1n = ax.t[ax.len + n], b2n = ax.t[2 * ax.len + n];
+  const double binv_n = 1.0 / sqrt(b2n);                 // beta^-n
+  double Q[kJ + 1];
+  double qi = ax.rho, qn = b1n * binv_n;                 // q_i, q_i^n
+#pragma unroll
+  for (int i = 0; i <= kJ; ++i) {
+    Q[i] = qi * (pr * R[(size_t)i * ax.len + s] - qn * R[(size_t)i * ax.len + e]);
+    qi *= ax.inv_beta;
+    qn *= binv_n;
+  }
+  // T_j = j-th forward difference of Q at 0 (in place)
+#pragma unroll
+  for (int j = 1; j <= kJ; ++j)
+#pragma unroll
+    for (int i = kJ; i >= j; --i) Q[i] -= Q[i - 1];
+#pragma unroll
+  for (int j = 0; j <= kJ; ++j) c.T[j] = (float)Q[j];
+  c.fp = (float)pr;
+  c.fm = (float)b1n;
+  c.fv = (float)b2n;
+}
+
+__device__ inline void replay_elem_closed(float& p, float& m, float& v, const ReplayCoef& c, float eps) {
+  const float den = sqrtf(v) + eps;
+  const float y = eps / den;
+  float poly = c.T[kJ];
+#pragma unroll
+  for (int j = kJ - 1; j >= 0; --j) poly = c.T[j] - y * poly;
+  p = p * c.fp - (m / den) * poly;
+  m *= c.fm;
+  v *= c.fv;
+}
 
 __device__ inline void closed_form_tail(int s, int to, const ReplayAux& ax, bool decayed,
                                         float& fp, float& fm, float& fv) {
@@ -123,6 +189,16 @@ struct TableGroup {
 __device__ inline void replay4(float4& p, float4& m, float4& v, int from, int to,
                                const float2* __restrict__ sched, int sched_len, float wd,
                                const AdamHyper& h, const ReplayAux& ax) {
+  if (ax.rows > 3 && to < ax.len) {       // O(1): the whole gap in closed form
+    if (to <= from) return;
+    ReplayCoef c;
+    replay_coef(from, to, ax, wd != 0.f, c);
+    replay_elem_closed(p.x, m.x, v.x, c, h.eps);
+    replay_elem_closed(p.y, m.y, v.y, c, h.eps);
+    replay_elem_closed(p.z, m.z, v.z, c, h.eps);
+    replay_elem_closed(p.w, m.w, v.w, c, h.eps);
+    return;
+  }
   int s = from;
   for (; s < to; ++s) {  // update s+1 uses sched[s]
     const float2 sc = sched[s < sched_len ? s : sched_len - 1];
@@ -176,6 +252,14 @@ __device__ inline void table_adam_row(const TableGroup& tg, int64_t r, int from,
   if (tg.p1 && lig == 0) {
     float p = tg.p1[r], m = tg.m1[r], v = tg.v1[r];
     int s = from;
+    if (ax.rows > 3 && target < ax.len) {
+      if (target > from) {
+        ReplayCoef c;
+        replay_coef(from, target, ax, tg.wd1 != 0.f, c);
+        replay_elem_closed(p, m, v, c, h.eps);
+      }
+      s = target;
+    }
     for (; s < target; ++s) {
       const float2 sc = sched[s < sched_len ? s : sched_len - 1];
       if (adam_elem_zero_grad(p, m, v, sc.x, sc.y * tg.wd1, h)) { ++s; break; }
@@ -298,7 +382,7 @@ extern "C" int mapx_table_adam(float* p0, float* m0, float* v0, int W0, float wd
                                const int32_t* rows, int64_t row_begin, int64_t n_rows,
                                const int32_t* n_rows_dev, const float* grad0, const float* grad1,
                                const float* sched, int sched_len, const int32_t* done,
-                               const double* aux, int aux_len, double beta1, double beta2,
+                               const double* aux, int aux_len, int aux_rows, double beta1, double beta2,
                                double eps, int rows_may_repeat, hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(p0 && m0 && v0 && last && sched && done && aux && aux_len > 1,
@@ -313,7 +397,10 @@ extern "C" int mapx_table_adam(float* p0, float* m0, float* v0, int W0, float wd
   const int grid = grid_for(n_rows * lg, 256, 4096);
   const AdamHyper h = make_hyper(beta1, beta2, eps);
   const float2* sc = reinterpret_cast<const float2*>(sched);
-  const ReplayAux ax{aux, aux_len};
+  MAPX_REQUIRE(aux_rows == 3 || aux_rows == 3 + 2 * (kJ + 1), "table_adam: aux must have 3 or %d rows",
+               3 + 2 * (kJ + 1));
+  const double beta = sqrt(beta2);
+  const ReplayAux ax{aux, aux_len, aux_rows, beta1 / beta, 1.0 / beta};
 #define MAPX_TA(LG_)                                                                              \
   do {                                                                                            \
     if (rows_may_repeat)                                                                          \

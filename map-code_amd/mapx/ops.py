@@ -699,16 +699,37 @@ def make_sched(lr0, lambdas, beta1, beta2):
     return torch.tensor(rows, dtype=torch.float64).to(torch.float32)
 
 
+REPLAY_TERMS = 7          # kJ + 1 in csrc/optim.hip
+CLOSED_REPLAY = os.environ.get("MAPX_CLOSED_REPLAY", "1") == "1"     # 0: step-by-step replay + closed-form tail
+
+
 def make_replay_aux(lr0, lambdas, beta1, beta2, wd):
-    """Host fp64 prefix tables [3, T+1] for the closed-form tail of lazy replays:
-    prod_{i<s}(1 - lr_i*wd), beta1^n, beta2^n (see csrc/optim.hip)."""
+    """Host fp64 tables [17, T+1] of the closed-form replay of zero-gradient AdamW steps
+    (csrc/optim.hip: replay_coef): prefix products prod_{i<s}(1 - lr_i*wd), beta1^n, beta2^n, and
+    R_i[s] = a_s + q_i / (1 - d_s) * R_i[s+1] for q_i = beta1 * beta2^(-(i+1)/2), i = 0..6, once with
+    d_s = lr_s*wd and once with d_s = 0.  a_s and lr_s are the fp32-rounded values the kernels read
+    from the schedule table.  MAPX_CLOSED_REPLAY=0: the first three rows only."""
     T = len(lambdas)
-    lr = torch.tensor([lr0 * l for l in lambdas], dtype=torch.float64)
+    sched = make_sched(lr0, lambdas, beta1, beta2).to(torch.float64)        # fp32 values, as doubles
+    a, lr = sched[:, 0].tolist(), sched[:, 1].tolist()
+    lr_exact = torch.tensor([lr0 * l for l in lambdas], dtype=torch.float64)
     cum = torch.ones(T + 1, dtype=torch.float64)
-    cum[1:] = torch.cumprod(1.0 - lr * wd, 0)
+    cum[1:] = torch.cumprod(1.0 - lr_exact * wd, 0)
     n = torch.arange(T + 1, dtype=torch.float64)
-    return torch.stack([cum, torch.pow(torch.tensor(beta1, dtype=torch.float64), n),
-                        torch.pow(torch.tensor(beta2, dtype=torch.float64), n)]).contiguous()
+    rows = [cum, torch.pow(torch.tensor(beta1, dtype=torch.float64), n),
+            torch.pow(torch.tensor(beta2, dtype=torch.float64), n)]
+    if CLOSED_REPLAY:
+        beta = math.sqrt(beta2)
+        cum_l = cum.tolist()
+        for decay in (True, False):
+            for i in range(REPLAY_TERMS):
+                q = (beta1 / beta) * beta ** (-i)
+                R = [0.0] * (T + 1)
+                for s in range(T - 1, -1, -1):
+                    keep = (cum_l[s + 1] / cum_l[s]) if decay else 1.0     # 1 - d_s, consistent with row 0
+                    R[s] = a[s] + q / keep * R[s + 1]
+                rows.append(torch.tensor(R, dtype=torch.float64))
+    return torch.stack(rows).contiguous()
 
 
 def adamw_dense(p, g, m, v, sched, done, beta1, beta2, eps, wd):
@@ -735,4 +756,4 @@ def table_adam(p0, m0, v0, wd0, last, sched, done, aux, beta1, beta2, eps, p1=No
         check(lib.mapx_table_adam(ptr(p0), ptr(m0), ptr(v0), W0, wd0, ptr(p1), ptr(m1), ptr(v1), wd1,
                                   ptr(last), ptr(rows), row_begin, n_rows, ptr(n_rows_dev), ptr(grad0),
                                   ptr(grad1), ptr(sched), sched.shape[0], ptr(done), ptr(aux),
-                                  aux.shape[1], beta1, beta2, eps, int(rows_may_repeat), stream()))
+                                  aux.shape[1], aux.shape[0], beta1, beta2, eps, int(rows_may_repeat), stream()))
