@@ -21,6 +21,10 @@ constexpr int kSortTile = 4096;   // keys per block
 constexpr int kSortItems = 16;    // per thread
 constexpr int kSortBits = 8;      // digit width (12-bit digits: 4096x156 scattered histogram cells cost more than the extra pass)
 
+// leading dimension of the digit-major histogram matrix: a multiple of 4 so that a row can be
+// read with 16-byte loads
+inline __host__ __device__ int radix_ld(int nblocks) { return (nblocks + 3) & ~3; }
+
 __global__ void __launch_bounds__(256) radix_hist_kernel(const int32_t* __restrict__ keys, int64_t n,
                                                          int shift, int bins, int nblocks,
                                                          int32_t* __restrict__ bh) {
@@ -34,7 +38,8 @@ __global__ void __launch_bounds__(256) radix_hist_kernel(const int32_t* __restri
     if (i < n) atomicAdd(&h[((uint32_t)keys[i] >> shift) & (bins - 1)], 1);
   }
   __syncthreads();
-  for (int d = threadIdx.x; d < bins; d += 256) bh[(int64_t)d * nblocks + blockIdx.x] = h[d];
+  const int ld = radix_ld(nblocks);
+  for (int d = threadIdx.x; d < bins; d += 256) bh[(int64_t)d * ld + blockIdx.x] = h[d];
 }
 
 // Exclusive scan of the digit-major histogram matrix (bins x nblocks <= 64 K ints) by ONE block:
@@ -70,22 +75,60 @@ __global__ void __launch_bounds__(1024) radix_scan_kernel(const int32_t* __restr
 // then the tile is laid out in LDS in its block-local sorted order and written from there, so
 // that consecutive lanes store to consecutive global addresses (runs of one digit) instead of
 // 4096 scattered 4-byte stores per block.
+// The global offset of (digit d, this block) = sum of all smaller digits' totals + the counts of
+// digit d in earlier blocks is computed HERE from the digit-major histogram matrix (thread d
+// reads row d with 16-byte loads, then one block scan over the digits): a pass is two launches
+// (histogram, scatter) instead of four (+ a 2-launch device scan of the matrix) — the sort is a
+// dependent chain of tiny kernels, its length is its cost.
 template <bool IOTA>
 __global__ void __launch_bounds__(256) radix_scatter_kernel(const int32_t* __restrict__ keys,
                                                             const int32_t* __restrict__ vals,
                                                             int64_t n, int shift, int bits, int nblocks,
-                                                            const int32_t* __restrict__ off,
+                                                            const int32_t* __restrict__ bh,
                                                             int32_t* __restrict__ keys_out,
                                                             int32_t* __restrict__ vals_out) {
   constexpr int MAXB = 1 << kSortBits;
   __shared__ int cntw[4 * MAXB];       // per-wave digit counts -> per-wave exclusive prefixes
   __shared__ int lbase[MAXB];          // block-local exclusive start of every digit
-  __shared__ int wtot[4];
+  __shared__ int gbase[MAXB];          // global start of (digit, this block)
+  __shared__ int wtot[4], gtot[4];
   __shared__ int32_t skey[kSortTile], sval[kSortTile];
   const int bins = 1 << bits;
   for (int d = threadIdx.x; d < 4 * bins; d += 256) cntw[d] = 0;
-  __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // digit d = threadIdx.x: total over all blocks and count in the blocks before this one
+  int gsum = 0, gpre = 0;
+  if (threadIdx.x < bins) {
+    const int ld = radix_ld(nblocks);
+    const int4* __restrict__ row = reinterpret_cast<const int4*>(bh + (int64_t)threadIdx.x * ld);
+    const int me = blockIdx.x;
+    for (int b4 = 0; b4 < ld / 4; b4 += 8) {
+      int4 x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = (b4 + u < ld / 4) ? row[b4 + u] : make_int4(0, 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = (b4 + u) * 4;        // columns >= nblocks of the padded row are never written: mask them
+        const int c0 = b + 0 < nblocks ? x[u].x : 0, c1 = b + 1 < nblocks ? x[u].y : 0;
+        const int c2 = b + 2 < nblocks ? x[u].z : 0, c3 = b + 3 < nblocks ? x[u].w : 0;
+        gsum += c0 + c1 + c2 + c3;
+        gpre += (b + 0 < me ? c0 : 0) + (b + 1 < me ? c1 : 0) + (b + 2 < me ? c2 : 0) + (b + 3 < me ? c3 : 0);
+      }
+    }
+  }
+  {
+    int incl = gsum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, kWave);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) gtot[w] = incl;
+    __syncthreads();                     // also publishes the zeroed cntw
+    int base = 0;
+    for (int i = 0; i < w; ++i) base += gtot[i];
+    if (threadIdx.x < bins) gbase[threadIdx.x] = base + incl - gsum + gpre;
+  }
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const int64_t tile0 = (int64_t)blockIdx.x * kSortTile;
   const int64_t seg0 = tile0 + w * (kSortTile / 4);
@@ -148,9 +191,79 @@ __global__ void __launch_bounds__(256) radix_scatter_kernel(const int32_t* __res
   for (int i = threadIdx.x; i < count; i += 256) {
     const int32_t k = skey[i];
     const int d = ((uint32_t)k >> shift) & (bins - 1);
-    const int64_t g = (int64_t)off[(int64_t)d * nblocks + blockIdx.x] + (i - lbase[d]);
+    const int64_t g = (int64_t)gbase[d] + (i - lbase[d]);
     keys_out[g] = k;
     vals_out[g] = sval[i];
+  }
+}
+
+// Runs of equal keys in the sorted sequence, two launches:
+//   seg_count  heads (first position of a run) per tile of kSortTile positions;
+//   seg_mark   each block adds the head counts of the tiles before it, scans its own tile and
+//              writes rank[j] (1-based run index), uniq[run], seg_start[run]; the last position
+//              closes seg_start and sets n_uniq = {number of runs, 0}.
+__global__ void __launch_bounds__(256) seg_count_kernel(const int32_t* __restrict__ sk, int64_t n,
+                                                        int32_t* __restrict__ cnt) {
+  __shared__ int wsum[4];
+  const int64_t t0 = (int64_t)blockIdx.x * kSortTile;
+  int c = 0;
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    const int64_t j = t0 + r * 256 + threadIdx.x;
+    if (j < n && (j == 0 || sk[j] != sk[j - 1])) ++c;
+  }
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, kWave);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) cnt[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ void __launch_bounds__(256) seg_mark_tiles_kernel(const int32_t* __restrict__ sk, int64_t n,
+                                                             const int32_t* __restrict__ cnt,
+                                                             int32_t* __restrict__ rank,
+                                                             int32_t* __restrict__ uniq,
+                                                             int32_t* __restrict__ seg_start,
+                                                             int32_t* __restrict__ n_uniq) {
+  __shared__ int wsum[4];
+  __shared__ int before_s;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // runs that start in earlier tiles
+  int part = 0;
+  for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) part += cnt[b];
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, kWave);
+  if (lane == 0) wsum[w] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) before_s = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  __syncthreads();
+  int run = before_s;
+  // the tile in 16 rounds of 256 consecutive positions: block scan of the head flags per round
+  const int64_t t0 = (int64_t)blockIdx.x * kSortTile;
+  for (int r = 0; r < kSortItems; ++r) {
+    const int64_t j = t0 + r * 256 + threadIdx.x;
+    const bool in = j < n;
+    const int32_t k = in ? sk[j] : 0;
+    const bool head = in && (j == 0 || k != sk[j - 1]);
+    const unsigned long long hb = __ballot(head);
+    const int lower = __popcll(hb & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+    __syncthreads();
+    if (lane == 0) wsum[w] = __popcll(hb);
+    __syncthreads();
+    int base = run;
+    for (int i = 0; i < w; ++i) base += wsum[i];
+    const int rj = base + lower + (head ? 1 : 0);
+    if (in) {
+      rank[j] = rj;
+      if (head) {
+        uniq[rj - 1] = k;
+        seg_start[rj - 1] = (int32_t)j;
+      }
+      if (j == n - 1) {
+        n_uniq[0] = rj;
+        n_uniq[1] = 0;      // owner counter of the one segment reduction that will use this plan
+        seg_start[rj] = (int32_t)n;
+      }
+    }
+    run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
   }
 }
 
@@ -158,7 +271,7 @@ inline int radix_passes(int bits) { return (bits + kSortBits - 1) / kSortBits; }
 inline int radix_blocks(int64_t n) { return (int)ceil_div(n > 0 ? n : 1, kSortTile); }
 // ints of workspace: two ping-pong arrays + histogram + offsets
 inline size_t radix_ws_ints(int64_t n) {
-  return 2 * (size_t)n + 2 * (size_t)(1 << kSortBits) * radix_blocks(n);
+  return 2 * (size_t)n + 2 * (size_t)(1 << kSortBits) * radix_ld(radix_blocks(n));
 }
 
 }  // namespace mapx

@@ -96,7 +96,7 @@ struct PlanWs {   // carve-up of the caller's workspace
 };
 static PlanWs plan_ws(void* ws, int64_t n) {
   PlanWs w;
-  const size_t hist = (size_t)(1 << kSortBits) * radix_blocks(n);
+  const size_t hist = (size_t)(1 << kSortBits) * radix_ld(radix_blocks(n));
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes); return at; };
   char* base = static_cast<char*>(ws);
@@ -157,29 +157,28 @@ extern "C" int mapx_seg_plan(const int32_t* keys, int64_t n, int64_t V, void* ws
     int32_t* dst_v = to_out ? perm : w.tv;
     hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(256), 0, stream, src_k, n, shift, bins,
                        nblocks, w.bh);
-    if (false && (int64_t)bins * nblocks <= 65536) {   // single-block scan measured slower (serial load latency)
-      hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, stream, (const int32_t*)w.bh,
-                         bins * nblocks, w.off);
-    } else {
-      size_t sb = w.scan_bytes;
-      MAPX_HIP(rocprim::exclusive_scan(w.scan, sb, (const int32_t*)w.bh, w.off, 0, (size_t)bins * nblocks,
-                                       rocprim::plus<int32_t>(), stream));
-    }
     if (p == 0)
       hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nblocks), dim3(256), 0, stream, src_k, src_v,
-                         n, shift, db, nblocks, w.off, dst_k, dst_v);
+                         n, shift, db, nblocks, (const int32_t*)w.bh, dst_k, dst_v);
     else
       hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nblocks), dim3(256), 0, stream, src_k, src_v,
-                         n, shift, db, nblocks, w.off, dst_k, dst_v);
+                         n, shift, db, nblocks, (const int32_t*)w.bh, dst_k, dst_v);
     src_k = dst_k;
     src_v = dst_v;
   }
-  auto flags = rocprim::make_transform_iterator(rocprim::counting_iterator<int32_t>(0),
-                                                HeadFlag{sorted_keys});
-  size_t sb = w.scan_bytes;
-  MAPX_HIP(rocprim::inclusive_scan(w.scan, sb, flags, rank, (size_t)n, rocprim::plus<int32_t>(), stream));
-  hipLaunchKernelGGL(seg_mark_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, sorted_keys, rank, n,
-                     uniq, seg_start, n_uniq);
+  if (sort_mode() == 1) {   // comparison path: device scan + mark
+    auto flags = rocprim::make_transform_iterator(rocprim::counting_iterator<int32_t>(0),
+                                                  HeadFlag{sorted_keys});
+    size_t sb = w.scan_bytes;
+    MAPX_HIP(rocprim::inclusive_scan(w.scan, sb, flags, rank, (size_t)n, rocprim::plus<int32_t>(), stream));
+    hipLaunchKernelGGL(seg_mark_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, sorted_keys, rank, n,
+                       uniq, seg_start, n_uniq);
+  } else {
+    hipLaunchKernelGGL(seg_count_kernel, dim3(nblocks), dim3(256), 0, stream, (const int32_t*)sorted_keys, n,
+                       w.off);
+    hipLaunchKernelGGL(seg_mark_tiles_kernel, dim3(nblocks), dim3(256), 0, stream, (const int32_t*)sorted_keys,
+                       n, (const int32_t*)w.off, rank, uniq, seg_start, n_uniq);
+  }
   return check_launch("seg_plan");
 }
 
