@@ -436,7 +436,7 @@ extern "C" int mapx_nce_table_grad(int64_t n, const int32_t* perm, const int32_t
   MAPX_REQUIRE(perm && rank && seg_start && dlogit && h && out_emb && out_bias,
                "nce_table_grad: null pointer");
   mapx::SegPlanView pl{n, perm, rank, seg_start};
-  mapx::NceContrib c{dlogit, h, K + 1, P, gscale_opt};
+  mapx::NceContrib c{dlogit, h, K + 1, P, gscale_opt, 1.f};
   return mapx::seg_reduce_launch<true>(pl, c, P, out_emb, out_bias, ws, ws_bytes, zeroed_counter_opt, stream,
                                        "nce_table_grad");
 }

@@ -34,6 +34,7 @@ struct SegPlanView {
 struct RowsContrib {
   const float* src;  // [n, W]
   int W;
+  __device__ inline void prepare() {}
   __device__ inline float4 operator()(int32_t p, int sub, float& extra) const {
     extra = 0.f;
     return *reinterpret_cast<const float4*>(src + (int64_t)p * W + 4 * sub);
@@ -50,6 +51,7 @@ struct RowsExtraContrib {
   int W;
   const float* extra;  // [n / group]
   int group;
+  __device__ inline void prepare() {}
   __device__ inline float4 operator()(int32_t p, int sub, float& ex) const {
     ex = extra[p / group];
     return *reinterpret_cast<const float4*>(src + (int64_t)p * W + 4 * sub);
@@ -61,8 +63,10 @@ struct NceContrib {
   const float* h;       // [T, P]
   int K1, P;
   const float* gscale;  // optional device scalar: incoming gradient of the loss (dlogit is per unit loss)
+  float gs;             // its value, fetched once per thread by prepare() (a load + wait per call otherwise)
+  __device__ inline void prepare() { gs = gscale ? *gscale : 1.f; }
   __device__ inline float4 operator()(int32_t p, int sub, float& extra) const {
-    const float d = gscale ? dlogit[p] * *gscale : dlogit[p];
+    const float d = dlogit[p] * gs;
     const int t = p / K1;
     float4 v = *reinterpret_cast<const float4*>(h + (int64_t)t * P + 4 * sub);
     extra = d;
@@ -90,6 +94,7 @@ __global__ void __launch_bounds__(256) seg_reduce_pass_a(SegPlanView pl, Contrib
                                                          int32_t* __restrict__ n_owners) {
   constexpr int NPL = kSegChunk / LG;          // entries each lane preloads
   constexpr int BATCH = 8;                     // contributions in flight per walk step
+  contrib.prepare();
   const int WS = EXTRA ? W + 4 : W;
   const int lane = threadIdx.x % kWave;
   const int lig = lane % LG, gbase = lane - lig;
@@ -124,7 +129,20 @@ __global__ void __launch_bounds__(256) seg_reduce_pass_a(SegPlanView pl, Contrib
         const int e = e0 + u;
         rk[u] = __shfl(myrank[e / LG], gbase + (e % LG), kWave);
         const int p = __shfl(myperm[e / LG], gbase + (e % LG), kWave);
-        if (rk[u] >= 0 && live) v[u] = contrib(p, sub, ex[u]);
+        // always load (p is a valid position even in the padding, idle lanes re-read column 0):
+        // a load inside a conditional block is waited for at the end of that block, which
+        // serialises the batch into 16 memory round trips
+        v[u] = contrib(p, live ? sub : 0, ex[u]);
+      }
+      // Retire the batch's loads HERE, once: the walk below stores conditionally (a run ends),
+      // and with a store possibly in flight the compiler cannot count how many memory operations
+      // are younger than a load, so it would put `s_waitcnt vmcnt(0)` in front of every later use
+      // of v[] / ex[] — each one draining the store just issued (measured: 42 us for the NCE
+      // table gradient instead of 12).  After these moves the values are plain ALU results.
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\tv_mov_b32 %2, %2\n\tv_mov_b32 %3, %3\n\tv_mov_b32 %4, %4"
+                     : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w), "+v"(ex[u]));
       }
 #pragma unroll
       for (int u = 0; u < BATCH; ++u) {
