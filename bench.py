@@ -185,13 +185,18 @@ def main():
     local %= torch.cuda.device_count()          # rehearsal: several ranks may share one GPU (gloo)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or os.environ.get("MAPX_FORCE_DP", "0") == "1":   # FORCE_DP: one-rank RCCL rehearsal of the exchange
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("MAPX_DIST_BACKEND", "nccl")     # "nccl" = RCCL over xGMI
         if backend == "nccl":
             torch.distributed.init_process_group(backend="nccl", device_id=device)
         else:
             torch.distributed.init_process_group(backend=backend)
     from mapx import ops, parallel
+    dp_path = parallel.exchanging()
     tr, cfg, ids, labels, feat_count = build(args, device, rank)
     train = tr._begin("bench")
     B = args.batch
@@ -237,7 +242,7 @@ def main():
     torch.cuda.synchronize()
     ops.serialize_streams = False
     ksteps = max(5, min(20, args.steps))
-    if world > 1:
+    if torch.distributed.is_initialized():
         parallel.barrier()
         torch.distributed.destroy_process_group()
     if rank != 0:
@@ -277,7 +282,9 @@ def main():
                                f"({'uniform' if args.uniform else 'Zipf(1.1)'} per field), F={cfg.num_fields}, "
                                f"V={cfg.input_size}, E=16, H=1000x3, cross x3, P=32, K=25, mask_ratio 0.3",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                   "launch": "hipGraph replay of the whole step" if (world == 1 and tr.use_graph) else "eager",
+                   "launch": ("eager" if not tr.use_graph else
+                              "hipGraph replay of mask + forward + backward, exchange and optimizer eager"
+                              if dp_path else "hipGraph replay of the whole step"),
                    "table_optimizer": "row-sparse AdamW with lazy replay of untouched rows, "
                                       + f"{args.preroll} untimed pre-roll steps"},
         "roofline": roofline,

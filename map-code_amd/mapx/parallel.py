@@ -16,12 +16,23 @@ Every replica then applies the identical update, so replicas stay bit-identical 
 ever broadcasting parameters.  The merge is injectable (`merge_fn`) so that the exchange
 logic is testable with gloo on a CPU-only box.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
 def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def exchanging():
+    """True when gradients go through the collectives: more than one rank, or a single rank with
+    MAPX_FORCE_DP=1 (a one-rank RCCL group on a one-GPU box runs the very calls — all-reduce,
+    MAX all-reduce of the counts, all-gathers, merge — that N ranks run; rehearsal only)."""
+    if world() > 1:
+        return True
+    return os.environ.get("MAPX_FORCE_DP", "0") == "1" and dist.is_available() and dist.is_initialized()
 
 
 def rank():
@@ -34,7 +45,7 @@ def _staged(t):
 
 
 def allreduce_mean_(flat):
-    if world() == 1:
+    if not exchanging():
         return flat
     s = _staged(flat)
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
@@ -101,7 +112,7 @@ def sync_table_grad(table, maxc, merge_fn=hip_merge):
 
 def sync_gradients(optimizer, merge_fn=hip_merge):
     """Call between backward() and optimizer.step()."""
-    if world() == 1:
+    if not exchanging():
         return
     from . import ops
     optimizer.collect_torch_grads()

@@ -62,10 +62,12 @@ class GraphedStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         gs, sd = trainer.global_step, trainer.optimizer.steps_done
-        with torch.cuda.graph(self.graph):
-            self.out = step_fn(self.X, self.Y)
-        # the capture pass ran the Python bookkeeping but no kernel
-        trainer.global_step, trainer.optimizer.steps_done = gs, sd
+        try:
+            with torch.cuda.graph(self.graph):
+                self.out = step_fn(self.X, self.Y)
+        finally:
+            # the capture pass ran the Python bookkeeping but no kernel
+            trainer.global_step, trainer.optimizer.steps_done = gs, sd
 
     def __call__(self, X, Y):
         self.X.copy_(X)
@@ -221,11 +223,19 @@ class Trainer:
             if g < self.GRAPH_AFTER:
                 self._graphs[key] = g + 1
                 return fn(X, Y)
-            if self.world == 1 and self.optimizer.max_grad_norm <= 0:
-                g = GraphedStep(self, fn, X, Y)
-            else:   # exchange sizes / the clipping norm are host decisions: graph up to the gradients
-                half = {"mfp": self._mfp_fwd_bwd, "rfd": self._rfd_fwd_bwd, "ctr": self._ctr_fwd_bwd}[kind]
-                g = GraphedBackward(self, half, X, Y)
+            try:
+                if not parallel.exchanging() and self.optimizer.max_grad_norm <= 0:
+                    g = GraphedStep(self, fn, X, Y)
+                else:   # exchange sizes / the clipping norm are host decisions: graph up to the gradients
+                    half = {"mfp": self._mfp_fwd_bwd, "rfd": self._rfd_fwd_bwd, "ctr": self._ctr_fwd_bwd}[kind]
+                    g = GraphedBackward(self, half, X, Y)
+            except RuntimeError as e:          # a runtime that cannot capture this step: stay eager
+                logger.warning(f"hipGraph capture of the {kind} step failed ({e}); continuing eagerly")
+                torch.cuda.synchronize()
+                self.use_graph = False
+                for t in self.optimizer.tables:
+                    t.table.sparse_grad = None
+                return fn(X, Y)
             self._graphs[key] = g
         return g(X, Y)
 
