@@ -260,7 +260,7 @@ int mapx_adamw_dense(float* p, const float* g, float* m, float* v, int64_t n, co
 int mapx_step_advance(int32_t* done, hipStream_t stream);
 /* Lazy exact row-sparse AdamW on a table group {p0 [V,W0] (+ optional p1 [V])} sharing
  * last[V].  rows NULL: rows row_begin..row_begin+n_rows-1 (flush / sweep); else rows[i],
- * i < *n_rows_dev (or n_rows if NULL).  grad0 NULL: catch-up to *done only; else catch-up
+ * i < *n_rows_dev (or n_rows if NULL); negative entries of rows[] are skipped (padding).  grad0 NULL: catch-up to *done only; else catch-up
  * then update *done+1 with grad0 [*, W0] (grad1 [*]) and last = *done+1.
  * aux [aux_rows][aux_len] f64 (device), the host tables of the CLOSED-FORM replay of zero-gradient
  * steps (csrc/optim.hip: replay_coef): row 0 prefix products P[s] = prod_{i<s}(1 - lr_i*wd), row 1

@@ -299,6 +299,7 @@ __global__ void __launch_bounds__(256) table_adam_kernel(TableGroup tg, const in
   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LG; i < count;
        i += ((int64_t)gridDim.x * blockDim.x) / LG) {
     const int64_t r = rows ? (int64_t)rows[i] : row_begin + i;
+    if (r < 0) continue;                 // padding entry of a gathered gradient list (mapx.parallel)
     const int from = tg.last[r];
     if (from >= target && !grad0) continue;
     table_adam_row<LG>(tg, r, from, target, i, grad0, grad1, sched, sched_len, h, ax, lig);

@@ -65,12 +65,18 @@ class RowTable:
     def dense_grad(self):
         """Reference-layout dense gradients [(V,W), (V,1)|None] from the sparse ones (tests)."""
         plan, r0, r1 = self.sparse_grad
-        U = plan.count()
-        uniq = plan.uniq[:U].long()
-        g0 = torch.zeros_like(self.p0).index_copy_(0, uniq, r0[:U])
+        if plan.n_uniq is None:                      # gathered list with -1 padding (mapx.parallel)
+            keep = plan.uniq >= 0
+            uniq, r0 = plan.uniq[keep].long(), r0[keep]
+            r1 = r1[keep] if r1 is not None else None
+        else:
+            U = plan.count()
+            uniq, r0 = plan.uniq[:U].long(), r0[:U]
+            r1 = r1[:U] if r1 is not None else None
+        g0 = torch.zeros_like(self.p0).index_copy_(0, uniq, r0)
         g1 = None
         if self.p1 is not None:
-            g1 = torch.zeros_like(self.p1).index_copy_(0, uniq, r1[:U].unsqueeze(1))
+            g1 = torch.zeros_like(self.p1).index_copy_(0, uniq, r1.unsqueeze(1))
         return g0, g1
 
 

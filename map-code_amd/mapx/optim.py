@@ -147,7 +147,10 @@ class MapxOptimizer:
         for t in self.tables:
             if t.table.sparse_grad is not None:
                 plan, r0, r1 = t.table.sparse_grad
-                live = (torch.arange(r0.shape[0], device=r0.device) < plan.n_uniq[0]).float()
+                if plan.n_uniq is None:          # gathered list (mapx.parallel): padding rows are zero
+                    live = torch.ones(r0.shape[0], device=r0.device)
+                else:
+                    live = (torch.arange(r0.shape[0], device=r0.device) < plan.n_uniq[0]).float()
                 sq = sq + ((r0 ** 2).sum(1) * live).sum()
                 if r1 is not None:
                     sq = sq + ((r1 ** 2) * live).sum()

@@ -110,6 +110,105 @@ def sync_table_grad(table, maxc, merge_fn=hip_merge):
         table.sparse_grad = (mplan, merged, None)
 
 
+# ------------------------------------------------------------------------- owner-partitioned exchange
+# the "reduce-scatter of sparse gradients".  Row ids are owned by contiguous id
+# ranges (V / world each).  A rank's deduplicated list is sorted by id, so the rows it owes each
+# owner are one contiguous slice: (1) all ranks all-gather the [world] slice sizes of every table
+# (ONE host sync per step), (2) all-to-all-v of (id, row) slices, (3) each owner merges what it
+# received — 1/world of the keys instead of all of them — with the deterministic reduce-by-key,
+# (4) all-gather of the owners' merged lists, padded with id -1 (the table optimizer skips
+# negative ids) to the largest owner load, which every rank can compute from the sizes of (1).
+# Against the all-gather of raw lists: a rank receives the union of touched rows once instead of
+# every rank's copy of it, and sorts world times fewer keys.
+# Which one is the default is a volume question: at Avazu-MFP a rank touches ~250 k of the 9.4 M NCE
+# rows per step and the ranks' sets overlap little, so the union all ranks must receive anyway is
+# most of the sum of the lists, and the padded owner gather moves about what the raw gather does;
+# the owner path then only saves the world-times-larger sort, against three more collectives and
+# ~0.25 ms of launches (one-rank RCCL rehearsal: 2.14 vs 1.89 ms per step).  "gather" stays the
+# default until an N-GPU measurement says otherwise (MAPX_DP_EXCHANGE=owner selects this path).
+EXCHANGE = os.environ.get("MAPX_DP_EXCHANGE", "gather")     # "gather" | "owner"
+
+
+class GatheredPlan:
+    """Row-id list of a gathered table gradient: `uniq` [n] int32 with -1 padding, all rows valid
+    or zero.  Stands in for a SegPlan where the optimizer / clipping read a sparse gradient."""
+
+    def __init__(self, uniq):
+        self.uniq, self.n, self.n_uniq = uniq, uniq.numel(), None
+
+    def count(self):
+        return int((self.uniq >= 0).sum())
+
+
+def _slice_sizes(plan, num_rows, w):
+    """[w] int64 (device): how many of this rank's unique ids fall into each owner's id range."""
+    dev = plan.uniq.device
+    cap = plan.uniq.shape[0]
+    big = torch.iinfo(torch.int32).max
+    keys = torch.where(torch.arange(cap, device=dev) < plan.n_uniq[0], plan.uniq,
+                       torch.full((), big, dtype=plan.uniq.dtype, device=dev))
+    chunk = -(-num_rows // w)
+    edges = torch.arange(w + 1, device=dev, dtype=torch.int64) * chunk
+    edges[w] = big                                   # the last owner takes the remainder
+    bounds = torch.searchsorted(keys.to(torch.int64), edges)
+    return bounds[1:] - bounds[:-1]
+
+
+def _all_to_all(out, inp, out_splits, in_splits):
+    so, si = _staged(out), _staged(inp)
+    dist.all_to_all_single(so, si, out_splits, in_splits)
+    if so is not out:
+        out.copy_(so)
+
+
+def exchange_owner(tables, merge_fn=hip_merge):
+    w, r = world(), rank()
+    dev = tables[0].sparse_grad[1].device
+    sizes = torch.stack([_slice_sizes(tb.sparse_grad[0], tb.num_rows, w) for tb in tables])      # [T, w]
+    flat = _staged(sizes).contiguous().view(-1)
+    all_sizes = torch.empty(w * flat.numel(), dtype=torch.int64, device=flat.device)
+    dist.all_gather_into_tensor(all_sizes, flat)
+    all_sizes = all_sizes.view(w, len(tables), w).tolist()      # the step's one host sync: [from][table][to]
+    for t, tb in enumerate(tables):
+        plan, r0, r1 = tb.sparse_grad
+        W0 = r0.shape[1]
+        send = [all_sizes[r][t][k] for k in range(w)]
+        recv = [all_sizes[j][t][r] for j in range(w)]
+        n_send, n_recv = sum(send), sum(recv)
+        loads = [sum(all_sizes[j][t][k] for j in range(w)) for k in range(w)]     # rows each owner receives
+        cap_o = max(1, max(loads))
+        if r1 is not None:                           # the scalar-per-row gradient rides in 4 extra columns
+            rows = torch.zeros(n_send, W0 + 4, dtype=torch.float32, device=dev)
+            rows[:, :W0] = r0[:n_send]
+            rows[:, W0] = r1[:n_send]
+        else:
+            rows = r0[:n_send].contiguous()
+        rows = rows / w                              # mean over ranks
+        keys = plan.uniq[:n_send].contiguous()
+        Wp = rows.shape[1]
+        k_in = torch.empty(n_recv, dtype=torch.int32, device=dev)
+        r_in = torch.empty(n_recv, Wp, dtype=torch.float32, device=dev)
+        _all_to_all(k_in, keys, recv, send)
+        _all_to_all(r_in, rows, recv, send)
+        k_own = torch.full((cap_o,), -1, dtype=torch.int32, device=dev)
+        r_own = torch.zeros(cap_o, Wp, dtype=torch.float32, device=dev)
+        if n_recv > 0:
+            mplan, merged = merge_fn(k_in, r_in, tb.num_rows)
+            live = torch.arange(n_recv, device=dev) < mplan.n_uniq[0]
+            k_own[:n_recv] = torch.where(live, mplan.uniq[:n_recv], k_own[:n_recv])
+            r_own[:n_recv] = torch.where(live.unsqueeze(1), merged[:n_recv], r_own[:n_recv])
+        k_all = torch.empty(w * cap_o, dtype=torch.int32, device=_staged(k_own).device)
+        r_all = torch.empty(w * cap_o, Wp, dtype=torch.float32, device=_staged(r_own).device)
+        dist.all_gather_into_tensor(k_all, _staged(k_own))
+        dist.all_gather_into_tensor(r_all, _staged(r_own))
+        k_all, r_all = k_all.to(dev), r_all.to(dev)
+        gplan = GatheredPlan(k_all)
+        if r1 is not None:
+            tb.sparse_grad = (gplan, r_all[:, :W0].contiguous(), r_all[:, W0].contiguous())
+        else:
+            tb.sparse_grad = (gplan, r_all, None)
+
+
 def sync_gradients(optimizer, merge_fn=hip_merge):
     """Call between backward() and optimizer.step()."""
     if not exchanging():
@@ -121,6 +220,9 @@ def sync_gradients(optimizer, merge_fn=hip_merge):
         allreduce_mean_(g["g"])
     tabs = [t.table for t in optimizer.tables if t.table.sparse_grad is not None]
     if not tabs:
+        return
+    if EXCHANGE == "owner":
+        exchange_owner(tabs, merge_fn)
         return
     counts = torch.stack([tb.sparse_grad[0].n_uniq[0] for tb in tabs]).to(torch.int64)
     for tb, maxc in zip(tabs, max_counts(counts)):

@@ -74,6 +74,56 @@ def _worker(rank, world, port, V, W, with_bias, out):
     dist.destroy_process_group()
 
 
+def _owner_worker(rank, world, port, V, out):
+    """Two tables (one with a scalar-per-row secondary) through the owner-partitioned exchange."""
+    sys.path.insert(0, os.path.join(ROOT, "map-code_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mapx import parallel
+    tables = []
+    for W, with_bias in ((16, False), (32, True)):
+        uniq, n, r0, r1 = _local_grad(rank, V, W, with_bias)
+        tb = _Table(V, W, with_bias)
+        tb.sparse_grad = (_Plan(uniq, r0.shape[0]), r0, r1)
+        tables.append(tb)
+    parallel.exchange_owner(tables, merge_fn=_torch_merge)
+    res = []
+    for tb in tables:
+        plan, m0, m1 = tb.sparse_grad
+        keep = plan.uniq >= 0
+        assert plan.n_uniq is None and plan.n == plan.uniq.numel()
+        ids = plan.uniq[keep].long()
+        assert ids.unique().numel() == ids.numel(), "an id reached the optimizer twice"
+        assert float(m0[~keep].abs().sum()) == 0.0, "padding rows must be zero"
+        d0 = torch.zeros(V, tb.W).index_add_(0, ids, m0[keep])
+        d1 = torch.zeros(V).index_add_(0, ids, m1[keep]) if tb.with_bias else torch.zeros(V)
+        res.append((d0, d1))
+    torch.save(res, f"{out}.{rank}")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_owner_partitioned_exchange(tmp_path, world):
+    """all-gather of slice sizes -> all-to-all-v of (id, row) slices -> owners merge -> all-gather of the
+    merged lists: every rank ends with the mean over ranks of all sparse gradients, each id once."""
+    V = 50
+    out = str(tmp_path / "res")
+    mp.spawn(_owner_worker, args=(world, _free_port(), V, out), nprocs=world, join=True)
+    for ti, (W, with_bias) in enumerate(((16, False), (32, True))):
+        exp0, exp1 = torch.zeros(V, W), torch.zeros(V)
+        for r in range(world):
+            uniq, n, r0, r1 = _local_grad(r, V, W, with_bias)
+            exp0.index_add_(0, uniq, r0[:n])
+            if with_bias:
+                exp1.index_add_(0, uniq, r1[:n])
+        exp0 /= world
+        exp1 /= world
+        for r in range(world):
+            d0, d1 = torch.load(f"{out}.{r}")[ti]
+            assert torch.allclose(d0, exp0, atol=1e-6), "every rank must hold the same merged mean"
+            assert torch.allclose(d1, exp1, atol=1e-6)
+
+
 @pytest.mark.parametrize("W,with_bias", [(16, False), (32, True)])
 def test_sparse_gradient_exchange_two_ranks(tmp_path, W, with_bias):
     V, world = 50, 2
