@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 17
+#define MAPX_ABI_VERSION 18
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -74,14 +74,23 @@ int mapx_seg_reduce_rows(int64_t n, const int32_t* perm, const int32_t* rank,
                          const int32_t* seg_start, const float* src, int W, float* out, void* ws,
                          size_t ws_bytes, int32_t* zeroed_counter_opt, hipStream_t stream);
 
-/* Same with one extra scalar per run: out_extra[u] = sum_{j in run u} extra[perm[j] / group].
- * DeepFM: the LR weight w[V,1] (models.py:134) is read with the embedding's ids,
- * so its gradient dL/dlr[b], shared by the F positions of row b (group = F), is reduced with the
- * embedding rows.  Workspace: mapx_seg_reduce_workspace_bytes(n, W). */
+/* Same with one extra scalar per run: out_extra[u] = sum_{j in run u} extra[(perm[j] / group) *
+ * extra_stride]; src rows have stride ld_src >= W.  DeepFM: the LR weight w[V,1]
+ * (models.py:134) is read with the embedding's ids, so its gradient dL/dlr[b], shared by the F
+ * positions of row b (group = F), is reduced with the embedding rows.  Data-parallel merge: rows
+ * [n, W+4] whose column W carries the scalar (extra = src + W, extra_stride = ld_src, group = 1).
+ * Workspace: mapx_seg_reduce_workspace_bytes(n, W). */
 int mapx_seg_reduce_rows_extra(int64_t n, const int32_t* perm, const int32_t* rank,
-                               const int32_t* seg_start, const float* src, int W, const float* extra,
-                               int group, float* out, float* out_extra, void* ws, size_t ws_bytes,
-                               int32_t* zeroed_counter_opt, hipStream_t stream);
+                               const int32_t* seg_start, const float* src, int W, int64_t ld_src,
+                               const float* extra, int group, int64_t extra_stride, float* out,
+                               float* out_extra, void* ws, size_t ws_bytes, int32_t* zeroed_counter_opt,
+                               hipStream_t stream);
+/* Data-parallel exchange message of one table (one process per GPU; mapx/parallel.py): keys_out
+ * [maxc], rows_out [maxc, W0 (+4 if rows1)] = the first *n_uniq pairs scaled by `scale`, then
+ * `pad_id` with zero rows. */
+int mapx_pack_sparse(const int32_t* uniq, const float* rows0, int W0, const float* rows1_opt,
+                     const int32_t* n_uniq, int64_t cap, int64_t maxc, float scale, int32_t pad_id,
+                     int32_t* keys_out, float* rows_out, hipStream_t stream);
 
 /* ------------------------------------------------------------------ DeepFM terms
  * LR  (models.py:129-143): out[b] = sum_f w[ids[b,f]]  (bias added by the caller).

@@ -207,17 +207,67 @@ extern "C" int mapx_seg_reduce_rows(int64_t n, const int32_t* perm, const int32_
 // extra[position / group] (DeepFM: the LR weight shares the embedding's ids, its gradient
 // dL/dlr[b] is common to the F positions of batch row b).
 extern "C" int mapx_seg_reduce_rows_extra(int64_t n, const int32_t* perm, const int32_t* rank,
-                                          const int32_t* seg_start, const float* src, int W,
-                                          const float* extra, int group, float* out, float* out_extra,
+                                          const int32_t* seg_start, const float* src, int W, int64_t ld_src,
+                                          const float* extra, int group, int64_t extra_stride, float* out,
+                                          float* out_extra,
                                           void* ws, size_t ws_bytes, int32_t* zeroed_counter_opt,
                                           hipStream_t stream) {
-  MAPX_REQUIRE(n >= 0 && group >= 1, "seg_reduce_rows_extra: bad sizes");
+  MAPX_REQUIRE(n >= 0 && group >= 1 && ld_src >= W && ld_src % 4 == 0 && extra_stride >= 1,
+               "seg_reduce_rows_extra: bad sizes");
   if (n == 0) return MAPX_OK;
   MAPX_REQUIRE(perm && rank && seg_start && src && extra && out && out_extra, "seg_reduce_rows_extra: null pointer");
   MAPX_REQUIRE(((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)ws % 16 == 0),
                "seg_reduce_rows_extra: pointers must be 16-byte aligned");
   mapx::SegPlanView pl{n, perm, rank, seg_start};
-  mapx::RowsExtraContrib c{src, W, extra, group};
+  mapx::RowsExtraContrib c{src, W, ld_src, extra, group, extra_stride};
   return mapx::seg_reduce_launch<true>(pl, c, W, out, out_extra, ws, ws_bytes, zeroed_counter_opt, stream,
                                        "seg_reduce_rows_extra");
+}
+
+// Data-parallel exchange (mapx/parallel.py): the first n_uniq (id, gradient row) pairs of a rank's
+// sparse gradient as a fixed-size message of `maxc` entries: keys_out[i] = uniq[i], rows_out[i] =
+// {rows0[i, :] * scale, rows1[i] * scale, 0, 0, 0} (rows1 optional: then W0 columns only); entries
+// at and beyond *n_uniq are id `pad_id` with a zero row.  One launch instead of a dozen tensor ops.
+namespace mapx {
+__global__ void __launch_bounds__(256) pack_sparse_kernel(const int32_t* __restrict__ uniq,
+                                                          const float* __restrict__ rows0, int W0,
+                                                          const float* __restrict__ rows1,
+                                                          const int32_t* __restrict__ n_uniq, int64_t cap,
+                                                          int64_t maxc, float scale, int32_t pad_id,
+                                                          int32_t* __restrict__ keys_out,
+                                                          float* __restrict__ rows_out) {
+  const int Wp = rows1 ? W0 + 4 : W0;
+  const int per = Wp / 4;
+  int64_t n = *n_uniq;
+  if (n > cap) n = cap;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < maxc * per;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / per;
+    const int c = (int)(t - i * per) * 4;
+    const bool live = i < n;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+      if (c < W0) {
+        v = *reinterpret_cast<const float4*>(rows0 + i * W0 + c);
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+      } else {
+        v.x = rows1[i] * scale;
+      }
+    }
+    *reinterpret_cast<float4*>(rows_out + i * Wp + c) = v;
+    if (c == 0) keys_out[i] = live ? uniq[i] : pad_id;
+  }
+}
+}  // namespace mapx
+
+extern "C" int mapx_pack_sparse(const int32_t* uniq, const float* rows0, int W0, const float* rows1_opt,
+                                const int32_t* n_uniq, int64_t cap, int64_t maxc, float scale,
+                                int32_t pad_id, int32_t* keys_out, float* rows_out, hipStream_t stream) {
+  MAPX_REQUIRE(uniq && rows0 && n_uniq && keys_out && rows_out, "pack_sparse: null pointer");
+  MAPX_REQUIRE(W0 > 0 && W0 % 4 == 0 && cap >= 0 && maxc >= 0, "pack_sparse: bad sizes");
+  if (maxc == 0) return MAPX_OK;
+  const int Wp = rows1_opt ? W0 + 4 : W0;
+  hipLaunchKernelGGL(mapx::pack_sparse_kernel, dim3(mapx::grid_for(maxc * (Wp / 4), 256)), dim3(256), 0, stream,
+                     uniq, rows0, W0, rows1_opt, n_uniq, cap, maxc, scale, pad_id, keys_out, rows_out);
+  return mapx::check_launch("pack_sparse");
 }

@@ -47,14 +47,16 @@ struct RowsContrib {
 // Rows plus one scalar per GROUP of consecutive positions: embedding gradient rows dL/dX[b,f,:]
 // together with the LR gradient dL/dlr[b] that every field of row b shares (group = F).
 struct RowsExtraContrib {
-  const float* src;    // [n, W]
+  const float* src;    // [n, ld]: the first W columns of a row are reduced
   int W;
-  const float* extra;  // [n / group]
+  int64_t ld;          // row stride of src (>= W)
+  const float* extra;  // scalar of position p: extra[(p / group) * estride]
   int group;
+  int64_t estride;
   __device__ inline void prepare() {}
   __device__ inline float4 operator()(int32_t p, int sub, float& ex) const {
-    ex = extra[p / group];
-    return *reinterpret_cast<const float4*>(src + (int64_t)p * W + 4 * sub);
+    ex = extra[(int64_t)(p / group) * estride];
+    return *reinterpret_cast<const float4*>(src + (int64_t)p * ld + 4 * sub);
   }
 };
 

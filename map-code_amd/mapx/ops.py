@@ -246,18 +246,34 @@ def seg_reduce_rows(plan, src, W):
     return out
 
 
-def seg_reduce_rows_extra(plan, src, W, extra, group):
-    """-> (rows [cap,W], scalars [cap]): the row reduction of seg_reduce_rows plus, per unique key,
-    the sum of extra[position // group] (DeepFM's LR weight gradient rides with the embedding's)."""
+def seg_reduce_rows_extra(plan, src, W, extra, group, extra_stride=1):
+    """-> (rows [cap,W], scalars [cap]): the row reduction of seg_reduce_rows over the first W columns
+    of src plus, per unique key, the sum of extra[(position // group) * extra_stride] (DeepFM's LR
+    weight gradient rides with the embedding's; DP merge of rows that carry a scalar column)."""
     require_gpu(src, extra)
     out = torch.empty(max(plan.n, 1), W, dtype=torch.float32, device=src.device)
     out1 = torch.empty(max(plan.n, 1), dtype=torch.float32, device=src.device)
     ws = scratch(lib.mapx_seg_reduce_workspace_bytes(plan.n, W), src.device)
     with _timed("seg_reduce_rows", plan.n * (4.0 * W + 12)):
         check(lib.mapx_seg_reduce_rows_extra(plan.n, ptr(plan.perm), ptr(plan.rank), ptr(plan.seg_start),
-                                             ptr(src), W, ptr(extra), group, ptr(out), ptr(out1), ptr(ws),
-                                             ws.numel(), plan.take_counter(), stream()))
+                                             src.data_ptr(), W, src.stride(0), extra.data_ptr(), group,
+                                             extra_stride, ptr(out), ptr(out1), ptr(ws), ws.numel(),
+                                             plan.take_counter(), stream()))
     return out, out1
+
+
+def pack_sparse(plan, rows0, rows1, maxc, scale, pad_id=0):
+    """The first n_uniq (id, row) pairs of a sparse gradient as a message of exactly `maxc` entries
+    (mapx/parallel.py): -> (keys int32 [maxc], rows f32 [maxc, W0 (+4 with rows1)])."""
+    require_gpu(rows0)
+    W0 = rows0.shape[1]
+    Wp = W0 + 4 if rows1 is not None else W0
+    keys = torch.empty(maxc, dtype=torch.int32, device=rows0.device)
+    rows = torch.empty(maxc, Wp, dtype=torch.float32, device=rows0.device)
+    check(lib.mapx_pack_sparse(ptr(plan.uniq), ptr(rows0), W0, ptr(rows1), ptr(plan.n_uniq),
+                               min(plan.uniq.shape[0], rows0.shape[0]), maxc, float(scale), pad_id, ptr(keys),
+                               ptr(rows), stream()))
+    return keys, rows
 
 
 # --------------------------------------------------------------------------- DeepFM terms

@@ -87,9 +87,31 @@ def hip_merge(keys, rows, num_rows):
     return plan, ops.seg_reduce_rows(plan, rows, rows.shape[1])
 
 
+def _sync_table_grad_hip(table, maxc):
+    """The gather exchange on device tensors with the fewest launches: one pack kernel (scale by
+    1/world folded in), two all-gathers, one plan, one reduction that splits rows / scalar again."""
+    from . import ops
+    plan, r0, r1 = table.sparse_grad
+    w, dev, W0 = world(), r0.device, r0.shape[1]
+    keys, rows = ops.pack_sparse(plan, r0, r1, maxc, 1.0 / w)
+    k_all = torch.empty(w * maxc, dtype=torch.int32, device=_staged(keys).device)
+    r_all = torch.empty(w * maxc, rows.shape[1], dtype=torch.float32, device=_staged(rows).device)
+    dist.all_gather_into_tensor(k_all, _staged(keys))
+    dist.all_gather_into_tensor(r_all, _staged(rows))
+    k_all, r_all = k_all.to(dev), r_all.to(dev)
+    mplan = ops.SegPlan(k_all, table.num_rows)
+    if r1 is not None:
+        m0, m1 = ops.seg_reduce_rows_extra(mplan, r_all, W0, r_all[:, W0], 1, extra_stride=r_all.stride(0))
+    else:
+        m0, m1 = ops.seg_reduce_rows(mplan, r_all, W0), None
+    table.sparse_grad = (mplan, m0, m1)
+
+
 def sync_table_grad(table, maxc, merge_fn=hip_merge):
     """Replace table.sparse_grad by the mean over ranks of all ranks' sparse gradients."""
     plan, r0, r1 = table.sparse_grad
+    if merge_fn is hip_merge and r0.is_cuda:
+        return _sync_table_grad_hip(table, maxc)
     W0 = r0.shape[1]
     if r1 is not None:                      # ride the scalar-per-row gradient in 4 extra columns
         packed = torch.zeros(r0.shape[0], W0 + 4, dtype=torch.float32, device=r0.device)
