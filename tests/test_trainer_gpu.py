@@ -319,3 +319,30 @@ def test_resume_state_continues_bit_exactly(tmp_path):
     tr_c.optimizer.flush()
     for k, v in tr_c.model.state_dict().items():
         assert torch.equal(v.detach().cpu(), ref[k]), k
+
+
+def test_run_py_deepfm_pretrain_then_finetune(tmp_path):
+    """run.py --model_name=DeepFM: MFP pretraining, then finetune from that checkpoint (LR / FM /
+    MLP weights are loaded by name, the pretraining head is reported as unmatched)."""
+    from mapx.dataset import write_synth_dataset
+    data = write_synth_dataset(str(tmp_path / "data" / "avazu"), num_rows=4000, num_fields=23, vocab=2000)
+    common = ["--dataset_name=avazu", f"--data_dir={data}", "--per_gpu_train_batch_size=512",
+              "--per_gpu_eval_batch_size=512", "--learning_rate=1e-3", "--model_name=DeepFM", "--embed_size=16",
+              "--hidden_size=64", "--num_hidden_layers=2", "--hidden_dropout_rate=0.0", "--logging_steps=3"]
+    out = str(tmp_path / "out" / "mfp")
+    r = _run_py(["--pretrain=True", f"--output_dir={out}", "--num_train_epochs=1", "--lr_sched=cosine",
+                 "--weight_decay=5e-2", "--pt_type=MFP", "--sampling_method=randint", "--mask_ratio=0.3",
+                 "--pt_neg_num=25", "--proj_size=32"] + common, str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    steps = (3200 + 511) // 512
+    ckpt = os.path.join(out, f"{steps}.model")
+    sd = torch.load(ckpt)
+    assert {"lr_layer.embed_w.weight", "lr_layer.bias", "ip_layer.field_p", "dnn.dnn.0.weight",
+            "feat_encoder.weight", "mfp_criterion.emb.weight"} <= set(sd)
+    fo = str(tmp_path / "out" / "finetune")
+    r2 = _run_py(["--finetune", f"--pretrained_model_path={ckpt}", f"--output_dir={fo}", "--num_train_epochs=1",
+                  "--lr_sched=const", "--weight_decay=1e-1"] + common, str(tmp_path))
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    log = open(os.path.join(fo, "results.log")).read()
+    assert "Load tensor: lr_layer.embed_w.weight" in log and "Unmatched tensor in the target model: feat_encoder.weight" in log
+    assert "eval_auc" in log
