@@ -16,6 +16,7 @@ Reference sites restated (paths under /root/reference/code):
   dnn              layers.py:173-188    [Linear, ReLU, Dropout(p=0)] x NL
   trunk            models.py:306-314    cat(cross, dnn)
   DNN / DeepFM     models.py:164-233, 129-143 (LR), layers.py:123-131 (FM product_sum)
+  AutoInt          models.py:440-488, layers.py:724-744, 848-914 (self-attention, view head split)
   mfp head         models.py:71-78, nce/nce_loss.py:79-144,158-173,201-230,
                    nce/index_linear.py:68-106
   rfd head         models.py:79-85,119-124
@@ -88,7 +89,36 @@ def trunk_deepfm(params, ids, num_hidden):
     return dnn(params, x3.flatten(1), num_hidden, tower="dnn"), lr_logit(params, ids) + fm_product_sum(x3)
 
 
-def final_of(backbone, params, ids, num_cross, num_hidden):
+def autoint_layer(params, x, i, num_heads, attn_size, res_conn, attn_scale):
+    """One MultiHeadSelfAttention (layers.py:848-914; AutoInt style, align_to="output") on [B,F,Din].
+    Heads are split by a plain .view(B*H, -1, A) of the projected [B,F,H*A] tensor (layers.py:886-888),
+    NOT by a transpose: each sample's F*H*A values are cut into H consecutive chunks of F*A."""
+    B = x.shape[0]
+    pre = f"self_attention.{i}."
+    q = x @ params[pre + "W_q.weight"].t()
+    k = x @ params[pre + "W_k.weight"].t()
+    v = x @ params[pre + "W_v.weight"].t()
+    HA = num_heads * attn_size
+    qh, kh, vh = (t.reshape(B * num_heads, -1, attn_size) for t in (q, k, v))
+    att = torch.bmm(qh, kh.transpose(1, 2))
+    if attn_scale:
+        att = att / (attn_size ** 0.5)
+    out = torch.bmm(torch.softmax(att, dim=2), vh).reshape(B, -1, HA)
+    res = x @ params[pre + "W_res.weight"].t() if (pre + "W_res.weight") in params else x
+    if res_conn:
+        out = out + res
+    return torch.relu(out)
+
+
+def trunk_autoint(params, ids, ai):
+    """AutoInt (models.py:440-488): stacked self-attention over the field embeddings, flattened."""
+    x = params["embed.embedding.weight"][ids]
+    for i in range(ai["num_attn_layers"]):
+        x = autoint_layer(params, x, i, ai["num_attn_heads"], ai["attn_size"], ai["res_conn"], ai["attn_scale"])
+    return x.flatten(1)
+
+
+def final_of(backbone, params, ids, num_cross, num_hidden, autoint=None):
     """The vector the pretraining heads see, per backbone."""
     if backbone == "DCNv2":
         return trunk(params, ids, num_cross, num_hidden)
@@ -96,10 +126,12 @@ def final_of(backbone, params, ids, num_cross, num_hidden):
         return trunk_dnn(params, ids, num_hidden)
     if backbone == "DeepFM":
         return torch.cat(trunk_deepfm(params, ids, num_hidden), dim=1)
+    if backbone == "AutoInt":
+        return trunk_autoint(params, ids, autoint)
     raise NotImplementedError(backbone)
 
 
-def ctr_logits_of(backbone, params, ids, num_cross, num_hidden):
+def ctr_logits_of(backbone, params, ids, num_cross, num_hidden, autoint=None):
     """CTR logits [B,1] per backbone (models.py:189-190, 228-231, 319)."""
     if backbone == "DCNv2":
         return ctr_head(params, trunk(params, ids, num_cross, num_hidden))[0]
@@ -108,6 +140,8 @@ def ctr_logits_of(backbone, params, ids, num_cross, num_hidden):
     if backbone == "DeepFM":
         vec, lr_fm = trunk_deepfm(params, ids, num_hidden)
         return vec @ params["dnn_fc_out.weight"].t() + params["dnn_fc_out.bias"] + lr_fm
+    if backbone == "AutoInt":     # use_lr False, num_dnn_layers 0 (models.py:481-487)
+        return trunk_autoint(params, ids, autoint) @ params["attn_out.weight"].t() + params["attn_out.bias"]
     raise NotImplementedError(backbone)
 
 

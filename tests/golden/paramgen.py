@@ -64,7 +64,12 @@ def make_param(case, name, shape, scale):
     return (_rng(case, "param", name).standard_normal(shape) * scale).astype(np.float32)
 
 
-BACKBONES = ("DCNv2", "DNN", "DeepFM")      # DNN / DeepFM: SURVEY §8(f4), fixtures for case B only
+BACKBONES = ("DCNv2", "DNN", "DeepFM", "AutoInt")      # the others: SURVEY §8(f4), fixtures for case B only
+# AutoInt settings of the fixtures (non-default on purpose: 2 heads, residual + scaling on, the
+# second layer has no W_res because its input width equals heads * attn_size)
+AUTOINT = dict(num_attn_layers=2, attn_size=12, num_attn_heads=2, res_conn=True, attn_scale=True,
+               attn_probs_dropout_rate=0.0, use_lr=False, num_dnn_layers=0, dnn_size=1000, dnn_act="relu",
+               dnn_drop=0.0)
 
 
 def param_shapes(cfg, mode, backbone="DCNv2"):
@@ -81,6 +86,19 @@ def param_shapes(cfg, mode, backbone="DCNv2"):
     elif backbone == "DeepFM":
         out["lr_layer.embed_w.weight"] = ((V, 1), 0.3)
         out["lr_layer.bias"] = ((1,), 0.1)
+    elif backbone == "AutoInt":
+        HA = AUTOINT["num_attn_heads"] * AUTOINT["attn_size"]
+        d_in = E
+        for i in range(AUTOINT["num_attn_layers"]):
+            for nm in ("W_q", "W_k", "W_v") + (("W_res",) if d_in != HA else ()):
+                out[f"self_attention.{i}.{nm}.weight"] = ((HA, d_in), d_in ** -0.5)
+            d_in = HA
+        Dfin = F * HA
+        if mode == "CTR":
+            out["attn_out.weight"] = ((1, Dfin), Dfin ** -0.5)
+            out["attn_out.bias"] = ((1,), 0.1)
+            return out
+        NL = 0                                       # no MLP tower
     elif backbone != "DNN":
         raise ValueError(backbone)
     tower = "parallel_dnn" if backbone == "DCNv2" else "dnn"
@@ -89,7 +107,8 @@ def param_shapes(cfg, mode, backbone="DCNv2"):
         out[f"{tower}.dnn.{3 * i}.weight"] = ((H, d_in), d_in ** -0.5)
         out[f"{tower}.dnn.{3 * i}.bias"] = ((H,), 0.1)
         d_in = H
-    Dfin = {"DCNv2": D + (H if NL > 0 else 0), "DNN": H, "DeepFM": H + 1}[backbone]
+    if backbone != "AutoInt":
+        Dfin = {"DCNv2": D + (H if NL > 0 else 0), "DNN": H, "DeepFM": H + 1}[backbone]
     if mode == "CTR" and backbone != "DCNv2":
         head = "fc_out" if backbone == "DNN" else "dnn_fc_out"       # models.py:180, 212: Linear(H, 1)
         out[f"{head}.weight"] = ((1, H), H ** -0.5)
