@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 18
+#define MAPX_ABI_VERSION 19
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -101,6 +101,15 @@ int mapx_lr_sum_fwd(const int64_t* ids, int64_t B, int F, const float* w, int64_
 int mapx_fm_fwd(const float* x, int64_t B, int F, int E, float* out, float* s, hipStream_t stream);
 int mapx_fm_bwd(const float* g, const float* s, const float* x, int64_t B, int F, int E, float* dx,
                 hipStream_t stream);
+
+/* ------------------------------------------------------------------ AutoInt attention core
+ * layers.py:724-744 on G = B*heads groups of [F, A] (the reference's .view(B*H, -1, A) head split:
+ * group g = floats [g*F*A, (g+1)*F*A) of the projected tensors): P = softmax(Q K^T / (scaled ?
+ * sqrt(A) : 1)) [G,F,F] (kept for backward), O = P V.  F <= 64, A <= 64. */
+int mapx_attn_fwd(const float* q, const float* k, const float* v, int64_t G, int F, int A, int scaled,
+                  float* o, float* p, hipStream_t stream);
+int mapx_attn_bwd(const float* q, const float* k, const float* v, const float* p, const float* d_o,
+                  int64_t G, int F, int A, int scaled, float* dq, float* dk, float* dv, hipStream_t stream);
 
 /* ------------------------------------------------------------------ NCE sampler (a7, a8)
  * nce/alias_multinomial.py:39-72: Walker table from the renormalised noise probabilities,

@@ -382,6 +382,90 @@ class CrossNetV2(nn.Module):
         return _CrossTower.apply(x0, out, *wb)
 
 
+class _SelfAttention(Function):
+    """One AutoInt-style MultiHeadSelfAttention (reference layers.py:848-914, align_to="output"):
+    out = relu(softmax(Q K^T [/ sqrt(A)]) V [+ residual]), Q/K/V/residual = bias-free projections
+    of x [B,F,Din]; heads are the reference's .view(B*H, -1, A) chunks.  Projections and all
+    weight / input gradients are MFMA GEMMs, the F x F core is csrc/attn.hip."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv, wres, heads, attn_size, res_conn, scaled):
+        B, F, Din = x.shape
+        HA = heads * attn_size
+        x2 = x.contiguous().view(B * F, Din)
+        M = B * F
+        q = ops.gemm(x2, wq, True, True, M, HA, Din)
+        k = ops.gemm(x2, wk, True, True, M, HA, Din)
+        v = ops.gemm(x2, wv, True, True, M, HA, Din)
+        o, p = ops.attn_fwd(q, k, v, B * heads, F, attn_size, scaled)
+        if res_conn:
+            pre = ops.gemm(x2, wres, True, True, M, HA, Din, epi=ops.N.EPI_ADD, aux1=o) if wres is not None \
+                else o + x2
+        else:
+            pre = o
+        out = torch.relu(pre)
+        ctx.cfg = (B, F, Din, heads, attn_size, res_conn, scaled)
+        ctx.slots = [_grad_slot(w) if w is not None else None for w in (wq, wk, wv, wres)]
+        ctx.save_for_backward(x2, wq, wk, wv, wres, q, k, v, p, out)
+        return out.view(B, F, HA)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, wq, wk, wv, wres, q, k, v, p, out = ctx.saved_tensors
+        B, F, Din, heads, A, res_conn, scaled = ctx.cfg
+        HA = heads * A
+        dpre = ops.relu_mask(g.contiguous().view(B * F, HA), out)
+        dq, dk, dv = ops.attn_bwd(q, k, v, p, dpre, B * heads, F, A, scaled)
+        sq, sk, sv, sr = ctx.slots
+        grads = []
+        for d, slot in ((dq, sq), (dk, sk), (dv, sv)):
+            dw = ops.linear_bwd_weight(d, x2, out=slot)
+            grads.append(None if slot is not None else dw)
+        dx = ops.linear_bwd_input(dq, wq)
+        dx = ops.linear_bwd_input(dk, wk, add=dx)
+        dx = ops.linear_bwd_input(dv, wv, add=dx)
+        gres = None
+        if res_conn:
+            if wres is not None:
+                dwr = ops.linear_bwd_weight(dpre, x2, out=sr)
+                gres = None if sr is not None else dwr
+                dx = ops.linear_bwd_input(dpre, wres, add=dx)
+            else:
+                dx = dx + dpre
+        return dx.view(B, F, Din), grads[0], grads[1], grads[2], gres, None, None, None, None
+
+
+class _ProjWeight(nn.Module):
+    """`weight` [out, in] of a bias-free nn.Linear (same default initialisation)."""
+
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+
+
+class MultiHeadSelfAttention(nn.Module):
+    """Reference layers.py:848-914 restricted to what AutoInt builds (models.py:451-460):
+    layer_norm off, align_to="output", attention dropout 0."""
+
+    def __init__(self, input_dim, attention_dim, num_heads, dropout_rate=0.0, use_residual=True, use_scale=False):
+        super().__init__()
+        if dropout_rate > 0:
+            raise NotImplementedError("attn_probs_dropout_rate > 0 is not built (deterministic parity path)")
+        self.attention_dim, self.num_heads = attention_dim, num_heads
+        self.output_dim = num_heads * attention_dim
+        self.use_residual, self.use_scale = use_residual, use_scale
+        self.W_q = _ProjWeight(input_dim, self.output_dim)
+        self.W_k = _ProjWeight(input_dim, self.output_dim)
+        self.W_v = _ProjWeight(input_dim, self.output_dim)
+        self.W_res = _ProjWeight(input_dim, self.output_dim) if input_dim != self.output_dim else None
+
+    def forward(self, x):
+        return _SelfAttention.apply(x, self.W_q.weight, self.W_k.weight, self.W_v.weight,
+                                    self.W_res.weight if self.W_res is not None else None, self.num_heads,
+                                    self.attention_dim, self.use_residual, self.use_scale)
+
+
 class _JoinColumns(Function):
     """torch.cat([a, b], dim=1) when a and b were already written into their column ranges of
     `buf` (ops.alias_cols): no copy forward, two slices backward."""

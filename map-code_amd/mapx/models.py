@@ -9,14 +9,14 @@ from torch import nn
 
 from . import ops
 from .arguments import Config
-from .layers import (_JoinColumns, CrossNetV2, Embeddings, HipLinear, MLPBlock, RowTable, TableWeight,
-                     bce_with_logits, fm_product_sum)
+from .layers import (_JoinColumns, CrossNetV2, Embeddings, HipLinear, MLPBlock, MultiHeadSelfAttention,
+                     RowTable, TableWeight, bce_with_logits, fm_product_sum)
 from .nce import IndexLinear
 
 logger = logging.getLogger(__name__)
 GROUPED_ENCODER = os.environ.get("MAPX_GROUPED_ENC", "1") == "1"
 
-_OTHER_BACKBONES = ("autoint", "trans", "fignn", "fgcnn", "xdeepfm")
+_OTHER_BACKBONES = ("trans", "fignn", "fgcnn", "xdeepfm")
 
 
 class _RfdPredictor(nn.ModuleDict):
@@ -47,10 +47,12 @@ class BaseModel(nn.Module):
             return DNN(config)
         if name == "deepfm":
             return DeepFM(config)
+        if name == "autoint":
+            return AutoInt(config)
         if name in _OTHER_BACKBONES:
             raise NotImplementedError(
                 f"{config.model_name}: mapx builds the DCNv2 hot path and, of the other backbones "
-                "(SURVEY §8 f4), DNN and DeepFM")
+                "(SURVEY §8 f4), DNN, DeepFM and AutoInt")
         raise NotImplementedError(config.model_name)
 
     def validate_model_config(self):
@@ -285,3 +287,37 @@ class DeepFM(BaseModel):
             final_vec = torch.cat([dnn_vec, lr_fm], dim=1)
             return self.get_outputs(final_vec, labels, masked_index, noise_samples=noise_samples)
         return self.get_outputs(self.dnn_fc_out(dnn_vec) + lr_fm, labels)
+
+
+class AutoInt(BaseModel):
+    """Stacked multi-head self-attention over the field embeddings (reference models.py:440-488);
+    the flattened [B, F*heads*attn_size] output feeds the MFP / RFD heads or `attn_out`.
+    Built: the attention path (use_lr = False, num_dnn_layers = 0, attention dropout 0)."""
+    used_params = ["embed_size", "num_attn_layers", "attn_size", "num_attn_heads", "attn_probs_dropout_rate",
+                   "use_lr", "res_conn", "attn_scale", "dnn_size", "num_dnn_layers", "dnn_act", "dnn_drop"]
+
+    def __init__(self, config: Config):
+        super().__init__(model_name="AutoInt", config=config)
+        if not config.pretrain and (config.use_lr or config.num_dnn_layers):
+            raise NotImplementedError("AutoInt with use_lr / num_dnn_layers > 0 is not built")
+        self.embed = Embeddings(config)
+        self.embed.defer_plan = True
+        HA = config.num_attn_heads * config.attn_size
+        self.self_attention = nn.Sequential(*[
+            MultiHeadSelfAttention(config.embed_size if i == 0 else HA, attention_dim=config.attn_size,
+                                   num_heads=config.num_attn_heads, dropout_rate=config.attn_probs_dropout_rate,
+                                   use_residual=config.res_conn, use_scale=config.attn_scale)
+            for i in range(config.num_attn_layers)])
+        final_dim = config.num_fields * HA
+        if config.pretrain:
+            self.create_pretraining_predictor(final_dim)
+        else:
+            self.attn_out = HipLinear(final_dim, 1)
+
+    def forward(self, input_ids, labels=None, masked_index=None, noise_samples=None):
+        x = self.embed(input_ids)
+        attention_out = self.self_attention(x).flatten(start_dim=1)
+        self.embed.table.start_plan()
+        if self.config.pretrain:
+            return self.get_outputs(attention_out, labels, masked_index, noise_samples=noise_samples)
+        return self.get_outputs(self.attn_out(attention_out), labels)

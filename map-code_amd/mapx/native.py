@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmapx_hip.so")
 
-MAPX_ABI_VERSION = 18
+MAPX_ABI_VERSION = 19
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_CROSS, EPI_ADD, EPI_RELU_MASK = range(6)
 
 _p, _i, _i64, _u64, _f, _d, _sz = (C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double,
@@ -32,6 +32,8 @@ SIGNATURES = {
     "mapx_lr_sum_fwd": (_i, [_p, _i64, _i, _p, _i64, _p, _p, _p]),
     "mapx_fm_fwd": (_i, [_p, _i64, _i, _i, _p, _p, _p]),
     "mapx_fm_bwd": (_i, [_p, _p, _p, _i64, _i, _i, _p, _p]),
+    "mapx_attn_fwd": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p, _p, _p]),
+    "mapx_attn_bwd": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _p, _p, _p, _p]),
     "mapx_alias_build_host": (_i, [_p, _i64, _p, _p]),
     "mapx_alias_pack": (_i, [_p, _p, _i64, _p, _p]),
     "mapx_alias_draw": (_i, [_p, _i64, _p, _i64, _i, _u64, _u64, _p, _p, _p]),

@@ -308,6 +308,23 @@ def fm_bwd(g, s, x3):
     return dx
 
 
+# --------------------------------------------------------------------------- AutoInt attention core
+def attn_fwd(q, k, v, G, F, A, scaled):
+    """q, k, v: G*F*A floats each (G = B*heads groups of [F, A]) -> (o same size, p [G,F,F])."""
+    require_gpu(q, k, v)
+    o = torch.empty_like(q)
+    p = torch.empty(G, F, F, dtype=torch.float32, device=q.device)
+    check(lib.mapx_attn_fwd(ptr(q), ptr(k), ptr(v), G, F, A, int(bool(scaled)), ptr(o), ptr(p), stream()))
+    return o, p
+
+
+def attn_bwd(q, k, v, p, d_o, G, F, A, scaled):
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    check(lib.mapx_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(p), ptr(d_o.contiguous()), G, F, A, int(bool(scaled)),
+                            ptr(dq), ptr(dk), ptr(dv), stream()))
+    return dq, dk, dv
+
+
 # --------------------------------------------------------------------------- NCE
 def alias_build(probs_cpu):
     """Host Walker table, bit-identical to the reference's (alias_multinomial.py:39-72)."""

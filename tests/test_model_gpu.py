@@ -258,6 +258,11 @@ def test_other_backbones_golden(case, backbone, mode):
             from mapx.layers import fm_product_sum
             # 0.5 * sum_e((sum_f x)^2 - sum_f x^2) cancels: absolute tolerance at the scale of its two terms
             np.testing.assert_allclose(fm_product_sum(x3).detach().cpu().numpy(), z["mid/fm"], rtol=1e-5, atol=5e-6)
+        if backbone == "AutoInt":
+            x = model.embed(ids)
+            for li, layer in enumerate(model.self_attention):
+                x = layer(x)
+                np.testing.assert_allclose(x.detach().cpu().numpy(), z[f"mid/attn{li}"], rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(float(loss.detach()), float(z["out/loss"]), rtol=1e-5)
     loss.backward()
     _check_grads(z, model)

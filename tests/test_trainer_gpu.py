@@ -54,13 +54,13 @@ def _oracle_loop(mode, cfg, params, steps, case, total, warmup, kind, lr0, wd, b
         if mode == "MFP":
             logq, _, _ = R.nce_buffers(si["feat_count"])
             masked, labels = R.dynamic_mask_mfp(ids, t(si["mi"]))
-            fin = R.final_of(backbone, P, masked, cfg["NC"], cfg["NL"])
+            fin = R.final_of(backbone, P, masked, cfg["NC"], cfg["NL"], pg.AUTOINT)
             loss, _, _ = R.mfp_head(P, fin, labels, t(si["mi"]), t(si["noise"]), logq, cfg["F"], cfg["P"], cfg["K"])
         elif mode == "RFD":
             rep, labels = R.dynamic_mask_rfd(ids, t(si["mi"]), t(si["repl"]))
-            loss = R.rfd_head(P, R.final_of(backbone, P, rep, cfg["NC"], cfg["NL"]), labels)[0]
+            loss = R.rfd_head(P, R.final_of(backbone, P, rep, cfg["NC"], cfg["NL"], pg.AUTOINT), labels)[0]
         else:
-            logits = R.ctr_logits_of(backbone, P, ids, cfg["NC"], cfg["NL"])
+            logits = R.ctr_logits_of(backbone, P, ids, cfg["NC"], cfg["NL"], pg.AUTOINT)
             loss = torch.nn.functional.binary_cross_entropy_with_logits(logits.view(-1), t(si["y"]).float())
         loss.backward()
         losses.append(float(loss.detach()))
@@ -76,7 +76,8 @@ def _oracle_loop(mode, cfg, params, steps, case, total, warmup, kind, lr0, wd, b
                          [("MFP", "cosine", 0.2, "DCNv2"), ("RFD", "cosine", 0.0, "DCNv2"), ("CTR", "const", 0.0, "DCNv2"),
                           ("MFP", "cosine", 0.0, "DNN"), ("CTR", "const", 0.0, "DNN"),
                           ("MFP", "cosine", 0.2, "DeepFM"), ("RFD", "cosine", 0.0, "DeepFM"),
-                          ("CTR", "const", 0.0, "DeepFM")])
+                          ("CTR", "const", 0.0, "DeepFM"),
+                          ("MFP", "cosine", 0.0, "AutoInt"), ("CTR", "const", 0.0, "AutoInt")])
 def test_training_trajectory_matches_reference_semantics(mode, kind, warm, backbone):
     from mapx import ops
     from mapx.optim import MapxOptimizer
@@ -120,7 +121,7 @@ def test_training_trajectory_matches_reference_semantics(mode, kind, warm, backb
         model.eval()
         with torch.no_grad():
             (logits,) = model(input_ids=t(held["ids"], DEV))
-            ref_logits = R.ctr_logits_of(backbone, ref_params, t(held["ids"]), cfg["NC"], cfg["NL"])
+            ref_logits = R.ctr_logits_of(backbone, ref_params, t(held["ids"]), cfg["NC"], cfg["NL"], pg.AUTOINT)
         y = held["y"]
         auc = roc_auc_score(y, torch.sigmoid(logits.view(-1)).cpu().numpy())
         auc_ref = roc_auc_score(y, torch.sigmoid(ref_logits.view(-1)).numpy())
