@@ -188,10 +188,13 @@ __device__ inline void epilogue_band(const GemmArgs& a, float* __restrict__ C, f
       // clamped, always-valid addresses: the loads carry no predicate (values of dead lanes are unused)
       uint32_t n = (uint32_t)(nbase + 32 * j + l31);
       n = (int)n < a.N ? n : (uint32_t)(a.N - 1);
-      const uint32_t o1 = mrow * ld1 + n, o2 = mrow * ld2 + n;
+      // lanes of the upper half-wave start 4 rows lower: in a partial band their first row may
+      // already be outside the matrix, so the load base is clamped as well (stores are guarded)
+      const uint32_t mload = (ROWS_OK || (int)mrow < a.M) ? mrow : (uint32_t)(a.M - 1);
+      const uint32_t o1 = mload * ld1 + n, o2 = mload * ld2 + n;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const uint32_t dr = ROWS_OK ? MAPX_ROW(r) : ((int)(mrow + MAPX_ROW(r)) < a.M ? MAPX_ROW(r) : 0u);
+        const uint32_t dr = ROWS_OK ? MAPX_ROW(r) : ((int)(mrow + MAPX_ROW(r)) < a.M ? MAPX_ROW(r) : 0u);   // mrow >= M: 0
         x1[j][r] = aux1[o1 + dr * ld1];
         if (kAux2) x2[j][r] = aux2[o2 + dr * ld2];
       }
