@@ -215,6 +215,11 @@ def main():
     for _ in range(args.preroll + args.warmup):
         mfp_step(tr, *next_batch())
     staged = [next_batch() for _ in range(args.steps)]      # inputs resident before the clock starts
+    graphed = [g for g in tr._graphs.values() if hasattr(g, "host_s")]
+    for g in graphed:
+        g.host_s = [0.0] * len(g.host_s)
+        g.poll_s = 0.0
+    captures0 = sum(g.captures for g in graphed)
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -223,6 +228,14 @@ def main():
     parallel.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    dp_info = None
+    if graphed:     # host-side phases of the data-parallel step (this rank), microseconds per step
+        names = ("launch", "counts", "tail_capture", "dense_allreduce", "tail")
+        dp_info = {"host_us_per_step": {n: round(1e6 * sum(g.host_s[i] for g in graphed) / args.steps, 1)
+                                        for i, n in enumerate(names)},
+                   "poll_us_per_step": round(1e6 * sum(g.poll_s for g in graphed) / args.steps, 1),
+                   "tail_captures_in_timed_region": sum(g.captures for g in graphed) - captures0,
+                   "message_sizes": sorted({sz for g in graphed for sz in g.tails})}
     if world > 1:                                       # the slowest rank sets the time
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -283,7 +296,7 @@ def main():
                                f"V={cfg.input_size}, E=16, H=1000x3, cross x3, P=32, K=25, mask_ratio 0.3",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "launch": ("eager" if not tr.use_graph else
-                              "hipGraph replay of mask + forward + backward, exchange and optimizer eager"
+                              "hipGraph replay of mask + forward + backward; pack and merge + optimizer replayed per message size, RCCL calls eager"
                               if dp_path else "hipGraph replay of the whole step"),
                    "table_optimizer": "row-sparse AdamW with lazy replay of untouched rows, "
                                       + f"{args.preroll} untimed pre-roll steps"},
@@ -291,6 +304,8 @@ def main():
         "roofline_hbm": dict(kernel=hbm_name, **{k: kernels[hbm_name][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}),
         "kernels": kernels, "final_loss": final_loss,
     }
+    if dp_info:
+        out["dp"] = dp_info
     if world == 1 and not args.no_cpu_baseline:
         del tr
         torch.cuda.empty_cache()

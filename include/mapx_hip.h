@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 19
+#define MAPX_ABI_VERSION 21
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -91,6 +91,18 @@ int mapx_seg_reduce_rows_extra(int64_t n, const int32_t* perm, const int32_t* ra
 int mapx_pack_sparse(const int32_t* uniq, const float* rows0, int W0, const float* rows1_opt,
                      const int32_t* n_uniq, int64_t cap, int64_t maxc, float scale, int32_t pad_id,
                      int32_t* keys_out, float* rows_out, hipStream_t stream);
+/* Publishes n (<= 64) int32 device values to host-visible pinned memory from inside a stream /
+ * captured graph, so that the host can read them before the rest of the stream has run (the
+ * data-parallel step reads its segment counts while forward/backward still execute):
+ * ++*stamp_dev; host_out[0..n) = src[0..n); host_out[n] = *stamp_dev; host_out[n+1] = sum of the
+ * n+1 values before it (checked by the reader against torn reads). */
+int mapx_publish_i32(const int32_t* src, int n, int32_t* stamp_dev, int32_t* host_out,
+                     hipStream_t stream);
+/* Host memory for mapx_publish_i32's `host_out`: fine-grained (coherent) pinned memory, so a
+ * kernel's store is visible to the polling host at once — ordinary pinned memory is only
+ * guaranteed to be coherent at stream synchronisation points, i.e. when the graph has ended. */
+int mapx_host_alloc_coherent(size_t bytes, void** out);
+int mapx_host_free(void* p);
 
 /* ------------------------------------------------------------------ DeepFM terms
  * LR  (models.py:129-143): out[b] = sum_f w[ids[b,f]]  (bias added by the caller).

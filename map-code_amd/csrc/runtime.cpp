@@ -1,6 +1,7 @@
 // Library-wide state of libmapx_hip.so: the thread-local error string behind
 // mapx_last_error(), the ABI version, and the host-side Walker alias table builder.
 #include <stdarg.h>
+#include <string.h>
 
 #include <vector>
 
@@ -21,6 +22,18 @@ void set_error(const char* fmt, ...) {
 extern "C" const char* mapx_last_error(void) { return mapx::g_err; }
 
 extern "C" int mapx_abi_version(void) { return MAPX_ABI_VERSION; }
+
+extern "C" int mapx_host_alloc_coherent(size_t bytes, void** out) {
+  MAPX_REQUIRE(out && bytes > 0, "host_alloc_coherent: bad arguments");
+  MAPX_HIP(hipHostMalloc(out, bytes, hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable));
+  memset(*out, 0, bytes);
+  return MAPX_OK;
+}
+
+extern "C" int mapx_host_free(void* p) {
+  if (p) MAPX_HIP(hipHostFree(p));
+  return MAPX_OK;
+}
 
 // Walker alias table for the NCE noise distribution.  Replaces the pure-Python O(V) loop
 // of reference code/nce/alias_multinomial.py:39-72 (minutes at V = 9.4 M) with the same

@@ -258,6 +258,21 @@ __global__ void __launch_bounds__(256) pack_sparse_kernel(const int32_t* __restr
     if (c == 0) keys_out[i] = live ? uniq[i] : pad_id;
   }
 }
+__global__ void __launch_bounds__(64) publish_i32_kernel(const int32_t* __restrict__ src, int n,
+                                                         int32_t* __restrict__ stamp,
+                                                         volatile int32_t* __restrict__ host_out) {
+  const int lane = threadIdx.x;
+  int v = lane < n ? src[lane] : 0;
+  if (lane < n) host_out[lane] = v;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+  __threadfence_system();
+  if (lane == 0) {
+    const int s = *stamp + 1;
+    *stamp = s;
+    __hip_atomic_store((int32_t*)host_out + n + 1, v + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store((int32_t*)host_out + n, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
 }  // namespace mapx
 
 extern "C" int mapx_pack_sparse(const int32_t* uniq, const float* rows0, int W0, const float* rows1_opt,
@@ -270,4 +285,12 @@ extern "C" int mapx_pack_sparse(const int32_t* uniq, const float* rows0, int W0,
   hipLaunchKernelGGL(mapx::pack_sparse_kernel, dim3(mapx::grid_for(maxc * (Wp / 4), 256)), dim3(256), 0, stream,
                      uniq, rows0, W0, rows1_opt, n_uniq, cap, maxc, scale, pad_id, keys_out, rows_out);
   return mapx::check_launch("pack_sparse");
+}
+
+extern "C" int mapx_publish_i32(const int32_t* src, int n, int32_t* stamp_dev, int32_t* host_out,
+                                hipStream_t stream) {
+  MAPX_REQUIRE(src && stamp_dev && host_out, "publish_i32: null pointer");
+  MAPX_REQUIRE(n >= 0 && n <= 64, "publish_i32: n must be in [0, 64]");
+  hipLaunchKernelGGL(mapx::publish_i32_kernel, dim3(1), dim3(64), 0, stream, src, n, stamp_dev, host_out);
+  return mapx::check_launch("publish_i32");
 }

@@ -71,13 +71,19 @@ class RowTable:
             r1 = r1[keep] if r1 is not None else None
         else:
             U = plan.count()
-            uniq, r0 = plan.uniq[:U].long(), r0[:U]
-            r1 = r1[:U] if r1 is not None else None
+            keep = plan.uniq[:U] >= 0                # a merged list ends with the -1 padding run
+            uniq, r0 = plan.uniq[:U][keep].long(), r0[:U][keep]
+            r1 = r1[:U][keep] if r1 is not None else None
         g0 = torch.zeros_like(self.p0).index_copy_(0, uniq, r0)
         g1 = None
         if self.p1 is not None:
             g1 = torch.zeros_like(self.p1).index_copy_(0, uniq, r1.unsqueeze(1))
         return g0, g1
+
+
+# callables (table, plan) run on the plan stream right after a table's plan has been enqueued
+# (trainer.GraphedBackward publishes the plan's unique-row count to the host from there)
+plan_observers = []
 
 
 class PlanSlot:
@@ -104,6 +110,8 @@ class PlanSlot:
         forked = ops.stream_wait_event(side, self.ready, self.origin)
         with torch.cuda.stream(side):
             self.value = ops.SegPlan(keys, self.table.num_rows)
+            for observe in plan_observers:
+                observe(self.table, self.value)
         if forked:
             keys.record_stream(side)
             for t in self.value.tensors():

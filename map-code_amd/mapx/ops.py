@@ -276,6 +276,41 @@ def pack_sparse(plan, rows0, rows1, maxc, scale, pad_id=0):
     return keys, rows
 
 
+class HostMailbox:
+    """`n` int32 words of fine-grained pinned host memory that a kernel can store into and the host
+    can poll while the stream is still running (mapx_host_alloc_coherent): `.np` is the numpy
+    view, `.address(i)` the address of word i for the kernel."""
+
+    def __init__(self, n):
+        import ctypes
+        import numpy as np
+        p = ctypes.c_void_p()
+        check(lib.mapx_host_alloc_coherent(4 * n, ctypes.byref(p)))
+        self._p, self.n = p.value, n
+        self.np = np.ctypeslib.as_array((ctypes.c_int32 * n).from_address(p.value))
+
+    def address(self, i=0):
+        return self._p + 4 * i
+
+    def __del__(self):
+        p, self._p = getattr(self, "_p", None), None
+        if p and lib is not None:
+            self.np = None
+            lib.mapx_host_free(p)
+
+
+def publish_i32(src, n, stamp_dev, mailbox, at=0):
+    """++stamp; mailbox[at : at+n] = src[:n] (int32, device); mailbox[at+n] = stamp;
+    mailbox[at+n+1] = checksum.  A kernel that stores straight into coherent host memory: usable
+    from inside a captured graph, readable by the host before the graph ends (mapx_publish_i32)."""
+    require_gpu(src, stamp_dev)
+    if src.dtype != torch.int32 or stamp_dev.dtype != torch.int32:
+        raise ValueError("publish_i32 moves int32 values")
+    if at < 0 or at + n + 2 > mailbox.n:
+        raise ValueError("publish_i32 needs n + 2 words of mailbox")
+    check(lib.mapx_publish_i32(ptr(src), n, ptr(stamp_dev), mailbox.address(at), stream()))
+
+
 # --------------------------------------------------------------------------- DeepFM terms
 def lr_sum(ids, w, validate=False):
     """out[b] = sum_f w[ids[b,f]]   (reference models.py:137-140, before the bias)."""

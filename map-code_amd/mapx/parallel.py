@@ -8,7 +8,7 @@ forward/backward on its own `per_gpu_train_batch_size` rows with its own masks/n
 
   * dense gradients: ONE all-reduce(sum) per flat group (~15 MB fp32 at Avazu-MFP), / world;
   * table gradients: each rank's deduplicated (row id, gradient row) list is all-gathered
-    (padded to the largest rank's count with zero rows on id 0), merged by the same
+    (padded to the largest rank's count with zero rows on id -1, which nothing applies), merged by the same
     deterministic reduce-by-key as the local gradient (csrc/segreduce.h), / world.  The
     largest counts of all tables travel in one MAX all-reduce: one host sync per step.
 
@@ -48,6 +48,9 @@ def allreduce_mean_(flat):
     if not exchanging():
         return flat
     s = _staged(flat)
+    if dist.get_backend() == "nccl":            # RCCL averages in the collective: no extra pass over the bucket
+        dist.all_reduce(s, op=dist.ReduceOp.AVG)
+        return flat
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     s.div_(world())
     if s is not flat:
@@ -87,24 +90,60 @@ def hip_merge(keys, rows, num_rows):
     return plan, ops.seg_reduce_rows(plan, rows, rows.shape[1])
 
 
-def _sync_table_grad_hip(table, maxc):
-    """The gather exchange on device tensors with the fewest launches: one pack kernel (scale by
-    1/world folded in), two all-gathers, one plan, one reduction that splits rows / scalar again."""
+# The gather exchange of one table on device tensors, in the three pieces a captured tail needs
+# (trainer.GraphedExchangeTail): pack (one kernel, 1/world folded in) | two all-gathers | merge
+# (one plan, one reduction that splits rows / scalar again).
+def pack_table(table, maxc):
     from . import ops
     plan, r0, r1 = table.sparse_grad
-    w, dev, W0 = world(), r0.device, r0.shape[1]
-    keys, rows = ops.pack_sparse(plan, r0, r1, maxc, 1.0 / w)
-    k_all = torch.empty(w * maxc, dtype=torch.int32, device=_staged(keys).device)
-    r_all = torch.empty(w * maxc, rows.shape[1], dtype=torch.float32, device=_staged(rows).device)
+    return ops.pack_sparse(plan, r0, r1, maxc, 1.0 / world(), pad_id=-1)
+
+
+def gather_buffers(keys, rows):
+    w = world()
+    return (torch.empty(w * keys.shape[0], dtype=torch.int32, device=_staged(keys).device),
+            torch.empty(w * rows.shape[0], rows.shape[1], dtype=torch.float32, device=_staged(rows).device))
+
+
+def all_gather_table(keys, rows, k_all, r_all):
     dist.all_gather_into_tensor(k_all, _staged(keys))
     dist.all_gather_into_tensor(r_all, _staged(rows))
-    k_all, r_all = k_all.to(dev), r_all.to(dev)
-    mplan = ops.SegPlan(k_all, table.num_rows)
+
+
+def all_gather_tables(msgs, gathered):
+    """The (keys, rows) messages of all tables in ONE grouped RCCL launch (keys travel as raw
+    32-bit words) instead of two collectives per table; plain calls on other backends."""
+    if dist.get_backend() != "nccl":
+        for (k, r), (k_all, r_all) in zip(msgs, gathered):
+            all_gather_table(k, r, k_all, r_all)
+        return
+    ins = [t for k, r in msgs for t in (k.view(torch.float32), r.view(-1))]
+    outs = [t for k, r in gathered for t in (k.view(torch.float32), r.view(-1))]
+    work = dist.group.WORLD.allgather_into_tensor_coalesced(outs, ins)
+    if work is not None:
+        work.wait()                 # stream-level: the current stream waits for the RCCL stream
+
+
+def merge_table(table, k_all, r_all):
+    from . import ops
+    _, r0, r1 = table.sparse_grad
+    W0 = r0.shape[1]
+    # padding entries carry id -1: with one more key bit than the table needs they sort behind
+    # every real id as one run of zero rows, which the table optimizer skips (negative id)
+    mplan = ops.SegPlan(k_all, table.num_rows + 1)
     if r1 is not None:
         m0, m1 = ops.seg_reduce_rows_extra(mplan, r_all, W0, r_all[:, W0], 1, extra_stride=r_all.stride(0))
     else:
         m0, m1 = ops.seg_reduce_rows(mplan, r_all, W0), None
     table.sparse_grad = (mplan, m0, m1)
+
+
+def _sync_table_grad_hip(table, maxc):
+    dev = table.sparse_grad[1].device
+    keys, rows = pack_table(table, maxc)
+    k_all, r_all = gather_buffers(keys, rows)
+    all_gather_table(keys, rows, k_all, r_all)
+    merge_table(table, k_all.to(dev), r_all.to(dev))
 
 
 def sync_table_grad(table, maxc, merge_fn=hip_merge):
@@ -231,23 +270,47 @@ def exchange_owner(tables, merge_fn=hip_merge):
             tb.sparse_grad = (gplan, r_all, None)
 
 
-def sync_gradients(optimizer, merge_fn=hip_merge):
-    """Call between backward() and optimizer.step()."""
-    if not exchanging():
-        return
+def sync_dense(optimizer):
+    """Mean over ranks of the dense gradients: one all-reduce per flat group."""
     from . import ops
     optimizer.collect_torch_grads()
     ops.flush_deferred()                # dense gradients must be final before the all-reduce
+    if exchanging() and dist.get_backend() == "nccl" and len(optimizer.groups) > 1:
+        opts = dist.AllreduceCoalescedOptions()
+        opts.reduceOp = dist.ReduceOp.AVG
+        work = dist.group.WORLD.allreduce_coalesced([g["g"] for g in optimizer.groups], opts)
+        if work is not None:
+            work.wait()
+        return
     for g in optimizer.groups:
         allreduce_mean_(g["g"])
+
+
+def message_size(maxc):
+    """Exchange message length for a largest count of `maxc`: rounded up to 1/16 of its power of
+    two (<= 6 % padding), so that a run sees a handful of distinct sizes and the tail of the step
+    can be replayed from a graph captured per size (trainer.GraphedExchangeTail).  Padding
+    entries are zero rows on id -1, like the entries that level a rank up to the largest count."""
+    g = max(256, (1 << max(0, int(maxc).bit_length() - 1)) >> 4)
+    return -(-int(maxc) // g) * g
+
+
+def sync_gradients(optimizer, merge_fn=hip_merge, known_max=None):
+    """Call between backward() and optimizer.step().  `known_max`: the tables' largest
+    unique-row counts over the ranks when the caller already has them (trainer.GraphedBackward
+    fetches them while backward still runs); otherwise one MAX all-reduce + host sync here."""
+    if not exchanging():
+        return
+    sync_dense(optimizer)
     tabs = [t.table for t in optimizer.tables if t.table.sparse_grad is not None]
     if not tabs:
         return
     if EXCHANGE == "owner":
         exchange_owner(tabs, merge_fn)
         return
-    counts = torch.stack([tb.sparse_grad[0].n_uniq[0] for tb in tabs]).to(torch.int64)
-    for tb, maxc in zip(tabs, max_counts(counts)):
+    if known_max is None:
+        known_max = max_counts(torch.stack([tb.sparse_grad[0].n_uniq[0] for tb in tabs]).to(torch.int64))
+    for tb, maxc in zip(tabs, known_max):
         sync_table_grad(tb, maxc, merge_fn)
 
 

@@ -87,25 +87,154 @@ class GraphedBackward:
     exchange (host-side sizes) and the optimizer run eagerly after each replay.  The graph leaves
     the dense gradients in the optimizer's flat buffers and the tables' sparse gradients in
     buffers of fixed address; the Python references to them (cleared by optimizer.step()) are
-    put back after every replay."""
+    put back after every replay.
+
+    The exchange needs one host-side number per table: the largest unique-row count over the
+    ranks.  A count exists as soon as the table's segment plan does — it depends on the step's
+    ids, not on any gradient — so during capture a tiny kernel right behind each plan stores the
+    count, stamped with the replay number, straight into pinned memory (mapx_publish_i32; a
+    node appended at the end of the capture would also run at the end of the replay).  The host
+    picks the counts up while forward/backward still run, takes the MAX over ranks on a side
+    stream, and enqueues the whole exchange + optimizer tail behind the graph before the graph
+    has finished: the GPU does not wait for Python between the last backward kernel and the
+    optimizer."""
+
+    MAX_TAILS = 12
 
     def __init__(self, trainer, fwd_bwd_fn, X, Y):
+        from . import layers
         self.trainer = trainer
         self.X, self.Y = X.clone(), Y.clone()
+        self.early = parallel.exchanging() and parallel.EXCHANGE == "gather" and X.is_cuda
+        self.replays = 0
+        self.tails, self.captures, self.poll_s = {}, 0, 0.0
+        self.host_s = [0.0] * 5         # launch | counts | tail capture | dense all-reduce | tail
+        tables = [t.table for t in trainer.optimizer.tables]
+        if self.early:                  # nothing below may be allocated while a stream is capturing
+            self.stamps = torch.zeros(len(tables), dtype=torch.int32, device=X.device)
+            self.mailbox = ops.HostMailbox(4 * len(tables))                 # per table [count, stamp, check, -]
+            self.pinned_np = self.mailbox.np.reshape(len(tables), 4)
+            self.staging = torch.zeros(len(tables), dtype=torch.int64).pin_memory()
+            self.counts_dev = torch.zeros(len(tables), dtype=torch.int64, device=X.device)
+            self.comm = ops.aux_stream("counts", X.device)
+            self.published = []
+
+            def publish(table, plan):
+                i = next(k for k, tb in enumerate(tables) if tb is table)
+                ops.publish_i32(plan.n_uniq, 1, self.stamps[i:i + 1], self.mailbox, at=4 * i)
+                self.published.append(i)
+            layers.plan_observers.append(publish)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = fwd_bwd_fn(self.X, self.Y)
+        try:
+            with torch.cuda.graph(self.graph):
+                self.out = fwd_bwd_fn(self.X, self.Y)
+        finally:
+            if self.early:
+                layers.plan_observers.remove(publish)
         self.sparse = [t.table.sparse_grad for t in trainer.optimizer.tables]
+        if self.early:
+            with_grad = [i for i, tb in enumerate(tables) if tb.sparse_grad is not None]
+            if sorted(self.published) != with_grad:
+                raise RuntimeError(f"tables with a gradient {with_grad} != tables that published a count {self.published}")
+            self.published = with_grad
+
+    def _max_counts(self):
+        """Spin until this replay's counts have landed, then MAX over ranks on a side stream (the
+        main stream is still busy with the graph)."""
+        a, t0 = self.pinned_np, time.perf_counter()
+        for i in self.published:
+            while not (int(a[i, 1]) == self.replays and int(a[i, 0]) + int(a[i, 1]) == int(a[i, 2])):
+                if time.perf_counter() - t0 > 60.0:
+                    raise RuntimeError("the step graph did not publish its segment counts within 60 s")
+        self.poll_s += time.perf_counter() - t0
+        T = len(self.published)
+        for k, i in enumerate(self.published):
+            self.staging[k] = int(a[i, 0])
+        with torch.cuda.stream(self.comm):
+            self.counts_dev[:T].copy_(self.staging[:T], non_blocking=True)
+            return parallel.max_counts(self.counts_dev[:T])
 
     def __call__(self, X, Y):
+        t = [time.perf_counter()]
         self.X.copy_(X)
         self.Y.copy_(Y)
         self.graph.replay()
-        for t, sg in zip(self.trainer.optimizer.tables, self.sparse):
-            t.table.sparse_grad = sg
-        self.trainer._optimizer_step()
+        self.replays += 1
+        for tb, sg in zip(self.trainer.optimizer.tables, self.sparse):
+            tb.table.sparse_grad = sg
+        if not (self.early and self.published):
+            self.trainer._optimizer_step()
+            return self.out
+        t.append(time.perf_counter())
+        sizes = tuple(parallel.message_size(m) for m in self._max_counts())
+        t.append(time.perf_counter())
+        tail = self.tails.get(sizes)
+        if tail is None:
+            if len(self.tails) >= self.MAX_TAILS:       # sizes drifted: drop the oldest capture
+                self.tails.pop(next(iter(self.tails)))
+            tables = [self.trainer.optimizer.tables[i].table for i in self.published]
+            tail = self.tails[sizes] = GraphedExchangeTail(self.trainer, tables, sizes)
+            self.captures += 1
+        t.append(time.perf_counter())
+        parallel.sync_dense(self.trainer.optimizer)
+        t.append(time.perf_counter())
+        tail()
+        self.trainer.global_step += 1
+        t.append(time.perf_counter())
+        for k in range(5):                              # host seconds per phase (diagnostics: bench.py --verbose)
+            self.host_s[k] += t[k + 1] - t[k]
         return self.out
+
+
+class GraphedExchangeTail:
+    """Everything between the last backward kernel and the next step, for ONE tuple of exchange
+    message sizes: graph 1 packs every table's (id, row) message; the all-gathers run eagerly
+    (RCCL calls stay outside the captures); graph 2 merges the gathered lists and applies the
+    optimizer.  ~45 launches and as many tensor allocations cost two graph launches and 2 RCCL
+    calls per table, which the host issues while backward is still running."""
+
+    def __init__(self, trainer, tables, sizes):
+        self.trainer, self.tables, self.sizes = trainer, tables, sizes
+        opt = trainer.optimizer
+        saved = [tb.sparse_grad for tb in tables]
+        torch.cuda.synchronize()
+        self.pack = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.pack):
+            self.msgs = [parallel.pack_table(tb, m) for tb, m in zip(tables, sizes)]
+        self.gathered = [parallel.gather_buffers(k, r) for k, r in self.msgs]
+        self.merge = torch.cuda.CUDAGraph()
+        sd = opt.steps_done
+        try:
+            with torch.cuda.graph(self.merge):
+                # the tables' merges are independent chains of small kernels: one branch each
+                # (largest message on the capture stream), joined before the optimizer
+                main = torch.cuda.current_stream()
+                order = sorted(range(len(tables)), key=lambda i: -sizes[i])
+                side = [ops.aux_stream(f"merge{j}", self.gathered[0][1].device) for j in range(len(order) - 1)]
+                for st in side:
+                    ops.stream_wait(st, main)
+                for j, i in enumerate(order):
+                    with torch.cuda.stream(main if j == 0 else side[j - 1]):
+                        parallel.merge_table(tables[i], *self.gathered[i])
+                for st in side:
+                    ops.stream_wait(main, st)
+                opt.step()
+        finally:
+            opt.steps_done = sd                         # the capture ran the bookkeeping but no kernel
+            for tb, sg in zip(tables, saved):
+                tb.sparse_grad = sg
+
+    def __call__(self):
+        opt = self.trainer.optimizer
+        self.pack.replay()
+        parallel.all_gather_tables(self.msgs, self.gathered)
+        self.merge.replay()
+        opt.steps_done += 1
+        for t in opt.tables:
+            if t.table.sparse_grad is not None:
+                t.table.sparse_grad = None
+                t.stale = True
 
 
 class Trainer:
@@ -166,8 +295,8 @@ class Trainer:
         self.global_step, self.eval_metrics = 0, []
         return train
 
-    def _optimizer_step(self):
-        parallel.sync_gradients(self.optimizer)
+    def _optimizer_step(self, max_counts=None):
+        parallel.sync_gradients(self.optimizer, known_max=max_counts)
         self.optimizer.step()                                # + scheduler.step() + zero_grad()
         self.global_step += 1
 

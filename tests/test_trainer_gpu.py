@@ -235,6 +235,26 @@ def test_data_parallel_two_ranks_equal_single_process(tmp_path):
         np.testing.assert_allclose(b0[k].numpy(), a[k].numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
 
 
+def test_one_rank_rccl_exchange_equals_plain_step(tmp_path):
+    """The N-rank gradient exchange rehearsed on one GPU (one-rank RCCL group, MAPX_FORCE_DP=1):
+    dense all-reduce, early segment counts published by the graph, MAX over ranks, pack,
+    all-gathers, merge.  With one rank the exchange is the identity, so parameters must equal the
+    plain single-GPU run bit for bit — through the captured graph (GraphedBackward) and eagerly."""
+    worker = os.path.join(ROOT, "tests", "dp_rehearsal_worker.py")
+    base = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "map-code_amd"),
+                                                         os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]))
+    outs = {}
+    for name, forced, mode in (("plain", "0", "eager"), ("dp_eager", "1", "eager"), ("dp_graph", "1", "graph")):
+        path = str(tmp_path / f"{name}.pt")
+        r = subprocess.run([sys.executable, worker, path, mode], env=dict(base, MAPX_FORCE_DP=forced),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (name, r.stderr[-3000:])
+        outs[name] = torch.load(path)
+    for k in outs["plain"]:
+        assert torch.equal(outs["plain"][k], outs["dp_eager"][k]), ("eager exchange", k)
+        assert torch.equal(outs["plain"][k], outs["dp_graph"][k]), ("graphed exchange", k)
+
+
 @pytest.mark.parametrize("max_grad_norm,backbone", [(0.0, "DCNv2"), (0.5, "DCNv2"), (0.0, "DeepFM")])
 def test_graph_replay_equals_eager_bitwise(max_grad_norm, backbone):
     """The captured-hipGraph step and the eager step draw the same Philox streams (device-side
