@@ -192,7 +192,8 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("MAPX_DIST_BACKEND", "nccl")     # "nccl" = RCCL over xGMI
         if backend == "nccl":
-            torch.distributed.init_process_group(backend="nccl", device_id=device)
+            from mapx import parallel as _par
+            _par.init_rccl(device)
         else:
             torch.distributed.init_process_group(backend=backend)
     from mapx import ops, parallel

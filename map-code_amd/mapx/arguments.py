@@ -146,7 +146,8 @@ class TrainingArguments(_Bag):
                 self.local_rank = int(os.environ.get("RANK", "0"))
                 torch.cuda.set_device(max(lr, 0))
                 if not torch.distributed.is_initialized():
-                    torch.distributed.init_process_group(backend="nccl")
+                    from . import parallel
+                    parallel.init_rccl()
             self._device = torch.device("cuda", max(lr, 0))
         return self._device
 

@@ -23,6 +23,7 @@ def native_byref(x):
     return ctypes.byref(x)
 
 _scratch = {}
+_scratch_retired = []
 
 # --------------------------------------------------------------------------- live kernel timing
 # bench.py brackets kernel classes with HIP events on the launch stream (torch's current
@@ -87,13 +88,15 @@ _aux_streams = {}
 serialize_streams = os.environ.get("MAPX_SERIAL", "0") == "1"
 
 
-def aux_stream(name, device):
+def aux_stream(name, device, high=False):
+    """Named side stream; `high`: high priority, i.e. hardware queues of its own class (work on it
+    does not wait behind packets of normal-priority streams that happen to share a queue)."""
     if serialize_streams:
         return torch.cuda.current_stream()
     key = (name, device.index)
     st = _aux_streams.get(key)
     if st is None:
-        st = _aux_streams[key] = torch.cuda.Stream(device=device)
+        st = _aux_streams[key] = torch.cuda.Stream(device=device, priority=-1 if high else 0)
     return st
 
 
@@ -161,6 +164,8 @@ def scratch(nbytes, device):
     key = (device.index, stream())
     buf = _scratch.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _scratch_retired.append(buf)    # a captured graph may have the old address baked in: never free it
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _scratch[key] = buf
     return buf

@@ -177,9 +177,7 @@ class MapxOptimizer:
         ops.flush_deferred()            # split-K slabs / colsum partials of this backward pass
         if self.max_grad_norm > 0:
             self.clip_grad_norm_()
-        b1, b2, eps = self.hyper
-        for g in self.groups:
-            ops.adamw_dense(g["p"], g["g"], g["m"], g["v"], self.sched, self.done, b1, b2, eps, g["wd"])
+        self._dense_update()
         for t in self.tables:
             t.update()
         ops.step_advance(self.done)
@@ -187,6 +185,11 @@ class MapxOptimizer:
         for t in self.tables:
             t.sweep_some()
         self.zero_grad()
+
+    def _dense_update(self):
+        b1, b2, eps = self.hyper
+        for g in self.groups:
+            ops.adamw_dense(g["p"], g["g"], g["m"], g["v"], self.sched, self.done, b1, b2, eps, g["wd"])
 
     def zero_grad(self):
         """Dense gradients are overwritten by the next backward (see layers._grad_slot); only

@@ -22,6 +22,17 @@ import torch
 import torch.distributed as dist
 
 
+def init_rccl(device=None):
+    """init_process_group("nccl").  MAPX_NCCL_PRIO=1 puts RCCL's stream at high priority (hardware
+    queues of their own class); measured on the one-rank rehearsal it costs 0.3-0.5 ms per step —
+    a high-priority queue pre-empts the step's GEMM waves — so the default is normal priority."""
+    kw = {"device_id": device} if device is not None else {}
+    if os.environ.get("MAPX_NCCL_PRIO", "0") == "1":
+        from torch.distributed import ProcessGroupNCCL
+        kw["pg_options"] = ProcessGroupNCCL.Options(is_high_priority_stream=True)
+    dist.init_process_group(backend="nccl", **kw)
+
+
 def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 

@@ -83,21 +83,20 @@ class GraphedStep:
 
 
 class GraphedBackward:
-    """Data-parallel steps: mask -> forward -> backward captured in a hipGraph, the gradient
-    exchange (host-side sizes) and the optimizer run eagerly after each replay.  The graph leaves
-    the dense gradients in the optimizer's flat buffers and the tables' sparse gradients in
-    buffers of fixed address; the Python references to them (cleared by optimizer.step()) are
+    """Data-parallel steps (and steps with gradient clipping): mask -> forward -> backward
+    captured in a hipGraph, the gradient exchange and the optimizer after each replay.  The graph
+    leaves the dense gradients in the optimizer's flat buffers and the tables' sparse gradients
+    in buffers of fixed address; the Python references to them (cleared by optimizer.step()) are
     put back after every replay.
 
-    The exchange needs one host-side number per table: the largest unique-row count over the
-    ranks.  A count exists as soon as the table's segment plan does — it depends on the step's
-    ids, not on any gradient — so during capture a tiny kernel right behind each plan stores the
-    count, stamped with the replay number, straight into pinned memory (mapx_publish_i32; a
-    node appended at the end of the capture would also run at the end of the replay).  The host
-    picks the counts up while forward/backward still run, takes the MAX over ranks on a side
-    stream, and enqueues the whole exchange + optimizer tail behind the graph before the graph
-    has finished: the GPU does not wait for Python between the last backward kernel and the
-    optimizer."""
+    Exchange sizes.  The exchange needs one host-side number per table: the largest unique-row
+    count over the ranks.  A count exists as soon as the table's segment plan does — it depends
+    on the step's ids, not on any gradient — so during capture a tiny kernel right behind each
+    plan stores the count, stamped with the replay number, straight into coherent host memory
+    (mapx_publish_i32; a node appended at the end of the capture would also run at the end of
+    the replay).  The host picks the counts up while forward/backward still run, takes the MAX
+    over ranks on a side stream, and enqueues the exchange + optimizer tail
+    (GraphedExchangeTail) behind the graph before it has finished."""
 
     MAX_TAILS = 12
 
@@ -116,7 +115,7 @@ class GraphedBackward:
             self.pinned_np = self.mailbox.np.reshape(len(tables), 4)
             self.staging = torch.zeros(len(tables), dtype=torch.int64).pin_memory()
             self.counts_dev = torch.zeros(len(tables), dtype=torch.int64, device=X.device)
-            self.comm = ops.aux_stream("counts", X.device)
+            self.comm = ops.aux_stream("counts", X.device, high=True)
             self.published = []
 
             def publish(table, plan):
@@ -132,7 +131,7 @@ class GraphedBackward:
         finally:
             if self.early:
                 layers.plan_observers.remove(publish)
-        self.sparse = [t.table.sparse_grad for t in trainer.optimizer.tables]
+        self.sparse = [tb.sparse_grad for tb in tables]
         if self.early:
             with_grad = [i for i, tb in enumerate(tables) if tb.sparse_grad is not None]
             if sorted(self.published) != with_grad:
@@ -177,25 +176,24 @@ class GraphedBackward:
             tail = self.tails[sizes] = GraphedExchangeTail(self.trainer, tables, sizes)
             self.captures += 1
         t.append(time.perf_counter())
-        parallel.sync_dense(self.trainer.optimizer)
-        t.append(time.perf_counter())
-        tail()
+        tail(self.host_s)
         self.trainer.global_step += 1
         t.append(time.perf_counter())
-        for k in range(5):                              # host seconds per phase (diagnostics: bench.py --verbose)
-            self.host_s[k] += t[k + 1] - t[k]
+        for k, j in enumerate((0, 1, 2, 4)):            # host seconds per phase (bench.py reports them)
+            self.host_s[j] += t[k + 1] - t[k]
         return self.out
 
 
 class GraphedExchangeTail:
     """Everything between the last backward kernel and the next step, for ONE tuple of exchange
-    message sizes: graph 1 packs every table's (id, row) message; the all-gathers run eagerly
-    (RCCL calls stay outside the captures); graph 2 merges the gathered lists and applies the
-    optimizer.  ~45 launches and as many tensor allocations cost two graph launches and 2 RCCL
-    calls per table, which the host issues while backward is still running."""
+    message sizes: graph 1 packs every table's (id, row) message; the all-gathers run eagerly as
+    one grouped RCCL launch (RCCL calls stay outside the captures); graph 2 merges the gathered
+    lists (one branch per table) and applies the optimizer.  ~45 launches and as many tensor
+    allocations cost two graph launches and two RCCL calls, which the host issues while backward
+    is still running."""
 
     def __init__(self, trainer, tables, sizes):
-        self.trainer, self.tables, self.sizes = trainer, tables, sizes
+        self.trainer = trainer
         opt = trainer.optimizer
         saved = [tb.sparse_grad for tb in tables]
         torch.cuda.synchronize()
@@ -208,10 +206,11 @@ class GraphedExchangeTail:
         try:
             with torch.cuda.graph(self.merge):
                 # the tables' merges are independent chains of small kernels: one branch each
-                # (largest message on the capture stream), joined before the optimizer
+                # (largest message on the capture stream), joined before the optimizer.  (The
+                # dense AdamW as a third branch was measured slower)
                 main = torch.cuda.current_stream()
                 order = sorted(range(len(tables)), key=lambda i: -sizes[i])
-                side = [ops.aux_stream(f"merge{j}", self.gathered[0][1].device) for j in range(len(order) - 1)]
+                side = [ops.aux_stream(f"merge{j}", main.device) for j in range(len(order) - 1)]
                 for st in side:
                     ops.stream_wait(st, main)
                 for j, i in enumerate(order):
@@ -225,8 +224,11 @@ class GraphedExchangeTail:
             for tb, sg in zip(tables, saved):
                 tb.sparse_grad = sg
 
-    def __call__(self):
+    def __call__(self, host_s):
         opt = self.trainer.optimizer
+        t0 = time.perf_counter()
+        parallel.sync_dense(opt)
+        host_s[3] += time.perf_counter() - t0
         self.pack.replay()
         parallel.all_gather_tables(self.msgs, self.gathered)
         self.merge.replay()

@@ -16,7 +16,10 @@ def main(out, use_graph):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
         torch.cuda.set_device(0)
-        dist.init_process_group("nccl", rank=0, world_size=1)
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        from mapx import parallel
+        parallel.init_rccl(torch.device("cuda:0"))
     from mapx.arguments import TrainingArguments
     from mapx.dataset import OurDataset, synth_table
     from mapx.models import BaseModel
@@ -40,6 +43,7 @@ def main(out, use_graph):
     kinds = [type(g).__name__ for g in tr._graphs.values() if not isinstance(g, int)]
     assert kinds == ((["GraphedBackward"] if forced else ["GraphedStep"]) if use_graph else []), kinds
     torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, out)
+    torch.cuda.synchronize()
     if forced:
         dist.destroy_process_group()
 

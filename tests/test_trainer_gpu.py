@@ -239,7 +239,8 @@ def test_one_rank_rccl_exchange_equals_plain_step(tmp_path):
     """The N-rank gradient exchange rehearsed on one GPU (one-rank RCCL group, MAPX_FORCE_DP=1):
     dense all-reduce, early segment counts published by the graph, MAX over ranks, pack,
     all-gathers, merge.  With one rank the exchange is the identity, so parameters must equal the
-    plain single-GPU run bit for bit — through the captured graph (GraphedBackward) and eagerly."""
+    plain single-GPU run bit for bit — through the captured graphs (GraphedBackward +
+    GraphedExchangeTail) and eagerly."""
     worker = os.path.join(ROOT, "tests", "dp_rehearsal_worker.py")
     base = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "map-code_amd"),
                                                          os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]))
@@ -248,7 +249,8 @@ def test_one_rank_rccl_exchange_equals_plain_step(tmp_path):
         path = str(tmp_path / f"{name}.pt")
         r = subprocess.run([sys.executable, worker, path, mode], env=dict(base, MAPX_FORCE_DP=forced),
                            capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, (name, r.stderr[-3000:])
+        errors = [ln for ln in r.stderr.splitlines() if "rror" in ln or "fault" in ln][:20]
+        assert r.returncode == 0, (name, errors, r.stderr[-2000:])
         outs[name] = torch.load(path)
     for k in outs["plain"]:
         assert torch.equal(outs["plain"][k], outs["dp_eager"][k]), ("eager exchange", k)
