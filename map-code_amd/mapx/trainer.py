@@ -104,7 +104,9 @@ class GraphedBackward:
         from . import layers
         self.trainer = trainer
         self.X, self.Y = X.clone(), Y.clone()
-        self.early = parallel.exchanging() and parallel.EXCHANGE == "gather" and X.is_cuda
+        # (gloo stages every message through host memory: its exchange stays eager)
+        self.early = (parallel.exchanging() and parallel.EXCHANGE == "gather" and X.is_cuda
+                      and torch.distributed.get_backend() == "nccl")
         self.replays = 0
         self.tails, self.captures, self.poll_s = {}, 0, 0.0
         self.host_s = [0.0] * 5         # launch | counts | tail capture | dense all-reduce | tail
