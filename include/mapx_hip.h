@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 21
+#define MAPX_ABI_VERSION 22
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -66,6 +66,15 @@ size_t mapx_seg_plan_workspace_bytes(int64_t n, int64_t V);
 int mapx_seg_plan(const int32_t* keys, int64_t n, int64_t V, void* ws, size_t ws_bytes,
                   int32_t* sorted_keys, int32_t* perm, int32_t* rank, int32_t* uniq,
                   int32_t* seg_start, int32_t* n_uniq, hipStream_t stream);
+/* The same plan for keys that are `lists` concatenated lists of `len` keys each, every list
+ * ascending as UNSIGNED 32-bit values (so -1 padding sits at its end) and free of repeats except
+ * the padding — the gathered per-rank messages of the data-parallel exchange.  One launch ranks
+ * every key by binary search in the other lists (ties: lower list first, i.e. exactly the order
+ * a stable sort of the concatenation gives) instead of 6 radix launches; outputs are identical to
+ * mapx_seg_plan(keys, lists * len, ...).  Workspace: mapx_seg_plan_workspace_bytes(lists * len, 0). */
+int mapx_seg_plan_merge(const int32_t* keys, int lists, int64_t len, void* ws, size_t ws_bytes,
+                        int32_t* sorted_keys, int32_t* perm, int32_t* rank, int32_t* uniq,
+                        int32_t* seg_start, int32_t* n_uniq, hipStream_t stream);
 
 /* out[u,:] = sum_{j in run u} src[perm[j],:]  (W floats per row, W % 4 == 0).  Embedding
  * table gradient: src = dL/dX0 viewed [B*F, E], plan over input_ids.flatten(). */

@@ -182,6 +182,65 @@ extern "C" int mapx_seg_plan(const int32_t* keys, int64_t n, int64_t V, void* ws
   return check_launch("seg_plan");
 }
 
+namespace mapx {
+// rank of every key of `lists` sorted lists in their stable merge
+__global__ void __launch_bounds__(256) merge_rank_kernel(const int32_t* __restrict__ keys, int lists,
+                                                         int64_t len, int32_t* __restrict__ sorted_keys,
+                                                         int32_t* __restrict__ perm) {
+  const int64_t n = (int64_t)lists * len;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e / len);
+    const uint32_t k = (uint32_t)keys[e];
+    int64_t pos = e - (int64_t)r * len;
+    for (int q = 0; q < lists; ++q) {
+      if (q == r) continue;
+      const int32_t* __restrict__ L = keys + (int64_t)q * len;
+      int64_t lo = 0, hi = len;            // q < r: #{L <= k};  q > r: #{L < k}
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        const uint32_t v = (uint32_t)L[mid];
+        const bool left = q < r ? v <= k : v < k;
+        lo = left ? mid + 1 : lo;
+        hi = left ? hi : mid;
+      }
+      pos += lo;
+    }
+    sorted_keys[pos] = (int32_t)k;
+    perm[pos] = (int32_t)e;
+  }
+}
+}  // namespace mapx
+
+extern "C" int mapx_seg_plan_merge(const int32_t* keys, int lists, int64_t len, void* ws, size_t ws_bytes,
+                                   int32_t* sorted_keys, int32_t* perm, int32_t* rank, int32_t* uniq,
+                                   int32_t* seg_start, int32_t* n_uniq, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(lists >= 1 && len >= 0 && (int64_t)lists * len < (1LL << 31), "seg_plan_merge: bad sizes");
+  MAPX_REQUIRE(n_uniq && seg_start, "seg_plan_merge: null output");
+  const int64_t n = (int64_t)lists * len;
+  if (n == 0) {
+    MAPX_HIP(hipMemsetAsync(n_uniq, 0, 2 * sizeof(int32_t), stream));
+    MAPX_HIP(hipMemsetAsync(seg_start, 0, sizeof(int32_t), stream));
+    return MAPX_OK;
+  }
+  MAPX_REQUIRE(keys && sorted_keys && perm && rank && uniq && ws, "seg_plan_merge: null pointer");
+  MAPX_REQUIRE((uintptr_t)ws % 256 == 0, "seg_plan_merge: workspace must be 256-byte aligned");
+  const PlanWs w = plan_ws(ws, n);
+  if (ws_bytes < w.total) {
+    set_error("seg_plan_merge: workspace %zu < %zu bytes", ws_bytes, w.total);
+    return MAPX_EWORKSPACE;
+  }
+  const int nblocks = radix_blocks(n);
+  hipLaunchKernelGGL(merge_rank_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, keys, lists, len,
+                     sorted_keys, perm);
+  hipLaunchKernelGGL(seg_count_kernel, dim3(nblocks), dim3(256), 0, stream, (const int32_t*)sorted_keys, n,
+                     w.off);
+  hipLaunchKernelGGL(seg_mark_tiles_kernel, dim3(nblocks), dim3(256), 0, stream, (const int32_t*)sorted_keys,
+                     n, (const int32_t*)w.off, rank, uniq, seg_start, n_uniq);
+  return check_launch("seg_plan_merge");
+}
+
 // Generic reduce-by-key of dense rows: out[u, :] = sum over the positions of key uniq[u] of
 // src[position, :], in sorted-position order.  Embedding-table gradient: src = dL/dX0
 // viewed as [B*F, E], keys = input_ids.flatten() (reference: aten::embedding_dense_backward).

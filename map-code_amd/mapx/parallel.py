@@ -139,9 +139,10 @@ def merge_table(table, k_all, r_all):
     from . import ops
     _, r0, r1 = table.sparse_grad
     W0 = r0.shape[1]
-    # padding entries carry id -1: with one more key bit than the table needs they sort behind
-    # every real id as one run of zero rows, which the table optimizer skips (negative id)
-    mplan = ops.SegPlan(k_all, table.num_rows + 1)
+    # every rank's message is sorted and ends with its -1 padding: the plan is a merge of world()
+    # sorted lists (one ranking launch; as unsigned keys the padding sorts behind every real id,
+    # as one run of zero rows which the table optimizer skips)
+    mplan = ops.SegPlan(k_all, table.num_rows + 1, sorted_lists=world())
     if r1 is not None:
         m0, m1 = ops.seg_reduce_rows_extra(mplan, r_all, W0, r_all[:, W0], 1, extra_stride=r_all.stride(0))
     else:

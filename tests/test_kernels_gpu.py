@@ -78,6 +78,32 @@ def test_seg_plan_and_reduce_rows(ops, n, V, W):
     assert torch.equal(out[:U], out2[:U])
 
 
+@pytest.mark.parametrize("lists,length,V", [(1, 1000, 5000), (2, 700, 900), (4, 5000, 100000), (8, 20000, 9_449_445),
+                                            (3, 64, 50)])
+def test_seg_plan_merge_equals_sort(ops, lists, length, V):
+    """The data-parallel merge plan (one ranking launch over `lists` sorted, -1-padded lists) must
+    give exactly what the stable radix sort of the concatenation gives — every output array."""
+    g = torch.Generator().manual_seed(lists * 7919 + length)
+    keys = torch.full((lists, length), -1, dtype=torch.int32)
+    for r in range(lists):
+        n_r = int(torch.randint(0 if r == 1 else length // 2, length + 1, (1,), generator=g))
+        n_r = min(n_r, V)
+        pick = torch.randperm(V, generator=g)[:n_r].sort().values
+        keys[r, :n_r] = pick.to(torch.int32)
+    flat = keys.reshape(-1).to(DEV)
+    a = ops.SegPlan(flat, V + 1, sorted_lists=lists)
+    b = ops.SegPlan(flat, V + 1)
+    U = b.count()
+    assert a.count() == U
+    n = lists * length
+    for name in ("sorted_keys", "perm", "rank"):
+        assert torch.equal(getattr(a, name)[:n], getattr(b, name)[:n]), name
+    assert torch.equal(a.uniq[:U], b.uniq[:U]) and torch.equal(a.seg_start[:U + 1], b.seg_start[:U + 1])
+    real = keys.reshape(-1)[keys.reshape(-1) >= 0].long()
+    assert torch.equal(_cpu(a.uniq[:U]).long()[_cpu(a.uniq[:U]) >= 0], torch.unique(real))
+    assert int(a.uniq[U - 1]) == -1 or bool((keys >= 0).all())      # the padding run sorts last
+
+
 def test_seg_plan_empty(ops):
     plan = ops.SegPlan(torch.empty(0, dtype=torch.int32, device=DEV), 10)
     assert plan.count() == 0
