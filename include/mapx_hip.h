@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 22
+#define MAPX_ABI_VERSION 23
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -112,6 +112,24 @@ int mapx_publish_i32(const int32_t* src, int n, int32_t* stamp_dev, int32_t* hos
  * guaranteed to be coherent at stream synchronisation points, i.e. when the graph has ended. */
 int mapx_host_alloc_coherent(size_t bytes, void** out);
 int mapx_host_free(void* p);
+
+/* ------------------------------------------------------------------ xDeepFM: CIN
+ * layers.py:696-721: X_{i+1}[b,o,:] = bias[o] + sum_{h,m} W[o, h*H_i+m] X_0[b,h,:] * X_i[b,m,:], every
+ * layer sum-pooled over the embedding axis.  With activations kept embedding-major
+ * (Xt[b,d,m] = X[b,m,d]; rows r = (b,d), R = B*E) the layer is  Xt_{i+1} = had W^T + bias  with
+ * had[r, h*H+m] = X0t[r,h] * Xt_i[r,m]  (mapx_gemm_f32 does the product); these are the pieces
+ * around it: transpose out[b,c,r] = x[b,r,c]; the outer product and its backward
+ * (dxi[r,m] = sum_h dhad[r,h,m] x0t[r,h]; dx0t[r,h] (+)= sum_m dhad[r,h,m] xi[r,m]); pooling
+ * out[b*ld_out+o] = sum_d xt[b,d,o] and its backward dxt[b,d,o] (+)= g[b*ld_g+o]. */
+int mapx_transpose_batched(const float* x, int64_t B, int R, int C, float* out, hipStream_t stream);
+int mapx_cin_outer_fwd(const float* x0t, int F, const float* xi, int H, int64_t R, float* had,
+                       hipStream_t stream);
+int mapx_cin_outer_bwd(const float* dhad, const float* x0t, int F, const float* xi, int H, int64_t R,
+                       float* dx0t, int accumulate_x0, float* dxi, hipStream_t stream);
+int mapx_cin_pool_fwd(const float* xt, int64_t B, int E, int H, float* out, int64_t ld_out,
+                      hipStream_t stream);
+int mapx_cin_pool_bwd(const float* g, int64_t ld_g, int64_t B, int E, int H, float* dxt, int accumulate,
+                      hipStream_t stream);
 
 /* ------------------------------------------------------------------ DeepFM terms
  * LR  (models.py:129-143): out[b] = sum_f w[ids[b,f]]  (bias added by the caller).

@@ -474,6 +474,85 @@ class MultiHeadSelfAttention(nn.Module):
                                     self.attention_dim, self.use_residual, self.use_scale)
 
 
+class _CinStack(Function):
+    """All CIN layers as one autograd node (reference layers.py:708-721).  Activations are kept
+    embedding-major (rows r = (b, d)), so a layer is: outer product of two short row vectors ->
+    Hadamard matrix [B*E, F*H_i] -> one MFMA GEMM with the 1x1 convolution's weight (+ bias) ->
+    the next layer's input as it is; every layer's output is sum-pooled over the E rows of a sample
+    into its columns of `out` [B, sum(units)].  Backward walks the layers in reverse: pooled
+    gradient broadcast (+ the gradient from the layer above), dW / db / dHad GEMMs, outer-product
+    backward accumulating into dX0."""
+
+    @staticmethod
+    def forward(ctx, x3, *wb):
+        B, F, E = x3.shape
+        ws, bs = wb[0::2], wb[1::2]
+        x0t = ops.transpose_batched(x3).view(B * E, F)
+        units = [w.shape[0] for w in ws]
+        out = torch.empty(B, sum(units), dtype=torch.float32, device=x3.device)
+        xi, saved, col = x0t, [], 0
+        for w, b in zip(ws, bs):
+            had = ops.cin_outer_fwd(x0t, xi)
+            nxt = ops.linear_fwd(had, w.view(w.shape[0], -1), b)
+            ops.cin_pool_fwd(nxt, B, E, out[:, col:col + w.shape[0]])
+            saved.append((xi, had))
+            xi, col = nxt, col + w.shape[0]
+        ctx.saved, ctx.x0t, ctx.shape = saved, x0t, (B, F, E)
+        ctx.ws = ws
+        ctx.slots = [(_grad_slot(w), _grad_slot(b)) for w, b in zip(ws, bs)]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, F, E = ctx.shape
+        ws, x0t = ctx.ws, ctx.x0t
+        dx0t = torch.empty_like(x0t)
+        grads = [None] * (2 * len(ws))
+        col = g.shape[1]
+        dnext = None                          # gradient w.r.t. the layer's output from the layer above
+        for i in range(len(ws) - 1, -1, -1):
+            w = ws[i]
+            u = w.shape[0]
+            col -= u
+            xi, had = ctx.saved[i]
+            dy = dnext if dnext is not None else torch.empty(B * E, u, dtype=torch.float32, device=g.device)
+            ops.cin_pool_bwd(g[:, col:col + u], B, E, dy, accumulate=dnext is not None)
+            sw, sb = ctx.slots[i]
+            w2 = w.view(u, -1)
+            dw = ops.linear_bwd_weight(dy, had, out=None if sw is None else sw.view(u, -1))
+            db = ops.colsum(dy, out=sb)
+            grads[2 * i] = None if sw is not None else dw.view_as(w)
+            grads[2 * i + 1] = None if sb is not None else db
+            dhad = ops.linear_bwd_input(dy, w2)
+            dxi = ops.cin_outer_bwd(dhad, x0t, xi, dx0t, accumulate_x0=i != len(ws) - 1)
+            if i == 0:                         # layer 1's X_i IS X_0
+                dx0t += dxi
+            dnext = dxi
+        dx3 = ops.transpose_batched(dx0t.view(B, E, F))
+        return (dx3,) + tuple(grads)
+
+
+class CIN(nn.Module):
+    """Reference layers.py:696-721; parameters keep nn.Conv1d's names and shapes
+    (`cin_layer.layer_{i}.weight` [out, F*H_{i-1}, 1], `.bias` [out])."""
+
+    def __init__(self, num_fields, cin_layer_units):
+        super().__init__()
+        self.cin_layer_units = list(cin_layer_units)
+        self.cin_layer = nn.ModuleDict()
+        h_in = num_fields
+        for i, unit in enumerate(self.cin_layer_units):
+            self.cin_layer["layer_" + str(i + 1)] = nn.Conv1d(num_fields * h_in, unit, kernel_size=1)
+            h_in = unit
+
+    def forward(self, x3):
+        wb = []
+        for i in range(len(self.cin_layer_units)):
+            conv = self.cin_layer["layer_" + str(i + 1)]
+            wb += [conv.weight, conv.bias]
+        return _CinStack.apply(x3, *wb)
+
+
 class _JoinColumns(Function):
     """torch.cat([a, b], dim=1) when a and b were already written into their column ranges of
     `buf` (ops.alias_cols): no copy forward, two slices backward."""

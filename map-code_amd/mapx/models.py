@@ -9,14 +9,14 @@ from torch import nn
 
 from . import ops
 from .arguments import Config
-from .layers import (_JoinColumns, CrossNetV2, Embeddings, HipLinear, MLPBlock, MultiHeadSelfAttention,
+from .layers import (_JoinColumns, CIN, CrossNetV2, Embeddings, HipLinear, MLPBlock, MultiHeadSelfAttention,
                      RowTable, TableWeight, bce_with_logits, fm_product_sum)
 from .nce import IndexLinear
 
 logger = logging.getLogger(__name__)
 GROUPED_ENCODER = os.environ.get("MAPX_GROUPED_ENC", "1") == "1"
 
-_OTHER_BACKBONES = ("trans", "fignn", "fgcnn", "xdeepfm")
+_OTHER_BACKBONES = ("trans", "fignn", "fgcnn")
 
 
 class _RfdPredictor(nn.ModuleDict):
@@ -49,10 +49,12 @@ class BaseModel(nn.Module):
             return DeepFM(config)
         if name == "autoint":
             return AutoInt(config)
+        if name == "xdeepfm":
+            return xDeepFM(config)
         if name in _OTHER_BACKBONES:
             raise NotImplementedError(
                 f"{config.model_name}: mapx builds the DCNv2 hot path and, of the other backbones "
-                "(SURVEY §8 f4), DNN, DeepFM and AutoInt")
+                "(SURVEY §8 f4), DNN, DeepFM, xDeepFM and AutoInt")
         raise NotImplementedError(config.model_name)
 
     def validate_model_config(self):
@@ -321,3 +323,47 @@ class AutoInt(BaseModel):
         if self.config.pretrain:
             return self.get_outputs(attention_out, labels, masked_index, noise_samples=noise_samples)
         return self.get_outputs(self.attn_out(attention_out), labels)
+
+
+class xDeepFM(BaseModel):
+    """CIN + MLP (reference models.py:235-279): cat([CIN(embed), MLP(embed.flatten)]) feeds the
+    MFP / RFD heads or `fc` (+ the LR term when use_lr).  The LR weight, when present, is the
+    secondary parameter of the embedding's RowTable as in DeepFM."""
+    used_params = ["embed_size", "hidden_size", "num_hidden_layers", "hidden_dropout_rate", "hidden_act",
+                   "cin_layer_units", "use_lr"]
+
+    def __init__(self, config: Config):
+        super().__init__(model_name="xDeepFM", config=config)
+        if config.num_hidden_layers <= 0:
+            raise NotImplementedError("xDeepFM without the MLP tower (num_hidden_layers = 0) is not built")
+        self.embed = Embeddings(config)
+        self.embed.defer_plan = True
+        units = [int(c) for c in str(config.cin_layer_units).split(",")]
+        self.cin = CIN(config.num_fields, units)
+        self.dnn = MLPBlock(input_dim=config.num_fields * config.embed_size, hidden_size=config.hidden_size,
+                            num_hidden_layers=config.num_hidden_layers,
+                            hidden_dropout_rate=config.hidden_dropout_rate, hidden_act=config.hidden_act)
+        final_dim = sum(units) + config.hidden_size
+        if config.pretrain:
+            self.create_pretraining_predictor(final_dim)
+        else:
+            self.lr_layer = LR(config) if config.use_lr else None
+            if self.lr_layer is not None:
+                self.embed.table = RowTable("embed.embedding", self.embed.embedding.weight,
+                                            self.lr_layer.embed_w.weight)
+            self.fc = HipLinear(final_dim, 1)
+
+    def forward(self, input_ids, labels=None, masked_index=None, noise_samples=None):
+        lr = None
+        if not self.config.pretrain and self.lr_layer is not None:
+            x3, lr = self.embed.forward_with_linear(input_ids, self.lr_layer.embed_w.weight)
+        else:
+            x3 = self.embed(input_ids)
+        final_vec = torch.cat([self.cin(x3), self.dnn(x3.flatten(start_dim=1))], dim=1)
+        self.embed.table.start_plan()
+        if self.config.pretrain:
+            return self.get_outputs(final_vec, labels, masked_index, noise_samples=noise_samples)
+        logits = self.fc(final_vec)
+        if lr is not None:
+            logits = logits + lr.view(-1, 1) + self.lr_layer.bias
+        return self.get_outputs(logits, labels)

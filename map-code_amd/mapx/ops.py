@@ -326,6 +326,54 @@ def publish_i32(src, n, stamp_dev, mailbox, at=0):
     check(lib.mapx_publish_i32(ptr(src), n, ptr(stamp_dev), mailbox.address(at), stream()))
 
 
+# --------------------------------------------------------------------------- xDeepFM: CIN pieces
+def transpose_batched(x):
+    """[B,R,C] -> [B,C,R] (contiguous)."""
+    require_gpu(x)
+    x = x.contiguous()
+    B, R, C = x.shape
+    out = torch.empty(B, C, R, dtype=torch.float32, device=x.device)
+    check(lib.mapx_transpose_batched(ptr(x), B, R, C, ptr(out), stream()))
+    return out
+
+
+def cin_outer_fwd(x0t, xi):
+    """had[r, h*H+m] = x0t[r,h] * xi[r,m]: x0t [R,F], xi [R,H] -> [R, F*H]  (layers.py:714-715)."""
+    require_gpu(x0t, xi)
+    R, F = x0t.shape
+    H = xi.shape[1]
+    had = torch.empty(R, F * H, dtype=torch.float32, device=x0t.device)
+    check(lib.mapx_cin_outer_fwd(ptr(x0t), F, ptr(xi), H, R, ptr(had), stream()))
+    return had
+
+
+def cin_outer_bwd(dhad, x0t, xi, dx0t, accumulate_x0):
+    """-> dxi [R,H]; dx0t [R,F] is written or accumulated in place."""
+    require_gpu(dhad, x0t, xi, dx0t)
+    R, F = x0t.shape
+    H = xi.shape[1]
+    dxi = torch.empty(R, H, dtype=torch.float32, device=x0t.device)
+    check(lib.mapx_cin_outer_bwd(ptr(dhad), ptr(x0t), F, ptr(xi), H, R, ptr(dx0t), int(accumulate_x0), ptr(dxi),
+                                 stream()))
+    return dxi
+
+
+def cin_pool_fwd(xt, B, E, out):
+    """out[b, :H] = sum_d xt[(b,d), :]: xt [B*E, H]; `out` may be a column slice (row stride ld)."""
+    require_gpu(xt, out)
+    H = xt.shape[1]
+    check(lib.mapx_cin_pool_fwd(ptr(xt), B, E, H, out.data_ptr(), out.stride(0), stream()))
+    return out
+
+
+def cin_pool_bwd(g, B, E, dxt, accumulate):
+    """dxt[(b,d), :] (+)= g[b, :H]; `g` may be a column slice."""
+    require_gpu(g, dxt)
+    H = dxt.shape[1]
+    check(lib.mapx_cin_pool_bwd(g.data_ptr(), g.stride(0), B, E, H, ptr(dxt), int(accumulate), stream()))
+    return dxt
+
+
 # --------------------------------------------------------------------------- DeepFM terms
 def lr_sum(ids, w, validate=False):
     """out[b] = sum_f w[ids[b,f]]   (reference models.py:137-140, before the bias)."""

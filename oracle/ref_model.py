@@ -118,8 +118,35 @@ def trunk_autoint(params, ids, ai):
     return x.flatten(1)
 
 
+def cin(params, x3, units):
+    """Compressed Interaction Network (layers.py:708-721): X_{i+1}[b,o,:] = bias[o] +
+    sum_{h,m} W[o, h*H_i + m] X_0[b,h,:] * X_i[b,m,:]  (a 1x1 Conv1d over the F*H_i Hadamard
+    channels, no activation); every layer's output is sum-pooled over the embedding axis."""
+    B, F, E = x3.shape
+    xi, pooled = x3, []
+    for i, u in enumerate(units):
+        had = torch.einsum("bhd,bmd->bhmd", x3, xi).reshape(B, -1, E)
+        w = params[f"cin.cin_layer.layer_{i + 1}.weight"][:, :, 0]
+        xi = torch.einsum("ok,bkd->bod", w, had) + params[f"cin.cin_layer.layer_{i + 1}.bias"].view(1, -1, 1)
+        pooled.append(xi.sum(-1))
+    return torch.cat(pooled, dim=-1)
+
+
+def trunk_xdeepfm(params, ids, num_hidden, units):
+    """xDeepFM (models.py:263-269): cat([CIN(embed), MLP(embed.flatten)])."""
+    x3 = params["embed.embedding.weight"][ids]
+    return torch.cat([cin(params, x3, units), dnn(params, x3.flatten(1), num_hidden, "dnn")], dim=1)
+
+
+def _units(extra):
+    return [int(c) for c in extra["cin_layer_units"].split(",")]
+
+
 def final_of(backbone, params, ids, num_cross, num_hidden, autoint=None):
-    """The vector the pretraining heads see, per backbone."""
+    """The vector the pretraining heads see, per backbone (`autoint`: the backbone's extra config
+    keys — AutoInt's attention settings or xDeepFM's cin_layer_units / use_lr)."""
+    if backbone == "xDeepFM":
+        return trunk_xdeepfm(params, ids, num_hidden, _units(autoint))
     if backbone == "DCNv2":
         return trunk(params, ids, num_cross, num_hidden)
     if backbone == "DNN":
@@ -132,7 +159,12 @@ def final_of(backbone, params, ids, num_cross, num_hidden, autoint=None):
 
 
 def ctr_logits_of(backbone, params, ids, num_cross, num_hidden, autoint=None):
-    """CTR logits [B,1] per backbone (models.py:189-190, 228-231, 319)."""
+    """CTR logits [B,1] per backbone (models.py:189-190, 228-231, 274-277, 319)."""
+    if backbone == "xDeepFM":
+        logits = trunk_xdeepfm(params, ids, num_hidden, _units(autoint)) @ params["fc.weight"].t() + params["fc.bias"]
+        if autoint.get("use_lr"):
+            logits = logits + lr_logit(params, ids)
+        return logits
     if backbone == "DCNv2":
         return ctr_head(params, trunk(params, ids, num_cross, num_hidden))[0]
     if backbone == "DNN":

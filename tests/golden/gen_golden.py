@@ -48,8 +48,7 @@ def ref_config(arguments, cfg, mode, feat_count, data_dir, backbone="DCNv2"):
         proj_size=cfg["P"], pretrain=(mode != "CTR"), pt_type=("RFD" if mode == "RFD" else "MFP"),
         RFD_replace="Unigram", feat_count=torch.from_numpy(feat_count), device=torch.device("cpu"),
         n_gpu=0, idx_low=None, idx_high=None, feat_num_per_field=None)
-    if backbone == "AutoInt":
-        d.update(pg.AUTOINT)
+    d.update(pg.extras_of(backbone))
     return arguments.Config.from_dict(d)
 
 
@@ -65,6 +64,8 @@ def trunk_of(model, backbone, emb3):
         return torch.cat([model.cross_net(flat), model.parallel_dnn(flat)], -1)
     if backbone == "AutoInt":
         return model.self_attention(emb3).flatten(1)
+    if backbone == "xDeepFM":
+        return torch.cat([model.cin(emb3), model.dnn(flat)], 1)
     return model.dnn(flat)      # DNN; DeepFM's pretrain vector also appends lr + fm (not needed below)
 
 
@@ -147,6 +148,8 @@ def run_case(arguments, models, case, cfg, mode, outdir, backbone="DCNv2"):
             if backbone == "DeepFM":
                 store["mid/lr"] = model.lr_layer(ids)[0].numpy()
                 store["mid/fm"] = model.ip_layer(model.embed(ids)).numpy()
+            if backbone == "xDeepFM":
+                store["mid/cin_out"] = model.cin(model.embed(ids)).numpy()
             if backbone == "AutoInt":
                 x = model.embed(ids)
                 for li, layer in enumerate(model.self_attention):

@@ -64,12 +64,22 @@ def make_param(case, name, shape, scale):
     return (_rng(case, "param", name).standard_normal(shape) * scale).astype(np.float32)
 
 
-BACKBONES = ("DCNv2", "DNN", "DeepFM", "AutoInt")      # the others: SURVEY §8(f4), fixtures for case B only
+BACKBONES = ("DCNv2", "DNN", "DeepFM", "AutoInt", "xDeepFM")      # the others: SURVEY §8(f4), fixtures for case B only
 # AutoInt settings of the fixtures (non-default on purpose: 2 heads, residual + scaling on, the
 # second layer has no W_res because its input width equals heads * attn_size)
 AUTOINT = dict(num_attn_layers=2, attn_size=12, num_attn_heads=2, res_conn=True, attn_scale=True,
                attn_probs_dropout_rate=0.0, use_lr=False, num_dnn_layers=0, dnn_size=1000, dnn_act="relu",
                dnn_drop=0.0)
+
+
+# xDeepFM settings of the fixtures: two CIN layers of different widths; the CTR model adds the LR term
+XDEEPFM = dict(cin_layer_units="12,8", use_lr=True)
+EXTRAS = {"AutoInt": AUTOINT, "xDeepFM": XDEEPFM}
+
+
+def extras_of(backbone):
+    """Backbone-specific config keys of the fixtures ({} for DCNv2 / DNN / DeepFM)."""
+    return dict(EXTRAS.get(backbone, {}))
 
 
 def param_shapes(cfg, mode, backbone="DCNv2"):
@@ -99,6 +109,16 @@ def param_shapes(cfg, mode, backbone="DCNv2"):
             out["attn_out.bias"] = ((1,), 0.1)
             return out
         NL = 0                                       # no MLP tower
+    elif backbone == "xDeepFM":
+        units = [int(c) for c in XDEEPFM["cin_layer_units"].split(",")]
+        h_in = F
+        for i, u in enumerate(units):                # nn.Conv1d(F * h_in, u, kernel_size=1): layers.py:701-706
+            out[f"cin.cin_layer.layer_{i + 1}.weight"] = ((u, F * h_in, 1), (F * h_in) ** -0.5)
+            out[f"cin.cin_layer.layer_{i + 1}.bias"] = ((u,), 0.1)
+            h_in = u
+        if mode == "CTR" and XDEEPFM["use_lr"]:
+            out["lr_layer.embed_w.weight"] = ((V, 1), 0.3)
+            out["lr_layer.bias"] = ((1,), 0.1)
     elif backbone != "DNN":
         raise ValueError(backbone)
     tower = "parallel_dnn" if backbone == "DCNv2" else "dnn"
@@ -108,7 +128,12 @@ def param_shapes(cfg, mode, backbone="DCNv2"):
         out[f"{tower}.dnn.{3 * i}.bias"] = ((H,), 0.1)
         d_in = H
     if backbone != "AutoInt":
-        Dfin = {"DCNv2": D + (H if NL > 0 else 0), "DNN": H, "DeepFM": H + 1}[backbone]
+        cin_out = sum(int(c) for c in XDEEPFM["cin_layer_units"].split(","))
+        Dfin = {"DCNv2": D + (H if NL > 0 else 0), "DNN": H, "DeepFM": H + 1, "xDeepFM": cin_out + H}[backbone]
+    if mode == "CTR" and backbone == "xDeepFM":       # models.py:261: nn.Linear(final_dim, 1)
+        out["fc.weight"] = ((1, Dfin), Dfin ** -0.5)
+        out["fc.bias"] = ((1,), 0.1)
+        return out
     if mode == "CTR" and backbone != "DCNv2":
         head = "fc_out" if backbone == "DNN" else "dnn_fc_out"       # models.py:180, 212: Linear(H, 1)
         out[f"{head}.weight"] = ((1, H), H ** -0.5)

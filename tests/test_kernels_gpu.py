@@ -638,3 +638,33 @@ def test_eval_metrics_one_class_raises(ops):
         ops.eval_metrics(x, torch.ones(100).to(DEV))
     with pytest.raises(ValueError):
         ops.eval_metrics(x, torch.ones(99).to(DEV))
+
+
+@pytest.mark.parametrize("B,F,E,H", [(3, 5, 4, 7), (64, 25, 16, 12), (17, 39, 16, 70)])
+def test_cin_pieces(ops, B, F, E, H):
+    """xDeepFM's CIN glue kernels against their one-line definitions (layers.py:714-718)."""
+    g = torch.Generator().manual_seed(B * F + H)
+    x3 = torch.randn(B, F, E, generator=g)
+    xt = ops.transpose_batched(x3.to(DEV))
+    assert torch.equal(_cpu(xt), x3.transpose(1, 2).contiguous())
+    x0t = xt.view(B * E, F)
+    xi = torch.randn(B * E, H, generator=g).to(DEV)
+    had = ops.cin_outer_fwd(x0t, xi)
+    ref = (_cpu(x0t)[:, :, None] * _cpu(xi)[:, None, :]).reshape(B * E, F * H)
+    assert torch.equal(_cpu(had), ref)
+    dhad = torch.randn(B * E, F * H, generator=g)
+    dx0t = torch.full((B * E, F), 0.5, device=DEV)
+    dxi = ops.cin_outer_bwd(dhad.to(DEV), x0t, xi, dx0t, accumulate_x0=True)
+    d3 = dhad.view(B * E, F, H).double()
+    np.testing.assert_allclose(_cpu(dxi).double().numpy(), (d3 * _cpu(x0t).double()[:, :, None]).sum(1).numpy(),
+                               rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(_cpu(dx0t).double().numpy(),
+                               0.5 + (d3 * _cpu(xi).double()[:, None, :]).sum(2).numpy(), rtol=1e-5, atol=1e-5)
+    out = torch.full((B, H + 3), -1.0, device=DEV)
+    ops.cin_pool_fwd(xi, B, E, out[:, 2:2 + H])
+    np.testing.assert_allclose(_cpu(out[:, 2:2 + H]).numpy(), _cpu(xi).view(B, E, H).sum(1).numpy(), rtol=1e-5, atol=1e-5)
+    assert bool((out[:, :2] == -1).all()) and bool((out[:, 2 + H:] == -1).all())
+    gp = torch.randn(B, H + 3, generator=g).to(DEV)
+    dxt = torch.ones(B * E, H, device=DEV)
+    ops.cin_pool_bwd(gp[:, 1:1 + H], B, E, dxt, accumulate=True)
+    assert torch.equal(_cpu(dxt).view(B, E, H), 1.0 + _cpu(gp[:, 1:1 + H])[:, None, :].expand(B, E, H))

@@ -188,7 +188,7 @@ def test_unknown_backbones_raise_like_the_reference():
     from mapx.models import BaseModel
     from util import make_config
     cfg = pg.CASES["A_f23_b7"]
-    for name in ("xdeepfm", "nonsense"):
+    for name in ("fignn", "nonsense"):
         c = make_config(cfg, "CTR")
         c.model_name = name
         with pytest.raises(NotImplementedError):

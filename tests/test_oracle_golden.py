@@ -28,7 +28,7 @@ def test_mfp_matches_reference(case, backbone):
     logq, lnV, _ = R.nce_buffers(inp["feat_count"])
     np.testing.assert_allclose(logq.numpy(), z["nce/logprob_noise"], rtol=1e-6, atol=1e-6)
     assert lnV == pytest.approx(float(z["nce/norm_term"]))
-    final = R.final_of(backbone, P, masked, cfg["NC"], cfg["NL"], pg.AUTOINT)
+    final = R.final_of(backbone, P, masked, cfg["NC"], cfg["NL"], pg.extras_of(backbone))
     loss, logits, acc = R.mfp_head(P, final, labels, mi, t(inp["noise"]), logq,
                                    cfg["F"], cfg["P"], cfg["K"])
     np.testing.assert_allclose(loss.item(), float(z["out/loss"]), rtol=2e-6)
@@ -48,7 +48,7 @@ def test_rfd_matches_reference(case, backbone):
     replaced, labels = R.dynamic_mask_rfd(ids, mi, t(inp["replace_feat"]))
     assert torch.equal(replaced, t(z["in/input_ids_replaced"]))
     assert torch.equal(labels, t(z["in/labels"]))
-    final = R.final_of(backbone, P, replaced, cfg["NC"], cfg["NL"], pg.AUTOINT)
+    final = R.final_of(backbone, P, replaced, cfg["NC"], cfg["NL"], pg.extras_of(backbone))
     loss, count, acc, pos, logits = R.rfd_head(P, final, labels)
     np.testing.assert_allclose(loss.item(), float(z["out/loss"]), rtol=2e-6)
     if "out/logits" in z.files:
@@ -77,13 +77,17 @@ def test_ctr_matches_reference(case, backbone):
         np.testing.assert_allclose(R.lr_logit(P, ids).detach().numpy(), z["mid/lr"], rtol=1e-5, atol=2e-6)
         np.testing.assert_allclose(R.fm_product_sum(P["embed.embedding.weight"][ids]).detach().numpy(),
                                    z["mid/fm"], rtol=1e-5, atol=2e-6)
+    if backbone == "xDeepFM":
+        units = [int(c) for c in pg.XDEEPFM["cin_layer_units"].split(",")]
+        np.testing.assert_allclose(R.cin(P, P["embed.embedding.weight"][ids], units).detach().numpy(),
+                                   z["mid/cin_out"], rtol=1e-5, atol=2e-6)
     if backbone == "AutoInt":
         x = P["embed.embedding.weight"][ids]
         ai = pg.AUTOINT
         for li in range(ai["num_attn_layers"]):
             x = R.autoint_layer(P, x, li, ai["num_attn_heads"], ai["attn_size"], ai["res_conn"], ai["attn_scale"])
             np.testing.assert_allclose(x.detach().numpy(), z[f"mid/attn{li}"], rtol=1e-5, atol=2e-6)
-    logits = R.ctr_logits_of(backbone, P, ids, cfg["NC"], cfg["NL"], pg.AUTOINT)
+    logits = R.ctr_logits_of(backbone, P, ids, cfg["NC"], cfg["NL"], pg.extras_of(backbone))
     loss = torch.nn.functional.binary_cross_entropy_with_logits(logits.view(-1), t(inp["y"]).float())
     np.testing.assert_allclose(loss.item(), float(z["out/loss"]), rtol=2e-6)
     np.testing.assert_allclose(logits.detach().numpy(), z["out/logits"], rtol=1e-5, atol=2e-6)

@@ -54,13 +54,13 @@ def _oracle_loop(mode, cfg, params, steps, case, total, warmup, kind, lr0, wd, b
         if mode == "MFP":
             logq, _, _ = R.nce_buffers(si["feat_count"])
             masked, labels = R.dynamic_mask_mfp(ids, t(si["mi"]))
-            fin = R.final_of(backbone, P, masked, cfg["NC"], cfg["NL"], pg.AUTOINT)
+            fin = R.final_of(backbone, P, masked, cfg["NC"], cfg["NL"], pg.extras_of(backbone))
             loss, _, _ = R.mfp_head(P, fin, labels, t(si["mi"]), t(si["noise"]), logq, cfg["F"], cfg["P"], cfg["K"])
         elif mode == "RFD":
             rep, labels = R.dynamic_mask_rfd(ids, t(si["mi"]), t(si["repl"]))
-            loss = R.rfd_head(P, R.final_of(backbone, P, rep, cfg["NC"], cfg["NL"], pg.AUTOINT), labels)[0]
+            loss = R.rfd_head(P, R.final_of(backbone, P, rep, cfg["NC"], cfg["NL"], pg.extras_of(backbone)), labels)[0]
         else:
-            logits = R.ctr_logits_of(backbone, P, ids, cfg["NC"], cfg["NL"], pg.AUTOINT)
+            logits = R.ctr_logits_of(backbone, P, ids, cfg["NC"], cfg["NL"], pg.extras_of(backbone))
             loss = torch.nn.functional.binary_cross_entropy_with_logits(logits.view(-1), t(si["y"]).float())
         loss.backward()
         losses.append(float(loss.detach()))
@@ -77,7 +77,9 @@ def _oracle_loop(mode, cfg, params, steps, case, total, warmup, kind, lr0, wd, b
                           ("MFP", "cosine", 0.0, "DNN"), ("CTR", "const", 0.0, "DNN"),
                           ("MFP", "cosine", 0.2, "DeepFM"), ("RFD", "cosine", 0.0, "DeepFM"),
                           ("CTR", "const", 0.0, "DeepFM"),
-                          ("MFP", "cosine", 0.0, "AutoInt"), ("CTR", "const", 0.0, "AutoInt")])
+                          ("MFP", "cosine", 0.0, "AutoInt"), ("CTR", "const", 0.0, "AutoInt"),
+                          ("MFP", "cosine", 0.2, "xDeepFM"), ("RFD", "cosine", 0.0, "xDeepFM"),
+                          ("CTR", "const", 0.0, "xDeepFM")])
 def test_training_trajectory_matches_reference_semantics(mode, kind, warm, backbone):
     from mapx import ops
     from mapx.optim import MapxOptimizer
@@ -121,7 +123,7 @@ def test_training_trajectory_matches_reference_semantics(mode, kind, warm, backb
         model.eval()
         with torch.no_grad():
             (logits,) = model(input_ids=t(held["ids"], DEV))
-            ref_logits = R.ctr_logits_of(backbone, ref_params, t(held["ids"]), cfg["NC"], cfg["NL"], pg.AUTOINT)
+            ref_logits = R.ctr_logits_of(backbone, ref_params, t(held["ids"]), cfg["NC"], cfg["NL"], pg.extras_of(backbone))
         y = held["y"]
         auc = roc_auc_score(y, torch.sigmoid(logits.view(-1)).cpu().numpy())
         auc_ref = roc_auc_score(y, torch.sigmoid(ref_logits.view(-1)).numpy())
@@ -368,4 +370,34 @@ def test_run_py_deepfm_pretrain_then_finetune(tmp_path):
     assert r2.returncode == 0, r2.stderr[-3000:]
     log = open(os.path.join(fo, "results.log")).read()
     assert "Load tensor: lr_layer.embed_w.weight" in log and "Unmatched tensor in the target model: feat_encoder.weight" in log
+    assert "eval_auc" in log
+
+
+def test_run_py_xdeepfm_pretrain_then_finetune(tmp_path):
+    """run.py --model_name=xDeepFM: RFD pretraining (graph replay of the CIN step), then finetune with
+    use_lr from that checkpoint (CIN / MLP weights loaded by name, the LR term starts fresh)."""
+    from mapx.dataset import write_synth_dataset
+    data = write_synth_dataset(str(tmp_path / "data" / "avazu"), num_rows=4000, num_fields=23, vocab=2000)
+    common = ["--dataset_name=avazu", f"--data_dir={data}", "--per_gpu_train_batch_size=512",
+              "--per_gpu_eval_batch_size=512", "--learning_rate=1e-3", "--model_name=xDeepFM", "--embed_size=16",
+              "--hidden_size=64", "--num_hidden_layers=2", "--hidden_dropout_rate=0.0", "--logging_steps=3",
+              "--cin_layer_units=16,8"]
+    out = str(tmp_path / "out" / "rfd")
+    r = _run_py(["--pretrain=True", f"--output_dir={out}", "--num_train_epochs=1", "--lr_sched=cosine",
+                 "--weight_decay=5e-2", "--pt_type=RFD", "--sampling_method=randint", "--mask_ratio=0.3",
+                 "--RFD_replace=Unigram", "--proj_size=32"] + common, str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    steps = (3200 + 511) // 512
+    ckpt = os.path.join(out, f"{steps}.model")
+    sd = torch.load(ckpt)
+    assert {"cin.cin_layer.layer_1.weight", "cin.cin_layer.layer_2.bias", "dnn.dnn.0.weight",
+            "pred_rfd.0.weight"} <= set(sd)
+    assert tuple(sd["cin.cin_layer.layer_1.weight"].shape) == (16, 23 * 23, 1)
+    assert tuple(sd["cin.cin_layer.layer_2.weight"].shape) == (8, 23 * 16, 1)
+    fo = str(tmp_path / "out" / "finetune")
+    r2 = _run_py(["--finetune", f"--pretrained_model_path={ckpt}", f"--output_dir={fo}", "--num_train_epochs=1",
+                  "--lr_sched=const", "--weight_decay=1e-1", "--use_lr=True"] + common, str(tmp_path))
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    log = open(os.path.join(fo, "results.log")).read()
+    assert "Load tensor: cin.cin_layer.layer_2.weight" in log and "Unmatched tensor in the target model: pred_rfd.0.weight" in log
     assert "eval_auc" in log

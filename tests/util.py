@@ -44,7 +44,7 @@ def assert_digest(z, prefix, name, got, rtol=2e-5, atol=1e-6):
 def make_config(cfg, mode, feat_count=None, data_dir=None, seed=42, backbone="DCNv2"):
     """mapx Config for a fixture case (the 11 runtime keys of reference run.py:50-61 + flags)."""
     from mapx.arguments import Config
-    extra = dict(pg.AUTOINT) if backbone == "AutoInt" else {}
+    extra = pg.extras_of(backbone)
     return Config(**extra, model_name=backbone, data_dir=data_dir, input_size=cfg["V"], num_fields=cfg["F"],
                   embed_size=cfg["E"], embed_dropout_rate=0.0, embed_norm=False, layer_norm_eps=1e-12,
                   hidden_size=cfg["H"], num_hidden_layers=cfg["NL"], hidden_act="relu",
