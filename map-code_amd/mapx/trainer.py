@@ -434,8 +434,10 @@ class Trainer:
                     logger.info(f"step = {self.global_step}, {_log}")
                     win_loss.zero_(); win_acc.zero_()
                     start_time = time.time()
+            self.optimizer.flush()      # on EVERY rank: replicas must replay their lazy rows at the same steps
             if self.args.local_rank in [-1, 0]:
                 self.MFP_pretrain_eval()
+        self.optimizer.flush()
         if self.args.local_rank in [-1, 0]:
             self.save_model(self.args.output_dir)
         logger.info(str(self.eval_metrics))
@@ -486,8 +488,10 @@ class Trainer:
                     logger.info(f"step = {self.global_step}, {_log}")
                     win.zero_()
                     start_time = time.time()
+            self.optimizer.flush()      # on EVERY rank: replicas must replay their lazy rows at the same steps
             if self.args.local_rank in [-1, 0]:
                 self.RFD_pretrain_eval()
+        self.optimizer.flush()
         if self.args.local_rank in [-1, 0]:
             self.save_model(self.args.output_dir)
         logger.info(str(self.eval_metrics))
