@@ -820,6 +820,148 @@ __global__ void __launch_bounds__(256) ew_colsum_kernel(const float* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight-gradient GEMM with a deep K-step:  C[m,n] = sum_k A[k*lda + m] * B[k*ldb + n]
+// (dW = dY^T X: both operands k-strided).  Output tiles of 64x64 put exactly one block on each
+// of the 256 CUs for the step's 1000x1000 gradients; at BK = 32 such a block spends a third of
+// its time in the per-K-step fixed costs (barrier, LDS round trip, staging latency) because a
+// K-step is only 16 MFMAs per wave.  Here a K-step is 128 deep — 64 MFMAs per wave between
+// barriers (hipBLASLt picks the same shape for this problem: MT64x64x128) — and the operands go
+// from global memory straight into LDS (global_load_lds_dwordx4: no staging registers, no
+// ds_write, nothing for the MFMA stream to wait on until the end of the step).
+//   * a wave-instruction of the LDS-DMA writes 64 lanes x 16 B = 1 KB contiguous = 4 rows k of a
+//     tile (row = 64 consecutive floats); thread t fetches, for i in 0..7, row (t >> 4) + 16 i;
+//   * LDS image: rows 0..63 dense from the buffer's base, rows 64..127 dense behind them.  An
+//     MFMA operand register takes row j on lanes 0-31 and row 64+j on lanes 32-63 (any pairing
+//     of k values is a valid contraction order as long as A and B use the same one); every
+//     ds_read is 32 consecutive floats per half-wave: conflict-free without padding.
+//     2 operands x 2 buffers x 32 KB = 128 KB of the CU's 160.
+// Needs K-chunks that are multiples of 128 (no zero fill on the DMA path) and M, N multiples of 4.
+// Measured (1000x1000x4096): 81-87 us against 96-100 for the BK = 32 kernel; 2.1-2.4 us per K-step
+// of 64 MFMAs (1.95 at the MFMA rate): what is left is the L2 -> CU fill rate a 64x64 tile needs
+// (512 B per k per CU, 6.2 TB/s chip-wide at this speed).
+constexpr int kDeepBK = 128;
+constexpr int kDeepTile = kDeepBK * 64;                     // floats per operand buffer
+constexpr size_t kDeepLds = (size_t)4 * kDeepTile * sizeof(float);
+
+__device__ inline void deep_dma16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+__global__ void __launch_bounds__(256, 1) gemm_tn_deep_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];     // buffer b: A at 2b tiles, B one tile behind
+  const int nb = a.tiles_m * a.tiles_n;
+  int lin = blockIdx.x;
+  const int per = nb / 8;
+  if (lin < per * 8) lin = (lin % 8) * per + lin / 8;      // XCD-aware tile order (see gemm_f32_kernel)
+  const int tm = lin / a.tiles_n, tn = lin % a.tiles_n;
+  const int m0 = tm * 64, n0 = tn * 64;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int abase = (wave >> 1) * 32, bbase = (wave & 1) * 32;
+
+  const int kbeg = blockIdx.y * a.k_chunk;
+  const int kend = (kbeg + a.k_chunk < a.K) ? kbeg + a.k_chunk : a.K;
+  const int nk = (kend - kbeg) / kDeepBK;                  // host-checked: whole K-steps only
+
+  // DMA map: this lane's source for instruction i of a K-step is row (wave*4 + lane/16) + 16 i,
+  // floats [4 (lane & 15), +4); its wave's destination is the 1 KB that holds those 4 rows
+  const int scol = (lane & 15) * 4;
+  const int ca = min(m0 + scol, a.M - 4), cb = min(n0 + scol, a.N - 4);     // clamped: never stored from
+  const float* __restrict__ ga = a.A + (int64_t)(kbeg + wave * 4 + (lane >> 4)) * a.lda + ca;
+  const float* __restrict__ gb = a.B + (int64_t)(kbeg + wave * 4 + (lane >> 4)) * a.ldb + cb;
+  const int64_t sa = 16 * a.lda, sb = 16 * a.ldb;          // row stride between two instructions
+  const int ldst = wave * 4 * 64;                          // floats: first of this wave's 4 rows
+#define MAPX_DEEP_DMA(buf, i)                                                                  \
+  do {                                                                                         \
+    deep_dma16(ga + (i) * sa, smem + (buf) * 2 * kDeepTile + ldst + (i) * 16 * 64);            \
+    deep_dma16(gb + (i) * sb, smem + ((buf) * 2 + 1) * kDeepTile + ldst + (i) * 16 * 64);      \
+  } while (0)
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if (nk > 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) MAPX_DEEP_DMA(0, i);
+    ga += (int64_t)kDeepBK * a.lda;
+    gb += (int64_t)kDeepBK * a.ldb;
+  }
+  __syncthreads();                                         // (drains the DMA: vmcnt(0) + barrier)
+  const int fa = kh * 64 * 64 + abase + l31, fb = kh * 64 * 64 + bbase + l31;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    // the last step has nothing to prefetch: it re-fetches its own rows into the idle buffer, so
+    // that the group bodies stay branch-free (a branch between an LDS read and its MFMA makes the
+    // compiler wait for ALL outstanding LDS traffic at the join)
+    if (kt + 1 == nk) {
+      ga -= (int64_t)kDeepBK * a.lda;
+      gb -= (int64_t)kDeepBK * a.ldb;
+    }
+    const float* __restrict__ pa = smem + cur * 2 * kDeepTile + fa;
+    const float* __restrict__ pb = smem + (cur * 2 + 1) * kDeepTile + fb;
+    // 64 k-pairs in 8 groups of 8 MFMAs, fragments two groups ahead in three register sets.  The
+    // compiler waits for ALL outstanding LDS reads at the first MFMA of a group (with LDS-DMA in
+    // flight it does not count them), so that MFMA comes BEFORE the reads of group g+2 are issued:
+    // what is outstanding at the wait was issued a whole group (512 cycles) ago.
+    float av[3][8], bv[3][8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      av[0][u] = pa[u * 64]; bv[0][u] = pb[u * 64];
+      av[1][u] = pa[(8 + u) * 64]; bv[1][u] = pb[(8 + u) * 64];
+    }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g % 3][0], bv[g % 3][0], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 2 < 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          av[(g + 2) % 3][u] = pa[((g + 2) * 8 + u) * 64];
+          bv[(g + 2) % 3][u] = pb[((g + 2) * 8 + u) * 64];
+        }
+      }
+      if (g < 4) {                            // the whole next K-step is in flight after half of this one
+        MAPX_DEEP_DMA(cur ^ 1, 2 * g);
+        MAPX_DEEP_DMA(cur ^ 1, 2 * g + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // (one accumulation chain: a second, independent chain was measured and changes nothing —
+      // a dependent 32x32x2 MFMA issues back to back)
+#pragma unroll
+      for (int u = 1; u < 8; ++u)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g % 3][u], bv[g % 3][u], acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    ga += (int64_t)kDeepBK * a.lda;
+    gb += (int64_t)kDeepBK * a.ldb;
+    __syncthreads();
+  }
+#undef MAPX_DEEP_DMA
+
+  float* __restrict__ C = a.C + (int64_t)blockIdx.y * a.slab_stride;
+  const int n = n0 + bbase + l31;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + abase + 4 * kh + (r & 3) + 8 * (r >> 2);     // C/D map of the 32x32 MFMA
+    if (m < a.M && n < a.N) C[(int64_t)m * a.ldc + n] = acc[r];
+  }
+}
+
+static hipError_t deep_raise_lds() {
+  static hipError_t done = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_deep_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDeepLds);
+  return done;
+}
+
+static bool tn_deep_enabled() {
+  static int v = [] { const char* e = getenv("MAPX_DW_DEEP"); return e ? atoi(e) : 1; }();
+  return v != 0;
+}
+
 template <int WMT, int WNT, bool A_KC, bool B_KC, int BK>
 static void launch_tile(const GemmArgs& a, bool vec, int nsplit, hipStream_t stream) {
   dim3 grid(a.tiles_m * a.tiles_n, nsplit);
@@ -904,7 +1046,15 @@ extern "C" int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   g.dbg = tile_hint >= 0 ? (tile_hint >> 8) : 0;
   if (tile_hint >= 0) tile_hint &= 255;
   if (tile_hint >= 0 && tile_hint <= 4) tile = tile_hint;   // 2: 128x128, 1: 128x64, 0: 64x64; 3/4: 128x128 / 64x64 with BK = 64
-  if (a_kc && b_kc) launch_layout<true, true>(g, vec, tile, nsplit, stream);
+  // weight gradients whose 64x64 tiles (x splits) make one round of blocks: the deep-K kernel
+  const bool deep = !a_kc && !b_kc && epi == MAPX_EPI_NONE && vec && tn_deep_enabled() && tile_hint < 0 &&
+                    M >= 64 && N >= 64 && K % kDeepBK == 0 && g.k_chunk % kDeepBK == 0 &&
+                    g.k_chunk >= 2 * kDeepBK && blocks(64, 64) <= 256;
+  if (deep) {
+    MAPX_HIP(deep_raise_lds());
+    g.tiles_m = (M + 63) / 64; g.tiles_n = (N + 63) / 64;
+    hipLaunchKernelGGL(gemm_tn_deep_kernel, dim3(g.tiles_m * g.tiles_n, nsplit), dim3(256), kDeepLds, stream, g);
+  } else if (a_kc && b_kc) launch_layout<true, true>(g, vec, tile, nsplit, stream);
   else if (a_kc) launch_layout<true, false>(g, vec, tile, nsplit, stream);
   else launch_layout<false, false>(g, vec, tile, nsplit, stream);
   if (nsplit_deferred) *nsplit_deferred = nsplit > 1 ? nsplit : 0;   // caller sums the slabs later
