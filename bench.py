@@ -38,7 +38,7 @@ WORKLOADS = {
 PMC_MAP = {
     "gemm_fwd_nt": ["gemm_f32_kernel<", ", true, true, true,"],
     "gemm_dx_nn": ["gemm_f32_kernel<", ", true, false, true,"],
-    "gemm_dw_tn": ["gemm_f32_kernel<", ", false, false, true,"],
+    "gemm_dw_tn": [["gemm_f32_kernel<", ", false, false, true,"], ["gemm_tn_deep_kernel"]],
     "gemm_enc_grouped_fwd": ["gemm_grouped_kernel<false>"],
     "gemm_enc_grouped_dw": ["gemm_grouped_kernel<true>"],
     "nce_fwd": ["nce_fwd_"],
@@ -61,7 +61,9 @@ def pmc_traffic(name):
     data = json.load(open(path))
     tot = n = 0
     for k, v in data.items():
-        if all(sub in k for sub in PMC_MAP[name]):
+        pats = PMC_MAP[name]
+        pats = pats if isinstance(pats[0], list) else [pats]        # alternatives, each a list of substrings
+        if any(all(sub in k for sub in alt) for alt in pats):
             tot += v["hbm_bytes_per_launch"] * v["launches"]
             n += v["launches"]
     return tot / n if n else None
