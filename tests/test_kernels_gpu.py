@@ -237,6 +237,29 @@ def test_gemm_backward_products(ops, M, N, K):
     assert bool(((_cpu(dxm).double() - ref * (act > 0)).abs() <= bound).all())
 
 
+@pytest.mark.parametrize("M,N,K,ns", [(128, 192, 512, 1), (128, 192, 512, 2), (1000, 1000, 256, 1), (1000, 1000, 4096, 1),
+                                      (64, 64, 384, 1), (100, 68, 256, 1), (1000, 368, 2048, 2)])
+def test_gemm_tn_deep_kernel(ops, M, N, K, ns):
+    """Shapes that take the deep-K weight-gradient kernel (64x64x128 tiles, LDS-DMA staging: K and
+    the split chunks multiples of 128, one round of blocks): edge tiles (1000 = 15 x 64 + 40,
+    100 x 68), split-K slabs, and bit-reproducibility."""
+    g = torch.Generator().manual_seed(M + N + K + ns)
+    a, b = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+    ad, bd = a.to(DEV), b.to(DEV)
+    out = ops.gemm(ad, bd, False, False, M, N, K, nsplit=ns)
+    ref = a.double().t() @ b.double()
+    bound = 4e-6 * (a.abs().double().t() @ b.abs().double()) + 1e-6
+    assert bool(((_cpu(out).double() - ref).abs() <= bound).all())
+    assert torch.equal(out, ops.gemm(ad, bd, False, False, M, N, K, nsplit=ns))
+    # a padded leading dimension and an output with its own row stride
+    ap, bp = torch.zeros(K, M + 12, device=DEV), torch.zeros(K, N + 4, device=DEV)
+    ap[:, :M], bp[:, :N] = ad, bd
+    if ns == 1:
+        big = torch.full((M, N + 8), 3.0, device=DEV)
+        ops.gemm(ap, bp, False, False, M, N, K, out=big[:, :N], lda=M + 12, ldb=N + 4)
+        assert torch.equal(big[:, :N], out) and bool((big[:, N:] == 3.0).all())
+
+
 def test_gemm_writes_into_column_slice(ops):
     x, w, b = torch.randn(50, 64, device=DEV), torch.randn(40, 64, device=DEV), torch.randn(40, device=DEV)
     final = torch.full((50, 100), 7.0, device=DEV)
