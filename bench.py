@@ -17,8 +17,10 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")     # before the HIP runtime starts; see mapx/__init__.py
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "map-code_amd"))

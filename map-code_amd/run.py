@@ -12,8 +12,10 @@ import os
 import random
 import sys
 
-import numpy as np
-import torch
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")     # before the HIP runtime starts; see mapx/__init__.py
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
