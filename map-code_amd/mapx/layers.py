@@ -573,6 +573,7 @@ class _Bce(Function):
         out3, dl = ops.bce_with_logits(logits, labels, want_grad=True)
         ctx.save_for_backward(dl)
         ctx.mark_non_differentiable(out3)
+        ctx.set_materialize_grads(False)
         return out3[0].clone(), out3
 
     @staticmethod

@@ -65,6 +65,7 @@ class _NceLoss(Function):
         ctx.save_for_backward(o["dlogit"], o["dh"], o["h"], masked_index)
         logits = o["logits"] if want_logits else torch.empty(0, device=enc.device)
         ctx.mark_non_differentiable(o["acc"], logits)
+        ctx.set_materialize_grads(False)    # else autograd fills zero gradients for them: a launch on the chain
         ctx.crit.last_acc_ratio = o["loss"][1]      # device float, same launch as the loss
         return o["loss"][0], o["acc"].view(()), logits
 
@@ -100,6 +101,7 @@ class _EncNceLoss(Function):
         ctx.save_for_backward(final, w_enc, o["dlogit"], o["dh"], o["h"], masked_index, dh_slots)
         logits = o["logits"] if want_logits else torch.empty(0, device=final.device)
         ctx.mark_non_differentiable(o["acc"], logits)
+        ctx.set_materialize_grads(False)    # else autograd fills zero gradients for them: a launch on the chain
         ctx.crit.last_acc_ratio = o["loss"][1]      # device float, same launch as the loss
         return o["loss"][0], o["acc"].view(()), logits
 

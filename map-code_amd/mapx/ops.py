@@ -100,6 +100,14 @@ def aux_stream(name, device, high=False):
     return st
 
 
+def reset_aux_streams():
+    """Forget the named side streams (new ones are made on demand): after a failed graph capture
+    the old ones may be stuck in the invalidated capture."""
+    _aux_streams.clear()
+    _scratch_retired.extend(_scratch.values())
+    _scratch.clear()
+
+
 def stream_wait(waiter, waited):
     """waiter.wait_stream(waited), skipped when both are the same HIP stream (a self-wait is a
     no-op when run eagerly, but inside a stream capture it hands hipStreamEndCapture a node that

@@ -50,6 +50,17 @@ class DeviceSplit:
         return nb // world if world > 1 else nb
 
 
+def _capture(graph):
+    """torch.cuda.graph(graph); with a process group alive the capture runs in "thread_local" error
+    mode.  In the default "global" mode ANY thread's unsafe HIP call invalidates the capture, and
+    ProcessGroupNCCL's watchdog thread queries events all the time: about one capture in eight
+    died with "operation failed due to a previous error during capture" (and took the process
+    with it).  thread_local still rejects unsafe calls from the capturing thread itself."""
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        return torch.cuda.graph(graph, capture_error_mode="thread_local")
+    return torch.cuda.graph(graph)
+
+
 class GraphedStep:
     """One whole training step (mask -> forward -> backward -> optimizer -> schedule) captured
     in a hipGraph and replayed on static input buffers: ~115 kernel launches per step cost one
@@ -63,7 +74,7 @@ class GraphedStep:
         self.graph = torch.cuda.CUDAGraph()
         gs, sd = trainer.global_step, trainer.optimizer.steps_done
         try:
-            with torch.cuda.graph(self.graph):
+            with _capture(self.graph):
                 self.out = step_fn(self.X, self.Y)
         finally:
             # the capture pass ran the Python bookkeeping but no kernel
@@ -128,7 +139,7 @@ class GraphedBackward:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(self.graph):
+            with _capture(self.graph):
                 self.out = fwd_bwd_fn(self.X, self.Y)
         finally:
             if self.early:
@@ -200,13 +211,13 @@ class GraphedExchangeTail:
         saved = [tb.sparse_grad for tb in tables]
         torch.cuda.synchronize()
         self.pack = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.pack):
+        with _capture(self.pack):
             self.msgs = [parallel.pack_table(tb, m) for tb, m in zip(tables, sizes)]
         self.gathered = [parallel.gather_buffers(k, r) for k, r in self.msgs]
         self.merge = torch.cuda.CUDAGraph()
         sd = opt.steps_done
         try:
-            with torch.cuda.graph(self.merge):
+            with _capture(self.merge):
                 # the tables' merges are independent chains of small kernels: one branch each
                 # (largest message on the capture stream), joined before the optimizer.  (The
                 # dense AdamW as a third branch was measured slower)
@@ -364,6 +375,7 @@ class Trainer:
                     g = GraphedBackward(self, half, X, Y)
             except RuntimeError as e:          # a runtime that cannot capture this step: stay eager
                 logger.warning(f"hipGraph capture of the {kind} step failed ({e}); continuing eagerly")
+                ops.reset_aux_streams()         # side streams forked into the dead capture are unusable
                 torch.cuda.synchronize()
                 self.use_graph = False
                 for t in self.optimizer.tables:
