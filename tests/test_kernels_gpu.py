@@ -691,3 +691,25 @@ def test_cin_pieces(ops, B, F, E, H):
     dxt = torch.ones(B * E, H, device=DEV)
     ops.cin_pool_bwd(gp[:, 1:1 + H], B, E, dxt, accumulate=True)
     assert torch.equal(_cpu(dxt).view(B, E, H), 1.0 + _cpu(gp[:, 1:1 + H])[:, None, :].expand(B, E, H))
+
+
+def test_publish_i32_mailbox(ops):
+    """mapx_publish_i32 into coherent host memory: values, stamp, checksum; stream-ordered and
+    usable from a captured graph (the data-parallel step reads its segment counts this way)."""
+    box = ops.HostMailbox(8)
+    stamp = torch.zeros(1, dtype=torch.int32, device=DEV)
+    src = torch.tensor([123456, 7, -3], dtype=torch.int32, device=DEV)
+    ops.publish_i32(src, 3, stamp, box, at=1)
+    torch.cuda.synchronize()
+    a = box.np
+    assert list(a[1:4]) == [123456, 7, -3] and int(a[4]) == 1 and int(a[5]) == 123456 + 7 - 3 + 1 and int(a[0]) == 0
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        src.add_(1)
+        ops.publish_i32(src, 3, stamp, box, at=1)
+    for k in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert list(a[1:4]) == [123459, 10, 0] and int(a[4]) == 4 and int(a[5]) == 123459 + 10 + 0 + 4
+    with pytest.raises(ValueError):
+        ops.publish_i32(src, 3, stamp, box, at=5)
