@@ -401,3 +401,84 @@ def test_run_py_xdeepfm_pretrain_then_finetune(tmp_path):
     log = open(os.path.join(fo, "results.log")).read()
     assert "Load tensor: cin.cin_layer.layer_2.weight" in log and "Unmatched tensor in the target model: pred_rfd.0.weight" in log
     assert "eval_auc" in log
+
+
+def test_full_vocabulary_step_properties():
+    """BASELINE configs[1] at its real sizes (F = 23, V = 9 449 445, B = 4096, H = 1000, K = 25)
+    through size-independent properties, since the oracle's dense step is too slow to iterate here:
+    (1) the captured-graph step and the eager step leave bit-identical parameters;
+    (2) linearity: the embedding table's sparse gradient rows sum to the column sums of dL/dX0, and
+        every sampled NCE row is listed exactly once;
+    (3) rows that no step touched hold, after flush(), what transformers-4.26 AdamW gives a
+        parameter with zero gradient (oracle hf_adamw_step iterated) — the lazy replay at scale."""
+    from mapx.arguments import TrainingArguments
+    from mapx.dataset import AVAZU_F23_V, OurDataset, synth_table
+    from mapx.models import BaseModel
+    from mapx.trainer import Trainer
+    from oracle import ref_model as R
+    from util import make_config
+    cfg = dict(F=23, V=AVAZU_F23_V, E=16, H=1000, NL=3, NC=3, P=32, K=25)
+    B, steps = 4096, 7
+    ids, labels, _, _ = synth_table(B * steps, 23, cfg["V"], seed=5)
+    cnt = np.bincount(ids.reshape(-1), minlength=cfg["V"]).astype(np.float32)
+    probe = torch.from_numpy(np.random.default_rng(0).choice(cfg["V"], 4000, replace=False)).to(DEV)
+    finals, first = [], {}
+    for use_graph in (True, False):
+        torch.manual_seed(5)
+        config = make_config(cfg, "MFP", cnt)
+        model = BaseModel.from_config(config)
+        targs = TrainingArguments(output_dir="/tmp/mapx_full_vocab", per_gpu_train_batch_size=B,
+                                  per_gpu_eval_batch_size=B, learning_rate=1e-3, lr_sched="cosine",
+                                  weight_decay=5e-2, num_train_epochs=1, pretrain=True, pt_type="MFP",
+                                  sampling_method="randint", mask_ratio=0.3, logging_steps=100, seed=11)
+        targs._device = torch.device(DEV)
+        os.makedirs(targs.output_dir, exist_ok=True)
+        tr = Trainer(model, config, targs, OurDataset(ids, labels), OurDataset(ids[:B], labels[:B]))
+        tr.use_graph = use_graph
+        train = tr._begin("full-vocabulary test")
+        model.train()
+        if not first:
+            first = {n: p.detach()[probe].clone() for n, p in model.named_parameters()
+                     if n in ("embed.embedding.weight", "mfp_criterion.emb.weight", "mfp_criterion.bias.weight")}
+        touched = torch.zeros(cfg["V"], dtype=torch.bool, device=DEV)
+        for k, (X, Y) in enumerate(train.batches(B, True, tr._generator(), (0, 1))):
+            if not use_graph and k == 0:           # (2) on one eager step, before the optimizer consumes the gradients
+                inputs = tr.dynamic_mask({"input_ids": X, "labels": Y}, "randint")
+                x3 = model.embed(inputs["input_ids"])
+                x3.retain_grad()
+                flat = x3.flatten(1)
+                final = torch.cat([model.cross_net(flat), model.parallel_dnn(flat)], -1)
+                loss, _, idx = model.mfp_criterion.forward_with_encoder(inputs["labels"], final, model.feat_encoder,
+                                                                       inputs["masked_index"])
+                loss.backward()
+                plan, rows, _ = model.embed.table.sparse_grad
+                U = plan.count()
+                np.testing.assert_allclose(rows[:U].double().sum(0).cpu().numpy(),
+                                           x3.grad.double().sum((0, 1)).cpu().numpy(), rtol=1e-4, atol=1e-7)
+                assert torch.equal(plan.uniq[:U].long(), torch.unique(inputs["input_ids"]))
+                nplan = model.mfp_criterion.table.sparse_grad[0]
+                assert torch.equal(nplan.uniq[:nplan.count()].long(), torch.unique(idx.long()))
+                for t in tr.optimizer.tables:
+                    t.table.sparse_grad = None
+            tr.run_step("mfp", X, Y)
+        assert tr.global_step == steps
+        tr.optimizer.flush()
+        finals.append({n: p.detach().clone() for n, p in model.named_parameters()})
+        del tr, model
+        torch.cuda.empty_cache()
+    for n in finals[0]:                                                   # (1)
+        assert torch.equal(finals[0][n], finals[1][n]), n
+    # (3) rows whose value equals "zero-gradient AdamW from the initial value" must be exactly the
+    # untouched ones; check the prediction on the probe rows that stayed untouched in every table
+    lambdas = [R.lr_lambda("cosine", s, steps, 0) for s in range(steps)]
+    for n, p0 in first.items():
+        p = p0.double().cpu()
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        for s in range(steps):
+            R.hf_adamw_step(p, torch.zeros_like(p), m, v, s + 1, 1e-3 * lambdas[s], wd=5e-2 if R.decays(n) else 0.0)
+        got = finals[0][n][probe].double().cpu()
+        same = ((got - p).abs() <= 1e-6 * p.abs() + 1e-9).all(dim=1)
+        assert int(same.sum()) >= int(0.9 * probe.numel()), (n, int(same.sum()))     # Zipf tails: most rows untouched
+        moved = ((got - p0.double().cpu()).abs() > 0).any(dim=1)
+        if R.decays(n):
+            assert bool(moved[same].all()), n          # decayed rows did move, by exactly the predicted amount
