@@ -403,8 +403,10 @@ def test_run_py_xdeepfm_pretrain_then_finetune(tmp_path):
     assert "eval_auc" in log
 
 
-def test_full_vocabulary_step_properties():
-    """BASELINE configs[1] at its real sizes (F = 23, V = 9 449 445, B = 4096, H = 1000, K = 25)
+@pytest.mark.parametrize("F,V", [(23, 9_449_445), (39, 33_762_577)])
+def test_full_vocabulary_step_properties(F, V):
+    """BASELINE configs[1] / [2] at their real sizes (Avazu: F = 23, V = 9 449 445; Criteo: F = 39,
+    V = 33 762 577; B = 4096, H = 1000, K = 25; fp32)
     through size-independent properties, since the oracle's dense step is too slow to iterate here:
     (1) the captured-graph step and the eager step leave bit-identical parameters;
     (2) linearity: the embedding table's sparse gradient rows sum to the column sums of dL/dX0, and
@@ -412,14 +414,14 @@ def test_full_vocabulary_step_properties():
     (3) rows that no step touched hold, after flush(), what transformers-4.26 AdamW gives a
         parameter with zero gradient (oracle hf_adamw_step iterated) — the lazy replay at scale."""
     from mapx.arguments import TrainingArguments
-    from mapx.dataset import AVAZU_F23_V, OurDataset, synth_table
+    from mapx.dataset import OurDataset, synth_table
     from mapx.models import BaseModel
     from mapx.trainer import Trainer
     from oracle import ref_model as R
     from util import make_config
-    cfg = dict(F=23, V=AVAZU_F23_V, E=16, H=1000, NL=3, NC=3, P=32, K=25)
+    cfg = dict(F=F, V=V, E=16, H=1000, NL=3, NC=3, P=32, K=25)
     B, steps = 4096, 7
-    ids, labels, _, _ = synth_table(B * steps, 23, cfg["V"], seed=5)
+    ids, labels, _, _ = synth_table(B * steps, F, cfg["V"], seed=5)
     cnt = np.bincount(ids.reshape(-1), minlength=cfg["V"]).astype(np.float32)
     probe = torch.from_numpy(np.random.default_rng(0).choice(cfg["V"], 4000, replace=False)).to(DEV)
     finals, first = [], {}
