@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""Time the input-gradient GEMM dX = dY W on the step's shapes (MAPX_DX_DEEP = 0 / 1 / 2 selects
-which shapes take the deep-K kernel; read once per process) and check it against float64."""
+"""Time the input-gradient GEMM dX = dY W on the step's shapes and check it against float64."""
 import os
 import sys
 
@@ -25,4 +24,4 @@ for M, N, K in ((4096, 1368, 736), (4096, 1000, 1000), (4096, 368, 1000), (4096,
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 50
-    print(f"dX [{M}x{N}] K={K}: {us:7.1f} us  {2.0 * M * N * K / us / 1e6:6.1f} TF  rel.err {err:.1e}  mode {os.environ.get('MAPX_DX_DEEP', '1')}")
+    print(f"dX [{M}x{N}] K={K}: {us:7.1f} us  {2.0 * M * N * K / us / 1e6:6.1f} TF  rel.err {err:.1e}")
