@@ -605,6 +605,21 @@ def test_grouped_feat_encoder_matches_dense(ops, B, F, D):
     rowmap = _cpu(groups.rowmap)
     assert torch.equal(rowmap[hpos].long(), torch.arange(B).repeat_interleave(L))
     assert int((rowmap >= 0).sum()) == B * L
+    # THE layout: slots ordered by (field, target index), every field's group padded to 128
+    flat = mi.reshape(-1)
+    counts = torch.bincount(flat, minlength=F)
+    starts = torch.cumsum(torch.cat([torch.zeros(1, dtype=torch.long), (counts + 127) // 128 * 128]), 0)
+    order = torch.sort(flat, stable=True).indices
+    want_pos = torch.empty(B * L, dtype=torch.long)
+    within = torch.arange(B * L) - torch.repeat_interleave(torch.cumsum(counts, 0) - counts, counts)
+    want_pos[order] = starts[flat[order]] + within
+    assert torch.equal(hpos, want_pos)
+    assert torch.equal(_cpu(groups.group_start).long(), starts)
+    tg = _cpu(groups.tile_group).long()
+    want_tg = torch.full_like(tg, -1)
+    for f_ in range(F):
+        want_tg[starts[f_] // 128:starts[f_ + 1] // 128] = f_
+    assert torch.equal(tg, want_tg)
     # dW from slot-ordered dh
     dh = torch.randn(B * L, P, generator=g)
     dh_slots = torch.zeros(groups.cap, P)
