@@ -15,6 +15,7 @@ from .nce import IndexLinear
 
 logger = logging.getLogger(__name__)
 GROUPED_ENCODER = os.environ.get("MAPX_GROUPED_ENC", "1") == "1"
+NCE_EARLY = os.environ.get("MAPX_NCE_EARLY", "1") == "1"
 
 _OTHER_BACKBONES = ("trans", "fignn", "fgcnn")
 
@@ -64,7 +65,7 @@ class BaseModel(nn.Module):
 
     # ------------------------------------------------------------------ heads
     def get_outputs(self, inputs, labels=None, masked_index=None, is_pretrain=None, noise_samples=None,
-                    groups=None):
+                    groups=None, nce_idx=None):
         """MFP -> (loss, #signals, #targets ranked first)            (models.py:71-78)
         RFD -> (loss, #signals, accuracy, positive ratio)            (models.py:79-85)
         CTR -> (loss, logits) or (logits,)                           (models.py:88-93)
@@ -78,7 +79,7 @@ class BaseModel(nn.Module):
                     # only the L masked fields' blocks of feat_encoder are computed (26 %)
                     loss, _logits, _idx = crit.forward_with_encoder(labels, inputs, self.feat_encoder,
                                                                     masked_index, noise_samples=noise_samples,
-                                                                    groups=groups)
+                                                                    groups=groups, idx=nce_idx)
                 else:
                     enc = self.feat_encoder(inputs)
                     loss, _logits, _idx = crit(labels, enc, masked_index=masked_index,
@@ -164,7 +165,7 @@ class DCNV2(BaseModel):
                 and self.feat_encoder.in_features % 4 == 0)
 
     def forward(self, input_ids, labels=None, masked_index=None, noise_samples=None):
-        groups = None
+        groups, nce_idx = None, None
         feat_embed = self.embed(input_ids).flatten(start_dim=1)
         if self.config.num_hidden_layers > 0:
             # Three independent chains leave the gather: the cross tower (small D x D GEMMs on a
@@ -186,8 +187,15 @@ class DCNV2(BaseModel):
                     # the cross tower has ~70 us of slack against the deep one: the slot layout of
                     # the grouped encoder (one single-workgroup launch) rides on its stream
                     groups = ops.EncGroups(masked_index, self.config.num_fields)
+                    if NCE_EARLY and labels is not None:
+                        # the NCE head's sampling and the lazy catch-up of the sampled rows need only
+                        # the targets: HBM-bound kernels that run beside the deep tower's first GEMMs
+                        # instead of alone between the towers and the loss (same branch, no new one)
+                        nce_idx = self.mfp_criterion.sample_ids(labels, noise_samples)
                 cross_output = self.cross_net(feat_embed, out=ops.alias_cols(final_buf, 0, D) if direct else None)
             dnn_output = self.parallel_dnn(feat_embed, out=ops.alias_cols(final_buf, D, H) if direct else None)
+            # (starting the sampled ids' sort here, ahead of the embedding's, was measured: 1.375 vs
+            # 1.21 ms — the plan stream then hangs off the tower stream's event)
             self.embed.table.start_plan()
             ops.stream_wait(main, tower)
             if forked:
@@ -197,13 +205,17 @@ class DCNV2(BaseModel):
                     masked_index.record_stream(tower)
                     for t in groups.tensors():
                         t.record_stream(main)
+                if nce_idx is not None:
+                    labels.record_stream(tower)
+                    nce_idx.record_stream(main)
             final_output = _JoinColumns.apply(cross_output, dnn_output, final_buf) if direct \
                 else torch.cat([cross_output, dnn_output], dim=-1)
         else:
             final_output = self.cross_net(feat_embed)
             self.embed.table.start_plan()
         if self.config.pretrain:
-            return self.get_outputs(final_output, labels, masked_index, noise_samples=noise_samples, groups=groups)
+            return self.get_outputs(final_output, labels, masked_index, noise_samples=noise_samples, groups=groups,
+                                    nce_idx=nce_idx)
         return self.get_outputs(self.fc_out(final_output), labels)
 
 

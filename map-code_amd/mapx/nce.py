@@ -198,11 +198,12 @@ class IndexLinear(nn.Module):
     def supports_grouped_encoder(self):
         return self.proj_size == 32 and self.noise_ratio + 1 <= 32
 
-    def forward_with_encoder(self, target, final, encoder, masked_index, noise_samples=None, groups=None):
-        """The MFP head from the trunk output: `encoder` (feat_encoder) is applied only to the
-        field blocks that `masked_index` selects.  Same returns as forward()."""
+    def sample_ids(self, target, noise_samples=None):
+        """The step's sampled row ids [B*L, K+1] (target in column 0) and the lazy catch-up of the
+        rows they name.  Depends on the targets only, not on the trunk: a model may call it early,
+        on a stream that has slack (DCNV2 does, ahead of the cross tower), and hand the result to
+        forward_with_encoder."""
         B, L = target.shape
-        P, F = self.proj_size, encoder.out_features // self.proj_size
         V = self.emb.weight.shape[0]
         if noise_samples is not None:
             idx = ops.nce_pack_idx(target.reshape(-1), noise_samples.reshape(B * L, -1), V)
@@ -210,6 +211,16 @@ class IndexLinear(nn.Module):
             idx = self.get_noise_index(target)
         need_grad = torch.is_grad_enabled() and self.emb.weight.requires_grad
         self.table.prepare(idx.view(-1), need_grad, defer_plan=True)
+        return idx
+
+    def forward_with_encoder(self, target, final, encoder, masked_index, noise_samples=None, groups=None,
+                             idx=None):
+        """The MFP head from the trunk output: `encoder` (feat_encoder) is applied only to the
+        field blocks that `masked_index` selects.  Same returns as forward()."""
+        B, L = target.shape
+        P, F = self.proj_size, encoder.out_features // self.proj_size
+        if idx is None:
+            idx = self.sample_ids(target, noise_samples)
         if groups is None:
             groups = ops.EncGroups(masked_index, F)       # one launch: counting sort of the targets by field
         loss, acc, logits = _EncNceLoss.apply(final, encoder.weight, encoder.bias, self.emb.weight,
