@@ -356,6 +356,7 @@ class _CrossTower(Function):
         ws = saved[2 * n:3 * n]
         if not ops.row_sliceable(g):
             g = g.contiguous()                   # else read in place: a slice of d(concat) costs no copy
+        ops.run_side_tasks()                     # this chain has slack against the deep tower's
         grads = [None] * (2 * n)
         dx0 = None
         for i in range(n - 1, -1, -1):

@@ -121,6 +121,18 @@ class _EncNceLoss(Function):
         plan = ctx.plan.get()
         ge, gb = ops.nce_table_grad(plan, dlogit, h, ctx.K, ctx.P, gscale=gl)
         ctx.crit.table.sparse_grad = (plan, ge, gb)
+        lazy = ctx.crit.table.lazy
+        if lazy is not None and getattr(lazy, "early_now", False):
+            # the table's row update (HBM-bound, 26 us at the end of the step) needs nothing else of
+            # this backward pass: queued as a side task, it runs at the start of the cross tower's
+            # backward chain, which has slack against the deep tower's (1.212 -> 1.201 ms).  The
+            # encoder's bias-gradient column sum queued the same way cost what this gains.
+            def update_rows():
+                cur = torch.cuda.current_stream()
+                for t in (ge, gb) + tuple(plan.tensors()):
+                    t.record_stream(cur)
+                lazy.update()
+            ops.add_side_task(update_rows)
         return (dfinal, None if sw is not None else dw, None if sb is not None else db,
                 None, None, None, None, None, None, None, None, None, None)
 

@@ -100,6 +100,22 @@ def aux_stream(name, device, high=False):
     return st
 
 
+# Side tasks: HBM-bound work that is independent of the trunk's backward (e.g. the row update of a
+# table whose gradient is final) queued by one backward node and run by another at the START of a
+# side-stream chain that has slack (the cross tower's backward) — the same placement that works in
+# forward for the NCE sampling; whatever is still queued when the optimizer starts runs there.
+_side_tasks = []
+
+
+def add_side_task(fn):
+    _side_tasks.append(fn)
+
+
+def run_side_tasks():
+    while _side_tasks:
+        _side_tasks.pop(0)()
+
+
 def reset_aux_streams():
     """Forget the named side streams (new ones are made on demand): after a failed graph capture
     the old ones may be stuck in the invalidated capture."""

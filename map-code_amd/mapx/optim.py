@@ -9,6 +9,7 @@ reference's Trainer.get_optimizer builds it (code/trainer.py:60-85), on device.
   int, so nothing is synchronised with the host during training.
 """
 import math
+import os
 
 import torch
 
@@ -123,6 +124,20 @@ class MapxOptimizer:
             wd0 = self.wd if decays(names[id(t.p0)]) else 0.0
             wd1 = (self.wd if decays(names[id(t.p1)]) else 0.0) if t.p1 is not None else 0.0
             self.tables.append(TableAdam(t, wd0, wd1, self.hyper, self.sched, self.done, self.aux, max_gap))
+        # a table may apply its update as soon as its gradient is final (ops.add_side_task) unless the
+        # step needs all gradients first: a global clipping norm, or the gradient exchange of N ranks
+        from . import parallel
+        early = (os.environ.get("MAPX_EARLY_TABLE_UPDATE", "1") == "1" and self.max_grad_norm <= 0
+                 and not parallel.exchanging())
+        for t in self.tables:
+            t.early_ok, t.early_now = early, False
+
+    def backward_window(self, open_):
+        """Between backward_window(True) and (False) — the Trainer brackets loss.backward() of a step
+        whose optimizer.step() follows at once — a table may apply its row update as soon as its
+        gradient is final.  Outside the window backward() never touches a parameter."""
+        for t in self.tables:
+            t.early_now = bool(open_) and t.early_ok
 
     @staticmethod
     def _flatten(members, wd, dev):
@@ -173,6 +188,7 @@ class MapxOptimizer:
                 p.grad = None
 
     def step(self):
+        ops.run_side_tasks()            # early table updates nobody picked up
         self.collect_torch_grads()
         ops.flush_deferred()            # split-K slabs / colsum partials of this backward pass
         if self.max_grad_norm > 0:

@@ -320,7 +320,11 @@ class Trainer:
     def _mfp_fwd_bwd(self, X, Y):
         inputs = self.dynamic_mask({"input_ids": X, "labels": Y}, self.args.sampling_method)
         loss, count, acc = self.model(**inputs)
-        loss.backward(self._one.view(loss.shape))
+        self.optimizer.backward_window(True)
+        try:
+            loss.backward(self._one.view(loss.shape))
+        finally:
+            self.optimizer.backward_window(False)
         return loss.detach(), self.model.mfp_criterion.last_acc_ratio      # = acc / count, from the loss kernel
 
     def _rfd_fwd_bwd(self, X, Y):
