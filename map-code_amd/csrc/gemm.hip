@@ -671,6 +671,78 @@ __global__ void __launch_bounds__(kLayoutThreads) enc_group_layout_kernel(
   }
 }
 
+// The same layout with one workgroup PER FIELD (grid = F).  The single-workgroup kernel above takes
+// 30-50 us at the head of the cross tower's stream, and since the NCE sampling joined it there that
+// chain is the longer one of the forward pass.  Every workgroup histograms all T field ids (LDS
+// atomics; the ids are cached as bytes in LDS), so each knows the padded start of its own field's
+// group without talking to the others; then its 4 waves place the targets of field f in target
+// order: wave w owns a contiguous quarter of the targets, counts its matches first (ballots), and
+// after one barrier walks the quarter again handing out consecutive slots.  Stable, like the
+// kernel above, so the dW summation order is unchanged.
+__global__ void __launch_bounds__(256) enc_group_layout_mw_kernel(
+    const int64_t* __restrict__ masked_index, int T, int L, int F, int cap_slots, int32_t* __restrict__ rowmap,
+    int32_t* __restrict__ hpos, int32_t* __restrict__ tile_group, int32_t* __restrict__ group_start) {
+  __shared__ int hist[64];
+  __shared__ int wave_match[4];
+  __shared__ int gs[64 + 1];
+  extern __shared__ uint8_t fld[];     // [T]
+  const int f = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+  __syncthreads();
+  // pass 1: histogram of every field + this wave's number of targets of field f
+  const int per = ((T + 255) / 256) * 64;            // targets per wave, a multiple of 64
+  const int w0 = wave * per, w1 = min(w0 + per, T);
+  int mine = 0;
+  for (int t = w0 + lane; t < w0 + per; t += 64) {
+    const bool live = t < w1;
+    int g = 0;
+    if (live) {
+      g = (int)masked_index[t];
+      g = g < 0 ? 0 : (g >= F ? F - 1 : g);
+      fld[t] = (uint8_t)g;
+      atomicAdd(&hist[g], 1);
+    }
+    mine += __popcll(__ballot(live && g == f));
+  }
+  if (lane == 0) wave_match[wave] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int g = 0; g < F; ++g) {
+      gs[g] = run;
+      run += (hist[g] + 127) / 128 * 128;
+    }
+    gs[F] = run;
+  }
+  __syncthreads();
+  const int start = gs[f], cnt = hist[f], padded = gs[f + 1];
+  if (threadIdx.x == 0) {
+    group_start[f] = start;
+    if (f == F - 1) group_start[F] = gs[F];
+  }
+  // padding slots of this group, the capacity behind the last group, and the tiles' fields
+  for (int sl = start + cnt + threadIdx.x; sl < padded; sl += 256) rowmap[sl] = -1;
+  for (int k = start / 128 + threadIdx.x; k < padded / 128; k += 256) tile_group[k] = f;
+  if (f == F - 1) {
+    for (int sl = gs[F] + threadIdx.x; sl < cap_slots; sl += 256) rowmap[sl] = -1;
+    for (int k = gs[F] / 128 + threadIdx.x; k < cap_slots / 128; k += 256) tile_group[k] = -1;
+  }
+  // pass 2: placement in target order
+  int base = start;
+  for (int w = 0; w < wave; ++w) base += wave_match[w];
+  for (int t = w0 + lane; t < w0 + per; t += 64) {
+    const bool hit = t < w1 && fld[t] == f;
+    const unsigned long long peers = __ballot(hit);
+    if (hit) {
+      const int sl = base + __popcll(peers & ((1ull << lane) - 1ull));
+      hpos[t] = sl;
+      rowmap[sl] = t / L;
+    }
+    base += __popcll(peers);
+  }
+}
+
 // out[i] = sum_s slabs[s][i] in slab order (deterministic split-K combine)
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ slabs,
                                                             int64_t slab_stride, int nsplit,
@@ -1083,8 +1155,20 @@ extern "C" int mapx_enc_group_layout(const int64_t* masked_index, int T, int L, 
                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLayoutMaxT));
     raised = true;
   }
-  hipLaunchKernelGGL(enc_group_layout_kernel, dim3(1), dim3(kLayoutThreads), dyn, stream, masked_index, T, L, F,
-                     cap_slots, rowmap, hpos, tile_group, group_start);
+  static const bool one_block = [] { const char* e = getenv("MAPX_LAYOUT_ONE_BLOCK"); return e && atoi(e) != 0; }();
+  if (one_block) {
+    hipLaunchKernelGGL(enc_group_layout_kernel, dim3(1), dim3(kLayoutThreads), dyn, stream, masked_index, T, L, F,
+                       cap_slots, rowmap, hpos, tile_group, group_start);
+  } else {
+    static bool raised_mw = false;
+    if (!raised_mw) {
+      MAPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_group_layout_mw_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLayoutMaxT));
+      raised_mw = true;
+    }
+    hipLaunchKernelGGL(enc_group_layout_mw_kernel, dim3(F), dim3(256), dyn, stream, masked_index, T, L, F,
+                       cap_slots, rowmap, hpos, tile_group, group_start);
+  }
   return check_launch("enc_group_layout");
 }
 
