@@ -249,6 +249,8 @@ def main():
     # the same step run eagerly right after the timed region (a graph replay has no
     # per-kernel launch points to bracket; kernel durations do not depend on the launch mode)
     ops.serialize_streams = True          # no side streams: every kernel is timed running alone
+    for t in tr.optimizer.tables:         # ... and in program order: no row update squeezed in front of the
+        t.early_ok = False                # cross tower's GEMMs (it leaves them a cold L2: +14 us each)
     with ops.Timers() as timers:
         for X, Y in staged[:max(5, min(20, args.steps))]:
             # park the GPU for ~4 ms first so that the host enqueues the whole step ahead of it:
