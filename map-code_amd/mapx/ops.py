@@ -116,6 +116,11 @@ def run_side_tasks():
         _side_tasks.pop(0)()
 
 
+def clear_side_tasks():
+    """Drop tasks that an aborted backward pass left behind."""
+    _side_tasks.clear()
+
+
 def reset_aux_streams():
     """Forget the named side streams (new ones are made on demand): after a failed graph capture
     the old ones may be stuck in the invalidated capture."""

@@ -136,6 +136,8 @@ class MapxOptimizer:
         """Between backward_window(True) and (False) — the Trainer brackets loss.backward() of a step
         whose optimizer.step() follows at once — a table may apply its row update as soon as its
         gradient is final.  Outside the window backward() never touches a parameter."""
+        if open_:
+            ops.clear_side_tasks()      # leftovers of a backward pass that raised
         for t in self.tables:
             t.early_now = bool(open_) and t.early_ok
 
