@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 23
+#define MAPX_ABI_VERSION 24
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -294,11 +294,13 @@ int mapx_bce_with_logits(const float* logits, const float* labels, int64_t n, fl
 size_t mapx_eval_metrics_workspace_bytes(int64_t n);
 int mapx_eval_metrics(const float* logits, const float* labels, int64_t n, double* out6, void* ws,
                       size_t ws_bytes, hipStream_t stream);
-/* trainer.py:217-232 (MFP, sampling_method="randint"): masked_index_in NULL -> Philox. */
+/* trainer.py:217-232 (MFP, sampling_method="randint"): masked_index_in NULL -> Philox.
+ * keys_out_opt [B*F] int32: the masked ids once more as the int32 row keys the embedding table's
+ * catch-up and segment plan take (saves the mapx_ids_to_i32 launch at the head of the step). */
 int mapx_dynamic_mask_mfp(const int64_t* ids, int64_t B, int F, int L,
                           const int64_t* masked_index_in, uint64_t seed, uint64_t offset,
                           const int32_t* offset_dev, int64_t* ids_out, int64_t* labels,
-                          int64_t* masked_index_out, hipStream_t stream);
+                          int64_t* masked_index_out, int32_t* keys_out_opt, hipStream_t stream);
 /* trainer.py:233-262 (RFD).  mode = RFD_replace: 0 Unigram, 1 Uniform (idx_low/idx_high [F]),
  * 2 Whole-Uniform (ids 10..V-1), 3 Whole-Unigram; x_train [N,F] device-resident; labels f32 [B,F]. */
 int mapx_dynamic_mask_rfd(const int64_t* ids, int64_t B, int F, int L,

@@ -66,7 +66,8 @@ __global__ void __launch_bounds__(256) mask_mfp_kernel(const int64_t* __restrict
                                                        const int32_t* __restrict__ offset_dev,
                                                        int64_t* __restrict__ ids_out,
                                                        int64_t* __restrict__ labels,
-                                                       int64_t* __restrict__ mi_out) {
+                                                       int64_t* __restrict__ mi_out,
+                                                       int32_t* __restrict__ keys_out) {
   if (offset_dev) offset += (uint64_t)(uint32_t)*offset_dev;   // graph-replay safe stream offset
   for (int64_t b0 = (int64_t)blockIdx.x * kMaskRows; b0 < B; b0 += (int64_t)gridDim.x * kMaskRows) {
     const int64_t rows = (B - b0) < kMaskRows ? (B - b0) : kMaskRows;
@@ -86,7 +87,10 @@ __global__ void __launch_bounds__(256) mask_mfp_kernel(const int64_t* __restrict
       labels[b * L + l] = ids[b * F + f];
       ids_out[b * F + f] = 3;  // '<mask>' (duplicates of f write the same value)
     }
+    __threadfence_block();
     __syncthreads();
+    if (keys_out)
+      for (int64_t i = threadIdx.x; i < rows * F; i += blockDim.x) keys_out[b0 * F + i] = (int32_t)ids_out[b0 * F + i];
   }
 }
 
@@ -185,13 +189,13 @@ extern "C" int mapx_bce_with_logits(const float* logits, const float* labels, in
 extern "C" int mapx_dynamic_mask_mfp(const int64_t* ids, int64_t B, int F, int L,
                                      const int64_t* masked_index_in, uint64_t seed, uint64_t offset,
                                      const int32_t* offset_dev, int64_t* ids_out, int64_t* labels,
-                                     int64_t* masked_index_out, hipStream_t stream) {
+                                     int64_t* masked_index_out, int32_t* keys_out_opt, hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(ids && ids_out && labels && B >= 0 && F > 0 && L >= 0, "dynamic_mask_mfp: bad arguments");
   MAPX_REQUIRE(ids != ids_out, "dynamic_mask_mfp: in-place masking is not supported");
   if (B == 0) return MAPX_OK;
   hipLaunchKernelGGL(mask_mfp_kernel, dim3(grid_for(B, kMaskRows)), dim3(256), 0, stream, ids, B, F, L,
-                     masked_index_in, seed, offset, offset_dev, ids_out, labels, masked_index_out);
+                     masked_index_in, seed, offset, offset_dev, ids_out, labels, masked_index_out, keys_out_opt);
   return check_launch("dynamic_mask_mfp");
 }
 

@@ -11,9 +11,12 @@ Differences that are deliberate:
     reference synchronises twice per step with .item());
   * the reference's NameError at trainer.py:341 (`log` undefined) is not reproduced.
 """
+import contextlib
+import gc
 import logging
 import os
 import time
+import weakref
 
 import numpy as np
 import torch
@@ -50,15 +53,35 @@ class DeviceSplit:
         return nb // world if world > 1 else nb
 
 
+def _weak(obj):
+    return obj if isinstance(obj, weakref.ProxyTypes) else weakref.proxy(obj)
+
+
+@contextlib.contextmanager
 def _capture(graph):
-    """torch.cuda.graph(graph); with a process group alive the capture runs in "thread_local" error
-    mode.  In the default "global" mode ANY thread's unsafe HIP call invalidates the capture, and
-    ProcessGroupNCCL's watchdog thread queries events all the time: about one capture in eight
-    died with "operation failed due to a previous error during capture" (and took the process
-    with it).  thread_local still rejects unsafe calls from the capturing thread itself."""
+    """torch.cuda.graph(graph), hardened against what other code may do while a stream captures:
+    * with a process group alive the capture runs in "thread_local" error mode.  In the default
+      "global" mode ANY thread's unsafe HIP call invalidates the capture, and ProcessGroupNCCL's
+      watchdog thread queries events all the time: about one capture in eight died with "operation
+      failed due to a previous error during capture" (and took the process with it).
+      thread_local still rejects unsafe calls from the capturing thread itself;
+    * Python's cyclic garbage collector is off for the duration: a collection that starts inside
+      the capture may destroy graphs / events / pinned buffers of objects that died earlier
+      (e.g. a previous Trainer and its captured step reference each other), and those
+      destructors are not capture-safe — observed as "Fatal Python error: Aborted ...
+      Garbage-collecting" in the middle of a forward pass being captured."""
+    kw = {}
     if torch.distributed.is_available() and torch.distributed.is_initialized():
-        return torch.cuda.graph(graph, capture_error_mode="thread_local")
-    return torch.cuda.graph(graph)
+        kw["capture_error_mode"] = "thread_local"
+    was_enabled = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, **kw):
+            yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 class GraphedStep:
@@ -68,7 +91,7 @@ class GraphedStep:
     that varies per step lives on the device (update counter, Philox offsets, LR table)."""
 
     def __init__(self, trainer, step_fn, X, Y):
-        self.trainer = trainer
+        self.trainer = _weak(trainer)       # no trainer <-> graph cycle: both die by reference count
         self.X, self.Y = X.clone(), Y.clone()
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
@@ -113,7 +136,7 @@ class GraphedBackward:
 
     def __init__(self, trainer, fwd_bwd_fn, X, Y):
         from . import layers
-        self.trainer = trainer
+        self.trainer = _weak(trainer)       # no trainer <-> graph cycle: both die by reference count
         self.X, self.Y = X.clone(), Y.clone()
         # (gloo stages every message through host memory: its exchange stays eager)
         self.early = (parallel.exchanging() and parallel.EXCHANGE == "gather" and X.is_cuda
@@ -206,7 +229,7 @@ class GraphedExchangeTail:
     is still running."""
 
     def __init__(self, trainer, tables, sizes):
-        self.trainer = trainer
+        self.trainer = _weak(trainer)       # no trainer <-> graph cycle: both die by reference count
         opt = trainer.optimizer
         saved = [tb.sparse_grad for tb in tables]
         torch.cuda.synchronize()
