@@ -151,3 +151,17 @@ def test_single_process_is_a_no_op():
     t = torch.ones(3)
     assert parallel.allreduce_mean_(t) is t
     parallel.barrier()
+
+
+def test_message_size_buckets():
+    """Exchange message sizes: never below the count, at most 1/16 of a power of two above it (so
+    <= 6.25 % padding), monotone, and few distinct values over a +-2 % drift of the count."""
+    from mapx import parallel
+    for c in list(range(1, 3000, 7)) + [17_000, 17_408, 17_409, 86_000, 90_113, 250_000, 2_000_000]:
+        m = parallel.message_size(c)
+        assert m >= c and m >= 256
+        if c >= 4096:
+            assert m - c <= (1 << (c.bit_length() - 1)) // 16
+    for c in range(1, 200_000, 997):
+        assert parallel.message_size(c + 1) >= parallel.message_size(c)
+    assert len({parallel.message_size(c) for c in range(84_000, 88_000)}) <= 2
