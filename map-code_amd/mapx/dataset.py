@@ -3,8 +3,9 @@ Avazu/Criteo-shaped data (no real data is reachable offline).
 
 On-disk contract (produced by the reference's data_preprocess/*.py):
   <data_dir>/<name>-meta.json   field_names, feat_map (str -> global id), field_map
-  <data_dir>/<name>.h5          feat_ids int64 [N,F], labels int64 [N]   (needs h5py), or
-  <data_dir>/<name>.npz         the same two arrays (np.savez) when h5py is not installed
+  <data_dir>/<name>.h5          feat_ids int64 [N,F], labels int64 [N]   (h5py, or mapx/h5lite.py = libhdf5
+                                through ctypes when h5py is not installed), or
+  <data_dir>/<name>.npz         the same two arrays (np.savez)
   <data_dir>/split.pkl          {train,valid,test}_index
   <data_dir>/feat-count.pt      float32 [V] train-split id counts (built on first pretrain run)
 """
@@ -79,9 +80,14 @@ class BaseDataset:
         elif os.path.exists(path):
             self.feat_count = torch.load(path)
         else:
+            # every rank counts for itself (np.bincount, deterministic); rank 0 alone writes the
+            # file, atomically, so no rank ever reads a half-written one
             cnt = np.bincount(self.X["train"].reshape(-1), minlength=len(self.feat_map))
             self.feat_count = torch.from_numpy(cnt.astype(np.float32))
-            torch.save(self.feat_count, path)
+            if int(os.environ.get("RANK", "0")) == 0:
+                tmp = f"{path}.tmp.{os.getpid()}"
+                torch.save(self.feat_count, tmp)
+                os.replace(tmp, path)
 
     def count_feat_per_field(self, feat_ids):
         if self.args.pt_type == "RFD" and self.args.RFD_replace == "Uniform":

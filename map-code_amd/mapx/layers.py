@@ -48,7 +48,12 @@ class RowTable:
           that must not queue behind the sort are enqueued (a captured graph keeps the first
           forked branch on the parent's queue); backward starts it itself if nobody did."""
         self.plan = PlanSlot(self, keys_i32) if need_plan else None      # fork point: keys are final
-        if self.lazy is not None and self.lazy.stale:
+        # `stale` is a host flag of the moment this code runs; a step being CAPTURED is replayed
+        # many times, nearly always with stale rows, so the catch-up is always part of a capture
+        # (it is a read of last[] and nothing else for rows that are current).  Capturing right
+        # after a flush (stale == False: first step of an epoch, or after eval / save) otherwise
+        # gave a graph whose replays read rows that had missed their zero-gradient updates.
+        if self.lazy is not None and (self.lazy.stale or torch.cuda.is_current_stream_capturing()):
             self.lazy.catch_up_raw(keys_i32)
         if need_plan and not defer_plan:
             self.plan.start()

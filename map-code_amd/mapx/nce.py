@@ -30,9 +30,13 @@ class AliasMultinomial(nn.Module):
                 raise ValueError(f"{pf} holds {prob.numel()} classes, expected {probs.numel()}")
         else:
             prob, alias = ops.alias_build(probs)
-            if pf and os.path.isdir(data_dir):
-                torch.save(prob, pf)
-                torch.save(alias, af)
+            if pf and os.path.isdir(data_dir) and int(getattr(config, "rank", 0)) == 0:
+                # rank 0 alone writes the cache, atomically and `prob` last (readers test for
+                # both files): another rank either loads whole files or builds the table itself
+                for obj, path in ((alias, af), (prob, pf)):
+                    tmp = f"{path}.tmp.{os.getpid()}"
+                    torch.save(obj, tmp)
+                    os.replace(tmp, path)
         self.register_buffer("prob", prob)
         self.register_buffer("alias", alias)
         self._packed = None

@@ -329,3 +329,17 @@ def sync_gradients(optimizer, merge_fn=hip_merge, known_max=None):
 def barrier():
     if world() > 1:
         dist.barrier()
+
+
+def all_agree(ok):
+    """True iff `ok` is true on EVERY rank (one MIN all-reduce of a host int; no collective and
+    plain `ok` on a single rank).  For decisions that change which collectives a rank issues
+    next — e.g. falling back from the captured step to the eager one — so that no rank takes
+    them alone."""
+    if not exchanging():
+        return bool(ok)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    if dist.get_backend() == "nccl":
+        flag = flag.cuda()
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(int(flag.item()))

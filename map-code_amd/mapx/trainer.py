@@ -36,11 +36,19 @@ class DeviceSplit:
         self.n = self.X.shape[0]
 
     def batches(self, batch_size, shuffle, generator=None, shard=(0, 1)):
-        """Yield (X_b, Y_b).  shard = (rank, world): rank r takes batches r, r+world, ..."""
+        """Yield (X_b, Y_b).  shard = (rank, world): rank r takes batches r, r+world, ...
+        With world > 1 only FULL batches are dealt, and only whole rounds of `world` of them (the
+        ragged tail of an epoch is dropped for every rank): all ranks then run the same number of
+        steps on the same batch shape, so they take the graph / eager decision together and issue
+        the same sequence of collectives, and the mean over ranks is the mean over the global
+        batch's rows."""
         order = torch.randperm(self.n, device=self.X.device, generator=generator) if shuffle else None
         r, w = shard
         starts = list(range(0, self.n, batch_size))
-        for bi in range(r, len(starts) - (len(starts) % w if w > 1 else 0), w):
+        if w > 1:
+            starts = starts[:self.n // batch_size]
+            starts = starts[:len(starts) - len(starts) % w]
+        for bi in range(r, len(starts), w):
             s = starts[bi]
             if order is None:
                 yield self.X[s:s + batch_size], self.Y[s:s + batch_size]
@@ -49,8 +57,9 @@ class DeviceSplit:
                 yield self.X[sel], self.Y[sel]
 
     def num_batches(self, batch_size, world=1):
-        nb = (self.n + batch_size - 1) // batch_size
-        return nb // world if world > 1 else nb
+        if world > 1:
+            return (self.n // batch_size) // world          # full batches only, whole rounds (see batches)
+        return (self.n + batch_size - 1) // batch_size
 
 
 def _weak(obj):
@@ -180,8 +189,21 @@ class GraphedBackward:
         a, t0 = self.pinned_np, time.perf_counter()
         for i in self.published:
             while not (int(a[i, 1]) == self.replays and int(a[i, 0]) + int(a[i, 1]) == int(a[i, 2])):
-                if time.perf_counter() - t0 > 60.0:
-                    raise RuntimeError("the step graph did not publish its segment counts within 60 s")
+                waited = time.perf_counter() - t0
+                if waited > 1e-3:
+                    time.sleep(0 if waited < 0.05 else 1e-3)     # past a step's length: stop burning the core
+                if waited > 60.0:
+                    seen = {j: tuple(int(x) for x in a[j, :3]) for j in self.published}
+                    try:
+                        torch.cuda.synchronize()                 # surface the HIP error behind a dead replay
+                    except RuntimeError as e:
+                        raise RuntimeError(f"the step graph failed before publishing its segment counts: {e}; "
+                                           f"mailbox (count, stamp, check) per table = {seen}, "
+                                           f"expected stamp {self.replays}") from e
+                    raise RuntimeError("the step graph did not publish its segment counts within 60 s: mailbox "
+                                       f"(count, stamp, check) per table = {seen}, expected stamp {self.replays} "
+                                       "(a stalled collective on another rank keeps the previous tail, and so "
+                                       "this replay, from running)")
         self.poll_s += time.perf_counter() - t0
         T = len(self.published)
         for k, i in enumerate(self.published):
@@ -394,6 +416,7 @@ class Trainer:
             if g < self.GRAPH_AFTER:
                 self._graphs[key] = g + 1
                 return fn(X, Y)
+            err = None
             try:
                 if not parallel.exchanging() and self.optimizer.max_grad_norm <= 0:
                     g = GraphedStep(self, fn, X, Y)
@@ -401,10 +424,20 @@ class Trainer:
                     half = {"mfp": self._mfp_fwd_bwd, "rfd": self._rfd_fwd_bwd, "ctr": self._ctr_fwd_bwd}[kind]
                     g = GraphedBackward(self, half, X, Y)
             except RuntimeError as e:          # a runtime that cannot capture this step: stay eager
-                logger.warning(f"hipGraph capture of the {kind} step failed ({e}); continuing eagerly")
+                err = e
+            # The graphed and the eager step issue different collective sequences, so the ranks
+            # switch together or not at all: one rank's failed capture sends every rank back to
+            # eager (a capture issues no collective itself, so this all-reduce is the next one on
+            # every rank whatever happened above).
+            if not parallel.all_agree(err is None):
+                if err is None:
+                    err = "another rank could not capture it"
+                logger.warning(f"hipGraph capture of the {kind} step failed ({err}); continuing eagerly")
                 ops.reset_aux_streams()         # side streams forked into the dead capture are unusable
-                torch.cuda.synchronize()
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
                 self.use_graph = False
+                self._graphs[key] = 0
                 for t in self.optimizer.tables:
                     t.table.sparse_grad = None
                 return fn(X, Y)
@@ -615,6 +648,9 @@ class Trainer:
                 self._patience += 1
             if self._patience > self.args.patience:
                 self._stop_training = True
+            # every rank runs eval() and takes the same branch (replicas are bit-identical); rank 0
+            # may have written {step}.model above, which other ranks load in test()
+            parallel.barrier()
         return _log
 
     # ------------------------------------------------------------------ checkpoints (a15)
@@ -625,7 +661,10 @@ class Trainer:
         if self.optimizer is not None:
             self.optimizer.flush()
         sd = {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}
-        torch.save(sd, os.path.join(model_dir, f"{self.global_step}.model"))
+        path = os.path.join(model_dir, f"{self.global_step}.model")
+        tmp = f"{path}.tmp.{os.getpid()}"
+        torch.save(sd, tmp)
+        os.replace(tmp, path)           # readers (other ranks' test()) never see a partial file
 
     def save_training_state(self, path):
         """Full resume state, beyond the reference's weights-only checkpoint: raw (un-flushed)

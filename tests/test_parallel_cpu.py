@@ -165,3 +165,97 @@ def test_message_size_buckets():
     for c in range(1, 200_000, 997):
         assert parallel.message_size(c + 1) >= parallel.message_size(c)
     assert len({parallel.message_size(c) for c in range(84_000, 88_000)}) <= 2
+
+
+# ------------------------------------------------------------------ the ranks stay in lockstep
+class _ToySplit:
+    pass
+
+
+def test_ragged_epoch_deals_full_batches_in_whole_rounds():
+    """n = 9 full batches + 100 rows, B = 512, 2 ranks used to hand the ragged
+    batch to the last rank only.  With world > 1 only full batches are dealt, in whole rounds."""
+    from mapx.trainer import DeviceSplit
+    import numpy as np
+
+    class DS:
+        X = np.arange((512 * 9 + 100) * 3, dtype=np.int64).reshape(-1, 3)
+        Y = np.arange(512 * 9 + 100, dtype=np.int64)
+    sp = DeviceSplit(DS, "cpu")
+    seen = []
+    for w in (2, 3, 4):
+        per_rank = [[tuple(x.shape) for x, _ in sp.batches(512, False, None, (r, w))] for r in range(w)]
+        assert all(shapes == per_rank[0] for shapes in per_rank), "every rank must see the same batch shapes"
+        assert all(s == (512, 3) for s in per_rank[0])
+        assert len(per_rank[0]) == sp.num_batches(512, w) == (9 // w)
+        rows = torch.cat([y for r in range(w) for _, y in sp.batches(512, False, None, (r, w))])
+        assert rows.unique().numel() == rows.numel() == 512 * w * (9 // w)      # no row twice
+        seen.append(len(per_rank[0]))
+    # one process keeps the reference's drop_last=False epoch (trainer.py:51-58)
+    shapes = [x.shape[0] for x, _ in sp.batches(512, False)]
+    assert shapes == [512] * 9 + [100] and sp.num_batches(512) == 10
+
+
+def _lockstep_worker(rank, world, port, out):
+    """Trainer.run_step's graph/eager switch with a capture that fails on rank 1 only: both ranks
+    must go back to the eager step together and issue the same collectives step for step."""
+    sys.path.insert(0, os.path.join(ROOT, "map-code_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mapx import parallel, trainer as T
+    calls = []
+    real_allreduce = dist.all_reduce
+
+    def spy(t, op=dist.ReduceOp.SUM, **kw):
+        calls.append(("all_reduce", str(op), tuple(t.shape)))
+        return real_allreduce(t, op=op, **kw)
+    dist.all_reduce = spy
+
+    class Args:
+        per_gpu_train_batch_size = 8
+        sampling_method = "randint"
+
+    class Opt:
+        max_grad_norm = 0.0
+        tables = []
+
+    tr = T.Trainer.__new__(T.Trainer)
+    tr.args, tr.optimizer, tr.use_graph, tr._graphs = Args(), Opt(), True, {}
+    modes = []
+
+    def eager_step(X, Y):                      # what an eager DP step does on the wire
+        flat = torch.ones(4)
+        parallel.allreduce_mean_(flat)
+        modes.append("eager")
+        return flat
+
+    class FakeGraph:                           # stands in for GraphedBackward (needs a GPU)
+        def __init__(self, trainer, fn, X, Y):
+            if rank == 1:
+                raise RuntimeError("injected capture failure")
+
+        def __call__(self, X, Y):
+            c = torch.ones(2, dtype=torch.int64)
+            dist.all_reduce(c, op=dist.ReduceOp.MAX)      # a graphed step starts with the counts
+            modes.append("graph")
+            return c
+    T.GraphedBackward = FakeGraph
+    tr._ctr_step = eager_step
+    tr._mfp_step = tr._rfd_step = eager_step
+    tr._ctr_fwd_bwd = tr._mfp_fwd_bwd = tr._rfd_fwd_bwd = eager_step
+    X, Y = torch.zeros(8, 3, dtype=torch.int64), torch.zeros(8, dtype=torch.int64)
+    for _ in range(T.Trainer.GRAPH_AFTER + 3):
+        tr.run_step("ctr", X, Y)
+    torch.save((calls, modes, tr.use_graph), f"{out}.{rank}")
+    dist.destroy_process_group()
+
+
+def test_capture_failure_on_one_rank_sends_every_rank_back_to_eager(tmp_path):
+    out = str(tmp_path / "res")
+    mp.spawn(_lockstep_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    (c0, m0, g0), (c1, m1, g1) = (torch.load(f"{out}.{r}") for r in range(2))
+    assert c0 == c1, "ranks issued different collective sequences"
+    assert m0 == m1 == ["eager"] * len(m0)
+    assert g0 is False and g1 is False
+    # the one extra collective is the agreement itself (MIN), at the step where capture was tried
+    assert sum(1 for c in c0 if "MIN" in c[1]) == 1

@@ -259,8 +259,13 @@ def test_one_rank_rccl_exchange_equals_plain_step(tmp_path):
         assert torch.equal(outs["plain"][k], outs["dp_graph"][k]), ("graphed exchange", k)
 
 
-@pytest.mark.parametrize("max_grad_norm,backbone", [(0.0, "DCNv2"), (0.5, "DCNv2"), (0.0, "DeepFM")])
-def test_graph_replay_equals_eager_bitwise(max_grad_norm, backbone):
+@pytest.mark.parametrize("max_grad_norm,backbone,full,epochs",
+                         [(0.0, "DCNv2", 9, 2), (0.5, "DCNv2", 9, 2), (0.0, "DeepFM", 9, 2),
+                          # GRAPH_AFTER full batches per epoch: the step is captured right after the
+                          # epoch-end flush (no stale row at trace time) — the lazy catch-up must be
+                          # in the graph all the same
+                          (0.0, "DCNv2", 3, 4), (0.5, "DCNv2", 3, 4)])
+def test_graph_replay_equals_eager_bitwise(max_grad_norm, backbone, full, epochs):
     """The captured-hipGraph step and the eager step draw the same Philox streams (device-side
     counter) and run the same kernels: identical parameters after two epochs, bit for bit.
     With gradient clipping (as with N > 1) only mask + forward + backward are captured and the
@@ -271,7 +276,7 @@ def test_graph_replay_equals_eager_bitwise(max_grad_norm, backbone):
     from mapx.trainer import Trainer
     from util import make_config
     cfg = dict(F=23, V=3000, E=16, H=64, NL=3, NC=3, P=32, K=25)
-    ids, labels, _, _ = synth_table(512 * 9 + 100, 23, cfg["V"], seed=3)       # ragged last batch
+    ids, labels, _, _ = synth_table(512 * full + 100, 23, cfg["V"], seed=3)    # ragged last batch
     cnt = np.bincount(ids.reshape(-1), minlength=cfg["V"]).astype(np.float32)
     out = []
     for use_graph in (True, False):
@@ -280,7 +285,7 @@ def test_graph_replay_equals_eager_bitwise(max_grad_norm, backbone):
         model = BaseModel.from_config(config)
         targs = TrainingArguments(output_dir="/tmp/mapx_graph_test", per_gpu_train_batch_size=512,
                                   per_gpu_eval_batch_size=512, learning_rate=1e-3, lr_sched="cosine",
-                                  weight_decay=5e-2, num_train_epochs=2, pretrain=True, pt_type="MFP",
+                                  weight_decay=5e-2, num_train_epochs=epochs, pretrain=True, pt_type="MFP",
                                   sampling_method="randint", mask_ratio=0.3, logging_steps=7, seed=11,
                                   max_grad_norm=max_grad_norm)
         targs._device = torch.device(DEV)
@@ -289,7 +294,7 @@ def test_graph_replay_equals_eager_bitwise(max_grad_norm, backbone):
         tr = Trainer(model, config, targs, ds, OurDataset(ids[:600], labels[:600]))
         tr.use_graph = use_graph
         tr.MFP_pretrain()
-        assert tr.global_step == 2 * 10
+        assert tr.global_step == epochs * (full + 1)
         assert (len(tr._graphs) == 1 and not isinstance(next(iter(tr._graphs.values())), int)) == use_graph
         if use_graph:
             kind = type(next(iter(tr._graphs.values()))).__name__
