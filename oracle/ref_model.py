@@ -50,19 +50,31 @@ def cross(params, x0, num_cross):
     return xi
 
 
-def dnn(params, x, num_hidden, tower="parallel_dnn"):
+def _relu(z, key, relu_masks, preacts):
+    """ReLU.  Test hooks (both None in normal use): `preacts` collects the pre-activations by layer
+    key; `relu_masks[key]` (bool) imposes an activation pattern instead of z > 0 — comparing two
+    arithmetics across a pre-activation that rounds to either side of zero compares ReLU branches,
+    not arithmetic, so the parity tests re-run the exact (fp64) pass on the pattern under test."""
+    if preacts is not None:
+        preacts[key] = z.detach()
+    if relu_masks is not None and key in relu_masks:
+        return z * relu_masks[key].to(z.dtype)
+    return torch.relu(z)
+
+
+def dnn(params, x, num_hidden, tower="parallel_dnn", relu_masks=None, preacts=None):
     for i in range(num_hidden):
         w = params[f"{tower}.dnn.{3 * i}.weight"]
         b = params[f"{tower}.dnn.{3 * i}.bias"]
-        x = torch.relu(x @ w.t() + b)
+        x = _relu(x @ w.t() + b, f"{tower}.dnn.{3 * i}", relu_masks, preacts)
     return x
 
 
-def trunk(params, ids, num_cross, num_hidden):
+def trunk(params, ids, num_cross, num_hidden, relu_masks=None, preacts=None):
     x0 = embed(params, ids)
     c = cross(params, x0, num_cross)
     if num_hidden > 0:
-        return torch.cat([c, dnn(params, x0, num_hidden)], dim=-1)
+        return torch.cat([c, dnn(params, x0, num_hidden, relu_masks=relu_masks, preacts=preacts)], dim=-1)
     return c
 
 
@@ -207,9 +219,9 @@ def mfp_head(params, final, labels, masked_index, noise, logq, num_fields, proj,
     return loss, s, total_acc
 
 
-def rfd_head(params, final, labels):
+def rfd_head(params, final, labels, relu_masks=None, preacts=None):
     """-> (loss, count, acc tensor, pos_ratio tensor, logits [B,F])."""
-    z = torch.relu(final @ params["pred_rfd.0.weight"].t() + params["pred_rfd.0.bias"])
+    z = _relu(final @ params["pred_rfd.0.weight"].t() + params["pred_rfd.0.bias"], "pred_rfd.0", relu_masks, preacts)
     logits = z @ params["pred_rfd.2.weight"].t() + params["pred_rfd.2.bias"]
     loss = Fn.binary_cross_entropy_with_logits(logits, labels)
     count = labels.numel()

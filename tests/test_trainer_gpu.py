@@ -408,10 +408,10 @@ def test_run_py_xdeepfm_pretrain_then_finetune(tmp_path):
     assert "eval_auc" in log
 
 
-@pytest.mark.parametrize("F,V", [(23, 9_449_445), (39, 33_762_577)])
-def test_full_vocabulary_step_properties(F, V):
-    """BASELINE configs[1] / [2] at their real sizes (Avazu: F = 23, V = 9 449 445; Criteo: F = 39,
-    V = 33 762 577; B = 4096, H = 1000, K = 25; fp32)
+@pytest.mark.parametrize("F,V,pt", [(23, 9_449_445, "MFP"), (39, 33_762_577, "MFP"), (23, 9_449_445, "RFD")])
+def test_full_vocabulary_step_properties(F, V, pt):
+    """BASELINE configs[1] / [2] / [3] at their real sizes (Avazu: F = 23, V = 9 449 445; Criteo: F = 39,
+    V = 33 762 577; B = 4096, H = 1000, K = 25; fp32; config [3] = RFD with Unigram replacement)
     through size-independent properties, since the oracle's dense step is too slow to iterate here:
     (1) the captured-graph step and the eager step leave bit-identical parameters;
     (2) linearity: the embedding table's sparse gradient rows sum to the column sums of dL/dX0, and
@@ -432,11 +432,12 @@ def test_full_vocabulary_step_properties(F, V):
     finals, first = [], {}
     for use_graph in (True, False):
         torch.manual_seed(5)
-        config = make_config(cfg, "MFP", cnt)
+        config = make_config(cfg, pt, cnt if pt == "MFP" else None)
         model = BaseModel.from_config(config)
         targs = TrainingArguments(output_dir="/tmp/mapx_full_vocab", per_gpu_train_batch_size=B,
                                   per_gpu_eval_batch_size=B, learning_rate=1e-3, lr_sched="cosine",
-                                  weight_decay=5e-2, num_train_epochs=1, pretrain=True, pt_type="MFP",
+                                  weight_decay=5e-2, num_train_epochs=1, pretrain=True, pt_type=pt,
+                                  RFD_replace="Unigram",
                                   sampling_method="randint", mask_ratio=0.3, logging_steps=100, seed=11)
         targs._device = torch.device(DEV)
         os.makedirs(targs.output_dir, exist_ok=True)
@@ -455,19 +456,26 @@ def test_full_vocabulary_step_properties(F, V):
                 x3.retain_grad()
                 flat = x3.flatten(1)
                 final = torch.cat([model.cross_net(flat), model.parallel_dnn(flat)], -1)
-                loss, _, idx = model.mfp_criterion.forward_with_encoder(inputs["labels"], final, model.feat_encoder,
-                                                                       inputs["masked_index"])
+                if pt == "MFP":
+                    loss, _, idx = model.mfp_criterion.forward_with_encoder(inputs["labels"], final,
+                                                                           model.feat_encoder, inputs["masked_index"])
+                else:
+                    # replaced ids stay inside the vocabulary and differ from the originals where labelled
+                    assert int(inputs["input_ids"].min()) >= 0 and int(inputs["input_ids"].max()) < V
+                    assert torch.equal(inputs["labels"] > 0, inputs["input_ids"] != X)
+                    loss = model.get_outputs(final, inputs["labels"])[0]
                 loss.backward()
                 plan, rows, _ = model.embed.table.sparse_grad
                 U = plan.count()
                 np.testing.assert_allclose(rows[:U].double().sum(0).cpu().numpy(),
                                            x3.grad.double().sum((0, 1)).cpu().numpy(), rtol=1e-4, atol=1e-7)
                 assert torch.equal(plan.uniq[:U].long(), torch.unique(inputs["input_ids"]))
-                nplan = model.mfp_criterion.table.sparse_grad[0]
-                assert torch.equal(nplan.uniq[:nplan.count()].long(), torch.unique(idx.long()))
+                if pt == "MFP":
+                    nplan = model.mfp_criterion.table.sparse_grad[0]
+                    assert torch.equal(nplan.uniq[:nplan.count()].long(), torch.unique(idx.long()))
                 for t in tr.optimizer.tables:
                     t.table.sparse_grad = None
-            tr.run_step("mfp", X, Y)
+            tr.run_step(pt.lower(), X, Y)
         assert tr.global_step == steps
         tr.optimizer.flush()
         finals.append({n: p.detach().clone() for n, p in model.named_parameters()})
@@ -489,3 +497,102 @@ def test_full_vocabulary_step_properties(F, V):
         moved = ((got - p0.double().cpu()).abs() > 0).any(dim=1)
         if R.decays(n):
             assert bool(moved[same].all()), n          # decayed rows did move, by exactly the predicted amount
+
+
+def test_pretrain_then_finetune_auc_on_10k_heldout_rows_vs_oracle():
+    """BASELINE configs[4]: "DCNv2 finetune after MFP — AUC parity vs reference within 1e-4"
+    (reference flow: run.py:64-67 load_for_finetune, trainer.py:87-161 train, :163-215 eval).
+    30 MFP steps -> name+shape transfer into the CTR model -> 40 finetune steps, on the GPU (HIP
+    kernels, lazy row-sparse AdamW) and on the oracle (dense grads, dense HF AdamW on every
+    parameter every step) from identical injected masks / negatives / batches; then AUC and
+    log-loss on 12 000 held-out rows (AUC granularity 1e-8 there, not the 1.2e-3 of a 64-row set)."""
+    from sklearn.metrics import log_loss, roc_auc_score
+    from mapx import ops
+    from mapx.dataset import synth_table
+    from mapx.models import BaseModel
+    from mapx.optim import MapxOptimizer, lr_lambda
+    from oracle import ref_model as R
+    from util import make_config
+    cfg = dict(F=23, V=3000, E=16, H=64, NL=3, NC=3, P=32, K=25)
+    F, V, K, B = cfg["F"], cfg["V"], cfg["K"], 256
+    n_pre, n_ft, n_held = 30, 40, 12000
+    L = int(F * 0.3)
+    ids_all, _, _, _ = synth_table((n_pre + n_ft) * B + n_held, F, V, seed=5)
+    rng = np.random.default_rng(77)
+    a = rng.normal(0.0, 0.6, V)
+    logit = a[ids_all].sum(1)
+    y_all = (rng.random(len(logit)) < 1.0 / (1.0 + np.exp(-(logit - np.median(logit) - 1.0)))).astype(np.int64)
+    cnt = np.bincount(ids_all[:n_pre * B].reshape(-1), minlength=V).astype(np.float32)
+    rows = lambda s: slice(s * B, (s + 1) * B)
+    mis = rng.integers(0, F, (n_pre, B, L)).astype(np.int64)
+    noises = rng.integers(0, V, (n_pre, B, L, K)).astype(np.int64)
+    held_ids, held_y = ids_all[-n_held:], y_all[-n_held:]
+
+    # ---- GPU: pretrain
+    torch.manual_seed(0)
+    pre = BaseModel.from_config(make_config(cfg, "MFP", cnt)).to(DEV)
+    P0 = {k: v.detach().cpu().clone() for k, v in pre.state_dict().items()}
+    opt = MapxOptimizer(pre, _targs(lr_sched="cosine", weight_decay=5e-2), num_training_steps=n_pre, num_warmup_steps=0)
+    pre.train()
+    for s in range(n_pre):
+        masked, labels, mi = ops.dynamic_mask_mfp(t(ids_all[rows(s)], DEV), L, masked_index=t(mis[s], DEV))
+        loss = pre(input_ids=masked, labels=labels, masked_index=mi, noise_samples=t(noises[s], DEV))[0]
+        loss.backward()
+        opt.step()
+    opt.flush()
+    pre_sd = {k: v.detach().cpu().clone() for k, v in pre.state_dict().items()}
+    # ---- GPU: finetune
+    torch.manual_seed(1)
+    ft = BaseModel.from_config(make_config(cfg, "CTR", None))
+    F0 = {k: v.detach().clone() for k, v in ft.state_dict().items()}
+    skipped = ft.load_from_target_model(pre_sd)
+    assert any(k.startswith("mfp_criterion") for k in skipped) and "embed.embedding.weight" not in skipped
+    ft = ft.to(DEV)
+    opt = MapxOptimizer(ft, _targs(lr_sched="const", weight_decay=1e-1, pretrain=False), num_training_steps=n_ft,
+                        num_warmup_steps=0)
+    ft.train()
+    for s in range(n_ft):
+        r = rows(n_pre + s)
+        loss = ft(input_ids=t(ids_all[r], DEV), labels=t(y_all[r], DEV))[0]
+        loss.backward()
+        opt.step()
+    opt.flush()
+    ft.eval()
+    with torch.no_grad():
+        logits = torch.cat([ft(input_ids=t(held_ids[i:i + 4096], DEV))[0].view(-1) for i in range(0, n_held, 4096)])
+    met = ops.eval_metrics(logits, t(held_y, DEV))
+
+    # ---- oracle: the same two phases with the reference's dense optimizer
+    def adam_all(Pm, m, v, step, lr, wd):
+        with torch.no_grad():
+            for k, p in Pm.items():
+                if p.requires_grad:
+                    R.hf_adamw_step(p, p.grad, m[k], v[k], step, lr, wd=wd if R.decays(k) else 0.0)
+                    p.grad = None
+    trainable = lambda k, v: v.dtype.is_floating_point and "alias" not in k and "logprob" not in k
+    Pm = {k: (v.clone().requires_grad_(True) if trainable(k, v) else v) for k, v in P0.items()}
+    m = {k: torch.zeros_like(p) for k, p in Pm.items() if p.requires_grad}
+    v = {k: torch.zeros_like(p) for k, p in Pm.items() if p.requires_grad}
+    logq = R.nce_buffers(cnt)[0]
+    for s in range(n_pre):
+        masked, labels = R.dynamic_mask_mfp(t(ids_all[rows(s)]), t(mis[s]))
+        fin = R.trunk(Pm, masked, cfg["NC"], cfg["NL"])
+        R.mfp_head(Pm, fin, labels, t(mis[s]), t(noises[s]), logq, F, cfg["P"], K)[0].backward()
+        adam_all(Pm, m, v, s + 1, 1e-3 * lr_lambda("cosine", s, n_pre, 0), 5e-2)
+    Pf = {k: (Pm[k].detach().clone() if k in Pm and Pm[k].shape == w.shape else w.clone()) for k, w in F0.items()}
+    Pf = {k: w.requires_grad_(True) for k, w in Pf.items()}
+    m = {k: torch.zeros_like(p) for k, p in Pf.items()}
+    v = {k: torch.zeros_like(p) for k, p in Pf.items()}
+    for s in range(n_ft):
+        r = rows(n_pre + s)
+        R.ctr_head(Pf, R.trunk(Pf, t(ids_all[r]), cfg["NC"], cfg["NL"]), t(y_all[r]))[0].backward()
+        adam_all(Pf, m, v, s + 1, 1e-3, 1e-1)
+    with torch.no_grad():
+        ref_logits = R.ctr_head(Pf, R.trunk(Pf, t(held_ids), cfg["NC"], cfg["NL"]))[0].view(-1)
+    prob = torch.sigmoid(ref_logits).double().numpy()
+    auc_ref, ll_ref = roc_auc_score(held_y, prob), log_loss(held_y, prob)
+    assert auc_ref > 0.6, f"the finetuned oracle learned nothing (AUC {auc_ref:.4f}): the comparison would be vacuous"
+    assert abs(met["auc"] - auc_ref) < 1e-4, (met["auc"], auc_ref)
+    assert abs(met["logloss"] - ll_ref) < 1e-4, (met["logloss"], ll_ref)
+    np.testing.assert_allclose(logits.cpu().numpy(), ref_logits.numpy(), rtol=2e-3, atol=2e-4)
+    print(f"held-out AUC hip {met['auc']:.6f} / oracle {auc_ref:.6f}; log-loss {met['logloss']:.6f} / {ll_ref:.6f}")
