@@ -31,12 +31,15 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 24
+#define MAPX_ABI_VERSION 25
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
 #define MAPX_EHIP (-2)       /* HIP runtime / launch error */
 #define MAPX_EWORKSPACE (-3) /* caller workspace too small */
+
+/* bf16 values cross the boundary as raw 16-bit words (the upper half of the IEEE fp32 pattern). */
+typedef uint16_t mapx_bf16;
 
 const char* mapx_last_error(void);
 int mapx_abi_version(void);
@@ -335,6 +338,48 @@ int mapx_table_adam(float* p0, float* m0, float* v0, int W0, float wd0, float* p
                     const float* grad1, const float* sched, int sched_len, const int32_t* done,
                     const double* aux, int aux_len, int aux_rows, double beta1, double beta2, double eps,
                     int rows_may_repeat, hipStream_t stream);
+
+/* ------------------------------------------------------------------ bf16 compute mode (g1)
+ * BASELINE configs[2] ("8 x MI355X DP bf16"; north star tolerance 1e-2): the same dense products as
+ * mapx_gemm_f32 — CrossNetV2 layers.py:197-201, MLPBlock layers.py:173-188, feat_encoder / pred_rfd /
+ * fc_out models.py:74,119-124,304 and their backward — on v_mfma_f32_32x32x16_bf16.  A, B, aux2, out2
+ * are bf16; accumulation, bias and every epilogue are fp32; C is bf16 or (c_f32) fp32 — the heads'
+ * logits and every weight gradient stay fp32; aux1 is bf16 or (aux1_f32, EPI_ADD only) fp32.  Same
+ * operand description (a_kc / b_kc), epilogues and split-K as mapx_gemm_f32; split-K needs
+ * c_f32 and a workspace of nsplit * M * N floats (mapx_gemm_splitk_workspace_bytes). */
+int mapx_gemm_bf16(int a_kc, int b_kc, int M, int N, int K, const mapx_bf16* A, int64_t lda,
+                   const mapx_bf16* B, int64_t ldb, void* C, int64_t ldc, int c_f32, int epi, const float* bias,
+                   const void* aux1, int64_t ld1, int aux1_f32, const mapx_bf16* aux2, int64_t ld2,
+                   mapx_bf16* out2, int64_t ldo2, int nsplit, int tile_hint, void* ws, size_t ws_bytes,
+                   hipStream_t stream);
+/* fp32 <-> bf16 (round to nearest even) of a flat array: weight shadows outside the optimizer,
+ * fp32 head gradients entering the bf16 trunk. */
+int mapx_cast_f32_bf16(const float* src, int64_t n, mapx_bf16* dst, hipStream_t stream);
+int mapx_cast_bf16_f32(const mapx_bf16* src, int64_t n, float* dst, hipStream_t stream);
+/* layers.py:97-102 with bf16 output rows (the table stays fp32); E % 8 == 0. */
+int mapx_emb_gather_fwd_bf16(const int64_t* ids, int64_t n, const float* table, int64_t V, int E,
+                             mapx_bf16* out, int* err_flag, hipStream_t stream);
+/* mapx_seg_reduce_rows over bf16 gradient rows (fp32 sums, fp32 output). */
+int mapx_seg_reduce_rows_bf16(int64_t n, const int32_t* perm, const int32_t* rank, const int32_t* seg_start,
+                              const mapx_bf16* src, int W, float* out, void* ws, size_t ws_bytes,
+                              int32_t* zeroed_counter_opt, hipStream_t stream);
+/* bf16 counterparts of mapx_colsum / mapx_relu_mask_colsum / mapx_cross_bwd_pre_colsum /
+ * mapx_relu_mask: activations and their gradients bf16, column sums (bias gradients) and the running
+ * dL/dX0 of the cross tower fp32.  Any N and leading dimensions. */
+size_t mapx_colsum_bf16_workspace_bytes(int N);
+int mapx_colsum_bf16(const mapx_bf16* x, int64_t ld, int M, int N, float* out, void* ws, size_t ws_bytes,
+                     hipStream_t stream);
+int mapx_relu_mask_colsum_bf16(const mapx_bf16* dy, int64_t ld_dy, const mapx_bf16* y, int64_t ld_y, int M, int N,
+                               mapx_bf16* dz, float* db, void* ws, size_t ws_bytes, hipStream_t stream);
+int mapx_cross_bwd_pre_colsum_bf16(const mapx_bf16* g, int64_t ld_g, const mapx_bf16* x0, const mapx_bf16* u, int M,
+                                   int N, mapx_bf16* t, float* dx0, int accumulate, float* db, void* ws,
+                                   size_t ws_bytes, hipStream_t stream);
+int mapx_relu_mask_bf16(const mapx_bf16* dy, const mapx_bf16* y, int64_t n, mapx_bf16* out, hipStream_t stream);
+/* mapx_adamw_dense that also stores the updated parameters as bf16 in `shadow` [n] (the weight
+ * operand of mapx_gemm_bf16): trainer.py:60-85 semantics on the fp32 master weights, unchanged. */
+int mapx_adamw_dense_shadow(float* p, const float* g, float* m, float* v, int64_t n, const float* sched,
+                            int sched_len, const int32_t* done, double beta1, double beta2, double eps,
+                            double weight_decay, mapx_bf16* shadow, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,33 @@ __global__ void __launch_bounds__(256) emb_gather_kernel(const int64_t* __restri
   }
 }
 
+// The same gather with bf16 output rows (bf16 compute mode: the trunk's first GEMMs read bf16; the
+// table stays fp32).  8 columns per thread: two 16-B table reads, one 16-B store.
+__global__ void __launch_bounds__(256) emb_gather_bf16_kernel(const int64_t* __restrict__ ids, int64_t n,
+                                                              const float* __restrict__ table, int64_t V, int E,
+                                                              __bf16* __restrict__ out, int* __restrict__ err) {
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+  const int per_row = E / 8;
+  const int64_t total = n * per_row;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = t / per_row;
+    const int c = (int)(t - row * per_row) * 8;
+    const int64_t id = ids[row];
+    const bool ok = (id >= 0) & (id < V);
+    if (!ok && err) atomicOr(err, 1);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (ok) {
+      a = *reinterpret_cast<const float4*>(table + id * E + c);
+      b = *reinterpret_cast<const float4*>(table + id * E + c + 4);
+    }
+    bf16x8_t o;
+    o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
+    o[4] = (__bf16)b.x; o[5] = (__bf16)b.y; o[6] = (__bf16)b.z; o[7] = (__bf16)b.w;
+    *reinterpret_cast<bf16x8_t*>(out + row * E + c) = o;
+  }
+}
+
 // int64 ids -> int32 keys for the sort / segment machinery (V < 2^31), range-checked.
 __global__ void __launch_bounds__(256) ids_to_i32_kernel(const int64_t* __restrict__ ids, int64_t n,
                                                          int64_t V, int32_t* __restrict__ out,
@@ -64,6 +91,18 @@ extern "C" int mapx_emb_gather_fwd(const int64_t* ids, int64_t n, const float* t
     hipLaunchKernelGGL(mapx::emb_gather_kernel<1>, dim3(grid), dim3(256), 0, stream, ids, n, table,
                        V, E, out, err_flag);
   return mapx::check_launch("emb_gather_fwd");
+}
+
+extern "C" int mapx_emb_gather_fwd_bf16(const int64_t* ids, int64_t n, const float* table, int64_t V, int E,
+                                        mapx_bf16* out, int* err_flag, hipStream_t stream) {
+  MAPX_REQUIRE(n >= 0 && V > 0 && E > 0 && E % 8 == 0, "emb_gather_fwd_bf16: bad sizes n=%lld V=%lld E=%d (E %% 8 == 0)",
+               (long long)n, (long long)V, E);
+  if (n == 0) return MAPX_OK;
+  MAPX_REQUIRE(ids && table && out && (uintptr_t)table % 16 == 0 && (uintptr_t)out % 16 == 0,
+               "emb_gather_fwd_bf16: null or unaligned pointer");
+  hipLaunchKernelGGL(mapx::emb_gather_bf16_kernel, dim3(mapx::grid_for(n * (E / 8), 256)), dim3(256), 0, stream, ids, n,
+                     table, V, E, reinterpret_cast<__bf16*>(out), err_flag);
+  return mapx::check_launch("emb_gather_fwd_bf16");
 }
 
 extern "C" int mapx_ids_to_i32(const int64_t* ids, int64_t n, int64_t V, int32_t* out,

@@ -1,0 +1,623 @@
+// bf16 compute mode (BASELINE configs[2]: "8 x MI355X DP bf16", north star tolerance 1e-2):
+// the dense part of DCNv2 — CrossNetV2 (code/layers.py:197-201), MLPBlock (layers.py:173-188),
+// feat_encoder / pred_rfd / fc_out (models.py:74,119-124,304) and their backward products — on
+// v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate).  Operands are bf16 in HBM (activations are
+// stored in bf16 by the producing kernel's epilogue; weights are bf16 shadows of the fp32 master
+// weights, refreshed by the optimizer kernel), accumulation, bias / ReLU / cross epilogues and
+// every weight gradient are fp32.
+//
+//   C[m,n] = epilogue( sum_k A(m,k) * B(k,n) )
+//
+// Same operand description as gemm.hip (no transposed copy of anything exists):
+//   A_KC : A(m,k) = A[m*lda + k]  (k contiguous)      else A(m,k) = A[k*lda + m]
+//   B_KC : B(k,n) = B[n*ldb + k]  (k contiguous)      else B(k,n) = B[k*ldb + n]
+//   forward  Y = X W^T : A_KC, B_KC       dX = dY W : A_KC, B k-strided       dW = dY^T X : both k-strided
+//
+// Tiling: 256 threads = 2x2 waves, wave tile (32 WMT) x (32 WNT), block tile (64 WMT) x (64 WNT),
+// BK = 64 (one 128-B line of bf16 per row and K-step).  Each operand keeps its GLOBAL orientation
+// in LDS, so global -> LDS is a straight 16-byte copy for every layout, and the MFMA fragment
+// (lane l: 8 consecutive k for row / column l & 31, k-half l >> 5) is fetched with
+//   k-contiguous operand: LDS [row][64 + 8]   one ds_read_b128 (row stride 36 dwords: the 16 rows
+//                                             of a b128 lane group land on 16 distinct 4-bank slots);
+//   k-strided operand:    LDS [k][rows + 32]  two ds_read_b64_tr_b16 — gfx950's transposing LDS read:
+//                                             per 16 lanes a block of 4 k-rows x 16 columns comes
+//                                             back column-major, i.e. as 4 consecutive k of one
+//                                             column per lane (row stride = 64 B mod 256 B: the 4
+//                                             rows of a block sit on the 4 quarters of the bank row).
+// Pipeline (one barrier per K-step, two LDS buffers, one register set): after the barrier the
+// registers holding tile t+1 are written to the other buffer and re-used at once for the global
+// loads of tile t+2, which have the MFMAs of tile t to land.
+#include "../../include/mapx_hip.h"
+#include "common.h"
+
+namespace mapx {
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmHArgs {
+  const bf16_t* A; int64_t lda;
+  const bf16_t* B; int64_t ldb;
+  void* C; int64_t ldc;              // bf16 or fp32 (c_f32)
+  int M, N, K;
+  int epi;
+  const float* bias;                 // [N] fp32
+  const void* aux1; int64_t ld1;     // CROSS: Xi (bf16)   ADD: aux (bf16 or fp32: aux1_f32)   RELU_MASK: y (bf16)
+  const bf16_t* aux2; int64_t ld2;   // CROSS: X0
+  bf16_t* out2; int64_t ldo2;        // CROSS: u = W Xi + b (kept for backward)
+  int k_chunk;                       // split-K: K range per blockIdx.y (multiple of 64)
+  int64_t slab_stride;               // split-K: fp32 C offset per split
+  int tiles_m, tiles_n;
+};
+
+constexpr int kHBK = 64;
+
+// One operand's staging: global tile -> registers (16-byte chunks of 8 bf16) -> LDS, and LDS -> fragments.
+// VEC requires: leading dimension % 8 == 0, 16-B aligned base, contiguous extent % 8 == 0: a chunk is
+// all-in or all-out.  Otherwise 8 scalar loads with per-element predicates.
+template <int ROWS, int T, bool KC, bool VEC>
+struct OperandH {
+  static constexpr int LD = KC ? kHBK + 8 : ROWS + 32;          // bf16 elements
+  static constexpr int LDS_ELEMS = KC ? ROWS * LD : kHBK * LD;
+  static constexpr int CPR = KC ? kHBK / 8 : ROWS / 8;            // 16-B chunks per stored row
+  static constexpr int NV = ROWS * kHBK / 8 / 256;                // chunks per thread per tile
+  uint4 r[NV];
+
+  __device__ static inline void coords(int f, int& row, int& col) {
+    row = f / CPR;
+    col = (f % CPR) * 8;
+  }
+
+  // tile at (row0 of the non-k extent, k0); rows beyond nrows / k beyond kend read as zero
+  __device__ inline void load(const bf16_t* __restrict__ g, int64_t ld, int row0, int nrows, int k0, int kend) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int tr, tc;
+      coords(threadIdx.x + i * 256, tr, tc);
+      const int gr = (KC ? row0 : k0) + tr, gc = (KC ? k0 : row0) + tc;
+      const int rlim = KC ? nrows : kend, clim = KC ? kend : nrows;
+      const bool rok = gr < rlim;
+      const bf16_t* p = g + (int64_t)(rok ? gr : 0) * ld;
+      if (VEC) {
+        const bool ok = rok && gc < clim;
+        uint4 v = *reinterpret_cast<const uint4*>(p + (ok ? gc : 0));
+        r[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+      } else {
+        unsigned short h[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const bool ok = rok && gc + e < clim;
+          const unsigned short x = reinterpret_cast<const unsigned short*>(p)[ok ? gc + e : 0];
+          h[e] = ok ? x : (unsigned short)0;
+        }
+        r[i] = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16),
+                          h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
+      }
+    }
+  }
+
+  __device__ inline void store(bf16_t* __restrict__ s) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int tr, tc;
+      coords(threadIdx.x + i * 256, tr, tc);
+      *reinterpret_cast<uint4*>(s + tr * LD + tc) = r[i];
+    }
+  }
+
+  // fragments of k16-step s4 (k = 16 s4 + 8 (lane >> 5) + j) for this wave's T tiles
+  __device__ static inline void frags(const bf16_t* __restrict__ s, int base, int lane, int s4, bf16x8 (&f)[T]) {
+    const int l31 = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      if (KC) {
+        f[t] = *reinterpret_cast<const bf16x8*>(s + (base + 32 * t + l31) * LD + 16 * s4 + 8 * kh);
+      } else {
+        // transposing read: lane 4q+p of a 16-lane group addresses block row q, columns 4p..4p+3, and
+        // receives column (lane & 15) of the block's 4 rows
+        const int q = (lane >> 2) & 3, p = lane & 3, half = (lane >> 4) & 1;
+        const bf16_t* a0 = s + (16 * s4 + 8 * kh + q) * LD + base + 32 * t + 16 * half + 4 * p;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (__attribute__((address_space(3))) bf16x4*)(a0));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (__attribute__((address_space(3))) bf16x4*)(a0 + 4 * LD));
+        f[t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    }
+  }
+};
+
+template <bool F32>
+__device__ inline float ld_as_f32(const void* __restrict__ p, uint32_t off) {
+  if (F32) return reinterpret_cast<const float*>(p)[off];
+  return (float)reinterpret_cast<const bf16_t*>(p)[off];
+}
+template <bool F32>
+__device__ inline void st_from_f32(void* __restrict__ p, uint32_t off, float v) {
+  if (F32) reinterpret_cast<float*>(p)[off] = v;
+  else reinterpret_cast<bf16_t*>(p)[off] = (bf16_t)v;      // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+}
+
+// C/D map of the 32x32 MFMA (dtype independent): col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// Same structure as gemm.hip's epilogue: per 32-row band the auxiliary operands of all elements are
+// fetched first (clamped, unpredicated loads), the stores follow; no control flow inside the loops.
+template <int EPI, bool C_F32, bool AUX_F32, int WMT, int WNT, bool ROWS_OK>
+__device__ inline void epilogue_band_h(const GemmHArgs& a, void* __restrict__ C, f32x16 (&acc)[WMT][WNT],
+                                       const float (&bias_r)[WNT], int i, uint32_t mrow, int nbase, int l31) {
+  constexpr bool kAux1 = EPI == MAPX_EPI_BIAS_CROSS || EPI == MAPX_EPI_ADD || EPI == MAPX_EPI_RELU_MASK;
+  constexpr bool kAux2 = EPI == MAPX_EPI_BIAS_CROSS;
+  const uint32_t ldc = (uint32_t)a.ldc, ld1 = (uint32_t)a.ld1, ld2 = (uint32_t)a.ld2, ldo = (uint32_t)a.ldo2;
+#define MAPX_ROW(r) ((uint32_t)(((r) & 3) + 8 * ((r) >> 2)))
+  float x1[WNT][16], x2[WNT][16];
+  if (kAux1) {
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) {
+      uint32_t n = (uint32_t)(nbase + 32 * j + l31);
+      n = (int)n < a.N ? n : (uint32_t)(a.N - 1);
+      const uint32_t mload = (ROWS_OK || (int)mrow < a.M) ? mrow : (uint32_t)(a.M - 1);
+      const uint32_t o1 = mload * ld1 + n, o2 = mload * ld2 + n;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t dr = ROWS_OK ? MAPX_ROW(r) : ((int)(mrow + MAPX_ROW(r)) < a.M ? MAPX_ROW(r) : 0u);
+        x1[j][r] = ld_as_f32<AUX_F32>(a.aux1, o1 + dr * ld1);
+        if (kAux2) x2[j][r] = (float)a.aux2[o2 + dr * ld2];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < WNT; ++j) {
+    const uint32_t n = (uint32_t)(nbase + 32 * j + l31);
+    if ((int)n < a.N) {
+      const uint32_t oc = mrow * ldc + n, oo = mrow * ldo + n;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[i][j][r];
+        if (EPI >= MAPX_EPI_BIAS && EPI <= MAPX_EPI_BIAS_CROSS) v += bias_r[j];
+        if (EPI == MAPX_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+        float u = v;
+        if (EPI == MAPX_EPI_BIAS_CROSS) v = x1[j][r] + x2[j][r] * v;
+        if (EPI == MAPX_EPI_ADD) v += x1[j][r];
+        if (EPI == MAPX_EPI_RELU_MASK) v = x1[j][r] > 0.f ? v : 0.f;
+        if (ROWS_OK || (int)(mrow + MAPX_ROW(r)) < a.M) {
+          if (EPI == MAPX_EPI_BIAS_CROSS) a.out2[oo + MAPX_ROW(r) * ldo] = (bf16_t)u;
+          st_from_f32<C_F32>(C, oc + MAPX_ROW(r) * ldc, v);
+        }
+      }
+    }
+  }
+#undef MAPX_ROW
+}
+
+template <int EPI, bool C_F32, bool AUX_F32, int WMT, int WNT>
+__device__ inline void epilogue_h(const GemmHArgs& a, void* __restrict__ C, f32x16 (&acc)[WMT][WNT],
+                                  const float (&bias_r)[WNT], int mbase, int nbase, int l31, int kh) {
+#pragma unroll
+  for (int i = 0; i < WMT; ++i) {
+    const uint32_t mrow = (uint32_t)(mbase + 32 * i + 4 * kh);
+    if (mbase + 32 * i + 32 <= a.M)
+      epilogue_band_h<EPI, C_F32, AUX_F32, WMT, WNT, true>(a, C, acc, bias_r, i, mrow, nbase, l31);
+    else if (mbase + 32 * i < a.M)
+      epilogue_band_h<EPI, C_F32, AUX_F32, WMT, WNT, false>(a, C, acc, bias_r, i, mrow, nbase, l31);
+  }
+}
+
+template <int WMT, int WNT, bool A_KC, bool B_KC, bool VEC>
+__global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmHArgs a, int c_f32, int aux1_f32) {
+  constexpr int BM = 64 * WMT, BN = 64 * WNT;
+  using OpA = OperandH<BM, WMT, A_KC, VEC>;
+  using OpB = OperandH<BN, WNT, B_KC, VEC>;
+  // one dynamic LDS object (72-80 KB: above the 64 KB of static LDS): buffer b holds A at
+  // b * kBuf and B behind it; every row starts 16-B aligned (b128 / transposing reads)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* const smem = reinterpret_cast<bf16_t*>(smem_raw);
+  constexpr int kBuf = OpA::LDS_ELEMS + OpB::LDS_ELEMS;
+
+  // XCD-aware tile order (see gemm.hip): blocks b, b+8, ... share an XCD's L2
+  const int nb = a.tiles_m * a.tiles_n;
+  int lin = blockIdx.x;
+  const int per = nb / 8;
+  if (lin < per * 8) lin = (lin % 8) * per + lin / 8;
+  const int tm = lin / a.tiles_n, tn = lin % a.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int kbeg = blockIdx.y * a.k_chunk;
+  const int kend = (kbeg + a.k_chunk < a.K) ? kbeg + a.k_chunk : a.K;
+  void* __restrict__ C = c_f32 ? (void*)(reinterpret_cast<float*>(a.C) + (int64_t)blockIdx.y * a.slab_stride) : a.C;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int abase = wr * 32 * WMT, bbase = wc * 32 * WNT;
+
+  f32x16 acc[WMT][WNT];
+#pragma unroll
+  for (int i = 0; i < WMT; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float bias_r[WNT];
+#pragma unroll
+  for (int j = 0; j < WNT; ++j) {
+    const int n = n0 + bbase + 32 * j + l31;
+    bias_r[j] = (a.epi >= MAPX_EPI_BIAS && a.epi <= MAPX_EPI_BIAS_CROSS && n < a.N) ? a.bias[n] : 0.f;
+  }
+
+  OpA la;
+  OpB lb;
+  const int nk = (kend - kbeg + kHBK - 1) / kHBK;
+  if (nk > 0) {
+    la.load(a.A, a.lda, m0, a.M, kbeg, kend);
+    lb.load(a.B, a.ldb, n0, a.N, kbeg, kend);
+    la.store(smem);
+    lb.store(smem + OpA::LDS_ELEMS);
+    if (nk > 1) {
+      la.load(a.A, a.lda, m0, a.M, kbeg + kHBK, kend);
+      lb.load(a.B, a.ldb, n0, a.N, kbeg + kHBK, kend);
+    }
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    bf16_t* const As_cur = smem + cur * kBuf;
+    bf16_t* const Bs_cur = As_cur + OpA::LDS_ELEMS;
+    if (kt + 1 < nk) {                 // tile kt+1 was loaded during the previous K-step
+      la.store(smem + (cur ^ 1) * kBuf);
+      lb.store(smem + (cur ^ 1) * kBuf + OpA::LDS_ELEMS);
+    }
+    if (kt + 2 < nk) {
+      la.load(a.A, a.lda, m0, a.M, kbeg + (kt + 2) * kHBK, kend);
+      lb.load(a.B, a.ldb, n0, a.N, kbeg + (kt + 2) * kHBK, kend);
+    }
+    bf16x8 af[2][WMT], bf[2][WNT];
+    OpA::frags(As_cur, abase, lane, 0, af[0]);
+    OpB::frags(Bs_cur, bbase, lane, 0, bf[0]);
+#pragma unroll
+    for (int s4 = 0; s4 < kHBK / 16; ++s4) {
+      const int c = s4 & 1;
+      if (s4 + 1 < kHBK / 16) {
+        OpA::frags(As_cur, abase, lane, s4 + 1, af[c ^ 1]);
+        OpB::frags(Bs_cur, bbase, lane, s4 + 1, bf[c ^ 1]);
+      }
+#pragma unroll
+      for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c][i], bf[c][j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  const int mbase = m0 + abase, nbase = n0 + bbase;
+#pragma unroll
+  for (int j = 0; j < WNT; ++j) asm volatile("v_mov_b32 %0, %1" : "=v"(bias_r[j]) : "v"(bias_r[j]));
+#define MAPX_EPI_CASE(E, CF, AF) epilogue_h<E, CF, AF, WMT, WNT>(a, C, acc, bias_r, mbase, nbase, l31, kh)
+  if (c_f32) {
+    switch (a.epi) {       // fp32 outputs: logits of the heads, weight-gradient slabs
+      case MAPX_EPI_BIAS: MAPX_EPI_CASE(MAPX_EPI_BIAS, true, false); break;
+      case MAPX_EPI_BIAS_RELU: MAPX_EPI_CASE(MAPX_EPI_BIAS_RELU, true, false); break;
+      default: MAPX_EPI_CASE(MAPX_EPI_NONE, true, false); break;
+    }
+  } else {
+    switch (a.epi) {
+      case MAPX_EPI_BIAS: MAPX_EPI_CASE(MAPX_EPI_BIAS, false, false); break;
+      case MAPX_EPI_BIAS_RELU: MAPX_EPI_CASE(MAPX_EPI_BIAS_RELU, false, false); break;
+      case MAPX_EPI_BIAS_CROSS: MAPX_EPI_CASE(MAPX_EPI_BIAS_CROSS, false, false); break;
+      case MAPX_EPI_ADD:
+        if (aux1_f32) MAPX_EPI_CASE(MAPX_EPI_ADD, false, true);
+        else MAPX_EPI_CASE(MAPX_EPI_ADD, false, false);
+        break;
+      case MAPX_EPI_RELU_MASK: MAPX_EPI_CASE(MAPX_EPI_RELU_MASK, false, false); break;
+      default: MAPX_EPI_CASE(MAPX_EPI_NONE, false, false); break;
+    }
+  }
+#undef MAPX_EPI_CASE
+}
+
+// out[i] = sum_s slabs[s][i] in slab order (deterministic split-K combine of the weight gradients)
+__global__ void __launch_bounds__(256) splitk_reduce_h_kernel(const float* __restrict__ slabs, int64_t slab_stride,
+                                                              int nsplit, int64_t n4, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 v = reinterpret_cast<const float4*>(slabs)[i];
+    for (int s = 1; s < nsplit; ++s) {
+      const float4 x = reinterpret_cast<const float4*>(slabs + s * slab_stride)[i];
+      v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+}
+__global__ void __launch_bounds__(256) splitk_reduce_h1_kernel(const float* __restrict__ slabs, int64_t slab_stride,
+                                                               int nsplit, int64_t n, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    for (int s = 0; s < nsplit; ++s) v += slabs[s * slab_stride + i];
+    out[i] = v;
+  }
+}
+
+template <int WMT, int WNT, bool A_KC, bool B_KC, bool VEC>
+static hipError_t launch_one_h(const GemmHArgs& a, int nsplit, int c_f32, int aux1_f32, hipStream_t stream) {
+  using OpA = OperandH<64 * WMT, WMT, A_KC, VEC>;
+  using OpB = OperandH<64 * WNT, WNT, B_KC, VEC>;
+  constexpr size_t lds = (size_t)2 * (OpA::LDS_ELEMS + OpB::LDS_ELEMS) * sizeof(bf16_t);
+  auto* fn = &gemm_bf16_kernel<WMT, WNT, A_KC, B_KC, VEC>;
+  static hipError_t raised = lds > 65536
+      ? hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+      : hipSuccess;
+  if (raised != hipSuccess) return raised;
+  hipLaunchKernelGGL(fn, dim3(a.tiles_m * a.tiles_n, nsplit), dim3(256), lds, stream, a, c_f32, aux1_f32);
+  return hipSuccess;
+}
+
+template <int WMT, int WNT, bool A_KC, bool B_KC>
+static hipError_t launch_tile_h(const GemmHArgs& a, bool vec, int nsplit, int c_f32, int aux1_f32, hipStream_t stream) {
+  return vec ? launch_one_h<WMT, WNT, A_KC, B_KC, true>(a, nsplit, c_f32, aux1_f32, stream)
+             : launch_one_h<WMT, WNT, A_KC, B_KC, false>(a, nsplit, c_f32, aux1_f32, stream);
+}
+
+template <bool A_KC, bool B_KC>
+static hipError_t launch_layout_h(GemmHArgs& a, bool vec, int tile, int nsplit, int c_f32, int aux1_f32,
+                                  hipStream_t stream) {
+  if (tile == 2) {
+    a.tiles_m = (a.M + 127) / 128; a.tiles_n = (a.N + 127) / 128;
+    return launch_tile_h<2, 2, A_KC, B_KC>(a, vec, nsplit, c_f32, aux1_f32, stream);
+  }
+  if (tile == 1) {
+    a.tiles_m = (a.M + 127) / 128; a.tiles_n = (a.N + 63) / 64;
+    return launch_tile_h<2, 1, A_KC, B_KC>(a, vec, nsplit, c_f32, aux1_f32, stream);
+  }
+  a.tiles_m = (a.M + 63) / 64; a.tiles_n = (a.N + 63) / 64;
+  return launch_tile_h<1, 1, A_KC, B_KC>(a, vec, nsplit, c_f32, aux1_f32, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 <-> bf16 conversion of a flat array (weights shadows outside the optimizer, head gradients)
+__global__ void __launch_bounds__(256) cast_f32_bf16_kernel(const float* __restrict__ src, int64_t n,
+                                                            bf16_t* __restrict__ dst) {
+  const int64_t n8 = n / 8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+    bf16x8 o;
+    o[0] = (bf16_t)a.x; o[1] = (bf16_t)a.y; o[2] = (bf16_t)a.z; o[3] = (bf16_t)a.w;
+    o[4] = (bf16_t)b.x; o[5] = (bf16_t)b.y; o[6] = (bf16_t)b.z; o[7] = (bf16_t)b.w;
+    reinterpret_cast<bf16x8*>(dst)[i] = o;
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = n8 * 8 + threadIdx.x; i < n; i += blockDim.x) dst[i] = (bf16_t)src[i];
+}
+__global__ void __launch_bounds__(256) cast_bf16_f32_kernel(const bf16_t* __restrict__ src, int64_t n,
+                                                            float* __restrict__ dst) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = (float)src[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Elementwise backward steps of the bf16 path fused with the bias-gradient column sum (the bf16
+// counterparts of gemm.hip's ew_colsum_kernel; activations bf16, sums fp32):
+//   OP 0 (ReLU layer):   dz = y > 0 ? dy : 0                      db = colsum(dz)
+//   OP 1 (cross layer):  t = g * x0 ; dx0 (+)= g * u (+ g)        db = colsum(t)     (dx0 kept in fp32)
+//   OP 2 (plain):        nothing written                          db = colsum(a)
+// Block = 64 column lanes x 4 row lanes over one of kColChunksH row chunks; a second launch adds the
+// chunks in order (deterministic).  Scalar columns: any N, any leading dimension.
+constexpr int kColChunksH = 64;
+template <int OP>
+__global__ void __launch_bounds__(256) ew_colsum_h_kernel(const bf16_t* __restrict__ a, int64_t lda,
+                                                          const bf16_t* __restrict__ b, int64_t ldb,
+                                                          const bf16_t* __restrict__ c, int64_t ldc, int M, int N,
+                                                          bf16_t* __restrict__ o1, float* __restrict__ o2,
+                                                          int accumulate, float* __restrict__ part) {
+  const int col = (blockIdx.x * 64 + (threadIdx.x & 63)) * 2;      // 2 columns per lane (one dword of bf16)
+  const int rl = threadIdx.x >> 6;
+  const int rows_per = (M + kColChunksH - 1) / kColChunksH;
+  const int r0 = blockIdx.y * rows_per;
+  const int r1 = (r0 + rows_per < M) ? r0 + rows_per : M;
+  float v0 = 0.f, v1 = 0.f;
+  const bool in0 = col < N, in1 = col + 1 < N;
+  if (in0) {
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const float a0 = (float)a[(int64_t)r * lda + col], a1 = in1 ? (float)a[(int64_t)r * lda + col + 1] : 0.f;
+      if (OP == 2) {
+        v0 += a0; v1 += a1;
+      } else if (OP == 0) {
+        const float y0 = (float)b[(int64_t)r * ldb + col], y1 = in1 ? (float)b[(int64_t)r * ldb + col + 1] : 0.f;
+        const float d0 = y0 > 0.f ? a0 : 0.f, d1 = y1 > 0.f ? a1 : 0.f;
+        o1[(int64_t)r * N + col] = (bf16_t)d0;
+        if (in1) o1[(int64_t)r * N + col + 1] = (bf16_t)d1;
+        v0 += d0; v1 += d1;
+      } else {
+        const float x0 = (float)b[(int64_t)r * ldb + col], x1 = in1 ? (float)b[(int64_t)r * ldb + col + 1] : 0.f;
+        const float u0 = (float)c[(int64_t)r * ldc + col], u1 = in1 ? (float)c[(int64_t)r * ldc + col + 1] : 0.f;
+        const bf16_t t0 = (bf16_t)(a0 * x0), t1 = (bf16_t)(a1 * x1);
+        float d0 = a0 * u0, d1 = a1 * u1;
+        if (accumulate & 1) { d0 += o2[(int64_t)r * N + col]; if (in1) d1 += o2[(int64_t)r * N + col + 1]; }
+        if (accumulate & 2) { d0 += a0; d1 += a1; }
+        o1[(int64_t)r * N + col] = t0;
+        o2[(int64_t)r * N + col] = d0;
+        if (in1) { o1[(int64_t)r * N + col + 1] = t1; o2[(int64_t)r * N + col + 1] = d1; }
+        v0 += (float)t0; v1 += (float)t1;        // db is the column sum of what the dW GEMM reads
+      }
+    }
+  }
+  __shared__ float s[4][128];
+  s[rl][2 * (threadIdx.x & 63)] = v0;
+  s[rl][2 * (threadIdx.x & 63) + 1] = v1;
+  __syncthreads();
+  if (rl == 0 && in0) {
+    const int k = 2 * threadIdx.x;
+    part[(int64_t)blockIdx.y * N + col] = s[0][k] + s[1][k] + s[2][k] + s[3][k];
+    if (in1) part[(int64_t)blockIdx.y * N + col + 1] = s[0][k + 1] + s[1][k + 1] + s[2][k + 1] + s[3][k + 1];
+  }
+}
+__global__ void __launch_bounds__(256) colsum_stage2_h_kernel(const float* __restrict__ part, int N,
+                                                              float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  float v = 0.f;
+  for (int i = 0; i < kColChunksH; ++i) v += part[(int64_t)i * N + c];
+  out[c] = v;
+}
+
+__global__ void __launch_bounds__(256) relu_mask_h_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y,
+                                                          int64_t n, bf16_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (float)y[i] > 0.f ? dy[i] : (bf16_t)0.f;
+}
+
+}  // namespace mapx
+
+extern "C" int mapx_gemm_bf16(int a_kc, int b_kc, int M, int N, int K, const mapx_bf16* A, int64_t lda,
+                              const mapx_bf16* B, int64_t ldb, void* C, int64_t ldc, int c_f32, int epi,
+                              const float* bias, const void* aux1, int64_t ld1, int aux1_f32,
+                              const mapx_bf16* aux2, int64_t ld2, mapx_bf16* out2, int64_t ldo2, int nsplit,
+                              int tile_hint, void* ws, size_t ws_bytes, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm_bf16: negative size");
+  if (M == 0 || N == 0) return MAPX_OK;
+  MAPX_REQUIRE(A && B && C, "gemm_bf16: null operand");
+  MAPX_REQUIRE(!(a_kc == 0 && b_kc != 0), "gemm_bf16: layout (A m-contiguous, B k-contiguous) unused");
+  MAPX_REQUIRE(epi >= MAPX_EPI_NONE && epi <= MAPX_EPI_RELU_MASK, "gemm_bf16: bad epilogue %d", epi);
+  {
+    const int64_t lim = (int64_t)1 << 31, rows = M > 0 ? M : 1;
+    MAPX_REQUIRE(rows * ldc < lim && rows * ld1 < lim && rows * ld2 < lim && rows * ldo2 < lim,
+                 "gemm_bf16: an output or auxiliary operand spans 2^31 elements or more");
+  }
+  if (epi >= MAPX_EPI_BIAS && epi <= MAPX_EPI_BIAS_CROSS) MAPX_REQUIRE(bias, "gemm_bf16: bias missing");
+  if (epi == MAPX_EPI_BIAS_CROSS) MAPX_REQUIRE(aux1 && aux2 && out2 && !c_f32, "gemm_bf16: cross operands missing / fp32 output");
+  if (epi == MAPX_EPI_ADD || epi == MAPX_EPI_RELU_MASK)
+    MAPX_REQUIRE(aux1 && !c_f32, "gemm_bf16: aux missing, or fp32 output with ADD / RELU_MASK");
+  MAPX_REQUIRE(!aux1_f32 || epi == MAPX_EPI_ADD, "gemm_bf16: an fp32 auxiliary operand is built for EPI_ADD only");
+  if (nsplit < 1) nsplit = 1;
+  MAPX_REQUIRE(nsplit == 1 || (epi == MAPX_EPI_NONE && c_f32), "gemm_bf16: split-K needs EPI_NONE and an fp32 output");
+
+  GemmHArgs g;
+  g.A = reinterpret_cast<const bf16_t*>(A); g.lda = lda;
+  g.B = reinterpret_cast<const bf16_t*>(B); g.ldb = ldb;
+  g.C = C; g.ldc = ldc;
+  g.M = M; g.N = N; g.K = K; g.epi = epi; g.bias = bias;
+  g.aux1 = aux1; g.ld1 = ld1; g.aux2 = reinterpret_cast<const bf16_t*>(aux2); g.ld2 = ld2;
+  g.out2 = reinterpret_cast<bf16_t*>(out2); g.ldo2 = ldo2;
+  g.k_chunk = K > 0 ? K : kHBK; g.slab_stride = 0;
+  if (nsplit > 1) {
+    const size_t need = (size_t)nsplit * M * N * sizeof(float);
+    if (!ws || ws_bytes < need) {
+      set_error("gemm_bf16: split-K workspace %zu < %zu", ws_bytes, need);
+      return MAPX_EWORKSPACE;
+    }
+    const int kc = (int)ceil_div(ceil_div(K, nsplit), kHBK) * kHBK;
+    g.k_chunk = kc;
+    nsplit = (int)ceil_div(K, kc);
+    g.C = ws;
+    g.ldc = N;
+    g.slab_stride = (int64_t)M * N;
+  }
+  // 16-byte chunks of 8 bf16: every chunk wholly inside or outside the matrix
+  const bool vec = (lda % 8 == 0) && (ldb % 8 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) &&
+                   (a_kc ? (K % 8 == 0) : (M % 8 == 0)) && (b_kc ? (K % 8 == 0) : (N % 8 == 0));
+  auto blocks = [&](int bm, int bn) { return ceil_div(M, bm) * ceil_div(N, bn) * nsplit; };
+  const int64_t big = blocks(128, 128);
+  int tile = (big >= 200) ? 2 : 0;
+  if (tile_hint >= 0 && tile_hint <= 2) tile = tile_hint;
+  hipError_t lerr;
+  if (a_kc && b_kc) lerr = launch_layout_h<true, true>(g, vec, tile, nsplit, c_f32, aux1_f32, stream);
+  else if (a_kc) lerr = launch_layout_h<true, false>(g, vec, tile, nsplit, c_f32, aux1_f32, stream);
+  else lerr = launch_layout_h<false, false>(g, vec, tile, nsplit, c_f32, aux1_f32, stream);
+  MAPX_HIP(lerr);
+  if (nsplit > 1) {
+    MAPX_REQUIRE(ldc == N, "gemm_bf16: split-K output must be dense (ldc == N)");
+    const int64_t n = (int64_t)M * N;
+    if (n % 4 == 0 && (uintptr_t)C % 16 == 0)
+      hipLaunchKernelGGL(splitk_reduce_h_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, stream,
+                         static_cast<const float*>(ws), g.slab_stride, nsplit, n / 4, static_cast<float*>(C));
+    else
+      hipLaunchKernelGGL(splitk_reduce_h1_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream,
+                         static_cast<const float*>(ws), g.slab_stride, nsplit, n, static_cast<float*>(C));
+  }
+  return check_launch("gemm_bf16");
+}
+
+extern "C" int mapx_cast_f32_bf16(const float* src, int64_t n, mapx_bf16* dst, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(n >= 0, "cast_f32_bf16: negative size");
+  if (n == 0) return MAPX_OK;
+  MAPX_REQUIRE(src && dst && (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0, "cast_f32_bf16: null or unaligned pointer");
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(ceil_div(n, 8), 256)), dim3(256), 0, stream, src, n,
+                     reinterpret_cast<bf16_t*>(dst));
+  return check_launch("cast_f32_bf16");
+}
+
+extern "C" int mapx_cast_bf16_f32(const mapx_bf16* src, int64_t n, float* dst, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(n >= 0, "cast_bf16_f32: negative size");
+  if (n == 0) return MAPX_OK;
+  MAPX_REQUIRE(src && dst, "cast_bf16_f32: null pointer");
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream,
+                     reinterpret_cast<const bf16_t*>(src), n, dst);
+  return check_launch("cast_bf16_f32");
+}
+
+extern "C" size_t mapx_colsum_bf16_workspace_bytes(int N) { return (size_t)mapx::kColChunksH * N * sizeof(float); }
+
+static int colsum_ws_ok(const char* what, void* ws, size_t ws_bytes, int N) {
+  if (!ws || ws_bytes < mapx_colsum_bf16_workspace_bytes(N)) {
+    mapx::set_error("%s: workspace too small", what);
+    return 0;
+  }
+  return 1;
+}
+
+extern "C" int mapx_colsum_bf16(const mapx_bf16* x, int64_t ld, int M, int N, float* out, void* ws, size_t ws_bytes,
+                                hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(x && out && M >= 0 && N > 0 && ld >= N, "colsum_bf16: bad arguments");
+  if (!colsum_ws_ok("colsum_bf16", ws, ws_bytes, N)) return MAPX_EWORKSPACE;
+  float* part = static_cast<float*>(ws);
+  const bf16_t* xb = reinterpret_cast<const bf16_t*>(x);
+  hipLaunchKernelGGL(ew_colsum_h_kernel<2>, dim3((N + 127) / 128, kColChunksH), dim3(256), 0, stream, xb, ld, xb, ld,
+                     xb, ld, M, N, (bf16_t*)nullptr, (float*)nullptr, 0, part);
+  hipLaunchKernelGGL(colsum_stage2_h_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, out);
+  return check_launch("colsum_bf16");
+}
+
+extern "C" int mapx_relu_mask_colsum_bf16(const mapx_bf16* dy, int64_t ld_dy, const mapx_bf16* y, int64_t ld_y, int M,
+                                          int N, mapx_bf16* dz, float* db, void* ws, size_t ws_bytes,
+                                          hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(dy && y && dz && db && M >= 0 && N > 0 && ld_dy >= N && ld_y >= N, "relu_mask_colsum_bf16: bad arguments");
+  if (!colsum_ws_ok("relu_mask_colsum_bf16", ws, ws_bytes, N)) return MAPX_EWORKSPACE;
+  float* part = static_cast<float*>(ws);
+  hipLaunchKernelGGL(ew_colsum_h_kernel<0>, dim3((N + 127) / 128, kColChunksH), dim3(256), 0, stream,
+                     reinterpret_cast<const bf16_t*>(dy), ld_dy, reinterpret_cast<const bf16_t*>(y), ld_y,
+                     reinterpret_cast<const bf16_t*>(y), ld_y, M, N, reinterpret_cast<bf16_t*>(dz), (float*)nullptr, 0,
+                     part);
+  hipLaunchKernelGGL(colsum_stage2_h_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, db);
+  return check_launch("relu_mask_colsum_bf16");
+}
+
+extern "C" int mapx_cross_bwd_pre_colsum_bf16(const mapx_bf16* g, int64_t ld_g, const mapx_bf16* x0, const mapx_bf16* u,
+                                              int M, int N, mapx_bf16* t, float* dx0, int accumulate, float* db,
+                                              void* ws, size_t ws_bytes, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(g && x0 && u && t && dx0 && db && M >= 0 && N > 0 && ld_g >= N, "cross_bwd_pre_colsum_bf16: bad arguments");
+  if (!colsum_ws_ok("cross_bwd_pre_colsum_bf16", ws, ws_bytes, N)) return MAPX_EWORKSPACE;
+  float* part = static_cast<float*>(ws);
+  hipLaunchKernelGGL(ew_colsum_h_kernel<1>, dim3((N + 127) / 128, kColChunksH), dim3(256), 0, stream,
+                     reinterpret_cast<const bf16_t*>(g), ld_g, reinterpret_cast<const bf16_t*>(x0), (int64_t)N,
+                     reinterpret_cast<const bf16_t*>(u), (int64_t)N, M, N, reinterpret_cast<bf16_t*>(t), dx0,
+                     accumulate, part);
+  hipLaunchKernelGGL(colsum_stage2_h_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, db);
+  return check_launch("cross_bwd_pre_colsum_bf16");
+}
+
+extern "C" int mapx_relu_mask_bf16(const mapx_bf16* dy, const mapx_bf16* y, int64_t n, mapx_bf16* out,
+                                   hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(dy && y && out && n >= 0, "relu_mask_bf16: bad arguments");
+  if (n == 0) return MAPX_OK;
+  hipLaunchKernelGGL(relu_mask_h_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream,
+                     reinterpret_cast<const bf16_t*>(dy), reinterpret_cast<const bf16_t*>(y), n,
+                     reinterpret_cast<bf16_t*>(out));
+  return check_launch("relu_mask_bf16");
+}

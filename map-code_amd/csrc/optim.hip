@@ -145,12 +145,15 @@ __device__ inline void closed_form_tail(int s, int to, const ReplayAux& ax, bool
   fv = (float)ax.t[2 * ax.len + nn];
 }
 
+// SHADOW: also store the updated parameter as bf16 (the weight operand of the bf16 GEMMs,
+// gemm_bf16.hip): the conversion rides on the one pass that touches every parameter anyway.
+template <bool SHADOW>
 __global__ void __launch_bounds__(256) adamw_dense_kernel(float* __restrict__ p,
                                                           const float* __restrict__ g,
                                                           float* __restrict__ m, float* __restrict__ v,
                                                           int64_t n, const float2* __restrict__ sched,
                                                           int sched_len, const int32_t* __restrict__ done,
-                                                          AdamHyper h, float wd) {
+                                                          AdamHyper h, float wd, __bf16* __restrict__ shadow) {
   int s = *done;  // updates applied so far; this is update s+1 -> sched[s]
   if (s >= sched_len) s = sched_len - 1;
   const float2 sc = sched[s];
@@ -169,11 +172,19 @@ __global__ void __launch_bounds__(256) adamw_dense_kernel(float* __restrict__ p,
     reinterpret_cast<float4*>(p)[i] = pv;
     reinterpret_cast<float4*>(m)[i] = mv;
     reinterpret_cast<float4*>(v)[i] = vv;
+    if (SHADOW) {
+      typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+      bf16x4_t o;
+      o[0] = (__bf16)pv.x; o[1] = (__bf16)pv.y; o[2] = (__bf16)pv.z; o[3] = (__bf16)pv.w;
+      reinterpret_cast<bf16x4_t*>(shadow)[i] = o;
+    }
   }
   // tail (n % 4)
   for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x)
+       i += (int64_t)gridDim.x * blockDim.x) {
     adam_elem(p[i], m[i], v[i], g[i], step, decay, h);
+    if (SHADOW) shadow[i] = (__bf16)p[i];
+  }
 }
 
 __global__ void step_advance_kernel(int32_t* done) { *done += 1; }
@@ -366,10 +377,26 @@ extern "C" int mapx_adamw_dense(float* p, const float* g, float* m, float* v, in
                    ((uintptr_t)v % 16 == 0),
                "adamw_dense: pointers must be 16-byte aligned");
   if (n == 0) return MAPX_OK;
-  hipLaunchKernelGGL(adamw_dense_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, stream, p, g, m,
+  hipLaunchKernelGGL(adamw_dense_kernel<false>, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, stream, p, g, m,
                      v, n, reinterpret_cast<const float2*>(sched), sched_len, done,
-                     make_hyper(beta1, beta2, eps), (float)weight_decay);
+                     make_hyper(beta1, beta2, eps), (float)weight_decay, (__bf16*)nullptr);
   return check_launch("adamw_dense");
+}
+
+extern "C" int mapx_adamw_dense_shadow(float* p, const float* g, float* m, float* v, int64_t n,
+                                       const float* sched, int sched_len, const int32_t* done,
+                                       double beta1, double beta2, double eps, double weight_decay,
+                                       mapx_bf16* shadow, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(p && g && m && v && sched && done && shadow && n >= 0 && sched_len > 0, "adamw_dense_shadow: bad arguments");
+  MAPX_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
+                   ((uintptr_t)v % 16 == 0) && ((uintptr_t)shadow % 8 == 0),
+               "adamw_dense_shadow: pointers must be 16-byte (shadow: 8-byte) aligned");
+  if (n == 0) return MAPX_OK;
+  hipLaunchKernelGGL(adamw_dense_kernel<true>, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, stream, p, g, m,
+                     v, n, reinterpret_cast<const float2*>(sched), sched_len, done,
+                     make_hyper(beta1, beta2, eps), (float)weight_decay, reinterpret_cast<__bf16*>(shadow));
+  return check_launch("adamw_dense_shadow");
 }
 
 extern "C" int mapx_step_advance(int32_t* done, hipStream_t stream) {

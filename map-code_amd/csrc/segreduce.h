@@ -41,6 +41,20 @@ struct RowsContrib {
   }
 };
 
+// bf16 gradient rows (bf16 compute mode: dL/dX0 leaves the trunk's backward GEMMs in bf16);
+// the sums are fp32 like everything else here.
+struct RowsBf16Contrib {
+  const __bf16* src;  // [n, W]
+  int W;
+  __device__ inline void prepare() {}
+  __device__ inline float4 operator()(int32_t p, int sub, float& extra) const {
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    extra = 0.f;
+    const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(src + (int64_t)p * W + 4 * sub);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+  }
+};
+
 // NCE output-table gradient, never materialised per (target, sample) pair:
 // d emb[idx[t,j]] += dlogit[t,j] * h[t,:]   d bias[idx[t,j]] += dlogit[t,j]
 // (backward of reference nce/index_linear.py:99-102; p = t*(K+1)+j)

@@ -80,6 +80,14 @@ MODEL_FLAGS = [
 ]
 
 
+# mapx extensions: flags the reference does not have (kept apart so that the reference surface
+# above stays pinned one-to-one by tests/golden/flag_surface.json)
+EXTENSION_MODEL_FLAGS = [
+    ("compute_dtype", str, "fp32", "fp32 | bf16: dtype of the trunk's activations and GEMM operands "
+                                   "(bf16: fp32 master weights, fp32 accumulation, fp32 tables and optimizer)"),
+]
+
+
 def _to_bool(v):
     if isinstance(v, bool):
         return v
@@ -121,7 +129,7 @@ class _Bag:
 
 
 class ModelArguments(_Bag):
-    _flags = MODEL_FLAGS
+    _flags = MODEL_FLAGS + EXTENSION_MODEL_FLAGS
 
 
 class TrainingArguments(_Bag):
@@ -167,7 +175,7 @@ class TrainingArguments(_Bag):
 def build_parser():
     ap = argparse.ArgumentParser(prog="run.py", allow_abbrev=False,
                                  description="DCNv2 scratch / MFP / RFD / finetune on MI355X")
-    for name, typ, default, hlp in MODEL_FLAGS + TRAINING_FLAGS:
+    for name, typ, default, hlp in MODEL_FLAGS + EXTENSION_MODEL_FLAGS + TRAINING_FLAGS:
         kw = dict(dest=name, help=hlp or None)
         if default is REQUIRED:
             kw["required"] = True
@@ -187,7 +195,7 @@ def parse_args_into_dataclasses(argv=None):
     """-> (ModelArguments, TrainingArguments), like HfArgumentParser((ModelArguments,
     TrainingArguments)).parse_args_into_dataclasses() in reference run.py:14-15."""
     ns = vars(build_parser().parse_args(argv))
-    margs = ModelArguments(**{n: ns[n] for n, *_ in MODEL_FLAGS})
+    margs = ModelArguments(**{n: ns[n] for n, *_ in MODEL_FLAGS + EXTENSION_MODEL_FLAGS})
     targs = TrainingArguments(**{n: ns[n] for n, *_ in TRAINING_FLAGS})
     return margs, targs
 

@@ -10,6 +10,16 @@ from torch.autograd import Function
 from . import ops
 
 
+def compute_dtype_of(config):
+    """torch dtype of the trunk's activations: Config key `compute_dtype` ("fp32" default | "bf16")."""
+    name = str(getattr(config, "compute_dtype", "fp32") or "fp32").lower()
+    if name in ("fp32", "float32", "f32"):
+        return torch.float32
+    if name in ("bf16", "bfloat16"):
+        return torch.bfloat16
+    raise NotImplementedError(f"compute_dtype={name!r}: fp32 | bf16")
+
+
 # ----------------------------------------------------------------------------- row tables
 def _side_stream(device, table_name=""):
     """All tables' plans share one side stream.  (One stream per table was tried: inside the
@@ -143,18 +153,18 @@ class TableWeight(nn.Module):
 
 class _Gather(Function):
     @staticmethod
-    def forward(ctx, weight, ids, table):
+    def forward(ctx, weight, ids, table, out_dtype=torch.float32):
         ctx.table, ctx.plan, ctx.width = table, table.plan, weight.shape[1]
-        return ops.emb_gather(ids, weight)
+        return ops.emb_gather(ids, weight, out_dtype=out_dtype)
 
     @staticmethod
     def backward(ctx, g):
         if ctx.plan is None:
             raise RuntimeError("embedding backward without a segment plan")
         plan = ctx.plan.get()
-        g = g.contiguous().view(-1, ctx.width)
+        g = g.contiguous().view(-1, ctx.width)           # bf16 rows in bf16 mode: summed in fp32
         ctx.table.sparse_grad = (plan, ops.seg_reduce_rows(plan, g, ctx.width), None)
-        return None, None, None
+        return None, None, None, None
 
 
 class _GatherLinear(Function):
@@ -218,6 +228,12 @@ class Embeddings(nn.Module):
         self.table = RowTable("embed.embedding", self.embedding.weight)
         self.validate_ids = False
         self.defer_plan = False     # the owning model calls table.start_plan() at its chosen fork point
+        # bf16 compute mode (mapx extension, BASELINE configs[2]): the gathered rows leave the kernel as
+        # bf16 and every dense layer behind them runs on the bf16 MFMA; the table itself, its gradient
+        # rows, every weight gradient and the optimizer state stay fp32
+        self.compute_dtype = compute_dtype_of(config)
+        if self.compute_dtype == torch.bfloat16 and config.embed_size % 8 != 0:
+            raise NotImplementedError("compute_dtype=bf16 needs embed_size % 8 == 0 (16-byte bf16 rows)")
 
     def forward(self, input_ids):
         w = self.embedding.weight
@@ -226,7 +242,7 @@ class Embeddings(nn.Module):
             if (need_grad or self.table.lazy is not None) else None
         if keys is not None:
             self.table.prepare(keys, need_grad, defer_plan=self.defer_plan)
-        return _Gather.apply(w, input_ids, self.table)
+        return _Gather.apply(w, input_ids, self.table, self.compute_dtype)
 
     def forward_with_linear(self, input_ids, lin_weight):
         """-> (embeddings [B,F,E], sum_f lin_weight[id] [B]).  `lin_weight` [V,1] must be the
@@ -265,19 +281,25 @@ def _weight_grads(ctx, dz, x, sw, sb, need=None):
 
 class _Linear(Function):
     @staticmethod
-    def forward(ctx, x, w, b, relu, out=None):
+    def forward(ctx, x, w, b, relu, out=None, out_f32=False):
         x = x.contiguous()
-        y = ops.linear_fwd(x, w, b, relu=relu, out=out)
-        ctx.relu = relu
+        half = ops.is_bf16(x)
+        if half and relu and out_f32:
+            raise NotImplementedError("a ReLU layer with an fp32 result inside the bf16 trunk")
+        wop = ops.bf16_weight(w) if half else w           # bf16 mode: the optimizer's bf16 shadow of w
+        y = ops.linear_fwd(x, wop, b, relu=relu, out=out, out_dtype=torch.float32 if (half and out_f32) else None)
+        ctx.relu, ctx.half = relu, half
         ctx.slots = (_grad_slot(w), _grad_slot(b))
-        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.save_for_backward(x, wop, y if relu else None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
         sw, sb = ctx.slots
-        if ctx.relu and gy.shape[1] % 4 == 0:      # ReLU mask and bias gradient in one pass over dY
+        if ctx.half and gy.dtype == torch.float32:
+            gy = ops.cast_bf16(gy)                 # the fp32 gradient of a head's logits enters the bf16 trunk
+        if ctx.relu and (ctx.half or gy.shape[1] % 4 == 0):      # ReLU mask and bias gradient in one pass over dY
             dz, db = ops.relu_mask_colsum(gy, y, db=sb, defer=True)      # gy may be a slice of d(concat)
             dw = ops.linear_bwd_weight(dz, x, out=sw, defer=True) if ctx.needs_input_grad[1] else None
             dw, db = (None if sw is not None else dw), (None if sb is not None else db)
@@ -285,16 +307,18 @@ class _Linear(Function):
             dz = ops.relu_mask(gy.contiguous(), y.contiguous()) if ctx.relu else gy.contiguous()
             dw, db = _weight_grads(ctx, dz, x, sw, sb)
         dx = ops.linear_bwd_input(dz, w) if ctx.needs_input_grad[0] else None
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 class HipLinear(nn.Module):
-    """nn.Linear (y = x W^T + b, optional fused ReLU) on the fp32 MFMA GEMM; parameters keep
-    nn.Linear's names, shapes and default initialisation."""
+    """nn.Linear (y = x W^T + b, optional fused ReLU) on the MFMA GEMM (fp32, or bf16 operands when
+    the input is bf16); parameters keep nn.Linear's names, shapes and default initialisation.
+    `out_fp32`: in bf16 mode the result stays fp32 (the heads' logits / encoder output)."""
 
-    def __init__(self, in_features, out_features, relu=False):
+    def __init__(self, in_features, out_features, relu=False, out_fp32=False):
         super().__init__()
         self.in_features, self.out_features, self.relu = in_features, out_features, relu
+        self.out_fp32 = out_fp32
         self.weight = nn.Parameter(torch.empty(out_features, in_features))
         self.bias = nn.Parameter(torch.empty(out_features))
         bound = 1.0 / math.sqrt(in_features)
@@ -304,7 +328,7 @@ class HipLinear(nn.Module):
 
     def forward(self, x, out=None):
         """`out`: optional pre-allocated destination (ops.alias_cols of a wider buffer)."""
-        return _Linear.apply(x, self.weight, self.bias, self.relu, out)
+        return _Linear.apply(x, self.weight, self.bias, self.relu, out, self.out_fp32)
 
 
 class MLPBlock(nn.Module):
@@ -341,14 +365,15 @@ class _CrossTower(Function):
     def forward(ctx, x0, out, *wb):
         x0 = x0.contiguous()
         n = len(wb) // 2
+        wops = [ops.bf16_weight(w) for w in wb[0::2]] if ops.is_bf16(x0) else list(wb[0::2])
         xi, xs, us = x0, [], []
         for i in range(n):
             xs.append(xi)
-            xi, u = ops.cross_layer_fwd(x0, xi, wb[2 * i], wb[2 * i + 1], out=out if i == n - 1 else None)
+            xi, u = ops.cross_layer_fwd(x0, xi, wops[i], wb[2 * i + 1], out=out if i == n - 1 else None)
             us.append(u)
         ctx.n = n
         ctx.slots = [(_grad_slot(wb[2 * i]), _grad_slot(wb[2 * i + 1])) for i in range(n)]
-        ctx.save_for_backward(x0, *xs[1:], *us, *wb[0::2])
+        ctx.save_for_backward(x0, *xs[1:], *us, *wops)
         return xi
 
     @staticmethod

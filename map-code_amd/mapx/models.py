@@ -25,7 +25,7 @@ class _RfdPredictor(nn.ModuleDict):
     (models.py:119-123); the ReLU is fused into the first GEMM's epilogue."""
 
     def __init__(self, input_dim, hidden, out):
-        super().__init__({"0": HipLinear(input_dim, hidden, relu=True), "2": HipLinear(hidden, out)})
+        super().__init__({"0": HipLinear(input_dim, hidden, relu=True), "2": HipLinear(hidden, out, out_fp32=True)})
 
     def forward(self, x):
         return self["2"](self["0"](x))
@@ -42,6 +42,9 @@ class BaseModel(nn.Module):
     @classmethod
     def from_config(cls, config: Config):
         name = config.model_name.lower()
+        from .layers import compute_dtype_of
+        if compute_dtype_of(config) != torch.float32 and name not in ("dcnv2", "dnn"):
+            raise NotImplementedError(f"compute_dtype=bf16 is built for DCNv2 and DNN, not {config.model_name}")
         if name == "dcnv2":
             return DCNV2(config)
         if name == "dnn":
@@ -75,15 +78,18 @@ class BaseModel(nn.Module):
         if (is_pretrain is None and cfg.pretrain) or is_pretrain:
             if cfg.pt_type == "MFP":
                 crit = self.mfp_criterion
-                if GROUPED_ENCODER and crit.supports_grouped_encoder() and inputs.shape[1] % 4 == 0:
+                if (GROUPED_ENCODER and crit.supports_grouped_encoder() and inputs.shape[1] % 4 == 0
+                        and inputs.dtype == torch.float32):
                     # only the L masked fields' blocks of feat_encoder are computed (26 %)
                     loss, _logits, _idx = crit.forward_with_encoder(labels, inputs, self.feat_encoder,
                                                                     masked_index, noise_samples=noise_samples,
                                                                     groups=groups, idx=nce_idx)
                 else:
+                    # (bf16 mode: the dense encoder GEMM — 16x the MFMA rate makes computing all F blocks
+                    # cheaper than the grouped GEMM's gathers; its output and the whole NCE head stay fp32)
                     enc = self.feat_encoder(inputs)
                     loss, _logits, _idx = crit(labels, enc, masked_index=masked_index,
-                                               noise_samples=noise_samples)
+                                               noise_samples=noise_samples, idx=nce_idx)
                 return (loss, labels.shape[0] * labels.shape[1], self.mfp_criterion.last_acc)
             if cfg.pt_type == "RFD":
                 logits = self.pred_rfd(inputs)
@@ -99,7 +105,7 @@ class BaseModel(nn.Module):
     def create_pretraining_predictor(self, input_dim):
         cfg = self.config
         if cfg.pt_type == "MFP":
-            self.feat_encoder = HipLinear(input_dim, cfg.num_fields * cfg.proj_size)
+            self.feat_encoder = HipLinear(input_dim, cfg.num_fields * cfg.proj_size, out_fp32=True)
             self.mfp_criterion = IndexLinear(cfg)
         elif cfg.pt_type == "RFD":
             self.pred_rfd = _RfdPredictor(input_dim, cfg.num_fields * cfg.proj_size, cfg.num_fields)
@@ -157,10 +163,13 @@ class DCNV2(BaseModel):
         if config.pretrain:
             self.create_pretraining_predictor(final_dim)
         else:
-            self.fc_out = HipLinear(final_dim, 1)
+            self.fc_out = HipLinear(final_dim, 1, out_fp32=True)
+
+    def _mfp_head(self, masked_index):
+        return self.config.pretrain and self.config.pt_type == "MFP" and masked_index is not None
 
     def _grouped_head(self, masked_index):
-        return (self.config.pretrain and self.config.pt_type == "MFP" and masked_index is not None
+        return (self._mfp_head(masked_index) and self.embed.compute_dtype == torch.float32
                 and GROUPED_ENCODER and self.mfp_criterion.supports_grouped_encoder()
                 and self.feat_encoder.in_features % 4 == 0)
 
@@ -181,17 +190,18 @@ class DCNV2(BaseModel):
             # both towers write their last layer straight into the concatenated buffer
             D, H = feat_embed.shape[1], self.config.hidden_size
             direct = self.config.num_cross_layers > 0
-            final_buf = torch.empty(feat_embed.shape[0], D + H, dtype=torch.float32, device=feat_embed.device)
+            final_buf = torch.empty(feat_embed.shape[0], D + H, dtype=feat_embed.dtype, device=feat_embed.device)
             with torch.cuda.stream(tower):
                 if self._grouped_head(masked_index):
                     # the cross tower has ~70 us of slack against the deep one: the slot layout of
                     # the grouped encoder (one single-workgroup launch) rides on its stream
                     groups = ops.EncGroups(masked_index, self.config.num_fields)
-                    if NCE_EARLY and labels is not None:
-                        # the NCE head's sampling and the lazy catch-up of the sampled rows need only
-                        # the targets: HBM-bound kernels that run beside the deep tower's first GEMMs
-                        # instead of alone between the towers and the loss (same branch, no new one)
-                        nce_idx = self.mfp_criterion.sample_ids(labels, noise_samples)
+                if self._mfp_head(masked_index) and NCE_EARLY and labels is not None \
+                        and (groups is not None or self.embed.compute_dtype != torch.float32):
+                    # the NCE head's sampling and the lazy catch-up of the sampled rows need only
+                    # the targets: HBM-bound kernels that run beside the deep tower's first GEMMs
+                    # instead of alone between the towers and the loss (same branch, no new one)
+                    nce_idx = self.mfp_criterion.sample_ids(labels, noise_samples)
                 cross_output = self.cross_net(feat_embed, out=ops.alias_cols(final_buf, 0, D) if direct else None)
             dnn_output = self.parallel_dnn(feat_embed, out=ops.alias_cols(final_buf, D, H) if direct else None)
             # (starting the sampled ids' sort here, ahead of the embedding's, was measured: 1.375 vs
@@ -234,7 +244,7 @@ class DNN(BaseModel):
         if config.pretrain:
             self.create_pretraining_predictor(config.hidden_size)
         else:
-            self.fc_out = HipLinear(config.hidden_size, 1)
+            self.fc_out = HipLinear(config.hidden_size, 1, out_fp32=True)
 
     def forward(self, input_ids, labels=None, masked_index=None, noise_samples=None):
         feat_embed = self.embed(input_ids).flatten(start_dim=1)

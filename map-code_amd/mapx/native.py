@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmapx_hip.so")
 
-MAPX_ABI_VERSION = 24
+MAPX_ABI_VERSION = 25
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_CROSS, EPI_ADD, EPI_RELU_MASK = range(6)
 
 _p, _i, _i64, _u64, _f, _d, _sz = (C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double,
@@ -57,6 +57,18 @@ SIGNATURES = {
     "mapx_gemm_splitk_workspace_bytes": (_sz, [_i, _i, _i]),
     "mapx_gemm_f32": (_i, [_i, _i, _i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _i, _p, _p, _i64, _p,
                            _i64, _p, _i64, _i, _i, _p, _sz, _p, _p]),
+    "mapx_gemm_bf16": (_i, [_i, _i, _i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _i, _i, _p, _p, _i64, _i, _p, _i64,
+                            _p, _i64, _i, _i, _p, _sz, _p]),
+    "mapx_cast_f32_bf16": (_i, [_p, _i64, _p, _p]),
+    "mapx_cast_bf16_f32": (_i, [_p, _i64, _p, _p]),
+    "mapx_emb_gather_fwd_bf16": (_i, [_p, _i64, _p, _i64, _i, _p, _p, _p]),
+    "mapx_seg_reduce_rows_bf16": (_i, [_i64, _p, _p, _p, _p, _i, _p, _p, _sz, _p, _p]),
+    "mapx_colsum_bf16_workspace_bytes": (_sz, [_i]),
+    "mapx_colsum_bf16": (_i, [_p, _i64, _i, _i, _p, _p, _sz, _p]),
+    "mapx_relu_mask_colsum_bf16": (_i, [_p, _i64, _p, _i64, _i, _i, _p, _p, _p, _sz, _p]),
+    "mapx_cross_bwd_pre_colsum_bf16": (_i, [_p, _i64, _p, _p, _i, _i, _p, _p, _i, _p, _p, _sz, _p]),
+    "mapx_relu_mask_bf16": (_i, [_p, _p, _i64, _p, _p]),
+    "mapx_adamw_dense_shadow": (_i, [_p, _p, _p, _p, _i64, _p, _i, _p, _d, _d, _d, _d, _p, _p]),
     "mapx_sum_tasks": (_i, [_p, _i, _p]),
     "mapx_enc_group_layout": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "mapx_enc_grouped_fwd": (_i, [_p, _i64, _i, _i, _p, _i64, _p, _p, _p, _i, _p, _p, _p]),

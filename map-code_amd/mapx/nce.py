@@ -183,7 +183,7 @@ class IndexLinear(nn.Module):
             offset, dev = (self.rank << 40) + self._draws, None
         return self.alias.draw_index_matrix(target.reshape(-1), self.noise_ratio, self.seed, offset, dev)
 
-    def forward(self, target, input, masked_index=None, noise_samples=None):
+    def forward(self, target, input, masked_index=None, noise_samples=None, idx=None):
         """target [B,L] i64.  `input` is either the selected hidden [B,L,P] (reference call
         form, models.py:76) or, with `masked_index` [B,L], the whole encoder output [B,F*P] —
         then the field gather is fused into the loss kernel.
@@ -197,13 +197,8 @@ class IndexLinear(nn.Module):
             masked_index = torch.arange(L, device=target.device).expand(B, L).contiguous()
         else:
             enc, F = input, input.shape[1] // P
-        V = self.emb.weight.shape[0]
-        if noise_samples is not None:
-            idx = ops.nce_pack_idx(target.reshape(-1), noise_samples.reshape(B * L, -1), V)
-        else:
-            idx = self.get_noise_index(target)
-        need_grad = torch.is_grad_enabled() and self.emb.weight.requires_grad
-        self.table.prepare(idx.view(-1), need_grad, defer_plan=True)
+        if idx is None:                      # else: sample_ids() ran earlier (ids drawn, rows caught up)
+            idx = self.sample_ids(target, noise_samples)
         loss, acc, logits = _NceLoss.apply(enc, self.emb.weight, self.bias.weight, self.logprob_noise,
                                            masked_index, idx, self, F, P, self.return_logits)
         self.last_acc = acc

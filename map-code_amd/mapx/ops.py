@@ -205,15 +205,48 @@ def _err_flag(device):
 
 
 # --------------------------------------------------------------------------- embedding
-def emb_gather(ids, table, validate=False):
-    """ids int64 [...], table [V,E] -> [..., E]  (layers.py:97-102)."""
+BF16 = torch.bfloat16
+
+
+def is_bf16(t):
+    return t is not None and t.dtype == torch.bfloat16
+
+
+def cast_bf16(x):
+    """fp32 -> bf16 copy (round to nearest even) by the library's kernel."""
+    require_gpu(x)
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    check(lib.mapx_cast_f32_bf16(ptr(x), x.numel(), ptr(out), stream()))
+    return out
+
+
+def cast_f32(x):
+    require_gpu(x)
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(lib.mapx_cast_bf16_f32(ptr(x), x.numel(), ptr(out), stream()))
+    return out
+
+
+def bf16_weight(w):
+    """The bf16 operand of a dense fp32 master weight: the shadow the optimizer keeps current
+    (`w._mapx_bf16`, written by the AdamW kernel itself), or a fresh conversion when no optimizer
+    owns the parameter (inference / tests)."""
+    sh = getattr(w, "_mapx_bf16", None)
+    return sh if sh is not None else cast_bf16(w.detach())
+
+
+def emb_gather(ids, table, validate=False, out_dtype=torch.float32):
+    """ids int64 [...], table [V,E] -> [..., E]  (layers.py:97-102); bf16 rows in bf16 compute mode."""
     require_gpu(ids, table)
     ids = ids.contiguous()
-    out = torch.empty(*ids.shape, table.shape[1], dtype=torch.float32, device=table.device)
+    out = torch.empty(*ids.shape, table.shape[1], dtype=out_dtype, device=table.device)
     err = _err_flag(table.device) if validate else None
-    with _timed("emb_gather", ids.numel() * (8 + 2 * 4 * table.shape[1])):
-        check(lib.mapx_emb_gather_fwd(ptr(ids), ids.numel(), ptr(table), table.shape[0], table.shape[1],
-                                      ptr(out), ptr(err), stream()))
+    fn = lib.mapx_emb_gather_fwd_bf16 if out_dtype == BF16 else lib.mapx_emb_gather_fwd
+    with _timed("emb_gather", ids.numel() * (8 + (4 + out.element_size()) * table.shape[1])):
+        check(fn(ptr(ids), ids.numel(), ptr(table), table.shape[0], table.shape[1],
+                 ptr(out), ptr(err), stream()))
     if validate and int(err.item()):
         raise IndexError("index out of range in self")          # reference CPU behaviour
     return out
@@ -288,10 +321,10 @@ def seg_reduce_rows(plan, src, W):
     out = torch.empty(max(plan.n, 1), W, dtype=torch.float32, device=src.device)
     nb = lib.mapx_seg_reduce_workspace_bytes(plan.n, W)
     ws = scratch(nb, src.device)
-    with _timed("seg_reduce_rows", plan.n * (4.0 * W + 8)):
-        check(lib.mapx_seg_reduce_rows(plan.n, ptr(plan.perm), ptr(plan.rank), ptr(plan.seg_start),
-                                       ptr(src), W, ptr(out), ptr(ws), ws.numel(), plan.take_counter(),
-                                       stream()))
+    fn = lib.mapx_seg_reduce_rows_bf16 if is_bf16(src) else lib.mapx_seg_reduce_rows
+    with _timed("seg_reduce_rows", plan.n * (float(src.element_size()) * W + 8)):
+        check(fn(plan.n, ptr(plan.perm), ptr(plan.rank), ptr(plan.seg_start),
+                 ptr(src), W, ptr(out), ptr(ws), ws.numel(), plan.take_counter(), stream()))
     return out
 
 
@@ -604,10 +637,55 @@ def scale_(x, g):
 
 
 # --------------------------------------------------------------------------- dense
-def gemm(a, b, a_kc, b_kc, M, N, K, out=None, ldc=None, epi=N.EPI_NONE, bias=None, aux1=None,
-         aux2=None, out2=None, nsplit=1, lda=None, ldb=None, tile=-1, defer=False):
-    """C[M,N] = epi(sum_k A(m,k) B(k,n)); see include/mapx_hip.h: mapx_gemm_f32."""
+def gemm_bf16(a, b, a_kc, b_kc, M, N, K, out=None, out_dtype=BF16, ldc=None, epi=N.EPI_NONE, bias=None,
+              aux1=None, aux2=None, out2=None, nsplit=1, lda=None, ldb=None, tile=-1):
+    """The bf16-operand GEMM (include/mapx_hip.h: mapx_gemm_bf16): a, b, aux2, out2 bf16; C bf16 or
+    fp32 (`out_dtype`, or the dtype of `out`); aux1 bf16 or fp32 (EPI_ADD only); fp32 accumulation."""
     require_gpu(a, b)
+    if not (is_bf16(a) and is_bf16(b)):
+        raise TypeError("gemm_bf16 takes bf16 operands")
+    dev = a.device
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype, device=dev)
+    c_f32 = out.dtype == torch.float32
+    if not (c_f32 or is_bf16(out)):
+        raise TypeError("gemm_bf16 writes bf16 or fp32")
+    ldc = ldc if ldc is not None else out.stride(0)
+    lda = lda if lda is not None else a.stride(0)
+    ldb = ldb if ldb is not None else b.stride(0)
+    ws, wsn = None, 0
+    if nsplit > 1:
+        wsn = lib.mapx_gemm_splitk_workspace_bytes(M, N, nsplit)
+        ws = scratch(wsn, dev)
+        wsn = ws.numel()
+    if bias is not None and bias.dtype != torch.float32:
+        raise TypeError("gemm_bf16: the bias stays fp32")
+    aux1_f32 = aux1 is not None and aux1.dtype == torch.float32
+    for t_ in (aux2, out2):
+        if t_ is not None and not is_bf16(t_):
+            raise TypeError("gemm_bf16: aux2 / out2 are bf16")
+    kind = "gemm_fwd_nt" if (a_kc and b_kc) else ("gemm_dx_nn" if a_kc else "gemm_dw_tn")
+    with _timed(kind, 2.0 * M * N * K):
+        check(lib.mapx_gemm_bf16(int(a_kc), int(b_kc), M, N, K, a.data_ptr(), lda, b.data_ptr(), ldb,
+                                 out.data_ptr(), ldc, int(c_f32), epi, ptr(bias),
+                                 aux1.data_ptr() if aux1 is not None else None,
+                                 aux1.stride(0) if aux1 is not None else 0, int(aux1_f32),
+                                 aux2.data_ptr() if aux2 is not None else None,
+                                 aux2.stride(0) if aux2 is not None else 0,
+                                 out2.data_ptr() if out2 is not None else None,
+                                 out2.stride(0) if out2 is not None else 0, nsplit, tile,
+                                 ws.data_ptr() if ws is not None else None, wsn, stream()))
+    return out
+
+
+def gemm(a, b, a_kc, b_kc, M, N, K, out=None, ldc=None, epi=N.EPI_NONE, bias=None, aux1=None,
+         aux2=None, out2=None, nsplit=1, lda=None, ldb=None, tile=-1, defer=False, out_dtype=None):
+    """C[M,N] = epi(sum_k A(m,k) B(k,n)); see include/mapx_hip.h: mapx_gemm_f32 (fp32 operands) /
+    mapx_gemm_bf16 (bf16 operands; `out_dtype` picks a bf16 or fp32 result)."""
+    require_gpu(a, b)
+    if is_bf16(a):
+        return gemm_bf16(a, b, a_kc, b_kc, M, N, K, out=out, out_dtype=out_dtype or BF16, ldc=ldc, epi=epi,
+                         bias=bias, aux1=aux1, aux2=aux2, out2=out2, nsplit=nsplit, lda=lda, ldb=ldb, tile=tile)
     dev = a.device
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=dev)
@@ -638,16 +716,19 @@ def gemm(a, b, a_kc, b_kc, M, N, K, out=None, ldc=None, epi=N.EPI_NONE, bias=Non
     return out
 
 
-def linear_fwd(x, w, b, relu=False, out=None):
-    """nn.Linear (+ReLU): x [M,K], w [N,K], b [N] -> [M,N]; `out` may be a column slice."""
+def linear_fwd(x, w, b, relu=False, out=None, out_dtype=None):
+    """nn.Linear (+ReLU): x [M,K], w [N,K], b [N] -> [M,N]; `out` may be a column slice.  bf16 x:
+    `w` is the weight's bf16 operand (ops.bf16_weight), b stays fp32, the result is bf16 or
+    (`out_dtype=torch.float32`: the heads' logits) fp32."""
     M, K = x.shape
     Nn = w.shape[0]
     return gemm(x, w, True, True, M, Nn, K, out=out, epi=N.EPI_BIAS_RELU if relu else N.EPI_BIAS,
-                bias=b)
+                bias=b, out_dtype=out_dtype)
 
 
 def linear_bwd_input(dy, w, out=None, add=None, relu_of=None):
-    """dX = dY W  (+ add)  or masked by relu_of > 0.  dy [M,N], w [N,K] -> [M,K]."""
+    """dX = dY W  (+ add)  or masked by relu_of > 0.  dy [M,N], w [N,K] -> [M,K] (dtype of dy;
+    bf16: `add` may be fp32 — the cross tower's running dL/dX0)."""
     M, Nn = dy.shape
     K = w.shape[1]
     epi, aux = N.EPI_NONE, None
@@ -679,6 +760,8 @@ def linear_bwd_weight(dy, x, out=None, defer=False):
     ns = _splits_for(Nn, K, Bn)
     if out is not None and out.stride(0) != K:
         ns = 1
+    if is_bf16(dy):                          # fp32 gradient from bf16 operands
+        return gemm_bf16(dy, x, False, False, Nn, K, Bn, out=out, out_dtype=torch.float32, nsplit=ns)
     return gemm(dy, x, False, False, Nn, K, Bn, out=out, nsplit=ns, defer=DEFER and defer and out is not None)
 
 
@@ -691,6 +774,14 @@ def colsum(x, out=None, defer=False):
     """Column sums; defer (needs out): leave the row-chunk partials for flush_deferred()."""
     require_gpu(x)
     M, Nn = x.shape
+    if is_bf16(x):
+        if out is None:
+            out = torch.empty(Nn, dtype=torch.float32, device=x.device)
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        ws = scratch(lib.mapx_colsum_bf16_workspace_bytes(Nn), x.device)
+        check(lib.mapx_colsum_bf16(x.data_ptr(), x.stride(0), M, Nn, ptr(out), ptr(ws), ws.numel(), stream()))
+        return out
     defer = DEFER and defer and out is not None
     if out is None:
         out = torch.empty(Nn, dtype=torch.float32, device=x.device)
@@ -705,7 +796,7 @@ def colsum(x, out=None, defer=False):
 def cross_layer_fwd(x0, xi, w, b, out=None):
     """-> (X_{i+1} = Xi + X0 * (Xi W^T + b), u = Xi W^T + b)   (layers.py:200)."""
     M, D = xi.shape
-    u = torch.empty(M, D, dtype=torch.float32, device=xi.device)
+    u = torch.empty(M, D, dtype=xi.dtype, device=xi.device)
     y = gemm(xi, w, True, True, M, D, D, out=out, epi=N.EPI_BIAS_CROSS, bias=b, aux1=xi, aux2=x0,
              out2=u)
     return y, u
@@ -739,6 +830,19 @@ def row_sliceable(x):
 
 def relu_mask_colsum(dy, y, db=None, defer=False):
     """-> (dz = y > 0 ? dy : 0, db = colsum(dz)) in one pass.  dy may be a column slice."""
+    if is_bf16(dy):
+        if dy.stride(1) != 1:
+            dy = dy.contiguous()
+        if y.stride(1) != 1:
+            y = y.contiguous()
+        M, Nn = dy.shape
+        dz = torch.empty(M, Nn, dtype=BF16, device=dy.device)
+        if db is None:
+            db = torch.empty(Nn, dtype=torch.float32, device=dy.device)
+        ws = scratch(lib.mapx_colsum_bf16_workspace_bytes(Nn), dy.device)
+        check(lib.mapx_relu_mask_colsum_bf16(dy.data_ptr(), dy.stride(0), y.data_ptr(), y.stride(0), M, Nn, ptr(dz),
+                                             ptr(db), ptr(ws), ws.numel(), stream()))
+        return dz, db
     if not row_sliceable(dy):
         dy = dy.contiguous()
     if not row_sliceable(y):
@@ -757,7 +861,23 @@ def relu_mask_colsum(dy, y, db=None, defer=False):
 
 
 def cross_bwd_pre_colsum(g, x0, u, dx0=None, db=None, defer=False, plus_g=False):
-    """-> (t = g*x0, dx0 (+)= g*u (+ g if plus_g), db = colsum(t)) in one pass.  g may be a column slice."""
+    """-> (t = g*x0, dx0 (+)= g*u (+ g if plus_g), db = colsum(t)) in one pass.  g may be a column slice.
+    bf16 mode: g, x0, u, t bf16; the running dx0 and db fp32."""
+    if is_bf16(g):
+        if g.stride(1) != 1:
+            g = g.contiguous()
+        M, Nn = g.shape
+        t = torch.empty(M, Nn, dtype=BF16, device=g.device)
+        acc = dx0 is not None
+        if dx0 is None:
+            dx0 = torch.empty(M, Nn, dtype=torch.float32, device=g.device)
+        if db is None:
+            db = torch.empty(Nn, dtype=torch.float32, device=g.device)
+        ws = scratch(lib.mapx_colsum_bf16_workspace_bytes(Nn), g.device)
+        check(lib.mapx_cross_bwd_pre_colsum_bf16(g.data_ptr(), g.stride(0), ptr(x0), ptr(u), M, Nn, ptr(t), ptr(dx0),
+                                                 int(acc) | (2 if plus_g else 0), ptr(db), ptr(ws), ws.numel(),
+                                                 stream()))
+        return t, dx0, db
     if not row_sliceable(g):
         g = g.contiguous()
     M, Nn = g.shape
@@ -779,7 +899,8 @@ def cross_bwd_pre_colsum(g, x0, u, dx0=None, db=None, defer=False, plus_g=False)
 
 def relu_mask(dy, y):
     out = torch.empty_like(dy)
-    check(lib.mapx_relu_mask(ptr(dy), ptr(y), dy.numel(), ptr(out), stream()))
+    fn = lib.mapx_relu_mask_bf16 if is_bf16(dy) else lib.mapx_relu_mask
+    check(fn(ptr(dy), ptr(y), dy.numel(), ptr(out), stream()))
     return out
 
 
@@ -899,11 +1020,17 @@ def make_replay_aux(lr0, lambdas, beta1, beta2, wd):
     return torch.stack(rows).contiguous()
 
 
-def adamw_dense(p, g, m, v, sched, done, beta1, beta2, eps, wd):
+def adamw_dense(p, g, m, v, sched, done, beta1, beta2, eps, wd, shadow=None):
+    """`shadow`: bf16 [n] copy of the updated parameters, written by the same kernel (bf16 mode)."""
     require_gpu(p, g, m, v, sched, done)
-    with _timed("adamw_dense", p.numel() * 28.0):
-        check(lib.mapx_adamw_dense(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(sched), sched.shape[0],
-                                   ptr(done), beta1, beta2, eps, wd, stream()))
+    with _timed("adamw_dense", p.numel() * (28.0 if shadow is None else 30.0)):
+        if shadow is None:
+            check(lib.mapx_adamw_dense(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(sched), sched.shape[0],
+                                       ptr(done), beta1, beta2, eps, wd, stream()))
+        else:
+            check(lib.mapx_adamw_dense_shadow(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(sched),
+                                              sched.shape[0], ptr(done), beta1, beta2, eps, wd, ptr(shadow),
+                                              stream()))
 
 
 def step_advance(done):

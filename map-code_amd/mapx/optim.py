@@ -113,11 +113,16 @@ class MapxOptimizer:
         table_ids = model.table_parameter_ids()
         named = [(n, p) for n, p in model.named_parameters() if id(p) not in table_ids and p.requires_grad]
         self.dense_params = [p for _, p in named]
+        # bf16 compute mode: every dense weight gets a bf16 shadow (`p._mapx_bf16`, the operand of the
+        # bf16 GEMMs) inside one flat buffer per group, written by the AdamW kernel with the update
+        from .layers import compute_dtype_of
+        self.bf16 = compute_dtype_of(getattr(model, "config", None)) == torch.bfloat16
         self.groups = []
         for wd, members in ((self.wd, [(n, p) for n, p in named if decays(n)]),
                             (0.0, [(n, p) for n, p in named if not decays(n)])):
             if members:
-                self.groups.append(self._flatten(members, wd, dev))
+                self.groups.append(self._flatten(members, wd, dev, self.bf16))
+        self.refresh_bf16()
         names = {id(p): n for n, p in model.named_parameters()}
         self.tables = []
         for t in model.row_tables():
@@ -142,11 +147,12 @@ class MapxOptimizer:
             t.early_now = bool(open_) and t.early_ok
 
     @staticmethod
-    def _flatten(members, wd, dev):
-        sizes = [(p.numel() + 3) // 4 * 4 for _, p in members]      # keep every view 16-B aligned
+    def _flatten(members, wd, dev, bf16=False):
+        sizes = [(p.numel() + 7) // 8 * 8 for _, p in members]      # keep every view 16-B aligned (fp32 and bf16)
         total = sum(sizes)
         flat_p = torch.zeros(total, device=dev)
         flat_g = torch.zeros(total, device=dev)
+        flat_h = torch.zeros(total, dtype=torch.bfloat16, device=dev) if bf16 else None
         off = 0
         for (_, p), sz in zip(members, sizes):
             view = flat_p[off:off + p.numel()].view_as(p)
@@ -154,9 +160,18 @@ class MapxOptimizer:
             p.data = view
             p.grad = None
             p._mapx_grad = flat_g[off:off + p.numel()].view_as(p)   # backward kernels write here
+            p._mapx_bf16 = flat_h[off:off + p.numel()].view_as(p) if bf16 else None
             off += sz
         return dict(p=flat_p, g=flat_g, m=torch.zeros_like(flat_p), v=torch.zeros_like(flat_p), wd=wd,
-                    names=[n for n, _ in members])
+                    names=[n for n, _ in members], h=flat_h)
+
+    def refresh_bf16(self):
+        """Re-derive the bf16 weight shadows from the fp32 master weights: after anything other than
+        step() wrote the parameters (construction, load_model / load_state_dict, a test poking .data)."""
+        if not self.bf16:
+            return
+        for g in self.groups:
+            ops.check(ops.lib.mapx_cast_f32_bf16(ops.ptr(g["p"]), g["p"].numel(), ops.ptr(g["h"]), ops.stream()))
 
     # ------------------------------------------------------------------
     def clip_grad_norm_(self):
@@ -207,7 +222,8 @@ class MapxOptimizer:
     def _dense_update(self):
         b1, b2, eps = self.hyper
         for g in self.groups:
-            ops.adamw_dense(g["p"], g["g"], g["m"], g["v"], self.sched, self.done, b1, b2, eps, g["wd"])
+            ops.adamw_dense(g["p"], g["g"], g["m"], g["v"], self.sched, self.done, b1, b2, eps, g["wd"],
+                            shadow=g["h"])
 
     def zero_grad(self):
         """Dense gradients are overwritten by the next backward (see layers._grad_slot); only
@@ -245,6 +261,7 @@ class MapxOptimizer:
             if t.m1 is not None:
                 t.m1.copy_(s["m1"]); t.v1.copy_(s["v1"])
             t.stale, t.cursor = bool(s["stale"]), int(s["cursor"])
+        self.refresh_bf16()
 
     def get_last_lr(self):
         return [self.lr0 * lr_lambda(self.kind, self.steps_done, self.total, self.warmup)]

@@ -678,7 +678,7 @@ class Trainer:
             own = self.model.state_dict()
             for k, v in st["model"].items():
                 own[k].copy_(v)
-        self.optimizer.load_state_dict(st["optimizer"])
+        self.optimizer.load_state_dict(st["optimizer"])      # (re-derives the bf16 weight shadows)
         self.global_step = int(st["global_step"])
         self._graphs = {}
 
@@ -693,6 +693,8 @@ class Trainer:
                                    f"unexpected {sorted(unexpected)}")
             for k, v in sd.items():
                 own[k].copy_(v)          # in place: parameters may be views of the flat buffers
+        if self.optimizer is not None:
+            self.optimizer.refresh_bf16()
 
     def test(self, test_dataset, load_step=-1, model_dir=None):
         if load_step == -1:

@@ -41,11 +41,11 @@ def assert_digest(z, prefix, name, got, rtol=2e-5, atol=1e-6):
                                    err_msg=f"{prefix}/{name}/{k}")
 
 
-def make_config(cfg, mode, feat_count=None, data_dir=None, seed=42, backbone="DCNv2"):
+def make_config(cfg, mode, feat_count=None, data_dir=None, seed=42, backbone="DCNv2", compute_dtype="fp32"):
     """mapx Config for a fixture case (the 11 runtime keys of reference run.py:50-61 + flags)."""
     from mapx.arguments import Config
     extra = pg.extras_of(backbone)
-    return Config(**extra, model_name=backbone, data_dir=data_dir, input_size=cfg["V"], num_fields=cfg["F"],
+    return Config(**extra, compute_dtype=compute_dtype, model_name=backbone, data_dir=data_dir, input_size=cfg["V"], num_fields=cfg["F"],
                   embed_size=cfg["E"], embed_dropout_rate=0.0, embed_norm=False, layer_norm_eps=1e-12,
                   hidden_size=cfg["H"], num_hidden_layers=cfg["NL"], hidden_act="relu",
                   hidden_dropout_rate=0.0, num_cross_layers=cfg["NC"], pt_neg_num=cfg["K"],
@@ -55,10 +55,10 @@ def make_config(cfg, mode, feat_count=None, data_dir=None, seed=42, backbone="DC
                   device=None, n_gpu=1, idx_low=None, idx_high=None, feat_num_per_field=None, seed=seed)
 
 
-def build_model(cfg, mode, params, feat_count, device="cuda", backbone="DCNv2"):
+def build_model(cfg, mode, params, feat_count, device="cuda", backbone="DCNv2", compute_dtype="fp32"):
     """The backbone with the fixture's reproducible parameters loaded."""
     from mapx.models import BaseModel
-    model = BaseModel.from_config(make_config(cfg, mode, feat_count, backbone=backbone))
+    model = BaseModel.from_config(make_config(cfg, mode, feat_count, backbone=backbone, compute_dtype=compute_dtype))
     with torch.no_grad():
         sd = model.state_dict()
         for k, v in params.items():
