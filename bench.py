@@ -27,7 +27,9 @@ sys.path.insert(0, os.path.join(ROOT, "map-code_amd"))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+MFMA_PEAK_TFLOPS = {"f32": 157.3,     # v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+                    "bf16": 2500.0}   # v_mfma_f32_32x32x16_bf16, dense bf16 peak (no 2:1 sparsity)
+ROUND = "r02"                # profiles/<ROUND>_pmc_hbm_traffic[_bf16].json is this round's PMC summary
 
 WORKLOADS = {
     "avazu": dict(F=23, V=9449445),
@@ -38,9 +40,10 @@ WORKLOADS = {
 
 # kernel class (ops.Timers name) -> substrings of the rocprof kernel names it launches
 PMC_MAP = {
-    "gemm_fwd_nt": ["gemm_f32_kernel<", ", true, true, true,"],
-    "gemm_dx_nn": ["gemm_f32_kernel<", ", true, false, true,"],
-    "gemm_dw_tn": [["gemm_f32_kernel<", ", false, false, true,"], ["gemm_tn_deep_kernel"]],
+    "gemm_fwd_nt": [["gemm_f32_kernel<", ", true, true, true,"], ["gemm_bf16_kernel<", ", true, true, "]],
+    "gemm_dx_nn": [["gemm_f32_kernel<", ", true, false, true,"], ["gemm_bf16_kernel<", ", true, false, "]],
+    "gemm_dw_tn": [["gemm_f32_kernel<", ", false, false, true,"], ["gemm_tn_deep_kernel"],
+                   ["gemm_bf16_kernel<", ", false, false, "]],
     "gemm_enc_grouped_fwd": ["gemm_grouped_kernel<false>"],
     "gemm_enc_grouped_dw": ["gemm_grouped_kernel<true>"],
     "nce_fwd": ["nce_fwd_"],
@@ -53,16 +56,52 @@ PMC_MAP = {
 }
 
 
-def pmc_traffic(name):
+def csrc_hash():
+    """sha1 over the kernel sources: stamps a PMC summary with the code it was measured on."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "map-code_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+_PMC = {}
+
+
+def pmc_file(dtype):
+    return os.path.join(ROOT, "profiles", f"{ROUND}_pmc_hbm_traffic{'' if dtype == 'f32' else '_' + dtype}.json")
+
+
+def pmc_data(dtype):
+    """The committed PMC summary for this dtype (tools/pmc_summary.py) or {}; `_meta.csrc_hash` says
+    which kernel sources it was taken on."""
+    if dtype not in _PMC:
+        path = pmc_file(dtype)
+        _PMC[dtype] = json.load(open(path)) if os.path.exists(path) else {}
+    return _PMC[dtype]
+
+
+def pmc_stale(dtype):
+    """True when the kernels changed since the PMC passes were taken (or none exists): every
+    `traffic` figure on the line is then from older code."""
+    meta = pmc_data(dtype).get("_meta", {})
+    return meta.get("csrc_hash") != csrc_hash()
+
+
+def pmc_traffic(name, dtype="f32"):
     """HBM bytes per launch of a kernel class from the committed PMC passes (rocprofv3 --pmc
     FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this bench; FETCH_SIZE doubled as
     MI355X_MICROARCH.md §HBM prescribes for gfx950; tools/pmc_summary.py).  None if unknown."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-    if name not in PMC_MAP or not os.path.exists(path):
+    data = pmc_data(dtype)
+    if name not in PMC_MAP or not data:
         return None
-    data = json.load(open(path))
     tot = n = 0
     for k, v in data.items():
+        if k == "_meta":
+            continue
         pats = PMC_MAP[name]
         pats = pats if isinstance(pats[0], list) else [pats]        # alternatives, each a list of substrings
         if any(all(sub in k for sub in alt) for alt in pats):
@@ -85,6 +124,9 @@ def parse():
                     help="untimed real training steps before the warm-up, so that the lazy table optimizer "
                          "carries a realistic replay debt (rows re-touched after long gaps)")
     ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="arithmetic type of the dense trunk (BASELINE configs[1] is f32, configs[2] bf16: fp32 "
+                         "master weights / tables / optimizer, bf16 GEMM operands and activations)")
     return ap.parse_args()
 
 
@@ -101,7 +143,7 @@ def build(args, device, rank):
                  embed_dropout_rate=0.0, embed_norm=False, hidden_size=1000, num_hidden_layers=3,
                  hidden_act="relu", hidden_dropout_rate=0.0, num_cross_layers=3, pt_neg_num=25,
                  proj_size=32, pretrain=True, pt_type="MFP", RFD_replace="Unigram",
-                 feat_count=feat_count, seed=42, rank=rank)
+                 feat_count=feat_count, seed=42, rank=rank, compute_dtype="bf16" if args.dtype == "bf16" else "fp32")
     torch.manual_seed(42)
     model = BaseModel.from_config(cfg)
     # the cosine schedule must outlast the run at every world size (the sharded epoch shrinks with N),
@@ -219,7 +261,12 @@ def main():
 
     for _ in range(args.preroll + args.warmup):
         mfp_step(tr, *next_batch())
-    staged = [next_batch() for _ in range(args.steps)]      # inputs resident before the clock starts
+    if os.environ.get("MAPX_GRAPH", "1") != "0" and args.preroll + args.warmup > tr.GRAPH_AFTER:
+        # the headline number is the captured step: a silent fall-back to eager must not pass for it
+        live = [g for g in tr._graphs.values() if not isinstance(g, int)]
+        if not (tr.use_graph and live):
+            raise SystemExit("bench.py: the step is not running from its hipGraph (capture failed?); "
+                             "set MAPX_GRAPH=0 to measure the eager step on purpose")
     graphed = [g for g in tr._graphs.values() if getattr(g, "early", False)]
     for g in graphed:
         g.host_s = [0.0] * len(g.host_s)
@@ -228,11 +275,14 @@ def main():
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for X, Y in staged:
-        loss = mfp_step(tr, X, Y)
+    for _ in range(args.steps):
+        # the batch is cut from the HBM-resident split inside the timed region (a row gather by the
+        # epoch's device permutation: 2 launches per step, plus one randperm per epoch)
+        loss = mfp_step(tr, *next_batch())
     parallel.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    staged = [next_batch() for _ in range(max(5, min(20, args.steps)))]      # for the per-kernel pass below
     dp_info = None
     if graphed:     # host-side phases of the data-parallel step (this rank), microseconds per step
         names = ("launch", "counts", "tail_capture", "dense_allreduce", "tail")
@@ -252,7 +302,7 @@ def main():
     for t in tr.optimizer.tables:         # ... and in program order: no row update squeezed in front of the
         t.early_ok = False                # cross tower's GEMMs (it leaves them a cold L2: +14 us each)
     with ops.Timers() as timers:
-        for X, Y in staged[:max(5, min(20, args.steps))]:
+        for X, Y in staged:
             # park the GPU for ~4 ms first so that the host enqueues the whole step ahead of it:
             # the event pairs then bracket back-to-back kernels, not host launch gaps
             torch.cuda._sleep(8_000_000)
@@ -274,20 +324,24 @@ def main():
     # a-priori byte count is only an upper bound, so their rate is priced with the HBM bytes the
     # committed PMC passes measured per launch
     data_dependent = ("table_adam_update", "table_adam_catchup", "nce_table_grad", "seg_reduce_rows")
+    # the grouped feat_encoder kernels compute in fp32 in either mode; the dense GEMM classes follow --dtype
+    mfma_peak = lambda name: MFMA_PEAK_TFLOPS["f32" if "grouped" in name else args.dtype]
+    gemm_flops = 0.0
     for name, s in ksum.items():
         per_launch = s["work"] / s["launches"]
-        measured = pmc_traffic(name) if name in data_dependent else None
+        measured = pmc_traffic(name, args.dtype) if name in data_dependent else None
         if measured:
             per_launch = measured
         rate = per_launch / (s["avg_us"] * 1e-6)
         if name.startswith("gemm"):
-            kernels[name] = dict(bound="mfma", achieved=rate / 1e12, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                                 frac=rate / 1e12 / MFMA_F32_PEAK_TFLOPS)
+            gemm_flops += s["work"] / ksteps
+            kernels[name] = dict(bound="mfma", achieved=rate / 1e12, peak=mfma_peak(name), unit="TFLOP/s",
+                                 frac=rate / 1e12 / mfma_peak(name))
         else:
             kernels[name] = dict(bound="hbm", achieved=rate / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                                  frac=rate / 1e9 / HBM_PEAK_GBS)
         kernels[name].update(avg_us=s["avg_us"], launches_per_step=s["launches"] / ksteps,
-                             ms_per_step=s["total_ms"] / ksteps, traffic=pmc_traffic(name),
+                             ms_per_step=s["total_ms"] / ksteps, traffic=pmc_traffic(name, args.dtype),
                              algorithmic_per_launch=per_launch,
                              bytes_from="pmc" if measured else "model")
     dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
@@ -297,10 +351,12 @@ def main():
         "metric": "pretrain samples/sec (DCNv2+MFP, Avazu, bs4096)", "value": world * B * args.steps / dt,
         "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"DCNv2+MFP pretrain step, {args.workload}-shaped synthetic ids "
                                f"({'uniform' if args.uniform else 'Zipf(1.1)'} per field), F={cfg.num_fields}, "
-                               f"V={cfg.input_size}, E=16, H=1000x3, cross x3, P=32, K=25, mask_ratio 0.3",
+                               f"V={cfg.input_size}, E=16, H=1000x3, cross x3, P=32, K=25, mask_ratio 0.3"
+                               + (", bf16 GEMM operands / activations over fp32 master weights, tables and optimizer"
+                                  if args.dtype == "bf16" else ""),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "launch": ("eager" if not tr.use_graph else
                               "hipGraph replay of mask + forward + backward; pack and merge + optimizer replayed per message size, RCCL calls eager"
@@ -309,6 +365,12 @@ def main():
                                       + f"{args.preroll} untimed pre-roll steps"},
         "roofline": roofline,
         "roofline_hbm": dict(kernel=hbm_name, **{k: kernels[hbm_name][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}),
+        # all GEMM flops of a step over the whole step's time, against the dtype's dense MFMA peak:
+        # what the step as a whole makes of the matrix cores (the per-kernel `roofline.frac` is a
+        # kernel running alone)
+        "step_mfma_frac": gemm_flops / (dt / args.steps) / 1e12 / MFMA_PEAK_TFLOPS[args.dtype],
+        "step_gemm_gflop": gemm_flops / 1e9,
+        "traffic_stale": pmc_stale(args.dtype), "traffic_from": os.path.relpath(pmc_file(args.dtype), ROOT),
         "kernels": kernels, "final_loss": final_loss,
     }
     if dp_info:

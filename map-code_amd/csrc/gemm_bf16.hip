@@ -24,9 +24,9 @@
 //                                             back column-major, i.e. as 4 consecutive k of one
 //                                             column per lane (row stride = 64 B mod 256 B: the 4
 //                                             rows of a block sit on the 4 quarters of the bank row).
-// Pipeline (one barrier per K-step, two LDS buffers, one register set): after the barrier the
-// registers holding tile t+1 are written to the other buffer and re-used at once for the global
-// loads of tile t+2, which have the MFMAs of tile t to land.
+// Pipeline: one barrier per K-step, two LDS buffers, two register sets — global loads are issued
+// two K-steps ahead of the MFMAs that consume them (a K-step of bf16 MFMAs is shorter than an L2
+// round trip), LDS stores one K-step ahead.
 #include "../../include/mapx_hip.h"
 #include "common.h"
 
@@ -50,6 +50,7 @@ struct GemmHArgs {
   int k_chunk;                       // split-K: K range per blockIdx.y (multiple of 64)
   int64_t slab_stride;               // split-K: fp32 C offset per split
   int tiles_m, tiles_n;
+  int dbg;                           // timing experiments only (tile_hint >> 8): 1 = no global stores, 2 = no K loop
 };
 
 constexpr int kHBK = 64;
@@ -64,6 +65,8 @@ struct OperandH {
   static constexpr int CPR = KC ? kHBK / 8 : ROWS / 8;            // 16-B chunks per stored row
   static constexpr int NV = ROWS * kHBK / 8 / 256;                // chunks per thread per tile
   uint4 r[NV];
+  bool ok[NV];      // VEC: chunk i lies inside the matrix; applied when the registers are WRITTEN to LDS, so
+                    // that no ALU instruction (and with it no s_waitcnt) touches a load's result early
 
   __device__ static inline void coords(int f, int& row, int& col) {
     row = f / CPR;
@@ -81,16 +84,16 @@ struct OperandH {
       const bool rok = gr < rlim;
       const bf16_t* p = g + (int64_t)(rok ? gr : 0) * ld;
       if (VEC) {
-        const bool ok = rok && gc < clim;
-        uint4 v = *reinterpret_cast<const uint4*>(p + (ok ? gc : 0));
-        r[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+        ok[i] = rok && gc < clim;
+        r[i] = *reinterpret_cast<const uint4*>(p + (ok[i] ? gc : 0));
       } else {
+        ok[i] = true;
         unsigned short h[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const bool ok = rok && gc + e < clim;
-          const unsigned short x = reinterpret_cast<const unsigned short*>(p)[ok ? gc + e : 0];
-          h[e] = ok ? x : (unsigned short)0;
+          const bool oke = rok && gc + e < clim;
+          const unsigned short x = reinterpret_cast<const unsigned short*>(p)[oke ? gc + e : 0];
+          h[e] = oke ? x : (unsigned short)0;
         }
         r[i] = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16),
                           h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
@@ -98,12 +101,14 @@ struct OperandH {
     }
   }
 
+  // MASK = false: the block's tile lies wholly inside the matrix and K (no zero fill needed)
+  template <bool MASK>
   __device__ inline void store(bf16_t* __restrict__ s) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       int tr, tc;
       coords(threadIdx.x + i * 256, tr, tc);
-      *reinterpret_cast<uint4*>(s + tr * LD + tc) = r[i];
+      *reinterpret_cast<uint4*>(s + tr * LD + tc) = (!MASK || ok[i]) ? r[i] : make_uint4(0u, 0u, 0u, 0u);
     }
   }
 
@@ -140,66 +145,94 @@ __device__ inline void st_from_f32(void* __restrict__ p, uint32_t off, float v) 
   else reinterpret_cast<bf16_t*>(p)[off] = (bf16_t)v;      // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
 }
 
-// C/D map of the 32x32 MFMA (dtype independent): col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-// Same structure as gemm.hip's epilogue: per 32-row band the auxiliary operands of all elements are
-// fetched first (clamped, unpredicated loads), the stores follow; no control flow inside the loops.
-template <int EPI, bool C_F32, bool AUX_F32, int WMT, int WNT, bool ROWS_OK>
-__device__ inline void epilogue_band_h(const GemmHArgs& a, void* __restrict__ C, f32x16 (&acc)[WMT][WNT],
-                                       const float (&bias_r)[WNT], int i, uint32_t mrow, int nbase, int l31) {
+// Epilogue.  The MFMA leaves a lane with ONE column and 16 scattered rows of a 32x32 tile (C/D map,
+// dtype independent: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)); storing bf16 from there is
+// 64 two-byte stores per lane in 64-byte row pieces, and the auxiliary operands would be gathered the
+// same way — measured: 8 of the 10 us a K = 64 GEMM took.  So the accumulators go through LDS (free
+// after the K loop) as fp32 [BM][BN + 4], and a second pass walks the tile row-major, 8 consecutive
+// columns per thread: bias, auxiliary operands and results all move as 16-byte accesses of whole
+// 128/256-byte row segments.  `vio`: every operand of this launch allows that (block-uniform); else
+// the same pass runs element by element.
+template <int EPI, bool C_F32, bool AUX_F32, int BM, int BN>
+__device__ inline void epilogue_rows_h(const GemmHArgs& a, void* __restrict__ C, const float* __restrict__ tile,
+                                       int m0, int n0, bool vio) {
+  constexpr int LDT = BN + 4;
+  constexpr bool kBias = EPI >= MAPX_EPI_BIAS && EPI <= MAPX_EPI_BIAS_CROSS;
   constexpr bool kAux1 = EPI == MAPX_EPI_BIAS_CROSS || EPI == MAPX_EPI_ADD || EPI == MAPX_EPI_RELU_MASK;
-  constexpr bool kAux2 = EPI == MAPX_EPI_BIAS_CROSS;
-  const uint32_t ldc = (uint32_t)a.ldc, ld1 = (uint32_t)a.ld1, ld2 = (uint32_t)a.ld2, ldo = (uint32_t)a.ldo2;
-#define MAPX_ROW(r) ((uint32_t)(((r) & 3) + 8 * ((r) >> 2)))
-  float x1[WNT][16], x2[WNT][16];
-  if (kAux1) {
+  for (int idx = threadIdx.x; idx < BM * BN / 8; idx += 256) {
+    const int row = idx / (BN / 8), c0 = (idx % (BN / 8)) * 8;
+    const int m = m0 + row, n = n0 + c0;
+    if (m >= a.M || n >= a.N) continue;
+    float v[8], x1[8], x2[8], u[8];
+    const float4 t0 = *reinterpret_cast<const float4*>(tile + row * LDT + c0);
+    const float4 t1 = *reinterpret_cast<const float4*>(tile + row * LDT + c0 + 4);
+    v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+    const int64_t oc = (int64_t)m * a.ldc + n, o1 = (int64_t)m * a.ld1 + n, o2 = (int64_t)m * a.ld2 + n,
+                  oo = (int64_t)m * a.ldo2 + n;
+    if (vio) {             // n + 8 <= N (N % 8 == 0), every address 16-byte aligned
+      if (kBias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(a.bias + n), b1 = *reinterpret_cast<const float4*>(a.bias + n + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+      }
+      if (kAux1) {
+        if (AUX_F32) {
+          const float4 p0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.aux1) + o1);
+          const float4 p1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.aux1) + o1 + 4);
+          x1[0] = p0.x; x1[1] = p0.y; x1[2] = p0.z; x1[3] = p0.w; x1[4] = p1.x; x1[5] = p1.y; x1[6] = p1.z; x1[7] = p1.w;
+        } else {
+          const bf16x8 p = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(a.aux1) + o1);
 #pragma unroll
-    for (int j = 0; j < WNT; ++j) {
-      uint32_t n = (uint32_t)(nbase + 32 * j + l31);
-      n = (int)n < a.N ? n : (uint32_t)(a.N - 1);
-      const uint32_t mload = (ROWS_OK || (int)mrow < a.M) ? mrow : (uint32_t)(a.M - 1);
-      const uint32_t o1 = mload * ld1 + n, o2 = mload * ld2 + n;
+          for (int e = 0; e < 8; ++e) x1[e] = (float)p[e];
+        }
+      }
+      if (EPI == MAPX_EPI_BIAS_CROSS) {
+        const bf16x8 p = *reinterpret_cast<const bf16x8*>(a.aux2 + o2);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const uint32_t dr = ROWS_OK ? MAPX_ROW(r) : ((int)(mrow + MAPX_ROW(r)) < a.M ? MAPX_ROW(r) : 0u);
-        x1[j][r] = ld_as_f32<AUX_F32>(a.aux1, o1 + dr * ld1);
-        if (kAux2) x2[j][r] = (float)a.aux2[o2 + dr * ld2];
+        for (int e = 0; e < 8; ++e) x2[e] = (float)p[e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bool in = n + e < a.N;
+        if (kBias) v[e] += in ? a.bias[n + e] : 0.f;
+        if (kAux1) x1[e] = in ? ld_as_f32<AUX_F32>(a.aux1, (uint32_t)(o1 + e)) : 0.f;
+        if (EPI == MAPX_EPI_BIAS_CROSS) x2[e] = in ? (float)a.aux2[o2 + e] : 0.f;
       }
     }
-  }
 #pragma unroll
-  for (int j = 0; j < WNT; ++j) {
-    const uint32_t n = (uint32_t)(nbase + 32 * j + l31);
-    if ((int)n < a.N) {
-      const uint32_t oc = mrow * ldc + n, oo = mrow * ldo + n;
+    for (int e = 0; e < 8; ++e) {
+      if (EPI == MAPX_EPI_BIAS_RELU) v[e] = fmaxf(v[e], 0.f);
+      u[e] = v[e];
+      if (EPI == MAPX_EPI_BIAS_CROSS) v[e] = x1[e] + x2[e] * v[e];
+      if (EPI == MAPX_EPI_ADD) v[e] += x1[e];
+      if (EPI == MAPX_EPI_RELU_MASK) v[e] = x1[e] > 0.f ? v[e] : 0.f;
+    }
+    if (vio) {
+      if (C_F32) {
+        float* c = reinterpret_cast<float*>(C) + oc;
+        *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        bf16x8 o;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = acc[i][j][r];
-        if (EPI >= MAPX_EPI_BIAS && EPI <= MAPX_EPI_BIAS_CROSS) v += bias_r[j];
-        if (EPI == MAPX_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-        float u = v;
-        if (EPI == MAPX_EPI_BIAS_CROSS) v = x1[j][r] + x2[j][r] * v;
-        if (EPI == MAPX_EPI_ADD) v += x1[j][r];
-        if (EPI == MAPX_EPI_RELU_MASK) v = x1[j][r] > 0.f ? v : 0.f;
-        if (ROWS_OK || (int)(mrow + MAPX_ROW(r)) < a.M) {
-          if (EPI == MAPX_EPI_BIAS_CROSS) a.out2[oo + MAPX_ROW(r) * ldo] = (bf16_t)u;
-          st_from_f32<C_F32>(C, oc + MAPX_ROW(r) * ldc, v);
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];          // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(C) + oc) = o;
+      }
+      if (EPI == MAPX_EPI_BIAS_CROSS) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)u[e];
+        *reinterpret_cast<bf16x8*>(a.out2 + oo) = o;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (n + e < a.N) {
+          st_from_f32<C_F32>(C, (uint32_t)(oc + e), v[e]);
+          if (EPI == MAPX_EPI_BIAS_CROSS) a.out2[oo + e] = (bf16_t)u[e];
         }
       }
     }
-  }
-#undef MAPX_ROW
-}
-
-template <int EPI, bool C_F32, bool AUX_F32, int WMT, int WNT>
-__device__ inline void epilogue_h(const GemmHArgs& a, void* __restrict__ C, f32x16 (&acc)[WMT][WNT],
-                                  const float (&bias_r)[WNT], int mbase, int nbase, int l31, int kh) {
-#pragma unroll
-  for (int i = 0; i < WMT; ++i) {
-    const uint32_t mrow = (uint32_t)(mbase + 32 * i + 4 * kh);
-    if (mbase + 32 * i + 32 <= a.M)
-      epilogue_band_h<EPI, C_F32, AUX_F32, WMT, WNT, true>(a, C, acc, bias_r, i, mrow, nbase, l31);
-    else if (mbase + 32 * i < a.M)
-      epilogue_band_h<EPI, C_F32, AUX_F32, WMT, WNT, false>(a, C, acc, bias_r, i, mrow, nbase, l31);
   }
 }
 
@@ -239,62 +272,107 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmHArgs a, int c_f32, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float bias_r[WNT];
-#pragma unroll
-  for (int j = 0; j < WNT; ++j) {
-    const int n = n0 + bbase + 32 * j + l31;
-    bias_r[j] = (a.epi >= MAPX_EPI_BIAS && a.epi <= MAPX_EPI_BIAS_CROSS && n < a.N) ? a.bias[n] : 0.f;
-  }
-
-  OpA la;
-  OpB lb;
-  const int nk = (kend - kbeg + kHBK - 1) / kHBK;
-  if (nk > 0) {
-    la.load(a.A, a.lda, m0, a.M, kbeg, kend);
-    lb.load(a.B, a.ldb, n0, a.N, kbeg, kend);
-    la.store(smem);
-    lb.store(smem + OpA::LDS_ELEMS);
-    if (nk > 1) {
-      la.load(a.A, a.lda, m0, a.M, kbeg + kHBK, kend);
-      lb.load(a.B, a.ldb, n0, a.N, kbeg + kHBK, kend);
-    }
-  }
+  // Two register sets per operand: set (t & 1) carries tile t from its global load (issued two
+  // K-steps before the tile is computed on) to its LDS store (one K-step before).  A K-step of
+  // bf16 MFMAs is only 128-512 cycles — less than an L2 round trip — so the loads of tile kt+3 are
+  // issued at the END of step kt, right after the registers they land in were stored to LDS, and
+  // have the whole of steps kt+1 and kt+2's MFMAs to arrive.
+  OpA la[2];
+  OpB lb[2];
+  const int nk = (a.dbg & 2) ? 0 : (kend - kbeg + kHBK - 1) / kHBK;
+#define MAPX_H_LOAD(SET, t)                                              \
+  do {                                                                   \
+    la[SET].load(a.A, a.lda, m0, a.M, kbeg + (t) * kHBK, kend);          \
+    lb[SET].load(a.B, a.ldb, n0, a.N, kbeg + (t) * kHBK, kend);          \
+  } while (0)
+#define MAPX_H_STORE_I(SET, buf)                                         \
+  do {                                                                   \
+    la[SET].template store<false>(smem + (buf) * kBuf);                  \
+    lb[SET].template store<false>(smem + (buf) * kBuf + OpA::LDS_ELEMS); \
+  } while (0)
+#define MAPX_H_STORE(SET, buf)                                           \
+  do {                                                                   \
+    la[SET].template store<true>(smem + (buf) * kBuf);                   \
+    lb[SET].template store<true>(smem + (buf) * kBuf + OpA::LDS_ELEMS);   \
+  } while (0)
+  // block-uniform: every chunk of every FULL K-step of this tile is inside the matrix (a K tail
+  // only touches the last tile, which the epilogue loop below stores with its predicates)
+  const bool interior = VEC && (m0 + BM <= a.M) && (n0 + BN <= a.N);
+  if (nk > 0) MAPX_H_LOAD(0, 0);
+  if (nk > 1) MAPX_H_LOAD(1, 1);
+  if (nk > 0) MAPX_H_STORE(0, 0);
+  if (nk > 2) MAPX_H_LOAD(0, 2);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    bf16_t* const As_cur = smem + cur * kBuf;
-    bf16_t* const Bs_cur = As_cur + OpA::LDS_ELEMS;
-    if (kt + 1 < nk) {                 // tile kt+1 was loaded during the previous K-step
-      la.store(smem + (cur ^ 1) * kBuf);
-      lb.store(smem + (cur ^ 1) * kBuf + OpA::LDS_ELEMS);
+  // one K-step on LDS buffer CUR (= kt & 1, a literal: the loop is unrolled by two so that the
+  // register sets are indexed statically — a runtime index would send them to scratch)
+#define MAPX_H_KSTEP(CUR, kt, STEADY, MASK)                                                            \
+  do {                                                                                                 \
+    const bf16_t* const As_cur = smem + (CUR) * kBuf;                                                  \
+    const bf16_t* const Bs_cur = As_cur + OpA::LDS_ELEMS;                                              \
+    bf16x8 af[2][WMT], bf[2][WNT];                                                                     \
+    OpA::frags(As_cur, abase, lane, 0, af[0]);                                                         \
+    OpB::frags(Bs_cur, bbase, lane, 0, bf[0]);                                                         \
+    _Pragma("unroll") for (int s4 = 0; s4 < kHBK / 16; ++s4) {                                         \
+      const int c = s4 & 1;                                                                            \
+      if (s4 + 1 < kHBK / 16) {                                                                        \
+        OpA::frags(As_cur, abase, lane, s4 + 1, af[c ^ 1]);                                            \
+        OpB::frags(Bs_cur, bbase, lane, s4 + 1, bf[c ^ 1]);                                            \
+      }                                                                                                \
+      _Pragma("unroll") for (int i = 0; i < WMT; ++i)                                                  \
+        _Pragma("unroll") for (int j = 0; j < WNT; ++j)                                                \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c][i], bf[c][j], acc[i][j], 0, 0, 0); \
+    }                                                                                                  \
+    if ((STEADY) && !(MASK)) MAPX_H_STORE_I((CUR) ^ 1, (CUR) ^ 1);  /* tile kt+1: loaded two steps ago */ \
+    else if ((STEADY) || (kt) + 1 < nk) MAPX_H_STORE((CUR) ^ 1, (CUR) ^ 1);                            \
+    if ((STEADY) || (kt) + 3 < nk) MAPX_H_LOAD((CUR) ^ 1, (kt) + 3);                                   \
+    /* (a sched_group_barrier pattern spreading LDS reads / stores / global loads between the MFMAs */ \
+    /*  was measured: 59.5 vs 55.2 us at K = 4096 — the compiler's own order is the better one)       */ \
+    __syncthreads();                                                                                   \
+  } while (0)
+  // steady state (STEADY literal: tiles kt+1 .. kt+4 exist): a branch-free body, so that the
+  // compiler counts the loads in flight exactly instead of draining them at every join
+  int kt = 0;
+  if (interior) {
+    for (; kt + 4 < nk; kt += 2) {
+      MAPX_H_KSTEP(0, kt, true, false);
+      MAPX_H_KSTEP(1, kt + 1, true, false);
     }
-    if (kt + 2 < nk) {
-      la.load(a.A, a.lda, m0, a.M, kbeg + (kt + 2) * kHBK, kend);
-      lb.load(a.B, a.ldb, n0, a.N, kbeg + (kt + 2) * kHBK, kend);
+  } else {
+    for (; kt + 4 < nk; kt += 2) {
+      MAPX_H_KSTEP(0, kt, true, true);
+      MAPX_H_KSTEP(1, kt + 1, true, true);
     }
-    bf16x8 af[2][WMT], bf[2][WNT];
-    OpA::frags(As_cur, abase, lane, 0, af[0]);
-    OpB::frags(Bs_cur, bbase, lane, 0, bf[0]);
-#pragma unroll
-    for (int s4 = 0; s4 < kHBK / 16; ++s4) {
-      const int c = s4 & 1;
-      if (s4 + 1 < kHBK / 16) {
-        OpA::frags(As_cur, abase, lane, s4 + 1, af[c ^ 1]);
-        OpB::frags(Bs_cur, bbase, lane, s4 + 1, bf[c ^ 1]);
-      }
-#pragma unroll
-      for (int i = 0; i < WMT; ++i)
-#pragma unroll
-        for (int j = 0; j < WNT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c][i], bf[c][j], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
   }
+  for (; kt < nk; kt += 2) {
+    MAPX_H_KSTEP(0, kt, false, true);
+    if (kt + 1 < nk) MAPX_H_KSTEP(1, kt + 1, false, true);
+  }
+#undef MAPX_H_KSTEP
+#undef MAPX_H_LOAD
+#undef MAPX_H_STORE
+#undef MAPX_H_STORE_I
 
-  const int mbase = m0 + abase, nbase = n0 + bbase;
+  // accumulators -> LDS as fp32 [BM][BN + 4] (the K loop's last barrier has retired every read of the
+  // operand buffers); a lane writes one column of 16 rows: per store instruction two runs of 32
+  // consecutive floats — conflict-free
+  float* const tile = reinterpret_cast<float*>(smem_raw);
+  constexpr int LDT = BN + 4;
 #pragma unroll
-  for (int j = 0; j < WNT; ++j) asm volatile("v_mov_b32 %0, %1" : "=v"(bias_r[j]) : "v"(bias_r[j]));
-#define MAPX_EPI_CASE(E, CF, AF) epilogue_h<E, CF, AF, WMT, WNT>(a, C, acc, bias_r, mbase, nbase, l31, kh)
+  for (int i = 0; i < WMT; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        tile[(abase + 32 * i + 4 * kh + (r & 3) + 8 * (r >> 2)) * LDT + bbase + 32 * j + l31] = acc[i][j][r];
+  __syncthreads();
+  // 16-byte row accesses for every operand of this launch? (block-uniform)
+  auto al = [](const void* p, int64_t ld, int elem) {
+    return p == nullptr || ((uintptr_t)p % 16 == 0 && (ld * elem) % 16 == 0);
+  };
+  const bool vio = a.N % 8 == 0 && al(C, a.ldc, c_f32 ? 4 : 2) && al(a.aux1, a.ld1, aux1_f32 ? 4 : 2) &&
+                   al(a.aux2, a.ld2, 2) && al(a.out2, a.ldo2, 2) && al(a.bias, 0, 4);
+#define MAPX_EPI_CASE(E, CF, AF) epilogue_rows_h<E, CF, AF, BM, BN>(a, C, tile, m0, n0, vio)
+  if (a.dbg & 1) return;
   if (c_f32) {
     switch (a.epi) {       // fp32 outputs: logits of the heads, weight-gradient slabs
       case MAPX_EPI_BIAS: MAPX_EPI_CASE(MAPX_EPI_BIAS, true, false); break;
@@ -343,6 +421,7 @@ static hipError_t launch_one_h(const GemmHArgs& a, int nsplit, int c_f32, int au
   using OpA = OperandH<64 * WMT, WMT, A_KC, VEC>;
   using OpB = OperandH<64 * WNT, WNT, B_KC, VEC>;
   constexpr size_t lds = (size_t)2 * (OpA::LDS_ELEMS + OpB::LDS_ELEMS) * sizeof(bf16_t);
+  static_assert(lds >= (size_t)(64 * WMT) * (64 * WNT + 4) * sizeof(float), "the epilogue's fp32 tile must fit the operand buffers");
   auto* fn = &gemm_bf16_kernel<WMT, WNT, A_KC, B_KC, VEC>;
   static hipError_t raised = lds > 65536
       ? hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
@@ -402,7 +481,7 @@ __global__ void __launch_bounds__(256) cast_bf16_f32_kernel(const bf16_t* __rest
 //   OP 2 (plain):        nothing written                          db = colsum(a)
 // Block = 64 column lanes x 4 row lanes over one of kColChunksH row chunks; a second launch adds the
 // chunks in order (deterministic).  Scalar columns: any N, any leading dimension.
-constexpr int kColChunksH = 64;
+constexpr int kColChunksH = 128;
 template <int OP>
 __global__ void __launch_bounds__(256) ew_colsum_h_kernel(const bf16_t* __restrict__ a, int64_t lda,
                                                           const bf16_t* __restrict__ b, int64_t ldb,
@@ -451,6 +530,77 @@ __global__ void __launch_bounds__(256) ew_colsum_h_kernel(const bf16_t* __restri
     if (in1) part[(int64_t)blockIdx.y * N + col + 1] = s[0][k + 1] + s[1][k + 1] + s[2][k + 1] + s[3][k + 1];
   }
 }
+// The same three operations, 8 columns (one 16-byte bf16 chunk) per lane: N % 8 == 0, leading
+// dimensions % 8 == 0, 16-byte aligned bases (the trunk's widths 368 / 400 / 624 / 1000 / 736 all are).
+template <int OP>
+__global__ void __launch_bounds__(256) ew_colsum_h8_kernel(const bf16_t* __restrict__ a, int64_t lda,
+                                                           const bf16_t* __restrict__ b, int64_t ldb,
+                                                           const bf16_t* __restrict__ c, int64_t ldc, int M, int N,
+                                                           bf16_t* __restrict__ o1, float* __restrict__ o2,
+                                                           int accumulate, float* __restrict__ part) {
+  const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = (blockIdx.x * 64 + lane) * 8;
+  const int rows_per = (M + kColChunksH - 1) / kColChunksH;
+  const int r0 = blockIdx.y * rows_per;
+  const int r1 = (r0 + rows_per < M) ? r0 + rows_per : M;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  if (col < N) {
+#pragma unroll 2
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const bf16x8 av = *reinterpret_cast<const bf16x8*>(a + (int64_t)r * lda + col);
+      if (OP == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)av[e];
+      } else if (OP == 0) {
+        const bf16x8 yv = *reinterpret_cast<const bf16x8*>(b + (int64_t)r * ldb + col);
+        bf16x8 d;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          d[e] = (float)yv[e] > 0.f ? av[e] : (bf16_t)0.f;
+          v[e] += (float)d[e];
+        }
+        *reinterpret_cast<bf16x8*>(o1 + (int64_t)r * N + col) = d;
+      } else {
+        const bf16x8 xv = *reinterpret_cast<const bf16x8*>(b + (int64_t)r * ldb + col);
+        const bf16x8 uv = *reinterpret_cast<const bf16x8*>(c + (int64_t)r * ldc + col);
+        float4 d0 = make_float4(0.f, 0.f, 0.f, 0.f), d1 = d0;
+        float* dp = o2 + (int64_t)r * N + col;
+        if (accumulate & 1) {
+          d0 = *reinterpret_cast<const float4*>(dp);
+          d1 = *reinterpret_cast<const float4*>(dp + 4);
+        }
+        float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        bf16x8 t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float g = (float)av[e];
+          t[e] = (bf16_t)(g * (float)xv[e]);
+          d[e] += g * (float)uv[e];
+          if (accumulate & 2) d[e] += g;
+          v[e] += (float)t[e];
+        }
+        *reinterpret_cast<bf16x8*>(o1 + (int64_t)r * N + col) = t;
+        *reinterpret_cast<float4*>(dp) = make_float4(d[0], d[1], d[2], d[3]);
+        *reinterpret_cast<float4*>(dp + 4) = make_float4(d[4], d[5], d[6], d[7]);
+      }
+    }
+  }
+  __shared__ float s[4][64][9];          // 9: the 8 values of a lane on distinct banks from its neighbours'
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[rl][lane][e] = v[e];
+  __syncthreads();
+  if (rl == 0 && col < N) {
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = s[0][lane][e] + s[1][lane][e] + s[2][lane][e] + s[3][lane][e];
+    float* dst = part + (int64_t)blockIdx.y * N + col;
+    *reinterpret_cast<float4*>(dst) = make_float4(t[0], t[1], t[2], t[3]);
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(t[4], t[5], t[6], t[7]);
+  }
+}
+
 __global__ void __launch_bounds__(256) colsum_stage2_h_kernel(const float* __restrict__ part, int N,
                                                               float* __restrict__ out) {
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -518,7 +668,9 @@ extern "C" int mapx_gemm_bf16(int a_kc, int b_kc, int M, int N, int K, const map
                    (a_kc ? (K % 8 == 0) : (M % 8 == 0)) && (b_kc ? (K % 8 == 0) : (N % 8 == 0));
   auto blocks = [&](int bm, int bn) { return ceil_div(M, bm) * ceil_div(N, bn) * nsplit; };
   const int64_t big = blocks(128, 128);
-  int tile = (big >= 200) ? 2 : 0;
+  int tile = (big >= 160) ? 2 : 0;        // 128x128 tiles once they (with the splits) cover most of the 256 CUs
+  g.dbg = tile_hint >= 0 ? (tile_hint >> 8) : 0;
+  if (tile_hint >= 0) tile_hint &= 255;
   if (tile_hint >= 0 && tile_hint <= 2) tile = tile_hint;
   hipError_t lerr;
   if (a_kc && b_kc) lerr = launch_layout_h<true, true>(g, vec, tile, nsplit, c_f32, aux1_f32, stream);
@@ -560,6 +712,23 @@ extern "C" int mapx_cast_bf16_f32(const mapx_bf16* src, int64_t n, float* dst, h
 
 extern "C" size_t mapx_colsum_bf16_workspace_bytes(int N) { return (size_t)mapx::kColChunksH * N * sizeof(float); }
 
+// 8-column lanes when every operand allows 16-byte accesses, scalar column pairs otherwise
+template <int OP>
+static void launch_ew_colsum_h(const mapx::bf16_t* a, int64_t lda, const mapx::bf16_t* b, int64_t ldb,
+                               const mapx::bf16_t* c, int64_t ldc, int M, int N, mapx::bf16_t* o1, float* o2,
+                               int accumulate, float* part, hipStream_t stream) {
+  using namespace mapx;
+  auto al16 = [](const void* p) { return (uintptr_t)p % 16 == 0; };
+  const bool vec = N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && al16(a) && al16(b) && al16(c) &&
+                   al16(o1) && al16(o2) && al16(part);
+  if (vec)
+    hipLaunchKernelGGL(ew_colsum_h8_kernel<OP>, dim3((N + 511) / 512, kColChunksH), dim3(256), 0, stream, a, lda, b,
+                       ldb, c, ldc, M, N, o1, o2, accumulate, part);
+  else
+    hipLaunchKernelGGL(ew_colsum_h_kernel<OP>, dim3((N + 127) / 128, kColChunksH), dim3(256), 0, stream, a, lda, b,
+                       ldb, c, ldc, M, N, o1, o2, accumulate, part);
+}
+
 static int colsum_ws_ok(const char* what, void* ws, size_t ws_bytes, int N) {
   if (!ws || ws_bytes < mapx_colsum_bf16_workspace_bytes(N)) {
     mapx::set_error("%s: workspace too small", what);
@@ -575,8 +744,7 @@ extern "C" int mapx_colsum_bf16(const mapx_bf16* x, int64_t ld, int M, int N, fl
   if (!colsum_ws_ok("colsum_bf16", ws, ws_bytes, N)) return MAPX_EWORKSPACE;
   float* part = static_cast<float*>(ws);
   const bf16_t* xb = reinterpret_cast<const bf16_t*>(x);
-  hipLaunchKernelGGL(ew_colsum_h_kernel<2>, dim3((N + 127) / 128, kColChunksH), dim3(256), 0, stream, xb, ld, xb, ld,
-                     xb, ld, M, N, (bf16_t*)nullptr, (float*)nullptr, 0, part);
+  launch_ew_colsum_h<2>(xb, ld, xb, ld, xb, ld, M, N, nullptr, nullptr, 0, part, stream);
   hipLaunchKernelGGL(colsum_stage2_h_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, out);
   return check_launch("colsum_bf16");
 }
@@ -588,10 +756,9 @@ extern "C" int mapx_relu_mask_colsum_bf16(const mapx_bf16* dy, int64_t ld_dy, co
   MAPX_REQUIRE(dy && y && dz && db && M >= 0 && N > 0 && ld_dy >= N && ld_y >= N, "relu_mask_colsum_bf16: bad arguments");
   if (!colsum_ws_ok("relu_mask_colsum_bf16", ws, ws_bytes, N)) return MAPX_EWORKSPACE;
   float* part = static_cast<float*>(ws);
-  hipLaunchKernelGGL(ew_colsum_h_kernel<0>, dim3((N + 127) / 128, kColChunksH), dim3(256), 0, stream,
-                     reinterpret_cast<const bf16_t*>(dy), ld_dy, reinterpret_cast<const bf16_t*>(y), ld_y,
-                     reinterpret_cast<const bf16_t*>(y), ld_y, M, N, reinterpret_cast<bf16_t*>(dz), (float*)nullptr, 0,
-                     part);
+  launch_ew_colsum_h<0>(reinterpret_cast<const bf16_t*>(dy), ld_dy, reinterpret_cast<const bf16_t*>(y), ld_y,
+                        reinterpret_cast<const bf16_t*>(y), ld_y, M, N, reinterpret_cast<bf16_t*>(dz), nullptr, 0, part,
+                        stream);
   hipLaunchKernelGGL(colsum_stage2_h_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, db);
   return check_launch("relu_mask_colsum_bf16");
 }
@@ -603,10 +770,9 @@ extern "C" int mapx_cross_bwd_pre_colsum_bf16(const mapx_bf16* g, int64_t ld_g, 
   MAPX_REQUIRE(g && x0 && u && t && dx0 && db && M >= 0 && N > 0 && ld_g >= N, "cross_bwd_pre_colsum_bf16: bad arguments");
   if (!colsum_ws_ok("cross_bwd_pre_colsum_bf16", ws, ws_bytes, N)) return MAPX_EWORKSPACE;
   float* part = static_cast<float*>(ws);
-  hipLaunchKernelGGL(ew_colsum_h_kernel<1>, dim3((N + 127) / 128, kColChunksH), dim3(256), 0, stream,
-                     reinterpret_cast<const bf16_t*>(g), ld_g, reinterpret_cast<const bf16_t*>(x0), (int64_t)N,
-                     reinterpret_cast<const bf16_t*>(u), (int64_t)N, M, N, reinterpret_cast<bf16_t*>(t), dx0,
-                     accumulate, part);
+  launch_ew_colsum_h<1>(reinterpret_cast<const bf16_t*>(g), ld_g, reinterpret_cast<const bf16_t*>(x0), (int64_t)N,
+                        reinterpret_cast<const bf16_t*>(u), (int64_t)N, M, N, reinterpret_cast<bf16_t*>(t), dx0,
+                        accumulate, part, stream);
   hipLaunchKernelGGL(colsum_stage2_h_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, db);
   return check_launch("cross_bwd_pre_colsum_bf16");
 }

@@ -761,6 +761,14 @@ def linear_bwd_weight(dy, x, out=None, defer=False):
     if out is not None and out.stride(0) != K:
         ns = 1
     if is_bf16(dy):                          # fp32 gradient from bf16 operands
+        # a K-step of bf16 MFMAs moves 16x fewer cycles per byte than fp32: 128x128 tiles (half the
+        # L2 -> LDS bytes per flop of 64x64 ones), split over K until they cover the 256 CUs
+        tiles = math.ceil(Nn / 128) * math.ceil(K / 128)
+        ns = 1
+        while ns < 16 and tiles * ns * 2 <= 288 and Bn // (ns * 2) >= 256:
+            ns *= 2
+        if out is not None and out.stride(0) != K:
+            ns = 1
         return gemm_bf16(dy, x, False, False, Nn, K, Bn, out=out, out_dtype=torch.float32, nsplit=ns)
     return gemm(dy, x, False, False, Nn, K, Bn, out=out, nsplit=ns, defer=DEFER and defer and out is not None)
 

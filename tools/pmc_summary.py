@@ -36,4 +36,16 @@ for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * 
     print(f"{k[:64]:64s} x{v['launches']:4d}  fetch(raw) {v['fetch_bytes_raw'] / 1e6:9.2f} MB  "
           f"fetch(x2) {v['fetch_bytes_x2'] / 1e6:9.2f} MB  write {v['write_bytes'] / 1e6:9.2f} MB")
 if len(sys.argv) > 3:
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "map-code_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    out["_meta"] = dict(csrc_hash=h.hexdigest()[:16],        # == bench.csrc_hash(): bench.py flags a mismatch
+                        note="HBM bytes per launch; FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM)")
     json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
