@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 25
+#define MAPX_ABI_VERSION 26
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -69,6 +69,16 @@ size_t mapx_seg_plan_workspace_bytes(int64_t n, int64_t V);
 int mapx_seg_plan(const int32_t* keys, int64_t n, int64_t V, void* ws, size_t ws_bytes,
                   int32_t* sorted_keys, int32_t* perm, int32_t* rank, int32_t* uniq,
                   int32_t* seg_start, int32_t* n_uniq, hipStream_t stream);
+/* The plans of `count` (<= 2) key lists — the step's tables: embedding ids and sampled NCE ids —
+ * from ONE chain of launches (a sort is a dependent chain of small kernels; two sorts one after the
+ * other cost two chains): block b of every launch works on the list it belongs to, so a 3-pass
+ * sort of both lists is 8 launches (mapx_seg_plan: 8 per list).  All arguments are HOST arrays of `count` entries holding what
+ * mapx_seg_plan takes per list; outputs are identical to `count` calls of mapx_seg_plan. */
+size_t mapx_seg_plan_multi_workspace_bytes(int count, const int64_t* n, const int64_t* V);
+int mapx_seg_plan_multi(int count, const int32_t* const* keys, const int64_t* n, const int64_t* V, void* ws,
+                        size_t ws_bytes, int32_t* const* sorted_keys, int32_t* const* perm,
+                        int32_t* const* rank, int32_t* const* uniq, int32_t* const* seg_start,
+                        int32_t* const* n_uniq, hipStream_t stream);
 /* The same plan for keys that are `lists` concatenated lists of `len` keys each, every list
  * ascending as UNSIGNED 32-bit values (so -1 padding sits at its end) and free of repeats except
  * the padding — the gathered per-rank messages of the data-parallel exchange.  One launch ranks

@@ -182,6 +182,91 @@ extern "C" int mapx_seg_plan(const int32_t* keys, int64_t n, int64_t V, void* ws
   return check_launch("seg_plan");
 }
 
+// ---------------------------------------------------------------------------------------------
+// The plans of up to kMaxSortProbs key lists (the step's tables) from ONE chain of launches
+// (radixsort.h, multi-problem form).  Workspace per problem: two ping-pong arrays, one histogram
+// matrix per pass, the tile counts.
+namespace mapx {
+struct MultiWs {
+  size_t tk, tv, bh[kMaxPasses], cnt, total;
+};
+static MultiWs multi_ws(int64_t n, int passes, size_t at) {
+  MultiWs w;
+  size_t o = at;
+  auto take = [&](size_t bytes) { size_t a = o; o = align_up(o + bytes); return a; };
+  const size_t hist = (size_t)(1 << kSortBits) * radix_ld(radix_blocks(n));
+  w.tk = take((size_t)n * 4);
+  w.tv = take((size_t)n * 4);
+  for (int p = 0; p < kMaxPasses; ++p) w.bh[p] = p < 1 ? take(hist * 4) : 0;
+  (void)passes;
+  w.cnt = take((size_t)radix_blocks(n) * 4);
+  w.total = o;
+  return w;
+}
+}  // namespace mapx
+
+extern "C" size_t mapx_seg_plan_multi_workspace_bytes(int count, const int64_t* n, const int64_t* V) {
+  using namespace mapx;
+  size_t at = 0;
+  for (int q = 0; q < count; ++q)
+    if (n[q] > 0) at = multi_ws(n[q], radix_passes(key_bits_for(V[q])), at).total;
+  return at + 256;
+}
+
+extern "C" int mapx_seg_plan_multi(int count, const int32_t* const* keys, const int64_t* n, const int64_t* V,
+                                   void* ws, size_t ws_bytes, int32_t* const* sorted_keys, int32_t* const* perm,
+                                   int32_t* const* rank, int32_t* const* uniq, int32_t* const* seg_start,
+                                   int32_t* const* n_uniq, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(count >= 1 && count <= kMaxSortProbs, "seg_plan_multi: 1..%d key lists per call", kMaxSortProbs);
+  MAPX_REQUIRE(keys && n && V && sorted_keys && perm && rank && uniq && seg_start && n_uniq, "seg_plan_multi: null array");
+  SortProbs ps;
+  memset(&ps, 0, sizeof(ps));
+  int blocks = 0, max_passes = 0;
+  size_t at = 0;
+  char* base = static_cast<char*>(ws);
+  for (int q = 0; q < count; ++q) {
+    MAPX_REQUIRE(n[q] >= 0 && n[q] < (1LL << 31) && V[q] > 0 && V[q] < (1LL << 31), "seg_plan_multi: bad sizes");
+    MAPX_REQUIRE(n_uniq[q] && seg_start[q], "seg_plan_multi: null output");
+    if (n[q] == 0) {          // an empty list: its plan is {0 runs}; it takes no part in the launches
+      MAPX_HIP(hipMemsetAsync(n_uniq[q], 0, 2 * sizeof(int32_t), stream));
+      MAPX_HIP(hipMemsetAsync(seg_start[q], 0, sizeof(int32_t), stream));
+      continue;
+    }
+    MAPX_REQUIRE(keys[q] && sorted_keys[q] && perm[q] && rank[q] && uniq[q] && ws, "seg_plan_multi: null pointer");
+    MAPX_REQUIRE((uintptr_t)ws % 256 == 0, "seg_plan_multi: workspace must be 256-byte aligned");
+    SortProb& pr = ps.p[ps.count];
+    pr.keys = keys[q]; pr.n = n[q];
+    pr.nblocks = radix_blocks(n[q]); pr.block0 = blocks;
+    pr.bits = key_bits_for(V[q]); pr.passes = radix_passes(pr.bits);
+    MAPX_REQUIRE(pr.passes <= kMaxPasses, "seg_plan_multi: keys wider than %d bits", kMaxPasses * kSortBits);
+    const MultiWs w = multi_ws(n[q], pr.passes, at);
+    if (ws_bytes < w.total) {
+      set_error("seg_plan_multi: workspace %zu < %zu bytes", ws_bytes, w.total);
+      return MAPX_EWORKSPACE;
+    }
+    at = w.total;
+    pr.tk = reinterpret_cast<int32_t*>(base + w.tk);
+    pr.tv = reinterpret_cast<int32_t*>(base + w.tv);
+    pr.bh[0] = reinterpret_cast<int32_t*>(base + w.bh[0]);
+    pr.cnt = reinterpret_cast<int32_t*>(base + w.cnt);
+    pr.sorted_keys = sorted_keys[q]; pr.perm = perm[q]; pr.rank = rank[q]; pr.uniq = uniq[q];
+    pr.seg_start = seg_start[q]; pr.n_uniq = n_uniq[q];
+    blocks += pr.nblocks;
+    if (pr.passes > max_passes) max_passes = pr.passes;
+    ++ps.count;
+  }
+  if (ps.count == 0) return MAPX_OK;
+  for (int p = 0; p < max_passes; ++p) {
+    hipLaunchKernelGGL(radix_hist_mp_kernel, dim3(blocks), dim3(256), 0, stream, ps, p);
+    if (p == 0) hipLaunchKernelGGL(radix_scatter_mp_kernel<true>, dim3(blocks), dim3(256), 0, stream, ps, p);
+    else hipLaunchKernelGGL(radix_scatter_mp_kernel<false>, dim3(blocks), dim3(256), 0, stream, ps, p);
+  }
+  hipLaunchKernelGGL(seg_count_mp_kernel, dim3(blocks), dim3(256), 0, stream, ps);
+  hipLaunchKernelGGL(seg_mark_mp_kernel, dim3(blocks), dim3(256), 0, stream, ps);
+  return check_launch("seg_plan_multi");
+}
+
 namespace mapx {
 // rank of every key of `lists` sorted lists in their stable merge
 __global__ void __launch_bounds__(256) merge_rank_kernel(const int32_t* __restrict__ keys, int lists,

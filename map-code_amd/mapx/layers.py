@@ -2,6 +2,7 @@
 Embeddings :83-102, MLPBlock :173-188, CrossNetV2 :191-201).  autograd.Function = glue only:
 every forward/backward body is a C-ABI call (mapx.ops)."""
 import math
+import os
 
 import torch
 from torch import nn
@@ -96,6 +97,8 @@ class RowTable:
         return g0, g1
 
 
+IMPLIED = os.environ.get("MAPX_PLAN_IMPLIED", "1") == "1"
+
 # callables (table, plan) run on the plan stream right after a table's plan has been enqueued
 # (trainer.GraphedBackward publishes the plan's unique-row count to the host from there)
 plan_observers = []
@@ -116,10 +119,14 @@ class PlanSlot:
         self.table, self.keys, self.value = table, keys_i32, None
         self.origin = torch.cuda.current_stream()
         self.ready = ops.record_event()
+        self.partners = []          # other tables' slots to build in the same chain of launches (start_many)
 
     def start(self):
         if self.value is not None:
             return
+        if self.partners:
+            partners, self.partners = self.partners, []
+            return PlanSlot.start_many([self] + partners, implied=partners if IMPLIED else ())
         keys, self.keys = self.keys, None
         side = _side_stream(keys.device, self.table.name)
         forked = ops.stream_wait_event(side, self.ready, self.origin)
@@ -131,6 +138,34 @@ class PlanSlot:
             keys.record_stream(side)
             for t in self.value.tensors():
                 t.record_stream(self.origin)
+
+    @staticmethod
+    def start_many(slots, implied=()):
+        """Build the plans of several tables' slots with ONE chain of launches (ops.SegPlan.build_many:
+        both sorts of a step cost one sort's chain of dependent kernels).  The side stream waits for
+        every slot's keys; slots that were started already are left alone."""
+        slots = [s for s in slots if s is not None and s.value is None]
+        if len(slots) <= 1:
+            for s in slots:
+                s.start()
+            return
+        keys = [s.keys for s in slots]
+        side = _side_stream(keys[0].device)
+        # `implied`: slots whose keys are known to be final once the OTHER slots' events have fired (the
+        # caller's stream order guarantees it): the side stream then forks from one point of the step
+        # instead of joining two streams (measured: no difference, 0.756 vs 0.757 ms in bf16 mode)
+        forked = [(s not in implied) and ops.stream_wait_event(side, s.ready, s.origin) for s in slots]
+        with torch.cuda.stream(side):
+            plans = ops.SegPlan.build_many(keys, [s.table.num_rows for s in slots])
+            for s, plan in zip(slots, plans):
+                s.value, s.keys = plan, None
+                for observe in plan_observers:
+                    observe(s.table, plan)
+        for s, k, f in zip(slots, keys, forked):
+            if f:
+                k.record_stream(side)
+                for t in s.value.tensors():
+                    t.record_stream(s.origin)
 
     def get(self):
         """The plan, usable on the current stream."""

@@ -16,6 +16,16 @@ from .nce import IndexLinear
 logger = logging.getLogger(__name__)
 GROUPED_ENCODER = os.environ.get("MAPX_GROUPED_ENC", "1") == "1"
 NCE_EARLY = os.environ.get("MAPX_NCE_EARLY", "1") == "1"
+# both tables' segment plans from one chain of launches (8 launches instead of 16, 0.112 instead of
+# 0.19 ms of sorting per step): "fwd" = started in forward behind the towers, "bwd" = started by the
+# head's backward node (where the sampled ids' sort alone starts otherwise), "off" = one chain per
+# table.  Measured (one MI355X, 200 steps): bf16 0.793 (off) / 0.752 (fwd) / 0.761 (bwd) ms per step;
+# fp32 1.200 (off) / 1.306 (fwd) / 1.305 (bwd) — the replayed graph runs on two hardware queues, a
+# side chain is appended to one of them, and the fp32 step's two queues are balanced with the small
+# embedding sort in forward and the sampled ids' sort in backward; the same two sorts as one lump (also
+# with the old single-table kernels back to back: 1.39 ms) unbalance them.  "auto": off for fp32, fwd
+# for bf16, where the GEMMs are short and the sort is the longest chain of the step.
+JOINT_PLAN = os.environ.get("MAPX_JOINT_PLAN", "auto")
 
 _OTHER_BACKBONES = ("trans", "fignn", "fgcnn")
 
@@ -204,9 +214,24 @@ class DCNV2(BaseModel):
                     nce_idx = self.mfp_criterion.sample_ids(labels, noise_samples)
                 cross_output = self.cross_net(feat_embed, out=ops.alias_cols(final_buf, 0, D) if direct else None)
             dnn_output = self.parallel_dnn(feat_embed, out=ops.alias_cols(final_buf, D, H) if direct else None)
-            # (starting the sampled ids' sort here, ahead of the embedding's, was measured: 1.375 vs
-            # 1.21 ms — the plan stream then hangs off the tower stream's event)
-            self.embed.table.start_plan()
+            # Both tables' segment plans from ONE chain of launches (8 instead of 8 + 8), when the
+            # sampled ids exist already (drawn early on the tower stream).  (Round 1 note: the sampled
+            # ids' sort as a chain of its own ahead of the embedding's cost 1.375 vs 1.21 ms.)
+            mode = JOINT_PLAN
+            if mode == "auto":
+                mode = "off" if self.embed.compute_dtype == torch.float32 else "fwd"
+            if nce_idx is not None and mode == "fwd":
+                from .layers import PlanSlot
+                from .layers import IMPLIED
+                # (the tower stream forked from the main one behind the gather: the sampled ids' event
+                # implies that the embedding's keys are final)
+                PlanSlot.start_many([self.embed.table.plan, self.mfp_criterion.table.plan],
+                                    implied=[self.embed.table.plan] if IMPLIED else ())
+            elif nce_idx is not None and mode == "bwd" and self.mfp_criterion.table.plan is not None:
+                # the head's backward node starts both (PlanSlot.start_many from IndexLinear's partner list)
+                self.mfp_criterion.table.plan.partners = [self.embed.table.plan]
+            else:
+                self.embed.table.start_plan()
             ops.stream_wait(main, tower)
             if forked:
                 feat_embed.record_stream(tower)

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmapx_hip.so")
 
-MAPX_ABI_VERSION = 25
+MAPX_ABI_VERSION = 26
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_CROSS, EPI_ADD, EPI_RELU_MASK = range(6)
 
 _p, _i, _i64, _u64, _f, _d, _sz = (C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double,
@@ -25,6 +25,8 @@ SIGNATURES = {
     "mapx_ids_to_i32": (_i, [_p, _i64, _i64, _p, _p, _p]),
     "mapx_seg_plan_workspace_bytes": (_sz, [_i64, _i64]),
     "mapx_seg_plan": (_i, [_p, _i64, _i64, _p, _sz, _p, _p, _p, _p, _p, _p, _p]),
+    "mapx_seg_plan_multi_workspace_bytes": (_sz, [_i, _p, _p]),
+    "mapx_seg_plan_multi": (_i, [_i, _p, _p, _p, _p, _sz, _p, _p, _p, _p, _p, _p, _p]),
     "mapx_seg_plan_merge": (_i, [_p, _i, _i64, _p, _sz, _p, _p, _p, _p, _p, _p, _p]),
     "mapx_seg_reduce_workspace_bytes": (_sz, [_i64, _i]),
     "mapx_seg_reduce_rows": (_i, [_i64, _p, _p, _p, _p, _i, _p, _p, _sz, _p, _p]),

@@ -271,10 +271,11 @@ def ids_to_i32(ids, V, validate=False):
 class SegPlan:
     """Sorted-run description of n int32 keys (see include/mapx_hip.h: mapx_seg_plan)."""
 
-    def __init__(self, keys_i32, V, sorted_lists=0):
+    def __init__(self, keys_i32, V, sorted_lists=0, launch=True):
         """`sorted_lists` = w > 0: the keys are w concatenated lists of equal length, each ascending
         as unsigned values and free of repeats except trailing -1 padding (the gathered messages
-        of mapx.parallel): ranked by one merge launch instead of the radix passes, same outputs."""
+        of mapx.parallel): ranked by one merge launch instead of the radix passes, same outputs.
+        `launch=False`: only allocate the outputs (SegPlan.build_many launches several plans at once)."""
         require_gpu(keys_i32)
         n, dev = keys_i32.numel(), keys_i32.device
         self.n, self.V = n, V
@@ -286,6 +287,8 @@ class SegPlan:
         self.seg_start = torch.empty(n + 1, **i32)
         self.n_uniq = torch.empty(2, **i32)         # [number of runs, owner counter (zeroed by the plan)]
         self._counter_fresh = n > 0
+        if not launch:
+            return
         nb = lib.mapx_seg_plan_workspace_bytes(n, V)
         ws = scratch(nb, dev)
         with _timed("seg_plan", n * 4.0):
@@ -299,6 +302,28 @@ class SegPlan:
                 check(lib.mapx_seg_plan(ptr(keys_i32), n, V, ptr(ws), ws.numel(), ptr(self.sorted_keys),
                                         ptr(self.perm), ptr(self.rank), ptr(self.uniq), ptr(self.seg_start),
                                         ptr(self.n_uniq), stream()))
+
+    @staticmethod
+    def build_many(key_lists, Vs):
+        """The plans of several key lists (the step's tables) from ONE chain of launches
+        (mapx_seg_plan_multi: 8 launches for two 24-bit lists instead of 8 each) -> [SegPlan]."""
+        import ctypes as C
+        plans = [SegPlan(k, V, launch=False) for k, V in zip(key_lists, Vs)]
+        cnt = len(plans)
+        if cnt == 1:          # same kernels, one problem
+            pass
+        I64, PP = C.c_int64 * cnt, C.c_void_p * cnt
+        n_arr, v_arr = I64(*[p.n for p in plans]), I64(*[int(v) for v in Vs])
+        dev = key_lists[0].device
+        ws = scratch(lib.mapx_seg_plan_multi_workspace_bytes(cnt, n_arr, v_arr), dev)
+        arr = lambda ts: PP(*[t.data_ptr() for t in ts])
+        with _timed("seg_plan", sum(p.n for p in plans) * 4.0):
+            check(lib.mapx_seg_plan_multi(cnt, arr(key_lists), n_arr, v_arr, ptr(ws), ws.numel(),
+                                          arr([p.sorted_keys for p in plans]), arr([p.perm for p in plans]),
+                                          arr([p.rank for p in plans]), arr([p.uniq for p in plans]),
+                                          arr([p.seg_start for p in plans]), arr([p.n_uniq for p in plans]),
+                                          stream()))
+        return plans
 
     def tensors(self):
         return (self.sorted_keys, self.perm, self.rank, self.uniq, self.seg_start, self.n_uniq)

@@ -104,6 +104,30 @@ def test_seg_plan_merge_equals_sort(ops, lists, length, V):
     assert int(a.uniq[U - 1]) == -1 or bool((keys >= 0).all())      # the padding run sorts last
 
 
+@pytest.mark.parametrize("sizes", [((94208, 9449445), (638976, 9449445)), ((159744, 33762577), (1171456, 33762577)),
+                                   ((31, 50), (5000, 70000)), ((4097, 5), (1, 9449445)), ((0, 100), (70001, 300)),
+                                   ((131073, 70000),), ((638976, 9449445), (94208, 200))])
+def test_seg_plan_build_many_equals_single_plans(ops, sizes):
+    """The multi-problem sort (both tables' plans from one chain of launches) must give, array by array, what
+    one mapx_seg_plan per list gives — including lists of different key widths (3 and 4 passes in
+    one launch sequence), an empty list, and a list of one key."""
+    keys = [_skewed_keys(n, V, n + q).to(torch.int32).to(DEV) if n else torch.empty(0, dtype=torch.int32, device=DEV)
+            for q, (n, V) in enumerate(sizes)]
+    many = ops.SegPlan.build_many(keys, [V for _, V in sizes])
+    again = ops.SegPlan.build_many(keys, [V for _, V in sizes])
+    for k, (n, V), a, a2 in zip(keys, sizes, many, again):
+        b = ops.SegPlan(k, V)
+        U = b.count()
+        assert a.count() == U == a2.count()
+        for name in ("sorted_keys", "perm", "rank"):
+            assert torch.equal(getattr(a, name)[:n], getattr(b, name)[:n]), (name, n, V)
+            assert torch.equal(getattr(a, name)[:n], getattr(a2, name)[:n]), (name, n, V)
+        assert torch.equal(a.uniq[:U], b.uniq[:U]) and torch.equal(a.seg_start[:U + 1], b.seg_start[:U + 1])
+        if n:
+            assert torch.equal(a.perm[:n].long().cpu(), torch.sort(k.long().cpu(), stable=True).indices)
+            assert int(a.n_uniq[1]) == 0
+
+
 def test_seg_plan_empty(ops):
     plan = ops.SegPlan(torch.empty(0, dtype=torch.int32, device=DEV), 10)
     assert plan.count() == 0
