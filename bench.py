@@ -124,6 +124,10 @@ def parse():
                     help="untimed real training steps before the warm-up, so that the lazy table optimizer "
                          "carries a realistic replay debt (rows re-touched after long gaps)")
     ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--fake-world", type=int, default=0, metavar="N",
+                    help="data-parallel tail rehearsal on ONE GPU: N real forward/backward passes on different "
+                         "batches give N ranks' sparse-gradient messages; the merge (gather exchange and "
+                         "owner-partitioned) and the optimizer over the gathered lists are timed.  No bench line.")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="arithmetic type of the dense trunk (BASELINE configs[1] is f32, configs[2] bf16: fp32 "
                          "master weights / tables / optimizer, bf16 GEMM operands and activations)")
@@ -221,6 +225,121 @@ def cpu_baseline(cfg, ids, labels, feat_count, batch, steps):
                        f"parameters, oracle/ref_model.py, torch CPU fp32, {cores} threads), {dt:.1f} s")
 
 
+XGMI_LINK_GBS = 153.0        # per link and direction; 7 links per GPU, fully connected
+
+
+def fake_world(tr, args, next_batch):
+    """What the tail of a data-parallel step costs at world N, measured on one GPU: the other ranks'
+    messages are REAL (N forward/backward passes on N different batches with their own masks and
+    negatives, packed exactly as parallel.pack_table packs them), only the wire is missing.
+    Timed with HIP events, GPU parked first: (a) gather exchange: merge of N sorted lists per table
+    (mapx_seg_plan_merge + segment reduction) and the optimizer over the merged rows; (b) owner-
+    partitioned exchange: this rank merges only the ids it owns (1/N of the id range) out of every
+    list, the optimizer then walks the concatenation of the owners' merged lists (same rows).
+    Wire time is MODELLED, never measured here: bytes / (7 links x 153 GB/s), direct sends."""
+    from mapx import ops, parallel
+    N = args.fake_world
+    opt = tr.optimizer
+    tables = [t.table for t in opt.tables]
+    for t in opt.tables:
+        t.early_ok = False            # as with N > 1: no table update before the exchange
+    per_rank = []                     # per rank: [(plan, r0, r1) per table]
+    for r in range(N):
+        X, Y = next_batch()
+        tr._mfp_fwd_bwd(X, Y)
+        ops.run_side_tasks()
+        per_rank.append([tb.sparse_grad for tb in tables])
+        for tb in tables:
+            tb.sparse_grad = None
+    torch.cuda.synchronize()
+    counts = [[int(sg[0].n_uniq[0]) for sg in rank] for rank in per_rank]
+    sizes = [parallel.message_size(max(c[t] for c in counts)) for t in range(len(tables))]
+    msgs = []                         # per table: (k_all [N*size], r_all [N*size, Wp])
+    for t, tb in enumerate(tables):
+        ks, rs = [], []
+        for r in range(N):
+            plan, r0, r1 = per_rank[r][t]
+            k, rows = ops.pack_sparse(plan, r0, r1, sizes[t], 1.0 / N, pad_id=-1)
+            ks.append(k)
+            rs.append(rows)
+        msgs.append((torch.cat(ks), torch.cat(rs)))
+    del per_rank
+
+    def timed(fn, reps=20):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(20_000_000)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+
+    def merge(t, lists, k_all, r_all):
+        tb = tables[t]
+        W0 = tb.p0.shape[1]
+        mplan = ops.SegPlan(k_all, tb.num_rows + 1, sorted_lists=lists)
+        if tb.p1 is not None:
+            m0, m1 = ops.seg_reduce_rows_extra(mplan, r_all, W0, r_all[:, W0], 1, extra_stride=r_all.stride(0))
+        else:
+            m0, m1 = ops.seg_reduce_rows(mplan, r_all, W0), None
+        return mplan, m0, m1
+
+    out = {"world": N, "tables": {}}
+    merged = []
+    for t, tb in enumerate(tables):
+        k_all, r_all = msgs[t]
+        ms_merge = timed(lambda: merge(t, N, k_all, r_all))
+        merged.append(merge(t, N, k_all, r_all))
+        # owner-partitioned: out of every rank's list only the ids this rank owns (range 0 of N)
+        chunk = -(-tb.num_rows // N)
+        own = [k_all[r * sizes[t]:(r + 1) * sizes[t]] for r in range(N)]
+        n_own = [int(((o >= 0) & (o < chunk)).sum()) for o in own]
+        osz = parallel.message_size(max(1, max(n_own)))
+        ko = torch.full((N * osz,), -1, dtype=torch.int32, device=k_all.device)
+        ro = torch.zeros(N * osz, r_all.shape[1], device=k_all.device)
+        for r in range(N):              # ids are ascending inside a list: the owned ones are its head
+            ko[r * osz:r * osz + n_own[r]] = own[r][:n_own[r]]
+            ro[r * osz:r * osz + n_own[r]] = r_all[r * sizes[t]:r * sizes[t] + n_own[r]]
+        ms_owner = timed(lambda: merge(t, N, ko, ro))
+        U = int(merged[-1][0].n_uniq[0])
+        out["tables"][tb.name] = {
+            "rows_per_rank": [c[t] for c in counts], "message_rows": sizes[t], "row_bytes": 4 * r_all.shape[1] + 4,
+            "merged_rows": U, "merge_ms_gather": round(ms_merge, 4), "merge_ms_owner": round(ms_owner, 4),
+            "owner_rows_per_list": n_own}
+
+    def tail():
+        for tb, m in zip(tables, merged):
+            tb.sparse_grad = m
+        opt.step()
+    ms_tail = timed(tail, reps=10)
+    for tb in tables:
+        tb.sparse_grad = None
+    out["optimizer_ms"] = round(ms_tail, 4)
+    # wire model (direct sends over 7 links): gather = every rank's message to every other rank;
+    # owner = slices to owners (1/N of a message to each peer) + the owners' merged lists to everyone
+    link = XGMI_LINK_GBS * 1e9
+    msg_bytes = sum(sizes[t] * out["tables"][tb.name]["row_bytes"] for t, tb in enumerate(tables))
+    merged_bytes = sum(out["tables"][tb.name]["merged_rows"] * out["tables"][tb.name]["row_bytes"] for tb in tables)
+    dense_bytes = sum(g["g"].numel() * 4 for g in opt.groups)
+    peers = max(N - 1, 1)
+    out["wire_model_ms"] = {
+        "gather_allgather": round(1e3 * msg_bytes / link, 4) if N > 1 else 0.0,     # one message per link, links in parallel
+        "owner_alltoall": round(1e3 * (msg_bytes / N) / link, 4) if N > 1 else 0.0,
+        "owner_allgather": round(1e3 * (merged_bytes / N) / link, 4) if N > 1 else 0.0,
+        "dense_allreduce": round(1e3 * 2 * (dense_bytes / N) / link, 4) if N > 1 else 0.0,
+        "bytes": {"message": msg_bytes, "merged": merged_bytes, "dense": dense_bytes, "links": min(peers, 7)}}
+    g_ms = sum(v["merge_ms_gather"] for v in out["tables"].values())
+    o_ms = sum(v["merge_ms_owner"] for v in out["tables"].values())
+    w = out["wire_model_ms"]
+    out["tail_ms"] = {"gather": round(g_ms + ms_tail + w["gather_allgather"] + w["dense_allreduce"], 4),
+                      "owner": round(o_ms + ms_tail + w["owner_alltoall"] + w["owner_allgather"] + w["dense_allreduce"], 4)}
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -261,6 +380,14 @@ def main():
 
     for _ in range(args.preroll + args.warmup):
         mfp_step(tr, *next_batch())
+    if args.fake_world:
+        torch.cuda.synchronize()
+        res = {"fake_world": [fake_world(tr, argparse.Namespace(**{**vars(args), "fake_world": n}), next_batch)
+                              for n in sorted({1, 2, 4, args.fake_world})],
+               "note": "merge and optimizer measured on one MI355X from N real per-rank messages; wire times are a "
+                       "model (bytes / 153 GB/s per link, 7 links, direct sends) — unmeasured on xGMI"}
+        print(json.dumps(res))
+        return
     if os.environ.get("MAPX_GRAPH", "1") != "0" and args.preroll + args.warmup > tr.GRAPH_AFTER:
         # the headline number is the captured step: a silent fall-back to eager must not pass for it
         live = [g for g in tr._graphs.values() if not isinstance(g, int)]

@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 26
+#define MAPX_ABI_VERSION 27
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -390,6 +390,20 @@ int mapx_relu_mask_bf16(const mapx_bf16* dy, const mapx_bf16* y, int64_t n, mapx
 int mapx_adamw_dense_shadow(float* p, const float* g, float* m, float* v, int64_t n, const float* sched,
                             int sched_len, const int32_t* done, double beta1, double beta2, double eps,
                             double weight_decay, mapx_bf16* shadow, hipStream_t stream);
+
+/* ------------------------------------------------------------------ options of the hot-path classes
+ * nn.Dropout of layers.py:95 (Embeddings) and :183 (MLPBlock): out = keep ? x / (1 - p) : 0 with the
+ * keep mask drawn from Philox(seed, offset + *offset_dev_opt, element) — never stored: backward calls
+ * the same kernel with the same (seed, offset) on the incoming gradient. */
+int mapx_dropout(const float* x, int64_t n, float p, uint64_t seed, uint64_t offset, const int32_t* offset_dev_opt,
+                 float* out, hipStream_t stream);
+/* nn.LayerNorm(embed_size, eps) of layers.py:92-94,99-100 over rows [R, E] (E % 4 == 0, E <= 64):
+ * y = (x - mean) rstd w + b; stats [R,2] = {mean, rstd} kept for backward.  Backward: dx, and
+ * dy_xhat [R,E] = dy * xhat whose column sums are dL/dw (dL/db = column sums of dy). */
+int mapx_layernorm_fwd(const float* x, int64_t R, int E, const float* w, const float* b, float eps, float* y,
+                       float* stats, hipStream_t stream);
+int mapx_layernorm_bwd(const float* dy, const float* x, const float* w, const float* stats, int64_t R, int E,
+                       float* dx, float* dy_xhat, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -244,15 +244,94 @@ def fm_product_sum(x3):
     return _FmProductSum.apply(x3)
 
 
+class _Dropout(Function):
+    @staticmethod
+    def forward(ctx, x, p, seed, offset, offset_dev, out):
+        ctx.cfg = (p, seed, offset, offset_dev)
+        if out is not None and not out.is_contiguous():      # a column slice of the concatenated buffer
+            out.copy_(ops.dropout(x, p, seed, offset, offset_dev))
+            return out
+        return ops.dropout(x, p, seed, offset, offset_dev, out=out)
+
+    @staticmethod
+    def backward(ctx, g):
+        p, seed, offset, offset_dev = ctx.cfg
+        return ops.dropout(g.contiguous(), p, seed, offset, offset_dev), None, None, None, None, None
+
+
+class HipDropout(nn.Module):
+    """nn.Dropout(p) (reference layers.py:95, 183) with a Philox mask that is regenerated, not stored.
+    Every site owns a Philox stream; inside a Trainer the stream advances with the optimizer's
+    device-side update counter (`step_counter`), so a captured step replays with fresh masks."""
+    _sites = 0
+
+    def __init__(self, p):
+        super().__init__()
+        if not 0.0 <= p < 1.0:
+            raise ValueError(f"dropout probability has to be in [0, 1), but got {p}")
+        self.p = float(p)
+        HipDropout._sites += 1
+        self.site, self.seed, self.rank, self._calls, self.step_counter = HipDropout._sites, 42, 0, 0, None
+
+    def forward(self, x, out=None):
+        if not self.training or self.p == 0.0:
+            if out is not None and out.data_ptr() != x.data_ptr():
+                out.copy_(x)
+                return out
+            return x
+        base = (self.rank << 48) + ((16 + self.site) << 36)
+        if self.step_counter is not None:
+            offset, dev = base, self.step_counter
+        else:
+            self._calls += 1
+            offset, dev = base + self._calls, None
+        return _Dropout.apply(x, self.p, self.seed, offset, dev, out)
+
+
+class _LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        shape = x.shape
+        x2 = x.contiguous().view(-1, shape[-1])
+        y, stats = ops.layernorm_fwd(x2, w, b, eps)
+        ctx.slots = (_grad_slot(w), _grad_slot(b))
+        ctx.save_for_backward(x2, w, stats)
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w, stats = ctx.saved_tensors
+        sw, sb = ctx.slots
+        g2 = g.contiguous().view(-1, x2.shape[1])
+        dx, dyx = ops.layernorm_bwd(g2, x2, w, stats)
+        dw = ops.colsum(dyx, out=sw)
+        db = ops.colsum(g2, out=sb)
+        return dx.view(g.shape), (None if sw is not None else dw), (None if sb is not None else db), None
+
+
+class HipLayerNorm(nn.Module):
+    """nn.LayerNorm(E, eps): `weight`, `bias` [E] (ones / zeros), normalisation over the last dimension."""
+
+    def __init__(self, width, eps):
+        super().__init__()
+        self.eps = float(eps)
+        self.weight = nn.Parameter(torch.ones(width))
+        self.bias = nn.Parameter(torch.zeros(width))
+
+    def forward(self, x):
+        return _LayerNorm.apply(x, self.weight, self.bias, self.eps)
+
+
 class Embeddings(nn.Module):
-    """One shared id space over all fields (reference layers.py:83-102)."""
+    """One shared id space over all fields (reference layers.py:83-102): gather, optional LayerNorm
+    over the embedding width (`embed_norm`), optional dropout (`embed_dropout_rate`)."""
 
     def __init__(self, config):
         super().__init__()
-        if getattr(config, "embed_norm", False):
-            raise NotImplementedError("embed_norm=True (LayerNorm on embeddings) is outside the DCNv2 scripts")
-        if getattr(config, "embed_dropout_rate", 0.0) > 0:
-            raise NotImplementedError("embed_dropout_rate > 0 is outside the DCNv2 scripts")
+        self.embed_norm = bool(getattr(config, "embed_norm", False))
+        p_drop = float(getattr(config, "embed_dropout_rate", 0.0) or 0.0)
+        if (self.embed_norm or p_drop > 0) and compute_dtype_of(config) != torch.float32:
+            raise NotImplementedError("embed_norm / embed_dropout_rate are built for compute_dtype=fp32")
         if config.embed_size % 4 != 0:
             raise NotImplementedError("embed_size must be a multiple of 4 (16-byte rows for the gather, "
                                       "segment-reduce and float4 elementwise kernels)")
@@ -260,6 +339,11 @@ class Embeddings(nn.Module):
         std = math.sqrt(2.0 / float(config.num_fields + config.embed_size))
         with torch.no_grad():
             self.embedding.weight.normal_(0.0, std)
+        if self.embed_norm:
+            if config.embed_size > 64:
+                raise NotImplementedError("embed_norm is built for embed_size <= 64")
+            self.layer_norm = HipLayerNorm(config.embed_size, getattr(config, "layer_norm_eps", 1e-12))
+        self.dropout = HipDropout(p_drop)
         self.table = RowTable("embed.embedding", self.embedding.weight)
         self.validate_ids = False
         self.defer_plan = False     # the owning model calls table.start_plan() at its chosen fork point
@@ -277,7 +361,10 @@ class Embeddings(nn.Module):
             if (need_grad or self.table.lazy is not None) else None
         if keys is not None:
             self.table.prepare(keys, need_grad, defer_plan=self.defer_plan)
-        return _Gather.apply(w, input_ids, self.table, self.compute_dtype)
+        x = _Gather.apply(w, input_ids, self.table, self.compute_dtype)
+        if self.embed_norm:
+            x = self.layer_norm(x)
+        return self.dropout(x)
 
     def forward_with_linear(self, input_ids, lin_weight):
         """-> (embeddings [B,F,E], sum_f lin_weight[id] [B]).  `lin_weight` [V,1] must be the
@@ -291,7 +378,10 @@ class Embeddings(nn.Module):
             if (need_grad or self.table.lazy is not None) else None
         if keys is not None:
             self.table.prepare(keys, need_grad, defer_plan=self.defer_plan)
-        return _GatherLinear.apply(w, lin_weight, input_ids, self.table)
+        x, lr = _GatherLinear.apply(w, lin_weight, input_ids, self.table)
+        if self.embed_norm:
+            x = self.layer_norm(x)
+        return self.dropout(x), lr
 
 
 # ----------------------------------------------------------------------------- dense layers
@@ -374,18 +464,26 @@ class MLPBlock(nn.Module):
                  hidden_dropout_rate=0.5, batch_norm=False):
         super().__init__()
         if str(hidden_act).lower() != "relu":
-            raise NotImplementedError(f"hidden_act={hidden_act!r}: only relu is built (DCNv2 scripts)")
-        if hidden_dropout_rate > 0:
-            raise NotImplementedError("hidden_dropout_rate > 0 is outside the DCNv2 scripts")
+            raise NotImplementedError(f"hidden_act={hidden_act!r}: only relu is built (all four DCNv2 scripts use it)")
         self.dnn = nn.ModuleDict()
+        self.p_drop = float(hidden_dropout_rate or 0.0)
         for i in range(num_hidden_layers):
             self.dnn[str(3 * i)] = HipLinear(input_dim, hidden_size, relu=True)
+            if self.p_drop > 0:                      # the reference's slot 3i+2 (no parameters, no state_dict key)
+                self.dnn[str(3 * i + 2)] = HipDropout(self.p_drop)
             input_dim = hidden_size
 
     def forward(self, x, out=None):
-        layers = list(self.dnn.values())
+        layers = [m for m in self.dnn.values() if isinstance(m, HipLinear)]
+        drops = [m for m in self.dnn.values() if isinstance(m, HipDropout)]
         for i, layer in enumerate(layers):
-            x = layer(x, out=out if i == len(layers) - 1 else None)
+            last = i == len(layers) - 1
+            if drops:
+                if x.dtype != torch.float32:
+                    raise NotImplementedError("hidden_dropout_rate > 0 is built for compute_dtype=fp32")
+                x = drops[i](layer(x), out=out if last else None)
+            else:
+                x = layer(x, out=out if last else None)
         return x
 
 

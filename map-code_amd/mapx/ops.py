@@ -937,6 +937,43 @@ def relu_mask(dy, y):
     return out
 
 
+# --------------------------------------------------------------------------- dropout / LayerNorm options
+def dropout(x, p, seed, offset, offset_dev=None, out=None):
+    """out = keep ? x / (1 - p) : 0, keep mask = Philox(seed, offset + *offset_dev) (never stored: the
+    backward pass calls this again on the gradient with the same seed / offset).  fp32."""
+    require_gpu(x)
+    if x.dtype != torch.float32:
+        raise NotImplementedError("dropout is built for the fp32 path")
+    x = x.contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    if not out.is_contiguous():
+        raise ValueError("dropout writes a contiguous tensor")
+    check(lib.mapx_dropout(ptr(x), x.numel(), float(p), int(seed), int(offset), ptr(offset_dev), ptr(out), stream()))
+    return out
+
+
+def layernorm_fwd(x2, w, b, eps):
+    """x2 [R,E] -> (y [R,E], stats [R,2] = {mean, rstd})   (nn.LayerNorm over the last dimension)."""
+    require_gpu(x2, w, b)
+    x2 = x2.contiguous()
+    R, E = x2.shape
+    y = torch.empty_like(x2)
+    stats = torch.empty(R, 2, dtype=torch.float32, device=x2.device)
+    check(lib.mapx_layernorm_fwd(ptr(x2), R, E, ptr(w), ptr(b), float(eps), ptr(y), ptr(stats), stream()))
+    return y, stats
+
+
+def layernorm_bwd(dy2, x2, w, stats):
+    """-> (dx [R,E], dy * xhat [R,E]: its column sums are dL/dw; dL/db = column sums of dy)."""
+    require_gpu(dy2, x2, w, stats)
+    dy2 = dy2.contiguous()
+    R, E = x2.shape
+    dx, dyx = torch.empty_like(x2), torch.empty_like(x2)
+    check(lib.mapx_layernorm_bwd(ptr(dy2), ptr(x2), ptr(w), ptr(stats), R, E, ptr(dx), ptr(dyx), stream()))
+    return dx, dyx
+
+
 # --------------------------------------------------------------------------- heads / masks
 def bce_with_logits(logits, labels, want_grad=True):
     """-> (out3 = [loss, acc, pos_ratio] f32 device, dlogits or None)."""

@@ -151,6 +151,7 @@ class GraphedBackward:
         self.early = (parallel.exchanging() and parallel.EXCHANGE == "gather" and X.is_cuda
                       and torch.distributed.get_backend() == "nccl")
         self.replays = 0
+        self.sizes_floor = None
         self.tails, self.captures, self.poll_s = {}, 0, 0.0
         self.host_s = [0.0] * 5         # launch | counts | tail capture | dense all-reduce | tail
         tables = [t.table for t in trainer.optimizer.tables]
@@ -224,7 +225,14 @@ class GraphedBackward:
             self.trainer._optimizer_step()
             return self.out
         t.append(time.perf_counter())
-        sizes = tuple(parallel.message_size(m) for m in self._max_counts())
+        # Message sizes never shrink: the counts wander by a few per cent around a bucket boundary, and
+        # every new size tuple is a new capture of the tail (~0.1 s, measured: one capture inside 200
+        # timed steps = +0.6 ms per step on average).  Holding the largest bucket seen so far (at most
+        # one 6 % bucket of extra zero rows) makes the run settle on ONE tail graph; every rank sees
+        # the same all-reduced counts, so every rank holds the same sizes.
+        sizes = tuple(max(parallel.message_size(m), lo) for m, lo in
+                      zip(self._max_counts(), self.sizes_floor or (0,) * len(self.published)))
+        self.sizes_floor = sizes
         t.append(time.perf_counter())
         tail = self.tails.get(sizes)
         if tail is None:
@@ -341,6 +349,10 @@ class Trainer:
         self.scheduler = self.optimizer                      # get_last_lr() lives there
         if hasattr(self.model, "mfp_criterion"):
             self.model.mfp_criterion.step_counter = self.optimizer.done
+        from .layers import HipDropout
+        drops = [m for m in self.model.modules() if isinstance(m, HipDropout)]
+        for i, m in enumerate(drops):           # masks advance with the device-side update counter; a site's
+            m.step_counter, m.seed, m.rank, m.site = self.optimizer.done, int(self.args.seed), self.rank, i + 1
         self._graphs = {}
         logger.info(f"***** running {what} *****")
         for k, v in (("dataset_name", self.args.dataset_name), ("input_size", self.model_config.input_size),

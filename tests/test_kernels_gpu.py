@@ -752,3 +752,42 @@ def test_publish_i32_mailbox(ops):
     assert list(a[1:4]) == [123459, 10, 0] and int(a[4]) == 4 and int(a[5]) == 123459 + 10 + 0 + 4
     with pytest.raises(ValueError):
         ops.publish_i32(src, 3, stamp, box, at=5)
+
+
+# --------------------------------------------------------------------------- dropout / LayerNorm options
+def test_dropout_mask_is_regenerated_not_stored(ops):
+    """nn.Dropout semantics (layers.py:95,183): keep rate 1 - p, survivors scaled by 1 / (1 - p); the
+    backward pass regenerates the very mask of the forward pass from (seed, offset); another offset
+    gives another mask; the device-side offset adds to the host one (graph replay)."""
+    n, p = 1_000_003, 0.3
+    x = torch.randn(n, device=DEV)
+    y = ops.dropout(x, p, 42, 7)
+    keep = y != 0
+    assert abs(float(keep.float().mean()) - (1 - p)) < 3e-3
+    assert torch.allclose(y[keep], x[keep] / (1 - p), rtol=1e-6)
+    g = torch.randn(n, device=DEV)
+    assert torch.equal(ops.dropout(g, p, 42, 7) != 0, keep)                       # same mask in backward
+    assert not torch.equal(ops.dropout(x, p, 42, 8) != 0, keep)
+    dev = torch.tensor([3], dtype=torch.int32, device=DEV)
+    assert torch.equal(ops.dropout(x, p, 42, 4, dev), y)                          # 4 + 3 == 7
+    assert torch.equal(ops.dropout(x, 0.0, 1, 1), x)
+    # independence of neighbouring elements / streams: correlation of two masks ~ 0
+    a, b = keep.float() - (1 - p), (ops.dropout(x, p, 43, 7) != 0).float() - (1 - p)
+    assert abs(float((a * b).mean())) < 2e-3
+
+
+@pytest.mark.parametrize("R,E", [(94208, 16), (7, 16), (1000, 32), (33, 64), (5, 4)])
+def test_layernorm_vs_torch(ops, R, E):
+    g = torch.Generator().manual_seed(R + E)
+    x = torch.randn(R, E, generator=g) * 2 + 0.5
+    w, b = torch.randn(E, generator=g), torch.randn(E, generator=g)
+    dy = torch.randn(R, E, generator=g)
+    xr = x.clone().double().requires_grad_(True)
+    wr, br = w.clone().double().requires_grad_(True), b.clone().double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (E,), wr, br, 1e-12)
+    yr.backward(dy.double())
+    y, stats = ops.layernorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), 1e-12)
+    np.testing.assert_allclose(_cpu(y).numpy(), yr.detach().numpy(), rtol=2e-5, atol=2e-5)
+    dx, dyx = ops.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), stats)
+    np.testing.assert_allclose(_cpu(dx).numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(_cpu(dyx).double().sum(0).numpy(), wr.grad.numpy(), rtol=1e-4, atol=1e-3)

