@@ -129,11 +129,36 @@ def reset_aux_streams():
     _scratch.clear()
 
 
+def _capturing(st):
+    """True if HIP stream `st` currently belongs to a stream capture (hipStreamIsCapturing)."""
+    with torch.cuda.stream(st):
+        return torch.cuda.is_current_stream_capturing()
+
+
+class CaptureIsolationError(RuntimeError):
+    pass
+
+
+def _check_capture_join(waiter, waited, what):
+    """A stream that belongs to a capture may only wait for work of the SAME capture.  Waiting for a
+    stream that never joined it (it did not fork, directly or through other streams, from the capture's
+    origin) puts un-captured work in front of captured work: HIP answers with
+    hipErrorStreamCaptureIsolation at best and — seen in round 1 as a crash inside
+    hipStreamEndCapture for a side-stream-to-side-stream join — invalidates the capture at worst.
+    Refused here, in Python, before the runtime sees it."""
+    if _capturing(waiter) and not _capturing(waited):
+        raise CaptureIsolationError(
+            f"{what}: the waiting stream belongs to a hipGraph capture but the stream it would wait for does not "
+            "(it never forked from the capture's origin): fork it from the origin first (ops.stream_wait(side, "
+            "origin)) or run that work on a stream of the capture")
+
+
 def stream_wait(waiter, waited):
     """waiter.wait_stream(waited), skipped when both are the same HIP stream (a self-wait is a
     no-op when run eagerly, but inside a stream capture it hands hipStreamEndCapture a node that
-    depends on itself)."""
+    depends on itself); refused when it would join un-captured work into a capture."""
     if waiter.cuda_stream != waited.cuda_stream:
+        _check_capture_join(waiter, waited, "stream_wait")
         waiter.wait_stream(waited)
         return True
     return False
@@ -148,8 +173,10 @@ def record_event():
 
 
 def stream_wait_event(waiter, event, origin):
-    """waiter.wait_event(event) unless waiter is the stream the event was recorded on."""
+    """waiter.wait_event(event) unless waiter is the stream the event was recorded on (`origin`);
+    refused when `waiter` belongs to a capture that `origin` is not part of (see stream_wait)."""
     if waiter.cuda_stream != origin.cuda_stream:
+        _check_capture_join(waiter, origin, "stream_wait_event")
         waiter.wait_event(event)
         return True
     return False

@@ -628,3 +628,34 @@ def test_graph_replay_equals_eager_bitwise_with_dropout():
         out.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
     for k in out[0]:
         assert torch.equal(out[0][k], out[1][k]), k
+
+
+def test_capture_refuses_a_join_with_a_stream_outside_the_capture():
+    """Round-1 DESIGN 4.5: a side-stream <- side-stream join once crashed hipStreamEndCapture.  The
+    family of that failure — a captured stream made to wait for a stream that never forked from the
+    capture's origin — is refused by ops.stream_wait / stream_wait_event with a Python error before
+    HIP sees it; legal joins (fork from the origin, join back) still capture and replay."""
+    from mapx import ops
+    a = torch.zeros(1024, device=DEV)
+    side, stranger = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        main = torch.cuda.current_stream()
+        assert ops.stream_wait(side, main)                     # fork: side joins the capture
+        with torch.cuda.stream(side):
+            a.add_(1)
+        ev = ops.record_event()
+        with pytest.raises(ops.CaptureIsolationError):
+            ops.stream_wait(side, stranger)                    # side is captured, stranger is not
+        with pytest.raises(ops.CaptureIsolationError):
+            with torch.cuda.stream(stranger):
+                ev2 = ops.record_event()
+            ops.stream_wait_event(main, ev2, stranger)
+        assert ops.stream_wait_event(side, ev, main)           # legal: event of the origin
+        assert not ops.stream_wait(main, main)                 # self-wait: skipped
+        assert ops.stream_wait(main, side)                     # join back
+    g.replay()
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(a[0]) == 2.0
