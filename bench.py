@@ -367,7 +367,7 @@ def main():
     train = tr._begin("bench")
     B = args.batch
     gen = tr._generator()
-    batches = train.batches(B, True, gen, (rank, world))
+    batches = train.batches(B, True, gen, (rank, world), rows=True)     # as Trainer.MFP_pretrain deals them
     tr.model.train()
 
     def next_batch():
@@ -375,7 +375,7 @@ def main():
         try:
             return next(batches)
         except StopIteration:
-            batches = train.batches(B, True, gen, (rank, world))
+            batches = train.batches(B, True, gen, (rank, world), rows=True)
             return next(batches)
 
     for _ in range(args.preroll + args.warmup):
@@ -403,8 +403,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        # the batch is cut from the HBM-resident split inside the timed region (a row gather by the
-        # epoch's device permutation: 2 launches per step, plus one randperm per epoch)
+        # the batch is cut from the HBM-resident split inside the timed region: its row numbers (a slice of
+        # the epoch's device permutation) go to the step, whose mask kernel reads the rows through them
         loss = mfp_step(tr, *next_batch())
     parallel.barrier()
     torch.cuda.synchronize()

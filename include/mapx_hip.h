@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 27
+#define MAPX_ABI_VERSION 28
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -314,6 +314,14 @@ int mapx_dynamic_mask_mfp(const int64_t* ids, int64_t B, int F, int L,
                           const int64_t* masked_index_in, uint64_t seed, uint64_t offset,
                           const int32_t* offset_dev, int64_t* ids_out, int64_t* labels,
                           int64_t* masked_index_out, int32_t* keys_out_opt, hipStream_t stream);
+/* mapx_dynamic_mask_mfp on batch rows that are still in the HBM-resident split: batch row b is row
+ * sel[b] (0 <= sel[b] < N, caller-checked) of split_ids [N,F].  Replaces the DataLoader's collate of
+ * trainer.py:51-58, 306-313 (and the row-gather + copy launches a resident split otherwise needs in
+ * front of every step).  Same outputs as mapx_dynamic_mask_mfp(split_ids[sel], ...). */
+int mapx_dynamic_mask_mfp_rows(const int64_t* split_ids, int64_t N, const int64_t* sel, int64_t B, int F, int L,
+                               const int64_t* masked_index_in, uint64_t seed, uint64_t offset,
+                               const int32_t* offset_dev, int64_t* ids_out, int64_t* labels,
+                               int64_t* masked_index_out, int32_t* keys_out_opt, hipStream_t stream);
 /* trainer.py:233-262 (RFD).  mode = RFD_replace: 0 Unigram, 1 Uniform (idx_low/idx_high [F]),
  * 2 Whole-Uniform (ids 10..V-1), 3 Whole-Unigram; x_train [N,F] device-resident; labels f32 [B,F]. */
 int mapx_dynamic_mask_rfd(const int64_t* ids, int64_t B, int F, int L,

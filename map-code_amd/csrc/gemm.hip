@@ -679,31 +679,46 @@ __global__ void __launch_bounds__(kLayoutThreads) enc_group_layout_kernel(
 // order: wave w owns a contiguous quarter of the targets, counts its matches first (ballots), and
 // after one barrier walks the quarter again handing out consecutive slots.  Stable, like the
 // kernel above, so the dW summation order is unchanged.
-__global__ void __launch_bounds__(256) enc_group_layout_mw_kernel(
+constexpr int kLayoutMwThreads = 1024;
+constexpr int kLayoutBatch = 8;          // field ids a thread fetches before it processes any of them
+__global__ void __launch_bounds__(kLayoutMwThreads) enc_group_layout_mw_kernel(
     const int64_t* __restrict__ masked_index, int T, int L, int F, int cap_slots, int32_t* __restrict__ rowmap,
     int32_t* __restrict__ hpos, int32_t* __restrict__ tile_group, int32_t* __restrict__ group_start) {
+  constexpr int NW = kLayoutMwThreads / 64;
   __shared__ int hist[64];
-  __shared__ int wave_match[4];
+  __shared__ int wave_match[NW];
   __shared__ int gs[64 + 1];
   extern __shared__ uint8_t fld[];     // [T]
   const int f = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x < 64) hist[threadIdx.x] = 0;
   __syncthreads();
-  // pass 1: histogram of every field + this wave's number of targets of field f
-  const int per = ((T + 255) / 256) * 64;            // targets per wave, a multiple of 64
+  // pass 1: histogram of every field + this wave's number of targets of field f.  16 waves share the
+  // T targets (the 4-wave version walked 96 rounds per wave, each one a dependent global load: 52 us
+  // alone, 100+ us beside the towers' GEMMs — the longest link of the forward pass's side chain); the
+  // ids of kLayoutBatch rounds are fetched together, so a wave pays the memory latency T / 8192 times.
+  const int per = ((T + kLayoutMwThreads - 1) / kLayoutMwThreads) * 64;      // targets per wave, a multiple of 64
   const int w0 = wave * per, w1 = min(w0 + per, T);
   int mine = 0;
-  for (int t = w0 + lane; t < w0 + per; t += 64) {
-    const bool live = t < w1;
-    int g = 0;
-    if (live) {
-      g = (int)masked_index[t];
-      g = g < 0 ? 0 : (g >= F ? F - 1 : g);
-      fld[t] = (uint8_t)g;
-      atomicAdd(&hist[g], 1);
+  for (int t0 = w0 + lane; t0 < w0 + per; t0 += 64 * kLayoutBatch) {
+    int g[kLayoutBatch];
+#pragma unroll
+    for (int u = 0; u < kLayoutBatch; ++u) {
+      const int t = t0 + 64 * u;
+      g[u] = (t < w1 && t < w0 + per) ? (int)masked_index[t] : -1;
     }
-    mine += __popcll(__ballot(live && g == f));
+#pragma unroll
+    for (int u = 0; u < kLayoutBatch; ++u) {
+      const int t = t0 + 64 * u;
+      const bool live = t < w1 && t < w0 + per;
+      int gg = g[u];
+      gg = gg < 0 ? 0 : (gg >= F ? F - 1 : gg);
+      if (live) {
+        fld[t] = (uint8_t)gg;
+        atomicAdd(&hist[gg], 1);
+      }
+      mine += __popcll(__ballot(live && gg == f));
+    }
   }
   if (lane == 0) wave_match[wave] = mine;
   __syncthreads();
@@ -722,13 +737,13 @@ __global__ void __launch_bounds__(256) enc_group_layout_mw_kernel(
     if (f == F - 1) group_start[F] = gs[F];
   }
   // padding slots of this group, the capacity behind the last group, and the tiles' fields
-  for (int sl = start + cnt + threadIdx.x; sl < padded; sl += 256) rowmap[sl] = -1;
-  for (int k = start / 128 + threadIdx.x; k < padded / 128; k += 256) tile_group[k] = f;
+  for (int sl = start + cnt + threadIdx.x; sl < padded; sl += kLayoutMwThreads) rowmap[sl] = -1;
+  for (int k = start / 128 + threadIdx.x; k < padded / 128; k += kLayoutMwThreads) tile_group[k] = f;
   if (f == F - 1) {
-    for (int sl = gs[F] + threadIdx.x; sl < cap_slots; sl += 256) rowmap[sl] = -1;
-    for (int k = gs[F] / 128 + threadIdx.x; k < cap_slots / 128; k += 256) tile_group[k] = -1;
+    for (int sl = gs[F] + threadIdx.x; sl < cap_slots; sl += kLayoutMwThreads) rowmap[sl] = -1;
+    for (int k = gs[F] / 128 + threadIdx.x; k < cap_slots / 128; k += kLayoutMwThreads) tile_group[k] = -1;
   }
-  // pass 2: placement in target order
+  // pass 2: placement in target order (field ids now come from LDS)
   int base = start;
   for (int w = 0; w < wave; ++w) base += wave_match[w];
   for (int t = w0 + lane; t < w0 + per; t += 64) {
@@ -1166,7 +1181,7 @@ extern "C" int mapx_enc_group_layout(const int64_t* masked_index, int T, int L, 
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLayoutMaxT));
       raised_mw = true;
     }
-    hipLaunchKernelGGL(enc_group_layout_mw_kernel, dim3(F), dim3(256), dyn, stream, masked_index, T, L, F,
+    hipLaunchKernelGGL(enc_group_layout_mw_kernel, dim3(F), dim3(kLayoutMwThreads), dyn, stream, masked_index, T, L, F,
                        cap_slots, rowmap, hpos, tile_group, group_start);
   }
   return check_launch("enc_group_layout");

@@ -67,11 +67,17 @@ __global__ void __launch_bounds__(256) mask_mfp_kernel(const int64_t* __restrict
                                                        int64_t* __restrict__ ids_out,
                                                        int64_t* __restrict__ labels,
                                                        int64_t* __restrict__ mi_out,
-                                                       int32_t* __restrict__ keys_out) {
+                                                       int32_t* __restrict__ keys_out,
+                                                       const int64_t* __restrict__ sel) {
+  // sel (optional): batch row b is row sel[b] of `ids` — the batch is cut out of the HBM-resident
+  // split here instead of by two index kernels and two copies in front of every step
   if (offset_dev) offset += (uint64_t)(uint32_t)*offset_dev;   // graph-replay safe stream offset
   for (int64_t b0 = (int64_t)blockIdx.x * kMaskRows; b0 < B; b0 += (int64_t)gridDim.x * kMaskRows) {
     const int64_t rows = (B - b0) < kMaskRows ? (B - b0) : kMaskRows;
-    for (int64_t i = threadIdx.x; i < rows * F; i += blockDim.x) ids_out[b0 * F + i] = ids[b0 * F + i];
+    for (int64_t i = threadIdx.x; i < rows * F; i += blockDim.x) {
+      const int64_t b = b0 + i / F;
+      ids_out[b0 * F + i] = sel ? ids[sel[b] * F + i % F] : ids[b0 * F + i];
+    }
     __threadfence_block();
     __syncthreads();
     for (int64_t w = threadIdx.x; w < rows * L; w += blockDim.x) {     // draws: one per thread
@@ -84,7 +90,7 @@ __global__ void __launch_bounds__(256) mask_mfp_kernel(const int64_t* __restrict
         f = bounded(r.x, (uint32_t)F);
       }
       if (mi_out) mi_out[b * L + l] = f;
-      labels[b * L + l] = ids[b * F + f];
+      labels[b * L + l] = ids[(sel ? sel[b] : b) * F + f];
       ids_out[b * F + f] = 3;  // '<mask>' (duplicates of f write the same value)
     }
     __threadfence_block();
@@ -195,8 +201,22 @@ extern "C" int mapx_dynamic_mask_mfp(const int64_t* ids, int64_t B, int F, int L
   MAPX_REQUIRE(ids != ids_out, "dynamic_mask_mfp: in-place masking is not supported");
   if (B == 0) return MAPX_OK;
   hipLaunchKernelGGL(mask_mfp_kernel, dim3(grid_for(B, kMaskRows)), dim3(256), 0, stream, ids, B, F, L,
-                     masked_index_in, seed, offset, offset_dev, ids_out, labels, masked_index_out, keys_out_opt);
+                     masked_index_in, seed, offset, offset_dev, ids_out, labels, masked_index_out, keys_out_opt,
+                     (const int64_t*)nullptr);
   return check_launch("dynamic_mask_mfp");
+}
+
+extern "C" int mapx_dynamic_mask_mfp_rows(const int64_t* split_ids, int64_t N, const int64_t* sel, int64_t B, int F,
+                                          int L, const int64_t* masked_index_in, uint64_t seed, uint64_t offset,
+                                          const int32_t* offset_dev, int64_t* ids_out, int64_t* labels,
+                                          int64_t* masked_index_out, int32_t* keys_out_opt, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(split_ids && sel && ids_out && labels && B >= 0 && N > 0 && F > 0 && L >= 0,
+               "dynamic_mask_mfp_rows: bad arguments");
+  if (B == 0) return MAPX_OK;
+  hipLaunchKernelGGL(mask_mfp_kernel, dim3(grid_for(B, kMaskRows)), dim3(256), 0, stream, split_ids, B, F, L,
+                     masked_index_in, seed, offset, offset_dev, ids_out, labels, masked_index_out, keys_out_opt, sel);
+  return check_launch("dynamic_mask_mfp_rows");
 }
 
 extern "C" int mapx_dynamic_mask_rfd(const int64_t* ids, int64_t B, int F, int L,

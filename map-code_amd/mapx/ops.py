@@ -1034,10 +1034,24 @@ def eval_metrics(logits, labels):
     return dict(auc=auc, logloss=ll, avg_logits=ml, avg_probs=mp, positives=int(npos), negatives=int(nneg))
 
 
-def dynamic_mask_mfp(ids, L, masked_index=None, seed=0, offset=0, offset_dev=None):
-    """-> (masked ids [B,F], labels [B,L], masked_index [B,L])  (trainer.py:217-232)."""
+def dynamic_mask_mfp(ids, L, masked_index=None, seed=0, offset=0, offset_dev=None, sel=None):
+    """-> (masked ids [B,F], labels [B,L], masked_index [B,L])  (trainer.py:217-232).
+    `sel` int64 [B]: `ids` is the whole HBM-resident split [N,F] and the batch is its rows sel."""
     require_gpu(ids)
     ids = ids.contiguous()
+    if sel is not None:
+        require_gpu(sel)
+        sel = sel.contiguous()
+        B, F = sel.numel(), ids.shape[1]
+        out = torch.empty(B, F, dtype=torch.int64, device=ids.device)
+        labels = torch.empty(B, L, dtype=torch.int64, device=ids.device)
+        mi_out = torch.empty(B, L, dtype=torch.int64, device=ids.device)
+        mi_in = masked_index.contiguous() if masked_index is not None else None
+        keys = torch.empty(B * F, dtype=torch.int32, device=ids.device)
+        check(lib.mapx_dynamic_mask_mfp_rows(ptr(ids), ids.shape[0], ptr(sel), B, F, L, ptr(mi_in), seed, offset,
+                                             ptr(offset_dev), ptr(out), ptr(labels), ptr(mi_out), ptr(keys), stream()))
+        _keys_of[0], _keys_of[1] = out, keys
+        return out, labels, mi_out
     B, F = ids.shape
     out = torch.empty_like(ids)
     labels = torch.empty(B, L, dtype=torch.int64, device=ids.device)

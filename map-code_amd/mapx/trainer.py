@@ -27,6 +27,43 @@ from .optim import MapxOptimizer
 logger = logging.getLogger(__name__)
 
 
+class RowsRef:
+    """A batch that is still inside the HBM-resident split: the rows `sel` of split.X / split.Y.  The MFP
+    mask kernel reads the rows through `sel` itself (mapx_dynamic_mask_mfp_rows), so a step needs no
+    gather of X and Y and no copy of them into a captured step's static buffers — only the 32 KB of
+    row numbers.  Quacks like the (X, Y) tensors where the step loop touches them."""
+
+    def __init__(self, split, sel):
+        self.split, self.sel = split, sel
+
+    @property
+    def shape(self):
+        return (self.sel.shape[0], self.split.X.shape[1])
+
+    @property
+    def is_cuda(self):
+        return self.sel.is_cuda
+
+    @property
+    def device(self):
+        return self.sel.device
+
+    @property
+    def X(self):
+        return self.split.X[self.sel]
+
+    @property
+    def Y(self):
+        return self.split.Y[self.sel]
+
+    def clone(self):
+        return RowsRef(self.split, self.sel.clone())
+
+    def copy_(self, other):
+        self.sel.copy_(other.sel)
+        return self
+
+
 class DeviceSplit:
     """A dataset split resident on the GPU: X int64 [N,F], Y int64 [N]."""
 
@@ -35,8 +72,10 @@ class DeviceSplit:
         self.Y = torch.as_tensor(np.ascontiguousarray(dataset.Y)).to(device)
         self.n = self.X.shape[0]
 
-    def batches(self, batch_size, shuffle, generator=None, shard=(0, 1)):
-        """Yield (X_b, Y_b).  shard = (rank, world): rank r takes batches r, r+world, ...
+    def batches(self, batch_size, shuffle, generator=None, shard=(0, 1), rows=False):
+        """Yield (X_b, Y_b) — or, with rows=True and shuffling, (RowsRef, RowsRef): the batch as row
+        numbers into the resident split (MFP pretraining: the mask kernel gathers the rows itself).
+        shard = (rank, world): rank r takes batches r, r+world, ...
         With world > 1 only FULL batches are dealt, and only whole rounds of `world` of them (the
         ragged tail of an epoch is dropped for every rank): all ranks then run the same number of
         steps on the same batch shape, so they take the graph / eager decision together and issue
@@ -54,7 +93,11 @@ class DeviceSplit:
                 yield self.X[s:s + batch_size], self.Y[s:s + batch_size]
             else:
                 sel = order[s:s + batch_size]
-                yield self.X[sel], self.Y[sel]
+                if rows:
+                    ref = RowsRef(self, sel)
+                    yield ref, ref
+                else:
+                    yield self.X[sel], self.Y[sel]
 
     def num_batches(self, batch_size, world=1):
         if world > 1:
@@ -459,6 +502,12 @@ class Trainer:
     # ------------------------------------------------------------------ masking (a1, a2)
     def dynamic_mask(self, inputs, sampling_method="normal", masked_index=None, replace_feat=None):
         ids = inputs["input_ids"]
+        sel = None
+        if isinstance(ids, RowsRef):                   # rows of the resident split
+            if self.args.pt_type == "MFP":
+                ids, sel = ids.split.X, ids.sel
+            else:
+                ids = ids.X
         F = self.model_config.num_fields
         L = int(F * self.args.mask_ratio)
         seed = int(self.args.seed)
@@ -471,13 +520,13 @@ class Trainer:
             offset, offset_dev = (self.rank << 40) + (3 << 36) + self._mask_calls, None
         if masked_index is None:
             if sampling_method == "normal":        # L distinct fields per row (trainer.py:222)
-                masked_index = torch.rand(ids.shape[0], F, device=ids.device,
+                masked_index = torch.rand(ids.shape[0] if sel is None else sel.shape[0], F, device=ids.device,
                                           generator=self._generator()).argsort(1)[:, :L].contiguous()
             elif sampling_method != "randint":
                 raise NotImplementedError(sampling_method)
         if self.args.pt_type == "MFP":
             inputs["input_ids"], inputs["labels"], inputs["masked_index"] = ops.dynamic_mask_mfp(
-                ids, L, masked_index=masked_index, seed=seed, offset=offset, offset_dev=offset_dev)
+                ids, L, masked_index=masked_index, seed=seed, offset=offset, offset_dev=offset_dev, sel=sel)
         elif self.args.pt_type == "RFD":
             x_train = self._split(self.train_dataset).X
             cfg = self.model_config
@@ -507,7 +556,7 @@ class Trainer:
         for epoch in range(self.args.num_train_epochs):
             logger.info(f"-------------------- epoch-{epoch} --------------------")
             self.model.train()
-            for X, Y in train.batches(B, True, self._generator(), (self.rank, self.world)):
+            for X, Y in train.batches(B, True, self._generator(), (self.rank, self.world), rows=True):
                 loss, step_acc = self.run_step("mfp", X, Y)
                 win_loss += loss
                 win_acc += step_acc
