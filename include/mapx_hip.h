@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 28
+#define MAPX_ABI_VERSION 29
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -233,6 +233,11 @@ int mapx_scale_inplace(float* x, int64_t n, const float* g, hipStream_t stream);
  * *nsplit_deferred receives the slab count (0 = C already final): the caller sums them later
  * with mapx_sum_tasks, together with every other deferred sum of the backward pass. */
 size_t mapx_gemm_splitk_workspace_bytes(int M, int N, int nsplit);
+/* Which kernel family mapx_gemm_f32 runs on: 1 = fp32 operands cut into three bf16 pieces, six
+ * v_mfma_f32_32x32x16_bf16 per product, fp32 accumulation (csrc/gemm_x3.hip; default), 0 = the exact
+ * fp32 FMA chain of v_mfma_f32_32x32x2_f32 (environment MAPX_GEMM=mfma32).  Callers use it to pick
+ * split-K factors (the two families prefer different tile shapes). */
+int mapx_gemm_f32_mode(void);
 int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, int64_t lda,
                   const float* B, int64_t ldb, float* C, int64_t ldc, int epi, const float* bias,
                   const float* aux1, int64_t ld1, const float* aux2, int64_t ld2, float* out2,

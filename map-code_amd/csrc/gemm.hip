@@ -1074,7 +1074,24 @@ static void launch_layout(GemmArgs& a, bool vec, int tile, int nsplit, hipStream
   }
 }
 
+// gemm_x3.hip: the same product on the bf16 matrix cores (three bf16 pieces per fp32 operand, six MFMAs)
+int gemm_f32x3_launch(int a_kc, int b_kc, int M, int N, int K, const float* A, int64_t lda, const float* B,
+                      int64_t ldb, float* C, int64_t ldc, int epi, const float* bias, const float* aux1, int64_t ld1,
+                      const float* aux2, int64_t ld2, float* out2, int64_t ldo2, int nsplit, int tile_hint, void* ws,
+                      size_t ws_bytes, int* nsplit_deferred, hipStream_t stream);
+
+// MAPX_GEMM = x3 (default): fp32 GEMMs as 3 x bf16 split products (gemm_x3.hip); mfma32: v_mfma_f32_32x32x2_f32
+static int gemm_mode() {
+  static int m = [] {
+    const char* e = getenv("MAPX_GEMM");
+    return (e && strcmp(e, "mfma32") == 0) ? 0 : 1;
+  }();
+  return m;
+}
+
 }  // namespace mapx
+
+extern "C" int mapx_gemm_f32_mode(void) { return mapx::gemm_mode(); }
 
 extern "C" size_t mapx_gemm_splitk_workspace_bytes(int M, int N, int nsplit) {
   return nsplit > 1 ? (size_t)nsplit * M * N * sizeof(float) : 0;
@@ -1101,6 +1118,9 @@ extern "C" int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   if (epi == MAPX_EPI_ADD || epi == MAPX_EPI_RELU_MASK) MAPX_REQUIRE(aux1, "gemm_f32: aux missing");
   if (nsplit < 1) nsplit = 1;
   MAPX_REQUIRE(nsplit == 1 || epi == MAPX_EPI_NONE, "gemm_f32: split-K needs EPI_NONE");
+  if (gemm_mode() == 1 && (tile_hint < 0 || (tile_hint >> 8) == 0))
+    return gemm_f32x3_launch(a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, epi, bias, aux1, ld1, aux2, ld2, out2, ldo2,
+                             nsplit, tile_hint, ws, ws_bytes, nsplit_deferred, stream);
 
   GemmArgs g;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;

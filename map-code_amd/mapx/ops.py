@@ -791,6 +791,19 @@ def linear_bwd_input(dy, w, out=None, add=None, relu_of=None):
     return gemm(dy, w, True, False, M, K, Nn, out=out, epi=epi, aux1=aux)
 
 
+GEMM_X3 = lib.mapx_gemm_f32_mode() == 1      # fp32 GEMMs as 3 x bf16 split products (csrc/gemm_x3.hip)
+
+
+def _splits_wide_tiles(M, Nn, Kred):
+    """split-K factor for the bf16-MFMA kernels (bf16 operands, or fp32 cut into three bf16 pieces):
+    128 x 128 tiles, split over K until they cover the 256 CUs, K chunk >= 256."""
+    tiles = math.ceil(M / 128) * math.ceil(Nn / 128)
+    ns = 1
+    while ns < 16 and tiles * ns * 2 <= 288 and Kred // (ns * 2) >= 256:
+        ns *= 2
+    return ns
+
+
 def _splits_for(M, Nn, Kred):
     """split-K factor for weight-gradient GEMMs (output [M,Nn] small, reduction Kred = batch
     long): aim at ~1024 blocks of 64x64 (4 per CU), power of two, K chunk >= 256
@@ -809,18 +822,11 @@ def linear_bwd_weight(dy, x, out=None, defer=False):
     """dW = dY^T X.  dy [B,N], x [B,K] -> [N,K].  defer: leave split-K slabs for flush_deferred()."""
     Bn, Nn = dy.shape
     K = x.shape[1]
-    ns = _splits_for(Nn, K, Bn)
+    # the bf16-MFMA kernels want 128 x 128 tiles (half the L2 -> LDS bytes per flop of 64 x 64 ones)
+    ns = _splits_wide_tiles(Nn, K, Bn) if (is_bf16(dy) or GEMM_X3) else _splits_for(Nn, K, Bn)
     if out is not None and out.stride(0) != K:
         ns = 1
     if is_bf16(dy):                          # fp32 gradient from bf16 operands
-        # a K-step of bf16 MFMAs moves 16x fewer cycles per byte than fp32: 128x128 tiles (half the
-        # L2 -> LDS bytes per flop of 64x64 ones), split over K until they cover the 256 CUs
-        tiles = math.ceil(Nn / 128) * math.ceil(K / 128)
-        ns = 1
-        while ns < 16 and tiles * ns * 2 <= 288 and Bn // (ns * 2) >= 256:
-            ns *= 2
-        if out is not None and out.stride(0) != K:
-            ns = 1
         return gemm_bf16(dy, x, False, False, Nn, K, Bn, out=out, out_dtype=torch.float32, nsplit=ns)
     return gemm(dy, x, False, False, Nn, K, Bn, out=out, nsplit=ns, defer=DEFER and defer and out is not None)
 

@@ -9,7 +9,8 @@ import pytest
 import torch
 
 import paramgen as pg
-from util import build_model, load_case, t
+from util import build_model, check_pattern as _check_pattern, hook_relu_pattern as _hook_relu_pattern, load_case, \
+    oracle_case_grads as _oracle_grads, t
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -213,50 +214,6 @@ def _grads_vs(model, ref_grads, tol, what):
                 worst = max(worst, (names[id(p)], e), key=lambda x: x[1])
                 assert e <= tol, f"{what}: {names[id(p)]} differs by {e:.3e} of its scale"
     return worst
-
-
-def _hook_relu_pattern(model):
-    """-> dict filled by forward hooks: layer name -> (output > 0) of every fused-ReLU layer."""
-    masks = {}
-    for name, mod in model.named_modules():
-        if getattr(mod, "relu", False):
-            mod.register_forward_hook(lambda m, i, o, name=name: masks.__setitem__(name, (o.detach() > 0).cpu()))
-    return masks
-
-
-def _check_pattern(masks, preacts, what):
-    """The bf16 step may put a unit on the other side of the ReLU's kink only where the fp32
-    pre-activation is zero to bf16 rounding (|z| <= 2e-2 of the layer's scale); -> number of such units."""
-    assert set(masks) == set(preacts), (sorted(masks), sorted(preacts))
-    flips = 0
-    for k, z in preacts.items():
-        differ = masks[k] != (z > 0)
-        flips += int(differ.sum())
-        if differ.any():
-            worst = float(z[differ].abs().max()) / float(z.abs().max())
-            assert worst <= 2e-2, f"{what}: {k}: a unit with pre-activation {worst:.3e} of the layer's scale flipped"
-    return flips
-
-
-def _oracle_grads(mode, cfg, params, inp, relu_masks=None, preacts=None):
-    """fp32 oracle (the reference's CPU arithmetic) on a fixture case: loss, outputs, gradients.
-    `relu_masks`: impose the activation pattern of the step under test (see oracle/ref_model._relu)."""
-    from oracle import ref_model as R
-    P = {k: t(v).clone().requires_grad_(True) for k, v in params.items()}
-    ids, mi = t(inp["input_ids"]), t(inp["masked_index"])
-    kw = dict(relu_masks=relu_masks, preacts=preacts)
-    if mode == "MFP":
-        logq = R.nce_buffers(inp["feat_count"])[0]
-        masked, labels = R.dynamic_mask_mfp(ids, mi)
-        loss, out, _ = R.mfp_head(P, R.trunk(P, masked, cfg["NC"], cfg["NL"], **kw), labels, mi, t(inp["noise"]), logq,
-                                  cfg["F"], cfg["P"], cfg["K"])
-    elif mode == "RFD":
-        rep, labels = R.dynamic_mask_rfd(ids, mi, t(inp["replace_feat"]))
-        loss, _, _, _, out = R.rfd_head(P, R.trunk(P, rep, cfg["NC"], cfg["NL"], **kw), labels, **kw)
-    else:
-        loss, out = R.ctr_head(P, R.trunk(P, ids, cfg["NC"], cfg["NL"], **kw), t(inp["y"]))
-    loss.backward()
-    return float(loss), out.detach().numpy(), {k: v.grad.numpy() for k, v in P.items()}
 
 
 @pytest.mark.parametrize("case", list(pg.CASES))

@@ -21,22 +21,51 @@ def _dense_named_grads(model):
     return {n: p.grad for n, p in model.named_parameters() if id(p) not in tab}
 
 
-def _check_grads(z, model):
-    for n, g in _dense_named_grads(model).items():
-        assert g is not None, n
-        assert_digest(z, "grad", n, g.cpu().numpy())
+def _all_grads(model):
+    out = dict(_dense_named_grads(model))
     names = {id(p): n for n, p in model.named_parameters()}
     for table in model.row_tables():
         g0, g1 = table.dense_grad()
-        assert_digest(z, "grad", names[id(table.p0)], g0.cpu().numpy())
+        out[names[id(table.p0)]] = g0
         if g1 is not None:
-            assert_digest(z, "grad", names[id(table.p1)], g1.cpu().numpy())
+            out[names[id(table.p1)]] = g1
+    return out
+
+
+def _check_grads(z, model, pattern=None):
+    """Every gradient against the fixture of the real reference.  `pattern` = (masks of the step's fused
+    ReLU layers, mode, cfg, params, inp): with 7 or 64 rows ONE hidden unit whose pre-activation is
+    zero to fp32 rounding, and which this arithmetic puts on the other side of the ReLU's kink than the
+    reference's did, is a visible share of a gradient row.  Then — and only then — the comparison
+    falls back to the oracle (pinned to the same fixture, tests/test_oracle_golden.py) re-run on the
+    step's own activation pattern, after checking that the patterns differ only at such units."""
+    grads = _all_grads(model)
+    try:
+        for n, g in grads.items():
+            assert g is not None, n
+            assert_digest(z, "grad", n, g.cpu().numpy())
+        return
+    except AssertionError:
+        if pattern is None:
+            raise
+    from util import check_pattern, oracle_case_grads
+    masks, mode, cfg, params, inp = pattern
+    pre = {}
+    oracle_case_grads(mode, cfg, params, inp, preacts=pre)
+    flips = check_pattern(masks, pre, f"golden {mode}", tol=2e-6)
+    assert flips > 0, "gradients differ from the fixture although the ReLU pattern is the reference's"
+    _, _, ref = oracle_case_grads(mode, cfg, params, inp, relu_masks=masks)
+    for n, g in grads.items():
+        scale = float(np.abs(ref[n]).max())
+        np.testing.assert_allclose(g.cpu().numpy(), ref[n], rtol=2e-5, atol=2e-5 * scale + 1e-12, err_msg=n)
 
 
 @pytest.mark.parametrize("case", CASES)
 def test_mfp_golden(case):
     cfg, z, inp, params = load_case(case, "MFP")
     model = build_model(cfg, "MFP", params, inp["feat_count"])
+    from util import hook_relu_pattern
+    masks = hook_relu_pattern(model)
     model.mfp_criterion.return_logits = True
     np.testing.assert_allclose(model.mfp_criterion.logprob_noise.cpu().numpy(), z["nce/logprob_noise"],
                                rtol=1e-6, atol=1e-6)
@@ -54,7 +83,7 @@ def test_mfp_golden(case):
     np.testing.assert_allclose(float(loss.detach()), float(z["out/loss"]), rtol=1e-5)
     assert count == int(z["out/count"]) and int(acc) == int(z["out/total_acc"])
     loss.backward()
-    _check_grads(z, model)
+    _check_grads(z, model, (masks, "MFP", cfg, params, inp))
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -78,6 +107,8 @@ def test_mfp_logits_golden(case):
 def test_rfd_golden(case):
     cfg, z, inp, params = load_case(case, "RFD")
     model = build_model(cfg, "RFD", params, None)
+    from util import hook_relu_pattern
+    masks = hook_relu_pattern(model)
     from mapx import ops
     ids, mi = t(inp["input_ids"], DEV), t(inp["masked_index"], DEV)
     replaced, labels, _ = ops.dynamic_mask_rfd(ids, mi.shape[1], masked_index=mi,
@@ -91,13 +122,15 @@ def test_rfd_golden(case):
     np.testing.assert_allclose(float(acc), float(z["out/acc"]), rtol=1e-6)
     np.testing.assert_allclose(float(pos), float(z["out/pos_ratio"]), rtol=1e-6)
     loss.backward()
-    _check_grads(z, model)
+    _check_grads(z, model, (masks, "RFD", cfg, params, inp))
 
 
 @pytest.mark.parametrize("case", CASES)
 def test_ctr_golden(case):
     cfg, z, inp, params = load_case(case, "CTR")
     model = build_model(cfg, "CTR", params, None)
+    from util import hook_relu_pattern
+    masks = hook_relu_pattern(model)
     ids = t(inp["input_ids"], DEV)
     model.train()
     feat = model.embed(ids).flatten(1)
@@ -110,7 +143,7 @@ def test_ctr_golden(case):
     np.testing.assert_allclose(float(loss.detach()), float(z["out/loss"]), rtol=1e-5)
     np.testing.assert_allclose(logits.detach().cpu().numpy(), z["out/logits"], rtol=1e-5, atol=1e-5)
     loss.backward()
-    _check_grads(z, model)
+    _check_grads(z, model, (dict(masks), "CTR", cfg, params, inp))
     (logits_only,) = model(input_ids=ids)
     np.testing.assert_allclose(logits_only.detach().cpu().numpy(), z["out/logits"], rtol=1e-5, atol=1e-5)
 

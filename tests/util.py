@@ -64,3 +64,49 @@ def build_model(cfg, mode, params, feat_count, device="cuda", backbone="DCNv2", 
         for k, v in params.items():
             sd[k].copy_(torch.from_numpy(v))
     return model.to(device)
+
+
+# ----------------------------------------------------------------------------- ReLU pattern of a step
+def hook_relu_pattern(model):
+    """-> dict filled by forward hooks: layer name -> (output > 0) of every fused-ReLU layer."""
+    masks = {}
+    for name, mod in model.named_modules():
+        if getattr(mod, "relu", False):
+            mod.register_forward_hook(lambda m, i, o, name=name: masks.__setitem__(name, (o.detach() > 0).cpu()))
+    return masks
+
+
+def check_pattern(masks, preacts, what, tol=2e-2):
+    """The step under test may put a unit on the other side of the ReLU's kink only where the oracle's
+    pre-activation is zero to the step's rounding (|z| <= tol of the layer's scale: 2e-2 for bf16
+    activations, 2e-6 for fp32); -> number of such units."""
+    assert set(masks) == set(preacts), (sorted(masks), sorted(preacts))
+    flips = 0
+    for k, z in preacts.items():
+        differ = masks[k] != (z > 0)
+        flips += int(differ.sum())
+        if differ.any():
+            worst = float(z[differ].abs().max()) / float(z.abs().max())
+            assert worst <= tol, f"{what}: {k}: a unit with pre-activation {worst:.3e} of the layer's scale flipped"
+    return flips
+
+
+def oracle_case_grads(mode, cfg, params, inp, relu_masks=None, preacts=None):
+    """fp32 oracle (the reference's CPU arithmetic) on a fixture case: loss, outputs, gradients.
+    `relu_masks`: impose the activation pattern of the step under test (see oracle/ref_model._relu)."""
+    from oracle import ref_model as R
+    P = {k: t(v).clone().requires_grad_(True) for k, v in params.items()}
+    ids, mi = t(inp["input_ids"]), t(inp["masked_index"])
+    kw = dict(relu_masks=relu_masks, preacts=preacts)
+    if mode == "MFP":
+        logq = R.nce_buffers(inp["feat_count"])[0]
+        masked, labels = R.dynamic_mask_mfp(ids, mi)
+        loss, out, _ = R.mfp_head(P, R.trunk(P, masked, cfg["NC"], cfg["NL"], **kw), labels, mi, t(inp["noise"]), logq,
+                                  cfg["F"], cfg["P"], cfg["K"])
+    elif mode == "RFD":
+        rep, labels = R.dynamic_mask_rfd(ids, mi, t(inp["replace_feat"]))
+        loss, _, _, _, out = R.rfd_head(P, R.trunk(P, rep, cfg["NC"], cfg["NL"], **kw), labels, **kw)
+    else:
+        loss, out = R.ctr_head(P, R.trunk(P, ids, cfg["NC"], cfg["NL"], **kw), t(inp["y"]))
+    loss.backward()
+    return float(loss), out.detach().numpy(), {k: v.grad.numpy() for k, v in P.items()}
