@@ -1118,7 +1118,7 @@ extern "C" int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   if (epi == MAPX_EPI_ADD || epi == MAPX_EPI_RELU_MASK) MAPX_REQUIRE(aux1, "gemm_f32: aux missing");
   if (nsplit < 1) nsplit = 1;
   MAPX_REQUIRE(nsplit == 1 || epi == MAPX_EPI_NONE, "gemm_f32: split-K needs EPI_NONE");
-  if (gemm_mode() == 1 && (tile_hint < 0 || (tile_hint >> 8) == 0))
+  if (gemm_mode() == 1)
     return gemm_f32x3_launch(a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, epi, bias, aux1, ld1, aux2, ld2, out2, ldo2,
                              nsplit, tile_hint, ws, ws_bytes, nsplit_deferred, stream);
 

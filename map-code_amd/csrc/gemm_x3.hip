@@ -44,6 +44,7 @@ struct GemmX3Args {
   int k_chunk;
   int64_t slab_stride;
   int tiles_m, tiles_n;
+  int dbg;      // timing experiments (tile_hint >> 8): 1 no global loads in the loop, 2 no cut / LDS stores, 4 no MFMAs
 };
 
 constexpr int kXBK = 32;
@@ -289,7 +290,15 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
   __syncthreads();
   // K-step on LDS buffer CUR (= kt & 1, literal): at its start set CUR^1 holds tile kt+1 (landed),
   // set CUR holds tile kt+2 (in flight, issued one step ago)
-#define MAPX_X_KSTEP(CUR, kt, STEADY, MASK)                                                            \
+  // Timing experiments (tools/gemm_f32_bench.py ablate): build with -DMAPX_X3_ABLATE to make the K loop's
+  // phases switchable from tile_hint >> 8; a plain build keeps the loop free of those branches (they cost
+  // about 10 % of a K-step even when never taken).
+#ifdef MAPX_X3_ABLATE
+  const int kDbg = a.dbg;
+#else
+  constexpr int kDbg = 0;
+#endif
+#define MAPX_X_COMPUTE(CUR)                                                                            \
   do {                                                                                                 \
     const bf16_t* const As_cur = smem + (CUR) * kBuf;                                                  \
     const bf16_t* const Bs_cur = As_cur + OpA::LDS_ELEMS;                                              \
@@ -301,6 +310,7 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
       OpB::frags(Bs_cur, 1, bbase, lane, s2, bm);                                                      \
       OpA::frags(As_cur, 2, abase, lane, s2, al);                                                      \
       OpB::frags(Bs_cur, 2, bbase, lane, s2, bl);                                                      \
+      if (!(kDbg & 4))                                                                                \
       _Pragma("unroll") for (int i = 0; i < WMT; ++i)                                                  \
         _Pragma("unroll") for (int j = 0; j < WNT; ++j) {                                              \
           f32x16 c = cor[i][j];                 /* smallest terms first */                             \
@@ -313,34 +323,48 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);       \
         }                                                                                              \
     }                                                                                                  \
-    if ((STEADY) || (kt) + 1 < nk) MAPX_X_STORE((CUR) ^ 1, (CUR) ^ 1, MASK);                           \
-    if ((STEADY) || (kt) + 3 < nk) MAPX_X_LOAD((CUR) ^ 1, (kt) + 3);                                   \
-    if (STEADY) {                                                                                      \
-      _Pragma("unroll") for (int z = 0; z < 12 * WMT * WNT; ++z) {                                     \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      /* 1 MFMA            */                \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      /* 1 LDS read        */                \
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      /* 4 VALU (the cut)  */                \
-        __builtin_amdgcn_sched_group_barrier(0x220, 1, 0);      /* 1 LDS store / global load */        \
-      }                                                                                                \
+  } while (0)
+#define MAPX_X_STAGE(CUR, kt, STEADY, MASK)                                                            \
+  do {                                                                                                 \
+    if (((STEADY) || (kt) + 1 < nk) && !(kDbg & 2)) MAPX_X_STORE((CUR) ^ 1, (CUR) ^ 1, MASK);         \
+    if (((STEADY) || (kt) + 3 < nk) && !(kDbg & 1)) MAPX_X_LOAD((CUR) ^ 1, (kt) + 3);                 \
+  } while (0)
+  // LATE (literal) swaps the two phases.  Tried for waves 4-7 (so one SIMD resident's MFMAs run beside
+  // the other's cut): 1.97 us per K-step against 1.90 without — the residents are not in lockstep here.
+#define MAPX_X_KSTEP(CUR, kt, STEADY, MASK, LATE)                                                      \
+  do {                                                                                                 \
+    if (LATE) {                                                                                        \
+      MAPX_X_STAGE(CUR, kt, STEADY, MASK);                                                             \
+      MAPX_X_COMPUTE(CUR);                                                                             \
+    } else {                                                                                           \
+      MAPX_X_COMPUTE(CUR);                                                                             \
+      MAPX_X_STAGE(CUR, kt, STEADY, MASK);                                                             \
     }                                                                                                  \
     __syncthreads();                                                                                   \
   } while (0)
-  int kt = 0;
-  if (interior) {
-    for (; kt + 4 < nk; kt += 2) {
-      MAPX_X_KSTEP(0, kt, true, false);
-      MAPX_X_KSTEP(1, kt + 1, true, false);
-    }
-  } else {
-    for (; kt + 4 < nk; kt += 2) {
-      MAPX_X_KSTEP(0, kt, true, true);
-      MAPX_X_KSTEP(1, kt + 1, true, true);
-    }
-  }
-  for (; kt < nk; kt += 2) {
-    MAPX_X_KSTEP(0, kt, false, true);
-    if (kt + 1 < nk) MAPX_X_KSTEP(1, kt + 1, false, true);
-  }
+#define MAPX_X_LOOPS(LATE)                                                                             \
+  do {                                                                                                 \
+    int kt = 0;                                                                                        \
+    if (interior) {                                                                                    \
+      for (; kt + 4 < nk; kt += 2) {                                                                   \
+        MAPX_X_KSTEP(0, kt, true, false, LATE);                                                        \
+        MAPX_X_KSTEP(1, kt + 1, true, false, LATE);                                                    \
+      }                                                                                                \
+    } else {                                                                                           \
+      for (; kt + 4 < nk; kt += 2) {                                                                   \
+        MAPX_X_KSTEP(0, kt, true, true, LATE);                                                         \
+        MAPX_X_KSTEP(1, kt + 1, true, true, LATE);                                                     \
+      }                                                                                                \
+    }                                                                                                  \
+    for (; kt < nk; kt += 2) {                                                                         \
+      MAPX_X_KSTEP(0, kt, false, true, LATE);                                                          \
+      if (kt + 1 < nk) MAPX_X_KSTEP(1, kt + 1, false, true, LATE);                                     \
+    }                                                                                                  \
+  } while (0)
+  MAPX_X_LOOPS(false);
+#undef MAPX_X_LOOPS
+#undef MAPX_X_COMPUTE
+#undef MAPX_X_STAGE
 #undef MAPX_X_KSTEP
 #undef MAPX_X_LOAD
 #undef MAPX_X_STORE
@@ -392,6 +416,8 @@ template <bool A_KC, bool B_KC>
 static hipError_t launch_layout_x3(GemmX3Args& a, bool vec, int tile, int nsplit, hipStream_t stream) {
 #define MAPX_X3(WR_, WC_, WM, WN) (vec ? launch_one_x3<WR_, WC_, WM, WN, A_KC, B_KC, true>(a, nsplit, stream) \
                                        : launch_one_x3<WR_, WC_, WM, WN, A_KC, B_KC, false>(a, nsplit, stream))
+  // (128x128 by 4 waves with 64x64 wave tiles — 2/3 of the LDS fragment reads per MFMA — measured 8-14 %
+  // slower on every shape of the step: one wave per SIMD leaves the cut nothing to hide behind.)
   if (tile == 2 || tile == 3) {
     a.tiles_m = (a.M + 127) / 128; a.tiles_n = (a.N + 127) / 128;
     return MAPX_X3(2, 4, 2, 1);
@@ -424,6 +450,7 @@ int gemm_f32x3_launch(int a_kc, int b_kc, int M, int N, int K, const float* A, i
   g.M = M; g.N = N; g.K = K; g.epi = epi; g.bias = bias;
   g.aux1 = aux1; g.ld1 = ld1; g.aux2 = aux2; g.ld2 = ld2; g.out2 = out2; g.ldo2 = ldo2;
   g.k_chunk = K > 0 ? K : kXBK; g.slab_stride = 0;
+  g.dbg = tile_hint >= 0 ? (tile_hint >> 8) : 0;
   if (nsplit > 1) {
     const size_t need = (size_t)nsplit * M * N * sizeof(float);
     if (!ws || ws_bytes < need) {
