@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 29
+#define MAPX_ABI_VERSION 30
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -266,15 +266,17 @@ int mapx_colsum_chunks(void);
  *   Slots are ordered by field, then by target index.  cap_slots = a multiple of 128 >= T + 127*F.
  * mapx_enc_grouped_fwd: h_slots[slot, 0:32] = final[rowmap[slot], :] . W[f*32:(f+1)*32, :]^T + bias;
  *   zero_slots_opt (may be NULL): a second [cap_slots, 32] buffer to clear in the same launch
- *   (the slot-ordered dL/dh that mapx_nce_fwd fills and mapx_enc_grouped_dw reads).
+ *   (the slot-ordered dL/dh that mapx_nce_fwd fills and mapx_enc_grouped_dw reads).  group_start_opt
+ *   (the layout's [F+1] array, or NULL) only orders the tiles over the workgroups — tiles that hold the
+ *   same batch rows go to the same XCD's L2 — and never changes a result.
  * mapx_enc_grouped_dw:  dW[f*32 + p, :] = sum_{slot in group f} dh_slots[slot, p] * final[rowmap[slot], :]
  *   (all F*32 rows written; dh_slots must be zero in unused slots), times *gscale_opt if given. */
 int mapx_enc_group_layout(const int64_t* masked_index, int T, int L, int F, int cap_slots, int32_t* rowmap,
                           int32_t* hpos, int32_t* tile_group, int32_t* group_start, hipStream_t stream);
 int mapx_enc_grouped_fwd(const float* final_act, int64_t ld_final, int nrows, int K, const float* W,
                          int64_t ldw, const float* bias, const int32_t* rowmap,
-                         const int32_t* tile_group, int cap_slots, float* h_slots, float* zero_slots_opt,
-                         hipStream_t stream);
+                         const int32_t* tile_group, const int32_t* group_start_opt, int F, int cap_slots,
+                         float* h_slots, float* zero_slots_opt, hipStream_t stream);
 int mapx_enc_grouped_dw(const float* dh_slots, const float* final_act, int64_t ld_final, int nrows, int N,
                         const int32_t* rowmap, const int32_t* group_start, int F, const float* gscale_opt,
                         float* dW, int64_t ldw, hipStream_t stream);

@@ -29,6 +29,7 @@
 // 4 MiB L2) works on consecutive tiles of the same A row-panel.
 #include "../../include/mapx_hip.h"
 #include "common.h"
+#include "gemm_grouped.h"
 
 namespace mapx {
 
@@ -416,19 +417,6 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs a) {
 //        slots, B rows gathered through rowmap.  Every weight row is written (zeros for fields
 //        nobody masked), so no split-K and no zero-fill pass.
 // P = 32 only (the reference default); other proj sizes use the dense path.
-struct GroupedArgs {
-  const float* A; int64_t lda;       // FWD: final [B, K]          DW: dh [slots, 32]
-  const float* B; int64_t ldb;       // FWD: W [F*32, K]           DW: final [B, N]
-  float* C; int64_t ldc;             // FWD: h [slots, 32]         DW: dW [F*32, N]
-  const float* bias;                 // FWD only
-  const int32_t* rowmap;             // [slots]
-  const int32_t* tile_group;         // FWD: [slots/128] field of the tile, -1 = unused
-  const int32_t* group_start;        // DW: [F+1] first slot of each field's group (multiples of 128)
-  int K, N, nrows;                   // FWD: K = D+H;  DW: N = D+H;  nrows = B (bounds of rowmap values)
-  float* zero_out;                   // FWD, optional: [slots, 32] buffer cleared tile by tile (dh_slots)
-  const float* gscale;               // DW, optional device scalar multiplied into the result
-};
-
 template <bool DW>
 __global__ void __launch_bounds__(256) gemm_grouped_kernel(GroupedArgs a) {
   constexpr int BK = 32;
@@ -1209,8 +1197,8 @@ extern "C" int mapx_enc_group_layout(const int64_t* masked_index, int T, int L, 
 
 extern "C" int mapx_enc_grouped_fwd(const float* final_act, int64_t ld_final, int nrows, int K, const float* W,
                                     int64_t ldw, const float* bias, const int32_t* rowmap,
-                                    const int32_t* tile_group, int cap_slots, float* h_slots,
-                                    float* zero_slots_opt, hipStream_t stream) {
+                                    const int32_t* tile_group, const int32_t* group_start_opt, int F,
+                                    int cap_slots, float* h_slots, float* zero_slots_opt, hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(final_act && W && bias && rowmap && tile_group && h_slots, "enc_grouped_fwd: null pointer");
   MAPX_REQUIRE(K % 4 == 0 && ld_final % 4 == 0 && ldw % 4 == 0 && cap_slots % 128 == 0,
@@ -1218,7 +1206,13 @@ extern "C" int mapx_enc_grouped_fwd(const float* final_act, int64_t ld_final, in
   GroupedArgs g{};
   g.A = final_act; g.lda = ld_final; g.B = W; g.ldb = ldw; g.C = h_slots; g.ldc = 32; g.bias = bias;
   g.rowmap = rowmap; g.tile_group = tile_group; g.K = K; g.N = 32; g.nrows = nrows;
+  g.group_start = group_start_opt; g.F = F;
   g.zero_out = zero_slots_opt;
+  // bf16-matrix-core form (gemm_x3.hip) whenever the dense GEMMs use it and chunks of 8 floats line up
+  if (gemm_mode() == 1 && K % 8 == 0 && (uintptr_t)final_act % 16 == 0 && (uintptr_t)W % 16 == 0) {
+    MAPX_HIP(enc_grouped_fwd_x3_launch(g, cap_slots, stream));
+    return check_launch("enc_grouped_fwd (3 x bf16)");
+  }
   hipLaunchKernelGGL(gemm_grouped_kernel<false>, dim3(cap_slots / 128), dim3(256), 0, stream, g);
   return check_launch("enc_grouped_fwd");
 }
@@ -1231,8 +1225,12 @@ extern "C" int mapx_enc_grouped_dw(const float* dh_slots, const float* final_act
   MAPX_REQUIRE(N % 4 == 0 && ld_final % 4 == 0 && F >= 1, "enc_grouped_dw: N, ld %% 4 must be 0");
   GroupedArgs g{};
   g.A = dh_slots; g.lda = 32; g.B = final_act; g.ldb = ld_final; g.C = dW; g.ldc = ldw;
-  g.rowmap = rowmap; g.group_start = group_start; g.K = 0; g.N = N; g.nrows = nrows;
+  g.rowmap = rowmap; g.group_start = group_start; g.F = F; g.K = 0; g.N = N; g.nrows = nrows;
   g.gscale = gscale_opt;
+  if (gemm_mode() == 1 && N % 8 == 0 && (uintptr_t)final_act % 16 == 0 && (uintptr_t)dh_slots % 16 == 0) {
+    MAPX_HIP(enc_grouped_dw_x3_launch(g, F, stream));
+    return check_launch("enc_grouped_dw (3 x bf16)");
+  }
   hipLaunchKernelGGL(gemm_grouped_kernel<true>, dim3((N + 127) / 128, F), dim3(256), 0, stream, g);
   return check_launch("enc_grouped_dw");
 }

@@ -23,6 +23,8 @@
 // through LDS as fp32 rows and moves every operand with 16-byte accesses.
 #include "../../include/mapx_hip.h"
 #include "common.h"
+#include "gemm_grouped.h"
+#include <utility>
 
 namespace mapx {
 
@@ -44,31 +46,54 @@ struct GemmX3Args {
   int k_chunk;
   int64_t slab_stride;
   int tiles_m, tiles_n;
-  int dbg;      // timing experiments (tile_hint >> 8): 1 no global loads in the loop, 2 no cut / LDS stores, 4 no MFMAs
 };
 
 constexpr int kXBK = 32;
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a constant expression
+template <class F, int... Z>
+__device__ __forceinline__ void unroll_seq(F&& f, std::integer_sequence<int, Z...>) {
+  (f(std::integral_constant<int, Z>{}), ...);
+}
+// order in which a k16 half's 12 fragments are read = order in which the MFMAs first need them
+// (tiles (0,0) (0,1) (1,0) (1,1); per tile lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi): {operand, plane, tile}
+__host__ __device__ constexpr int frag_order(int q, int what) {
+  constexpr int order[12][3] = {{0, 2, 0}, {1, 0, 0}, {0, 0, 0}, {1, 2, 0}, {0, 1, 0}, {1, 1, 0},
+                                {1, 0, 1}, {1, 2, 1}, {1, 1, 1}, {0, 2, 1}, {0, 0, 1}, {0, 1, 1}};
+  return order[q][what];
+}
 
 // Cut of 8 fp32 values into three planes of 8 bf16, each piece ROUNDED to nearest (v_cvt_pk_bf16_f32)
 // and the residual taken exactly in fp32: a = hi + mid + lo to within 2^-25 |a|, with pieces of either
 // sign, so that what the six-term product drops has no preferred sign (a truncating cut biased every
 // product toward zero by 3/4 of an fp32 ulp — measured, tools/scratch/bias_probe.py).
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// Written as the instructions themselves, one asm block per piece: from `(__bf16)x` the compiler re-derives
+// each residual's bf16 value with a conversion of its own (80 v_cvt_pk per 16 pairs instead of 48) and packs
+// the two subtractions of a pair into v_pk_add_f32, which is slow beside MFMAs; and between two dependent
+// asm statements it puts an s_nop (4 cycles of issue each).  11 VALU per pair of floats.
 __device__ inline uint32_t pk_bf16(float x0, float x1) {
-  bf16x2 p;
-  p[0] = (__bf16)x0;
-  p[1] = (__bf16)x1;
-  return __builtin_bit_cast(uint32_t, p);
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x0), "v"(x1));
+  return r;
+}
+// P = the pair rounded to bf16 (packed); r0, r1 = what it leaves of x0, x1 (exact).  5 VALU.
+__device__ inline void piece(float x0, float x1, uint32_t& P, float& r0, float& r1) {
+  uint32_t h0, h1;
+  asm("v_cvt_pk_bf16_f32 %0, %5, %6\n\t"
+      "v_lshlrev_b32 %1, 16, %0\n\t"
+      "v_and_b32 %2, 0xffff0000, %0\n\t"
+      "v_sub_f32 %3, %5, %1\n\t"
+      "v_sub_f32 %4, %6, %2"
+      : "=&v"(P), "=&v"(h0), "=&v"(h1), "=&v"(r0), "=&v"(r1)
+      : "v"(x0), "v"(x1));
 }
 __device__ inline void cut3(const float (&x)[8], uint4& hi, uint4& mid, uint4& lo) {
   uint32_t H[4], M[4], L[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const float x0 = x[2 * e], x1 = x[2 * e + 1];
-    H[e] = pk_bf16(x0, x1);
-    const float r0 = x0 - __uint_as_float(H[e] << 16), r1 = x1 - __uint_as_float(H[e] & 0xffff0000u);   // exact
-    M[e] = pk_bf16(r0, r1);
-    const float s0 = r0 - __uint_as_float(M[e] << 16), s1 = r1 - __uint_as_float(M[e] & 0xffff0000u);   // exact
+    float r0, r1, s0, s1;
+    piece(x[2 * e], x[2 * e + 1], H[e], r0, r1);
+    piece(r0, r1, M[e], s0, s1);
     L[e] = pk_bf16(s0, s1);
   }
   hi = make_uint4(H[0], H[1], H[2], H[3]);
@@ -85,8 +110,10 @@ struct OperandX3 {
   static constexpr int PLANE = KC ? ROWS * LD : kXBK * LD;         // elements of one plane
   static constexpr int LDS_ELEMS = 3 * PLANE;
   static constexpr int CPR = KC ? kXBK / 8 : ROWS / 8;             // chunks per stored row
-  static constexpr int NV = ROWS * kXBK / 8 / NT;                  // chunks per thread per tile (NT threads)
-  static_assert(NV >= 1, "tile too small for the block");
+  static constexpr int TOTAL = ROWS * kXBK / 8;                    // chunks per tile
+  static constexpr int NV = (TOTAL + NT - 1) / NT;                 // chunks per thread per tile (NT threads)
+  static constexpr bool PARTIAL = TOTAL % NT != 0;                 // the last round is for the first waves only
+  static_assert(!PARTIAL || TOTAL % 64 == 0, "a partial round must end on a wave boundary");
   float4 r[NV][2];
   bool ok[NV];
 
@@ -95,32 +122,37 @@ struct OperandX3 {
     col = (f % CPR) * 8;
   }
 
+  __device__ inline void load_one(int i, const float* __restrict__ g, int64_t ld, int row0, int nrows, int k0,
+                                  int kend) {
+    int tr, tc;
+    coords(threadIdx.x + i * NT, tr, tc);
+    const int gr = (KC ? row0 : k0) + tr, gc = (KC ? k0 : row0) + tc;
+    const int rlim = KC ? nrows : kend, clim = KC ? kend : nrows;
+    const bool rok = gr < rlim;
+    const float* p = g + (int64_t)(rok ? gr : 0) * ld;
+    if (VEC) {
+      ok[i] = rok && gc < clim;
+      const float* q = p + (ok[i] ? gc : 0);
+      r[i][0] = *reinterpret_cast<const float4*>(q);
+      r[i][1] = *reinterpret_cast<const float4*>(q + 4);
+    } else {
+      ok[i] = true;
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bool oke = rok && gc + e < clim;
+        const float v = p[oke ? gc + e : 0];
+        x[e] = oke ? v : 0.f;
+      }
+      r[i][0] = make_float4(x[0], x[1], x[2], x[3]);
+      r[i][1] = make_float4(x[4], x[5], x[6], x[7]);
+    }
+  }
   __device__ inline void load(const float* __restrict__ g, int64_t ld, int row0, int nrows, int k0, int kend) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      int tr, tc;
-      coords(threadIdx.x + i * NT, tr, tc);
-      const int gr = (KC ? row0 : k0) + tr, gc = (KC ? k0 : row0) + tc;
-      const int rlim = KC ? nrows : kend, clim = KC ? kend : nrows;
-      const bool rok = gr < rlim;
-      const float* p = g + (int64_t)(rok ? gr : 0) * ld;
-      if (VEC) {
-        ok[i] = rok && gc < clim;
-        const float* q = p + (ok[i] ? gc : 0);
-        r[i][0] = *reinterpret_cast<const float4*>(q);
-        r[i][1] = *reinterpret_cast<const float4*>(q + 4);
-      } else {
-        ok[i] = true;
-        float x[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const bool oke = rok && gc + e < clim;
-          const float v = p[oke ? gc + e : 0];
-          x[e] = oke ? v : 0.f;
-        }
-        r[i][0] = make_float4(x[0], x[1], x[2], x[3]);
-        r[i][1] = make_float4(x[4], x[5], x[6], x[7]);
-      }
+      if (PARTIAL && threadIdx.x + i * NT >= TOTAL) break;
+      load_one(i, g, ld, row0, nrows, k0, kend);
     }
   }
 
@@ -130,6 +162,7 @@ struct OperandX3 {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       int tr, tc;
+      if (PARTIAL && threadIdx.x + i * NT >= TOTAL) break;
       coords(threadIdx.x + i * NT, tr, tc);
       const bool keep = !MASK || ok[i];
       const float x[8] = {keep ? r[i][0].x : 0.f, keep ? r[i][0].y : 0.f, keep ? r[i][0].z : 0.f, keep ? r[i][0].w : 0.f,
@@ -143,23 +176,21 @@ struct OperandX3 {
     }
   }
 
-  // fragments of k16-step s2 (k = 16 s2 + 8 (lane >> 5) + j) of plane `pl` for this wave's T tiles
-  __device__ static inline void frags(const bf16_t* __restrict__ s, int pl, int base, int lane, int s2,
-                                      bf16x8 (&f)[T]) {
+  // fragment of k16-step s2 (k = 16 s2 + 8 (lane >> 5) + j) of plane `pl` for the wave's tile t
+  __device__ static inline bf16x8 frag1(const bf16_t* __restrict__ s, int pl, int base, int lane, int s2, int t) {
     const int l31 = lane & 31, kh = lane >> 5;
     const bf16_t* sp = s + pl * PLANE;
+    if (KC) return *reinterpret_cast<const bf16x8*>(sp + (base + 32 * t + l31) * LD + 16 * s2 + 8 * kh);
+    const int q = (lane >> 2) & 3, p = lane & 3, half = (lane >> 4) & 1;
+    const bf16_t* a0 = sp + (16 * s2 + 8 * kh + q) * LD + base + 32 * t + 16 * half + 4 * p;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0 + 4 * LD));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+  __device__ static inline void frags(const bf16_t* __restrict__ s, int pl, int base, int lane, int s2,
+                                      bf16x8 (&f)[T]) {
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      if (KC) {
-        f[t] = *reinterpret_cast<const bf16x8*>(sp + (base + 32 * t + l31) * LD + 16 * s2 + 8 * kh);
-      } else {
-        const int q = (lane >> 2) & 3, p = lane & 3, half = (lane >> 4) & 1;
-        const bf16_t* a0 = sp + (16 * s2 + 8 * kh + q) * LD + base + 32 * t + 16 * half + 4 * p;
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0));
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0 + 4 * LD));
-        f[t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-      }
-    }
+    for (int t = 0; t < T; ++t) f[t] = frag1(s, pl, base, lane, s2, t);
   }
 };
 
@@ -290,14 +321,14 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
   __syncthreads();
   // K-step on LDS buffer CUR (= kt & 1, literal): at its start set CUR^1 holds tile kt+1 (landed),
   // set CUR holds tile kt+2 (in flight, issued one step ago)
-  // Timing experiments (tools/gemm_f32_bench.py ablate): build with -DMAPX_X3_ABLATE to make the K loop's
-  // phases switchable from tile_hint >> 8; a plain build keeps the loop free of those branches (they cost
-  // about 10 % of a K-step even when never taken).
+  // Timing experiments (tools/x3_ablate.sh): -DMAPX_X3_ABLATE=<bits> builds the K loop without some of its
+  // phases (1 no global loads, 2 no cut / LDS stores / loads, 4 no MFMAs); results are then wrong.
 #ifdef MAPX_X3_ABLATE
-  const int kDbg = a.dbg;
+  constexpr int kDbg = MAPX_X3_ABLATE;       // compile-time: a run-time switch would put branches into the slots
 #else
   constexpr int kDbg = 0;
 #endif
+  constexpr bool kWeave = (WR * WC == 4 && WMT * WNT == 4 && VEC);
 #define MAPX_X_COMPUTE(CUR)                                                                            \
   do {                                                                                                 \
     const bf16_t* const As_cur = smem + (CUR) * kBuf;                                                  \
@@ -342,6 +373,116 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
     }                                                                                                  \
     __syncthreads();                                                                                   \
   } while (0)
+  // One wave per SIMD (kWeave: 4 waves, wave tile 64 x 64): nothing but the ORDER of the wave's own
+  // instructions can put the cut of tile kt+1 into the shadow of tile kt's MFMAs, and left alone the
+  // compiler emits the 48 MFMAs, then the whole cut.  An MFMA holds the SIMD's vector issue for 8 of its 32
+  // cycles and every other instruction costs about 4 (MI355X_MICROARCH.md, 'vector-instruction ISSUE
+  // cost'): 5 instructions per MFMA gap hide.  So the steady-state K-step is 48 slots fenced by
+  // sched_barrier(0); slot z = MFMA z + at most one UNIT of the cut (4 chunks x 4 pairs x 3 pieces = 48
+  // units of 5, 5 and 1 VALU) + at most one memory instruction:
+  //   before MFMA 0   the first half's 12 fragment reads, then units 0..5 under their latency
+  //   slots 0..41     unit 6 + z;  even slots < 24: a fragment of the second k16 half (for MFMAs 24..47);
+  //                   the 1-VALU units of chunk c carry chunk c-1's three LDS stores and its two global loads
+  //   slots 42..45    the last chunk's stores and loads
+  // Out-of-range rows / columns of an edge tile are not masked here: their addresses are clamped to the
+  // operand's first row / column and what they contribute lands in outputs the epilogue does not store
+  // (only the K bound needs zeros, and the steady loop never meets it).
+#define MAPX_X_WSTORE(CUR, c, pl)                                                                      \
+  do {                                                                                                 \
+    constexpr bool isA_ = (c) < OpA::NV;                                                               \
+    constexpr int i_ = isA_ ? (c) : (c) - OpA::NV, plane_ = isA_ ? OpA::PLANE : OpB::PLANE;            \
+    bf16_t* const d_ = smem + ((CUR) ^ 1) * kBuf + (isA_ ? soffA[i_] : soffB[i_]) + (pl) * plane_;     \
+    const uint32_t* const w_ = (pl) == 0 ? cH[(c) & 1] : (pl) == 1 ? cM[(c) & 1] : cL[(c) & 1];        \
+    *reinterpret_cast<uint4*>(d_) = make_uint4(w_[0], w_[1], w_[2], w_[3]);                            \
+  } while (0)
+#define MAPX_X_WLOAD(CUR, kt, c, LD)                                                                   \
+  do {                                                                                                 \
+    constexpr bool isA_ = (c) < OpA::NV;                                                               \
+    constexpr int i_ = isA_ ? (c) : (c) - OpA::NV;                                                     \
+    if ((LD) == 2) {           /* the last tile: K bound checked, `ok` set for the masked cut */       \
+      if (isA_) la[(CUR) ^ 1].load_one(i_, a.A, a.lda, m0, a.M, kbeg + ((kt) + 3) * kXBK, kend);       \
+      else lb[(CUR) ^ 1].load_one(i_, a.B, a.ldb, n0, a.N, kbeg + ((kt) + 3) * kXBK, kend);            \
+      break;                                                                                           \
+    }                                                                                                  \
+    const float* const q_ = isA_ ? wA + goffA[i_] : wB + goffB[i_];                                    \
+    if (isA_) {                                                                                        \
+      la[(CUR) ^ 1].r[i_][0] = *reinterpret_cast<const float4*>(q_);                                   \
+      la[(CUR) ^ 1].r[i_][1] = *reinterpret_cast<const float4*>(q_ + 4);                               \
+    } else {                                                                                           \
+      lb[(CUR) ^ 1].r[i_][0] = *reinterpret_cast<const float4*>(q_);                                   \
+      lb[(CUR) ^ 1].r[i_][1] = *reinterpret_cast<const float4*>(q_ + 4);                               \
+    }                                                                                                  \
+  } while (0)
+#define MAPX_X_CUT_UNIT(CUR, kt, u, MK, LD)                                                                      \
+  do {                                                                                                 \
+    constexpr int c_ = (u) / 12, e_ = ((u) % 12) / 3, st_ = (u) % 3;                                   \
+    constexpr bool isA_ = c_ < OpA::NV;                                                                \
+    constexpr int i_ = isA_ ? c_ : c_ - OpA::NV;                                                       \
+    if (st_ == 0) {                                                                                    \
+      const float4 v_ = isA_ ? la[(CUR) ^ 1].r[i_][e_ >> 1] : lb[(CUR) ^ 1].r[i_][e_ >> 1];            \
+      const bool keep_ = !(MK) || (isA_ ? la[(CUR) ^ 1].ok[i_] : lb[(CUR) ^ 1].ok[i_]);                \
+      piece(keep_ ? ((e_ & 1) ? v_.z : v_.x) : 0.f, keep_ ? ((e_ & 1) ? v_.w : v_.y) : 0.f, cH[c_ & 1][e_], cr0, cr1); \
+    } else if (st_ == 1) {                                                                             \
+      float t0_, t1_;                                                                                  \
+      piece(cr0, cr1, cM[c_ & 1][e_], t0_, t1_);                                                       \
+      cr0 = t0_; cr1 = t1_;                                                                            \
+    } else {                                                                                           \
+      cL[c_ & 1][e_] = pk_bf16(cr0, cr1);                                                              \
+      if (c_ > 0 && e_ < 3) MAPX_X_WSTORE(CUR, (c_ > 0 ? c_ - 1 : 0), e_);                             \
+      if ((LD) != 0 && c_ > 0 && e_ == 3) MAPX_X_WLOAD(CUR, kt, (c_ > 0 ? c_ - 1 : 0), LD);            \
+    }                                                                                                  \
+  } while (0)
+#define MAPX_X_WSLOTS(CUR, kt, ST, MK, LD)                                                                          \
+  unroll_seq([&](auto zc) __attribute__((always_inline)) {                                             \
+    constexpr int z = decltype(zc)::value;                                                             \
+    constexpr int h = z / 24, t4 = (z % 24) / 6, i = t4 / 2, j = t4 % 2, term = z % 6;                 \
+    if (!(kDbg & 4)) {                                                                                 \
+    if (term == 0) cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][2][i], fb[h][0][j], cor[i][j], 0, 0, 0); \
+    if (term == 1) cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][0][i], fb[h][2][j], cor[i][j], 0, 0, 0); \
+    if (term == 2) cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][1][i], fb[h][1][j], cor[i][j], 0, 0, 0); \
+    if (term == 3) cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][1][i], fb[h][0][j], cor[i][j], 0, 0, 0); \
+    if (term == 4) cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][0][i], fb[h][1][j], cor[i][j], 0, 0, 0); \
+    if (term == 5) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][0][i], fb[h][0][j], acc[i][j], 0, 0, 0); \
+    }                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    if constexpr (z < 24 && z % 2 == 0) {                                                              \
+      constexpr int q = z / 2, op = frag_order(q, 0), pl = frag_order(q, 1), t = frag_order(q, 2);     \
+      if (op == 0) fa[1][pl][t] = OpA::frag1(As_cur, pl, abase, lane, 1, t);                           \
+      else fb[1][pl][t] = OpB::frag1(Bs_cur, pl, bbase, lane, 1, t);                                   \
+    }                                                                                                  \
+    if ((ST) && !(kDbg & 2)) {                                                                         \
+      if constexpr (z < 42) MAPX_X_CUT_UNIT(CUR, kt, (z < 42 ? 6 + z : 0), MK, LD);                    \
+      if constexpr (z >= 42 && z < 45) MAPX_X_WSTORE(CUR, 3, (z >= 42 && z < 45 ? z - 42 : 0));        \
+      if constexpr (z == 45) { if ((LD) != 0) MAPX_X_WLOAD(CUR, kt, 3, LD); }                          \
+    }                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+  }, std::make_integer_sequence<int, 48>{})
+  // ST: tile kt+1 exists (cut + store it);  MK: it is the last, K-partial tile (zero-fill by its `ok` flags);
+  // LD: 0 no tile kt+3, 1 a full tile (steady loop), 2 the last tile (bounds-checked loads that set `ok`).
+#define MAPX_X_KSTEP_WEAVE(CUR, kt, ST, MK, LD)                                                                 \
+  do {                                                                                                 \
+    static_assert(OpA::NV == 2 && OpB::NV == 2 && WMT * WNT == 4, "weave: 4 chunks and 48 MFMAs per K-step"); \
+    const bf16_t* const As_cur = smem + (CUR) * kBuf;                                                  \
+    const bf16_t* const Bs_cur = As_cur + OpA::LDS_ELEMS;                                              \
+    bf16x8 fa[2][3][WMT], fb[2][3][WNT];          /* [k16 half][plane hi/mid/lo][tile] */              \
+    unroll_seq([&](auto qc) __attribute__((always_inline)) {                                           \
+      constexpr int q = decltype(qc)::value, op = frag_order(q, 0), pl = frag_order(q, 1), t = frag_order(q, 2); \
+      if (op == 0) fa[0][pl][t] = OpA::frag1(As_cur, pl, abase, lane, 0, t);                           \
+      else fb[0][pl][t] = OpB::frag1(Bs_cur, pl, bbase, lane, 0, t);                                   \
+    }, std::make_integer_sequence<int, 12>{});                                                         \
+    uint32_t cH[2][4], cM[2][4], cL[2][4];        /* [chunk parity][pair] */                           \
+    float cr0 = 0.f, cr1 = 0.f;                                                                        \
+    const float* const wA = a.A + (int64_t)(kbeg + ((kt) + 3) * kXBK) * (A_KC ? 1 : a.lda);            \
+    const float* const wB = a.B + (int64_t)(kbeg + ((kt) + 3) * kXBK) * (B_KC ? 1 : a.ldb);            \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    if ((ST) && !(kDbg & 2)) {                                                                         \
+      MAPX_X_CUT_UNIT(CUR, kt, 0, MK, LD); MAPX_X_CUT_UNIT(CUR, kt, 1, MK, LD); MAPX_X_CUT_UNIT(CUR, kt, 2, MK, LD); \
+      MAPX_X_CUT_UNIT(CUR, kt, 3, MK, LD); MAPX_X_CUT_UNIT(CUR, kt, 4, MK, LD); MAPX_X_CUT_UNIT(CUR, kt, 5, MK, LD); \
+    }                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    MAPX_X_WSLOTS(CUR, kt, ST, MK, LD);                                                                             \
+    __syncthreads();                                                                                   \
+  } while (0)
 #define MAPX_X_LOOPS(LATE)                                                                             \
   do {                                                                                                 \
     int kt = 0;                                                                                        \
@@ -361,8 +502,75 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
       if (kt + 1 < nk) MAPX_X_KSTEP(1, kt + 1, false, true, LATE);                                     \
     }                                                                                                  \
   } while (0)
-  MAPX_X_LOOPS(false);
+  if constexpr (kWeave) {
+    // per chunk: element offset from the K-step's (uniform) operand base, with the out-of-range row / column
+    // of an edge tile clamped to 0 — the chunk's `ok` flag (set by the prologue's loads) zero-fills it at the cut
+    int64_t goffA[OpA::NV], goffB[OpB::NV];
+#pragma unroll
+    for (int i = 0; i < OpA::NV; ++i) {
+      int tr, tc;
+      OpA::coords(threadIdx.x + i * NT, tr, tc);
+      const bool in = (A_KC ? m0 + tr : m0 + tc) < a.M;
+      goffA[i] = A_KC ? (int64_t)(in ? m0 + tr : 0) * a.lda + tc : (int64_t)tr * a.lda + (in ? m0 + tc : 0);
+    }
+#pragma unroll
+    for (int i = 0; i < OpB::NV; ++i) {
+      int tr, tc;
+      OpB::coords(threadIdx.x + i * NT, tr, tc);
+      const bool in = (B_KC ? n0 + tr : n0 + tc) < a.N;
+      goffB[i] = B_KC ? (int64_t)(in ? n0 + tr : 0) * a.ldb + tc : (int64_t)tr * a.ldb + (in ? n0 + tc : 0);
+    }
+    int soffA[OpA::NV], soffB[OpB::NV];          // LDS element offset of the chunk inside a buffer (plane 0)
+#pragma unroll
+    for (int i = 0; i < OpA::NV; ++i) {
+      int tr, tc;
+      OpA::coords(threadIdx.x + i * NT, tr, tc);
+      soffA[i] = tr * OpA::LD + tc;
+    }
+#pragma unroll
+    for (int i = 0; i < OpB::NV; ++i) {
+      int tr, tc;
+      OpB::coords(threadIdx.x + i * NT, tr, tc);
+      soffB[i] = OpA::LDS_ELEMS + tr * OpB::LD + tc;
+    }
+    // K-steps 0 .. nk-5 are steady (tile kt+3 is a full one); the last four are the same woven body with
+    // the last tile's special cases switched in by literals.  kt is even after the loop and 4 or 5 K-steps
+    // remain (nk >= 4), so the tail exists in two parities.
+#define MAPX_X_TAIL4(C0, C1, k0)                                                                       \
+  do {                                                                                                 \
+    MAPX_X_KSTEP_WEAVE(C0, (k0), true, false, 2);          /* loads the last tile */                   \
+    MAPX_X_KSTEP_WEAVE(C1, (k0) + 1, true, false, 0);                                                  \
+    MAPX_X_KSTEP_WEAVE(C0, (k0) + 2, true, true, 0);       /* cuts the last tile */                    \
+    MAPX_X_KSTEP_WEAVE(C1, (k0) + 3, false, false, 0);                                                 \
+  } while (0)
+    if (nk >= 4) {
+      int kt = 0;
+      for (; kt + 5 < nk; kt += 2) {
+        MAPX_X_KSTEP_WEAVE(0, kt, true, false, 1);
+        MAPX_X_KSTEP_WEAVE(1, kt + 1, true, false, 1);
+      }
+      if (nk - kt == 5) {
+        MAPX_X_KSTEP_WEAVE(0, kt, true, false, 1);
+        MAPX_X_TAIL4(1, 0, kt + 1);
+      } else {
+        MAPX_X_TAIL4(0, 1, kt);
+      }
+    } else {
+      for (int kt = 0; kt < nk; kt += 2) {
+        MAPX_X_KSTEP(0, kt, false, true, false);
+        if (kt + 1 < nk) MAPX_X_KSTEP(1, kt + 1, false, true, false);
+      }
+    }
+#undef MAPX_X_TAIL4
+  } else {
+    MAPX_X_LOOPS(false);
+  }
 #undef MAPX_X_LOOPS
+#undef MAPX_X_KSTEP_WEAVE
+#undef MAPX_X_WSLOTS
+#undef MAPX_X_CUT_UNIT
+#undef MAPX_X_WSTORE
+#undef MAPX_X_WLOAD
 #undef MAPX_X_COMPUTE
 #undef MAPX_X_STAGE
 #undef MAPX_X_KSTEP
@@ -418,7 +626,11 @@ static hipError_t launch_layout_x3(GemmX3Args& a, bool vec, int tile, int nsplit
                                        : launch_one_x3<WR_, WC_, WM, WN, A_KC, B_KC, false>(a, nsplit, stream))
   // (128x128 by 4 waves with 64x64 wave tiles — 2/3 of the LDS fragment reads per MFMA — measured 8-14 %
   // slower on every shape of the step: one wave per SIMD leaves the cut nothing to hide behind.)
-  if (tile == 2 || tile == 3) {
+  if (tile == 3) {
+    a.tiles_m = (a.M + 127) / 128; a.tiles_n = (a.N + 127) / 128;
+    return MAPX_X3(2, 2, 2, 2);
+  }
+  if (tile == 2) {
     a.tiles_m = (a.M + 127) / 128; a.tiles_n = (a.N + 127) / 128;
     return MAPX_X3(2, 4, 2, 1);
   }
@@ -450,7 +662,6 @@ int gemm_f32x3_launch(int a_kc, int b_kc, int M, int N, int K, const float* A, i
   g.M = M; g.N = N; g.K = K; g.epi = epi; g.bias = bias;
   g.aux1 = aux1; g.ld1 = ld1; g.aux2 = aux2; g.ld2 = ld2; g.out2 = out2; g.ldo2 = ldo2;
   g.k_chunk = K > 0 ? K : kXBK; g.slab_stride = 0;
-  g.dbg = tile_hint >= 0 ? (tile_hint >> 8) : 0;
   if (nsplit > 1) {
     const size_t need = (size_t)nsplit * M * N * sizeof(float);
     if (!ws || ws_bytes < need) {
@@ -468,7 +679,14 @@ int gemm_f32x3_launch(int a_kc, int b_kc, int M, int N, int K, const float* A, i
                    (g.k_chunk % 8 == 0) && (a_kc ? (K % 8 == 0) : (M % 8 == 0)) && (b_kc ? (K % 8 == 0) : (N % 8 == 0));
   auto blocks = [&](int bm, int bn) { return ceil_div(M, bm) * ceil_div(N, bn) * nsplit; };
   const int64_t big = blocks(128, 128);
-  int tile = (big >= 160) ? 2 : 0;
+  // 128 x 128 layout of the NT / NN / TN products, three digits (3: 4 waves, hand-woven K-step; 2: 8 waves).
+  // Alone the two are within 5 % of each other; inside the step's graph the 4-wave layout is worth 10 % of
+  // the whole step (0.958 vs 1.069 ms): its one wave per SIMD and ~360 of 512 registers leave room for the
+  // small kernels the other queue runs beside a GEMM, where the 8-wave layout (2 x 250 registers per SIMD)
+  // owns the CU and every such kernel waits for a CU to drain.
+  static const int big_tile = [] { const char* e = getenv("MAPX_X3_TILE"); return e ? atoi(e) : 333; }();
+  const int cls = (a_kc && b_kc) ? 0 : a_kc ? 1 : 2;
+  int tile = (big >= 160) ? (cls == 0 ? big_tile / 100 : cls == 1 ? big_tile / 10 % 10 : big_tile % 10) : 0;
   if (tile_hint >= 0 && (tile_hint & 255) <= 3) tile = tile_hint & 255;
   hipError_t e;
   if (a_kc && b_kc) e = launch_layout_x3<true, true>(g, vec, tile, nsplit, stream);
@@ -483,6 +701,246 @@ int gemm_f32x3_launch(int a_kc, int b_kc, int M, int N, int K, const float* A, i
                        static_cast<const float*>(ws), g.slab_stride, nsplit, n, C);
   }
   return check_launch("gemm_f32 (3 x bf16)");
+}
+
+// ------------------------------------------------------------------------------------------
+// Grouped feat_encoder products (gemm.hip, "Grouped GEMMs": models.py:74-75) on the bf16 matrix cores.
+// Same slot layout, same two products, same outputs as gemm_grouped_kernel:
+//   FWD  h[slot, 0:32]   = final[rowmap[slot], :] . W[32 f : 32 f + 32, :]^T + bias    tile 128 slots x 32
+//   DW   dW[32 f + p, n] = sum_{slot in group f} dh[slot, p] final[rowmap[slot], n]     tile 32 x 128 columns
+// A tile has only four 32 x 32 MFMA tiles, so the block runs EIGHT waves and splits every K-step of 32
+// between two sets of four: waves 0-3 take its first k16 half, waves 4-7 the second (each wave 6 MFMAs per
+// K-step on its own accumulator pair), and the two partial tiles meet in LDS once, after the K loop.
+// That puts two waves on every SIMD — one's cut of the next tile (VALU + LDS stores) beside the other's
+// MFMAs — where four waves would leave each SIMD a single in-order instruction stream.
+// Global loads: 640 chunks of 8 floats per K-step for 512 threads (the 128-row operand one chunk per
+// thread, the 32-row operand by waves 0-1); gathered rows as in gemm_grouped_kernel (FWD resolves its
+// rowmap entries once, DW fetches them one K-step ahead of the row loads that need them).
+template <bool DW>
+__global__ void __launch_bounds__(512) gemm_grouped_x3_kernel(GroupedArgs a) {
+  constexpr int NT = 512;
+  constexpr int BM = DW ? 32 : 128, BN = DW ? 128 : 32;
+  using OpA = OperandX3<BM, 1, !DW, true, NT>;     // FWD: k-contiguous gathered rows;  DW: dh, [k = slot][p]
+  using OpB = OperandX3<BN, 1, !DW, true, NT>;     // FWD: the field's 32 weight rows;  DW: gathered rows, [k = slot][n]
+  static_assert(OpA::NV == 1 && OpB::NV == 1, "one chunk per thread per operand");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* const smem = reinterpret_cast<bf16_t*>(smem_raw);
+  constexpr int kBuf = OpA::LDS_ELEMS + OpB::LDS_ELEMS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int w4 = wave & 3, half = wave >> 2;       // output tile of the wave, k16 half of every K-step
+  const int abase = DW ? 0 : w4 * 32, bbase = DW ? w4 * 32 : 0;
+
+  // Block -> tile, XCD-aware (workgroups go round-robin to the 8 XCDs, each with its own 4 MB L2).  Both
+  // products read every row of `final` once per masked field of that row (~7 times): in the launch order
+  // of the plain grids each XCD sees all of `final` (22 MB) and re-fetches it through the fabric; ordered
+  // so that one XCD works on one eighth of the batch rows (FWD) or on one or two 128-column slices
+  // (DW), the re-reads hit its L2.
+  int f, kbeg, kend, n0 = 0, slot0 = 0;
+  if (DW) {
+    const int nb = gridDim.x, per = nb / 8;
+    int lin = blockIdx.x;
+    if (lin < per * 8) lin = (lin % 8) * per + lin / 8;
+    f = lin % a.F;                                   // column-slice-major: consecutive blocks share their columns
+    n0 = (lin / a.F) * BN;
+    kbeg = a.group_start[f];
+    kend = a.group_start[f + 1];
+  } else {
+    if (a.zero_out) {
+      float4* z = reinterpret_cast<float4*>(a.zero_out + (int64_t)blockIdx.x * BM * 32);
+      for (int i = threadIdx.x; i < BM * 32 / 4; i += NT) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    int tile = blockIdx.x;
+    if (a.group_start) {
+      // Tiles sorted by (eighth of their group they lie in, field, index in the group): a group's slots
+      // are in batch-row order, so equal eighths of different groups hold the same batch rows.  Block b
+      // takes sorted position (b % 8) * per + b / 8 — a bijection on [0, 8 per) that covers the used tiles.
+      // (computed by the whole block at once: wave x sums the tiles below key x over the fields, its lanes)
+      const int used = a.group_start[a.F] / BM, per = (used + 7) / 8;
+      if ((int)gridDim.x >= 8 * per && a.F <= 64) {
+        const int i = blockIdx.x / 8, pos = (blockIdx.x % 8) * per + i;
+        if (i >= per || pos >= used) return;
+        __shared__ int below[8];                     // tiles with key < x:  sum_f ceil(x nf / 8)
+        const int gs0 = lane < a.F ? a.group_start[lane] : 0, gs1 = lane < a.F ? a.group_start[lane + 1] : 0;
+        const int nf = (gs1 - gs0) / BM;
+        int v = (wave * nf + 7) >> 3;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+        if (lane == 0) below[wave] = v;
+        __syncthreads();
+        int X = 0;
+#pragma unroll
+        for (int x = 1; x < 8; ++x)
+          if (below[x] <= pos) X = x;
+        const int q = pos - below[X];                // index among the tiles of key X, ordered by (field, j)
+        const int j0 = (X * nf + 7) >> 3, c = (((X + 1) * nf + 7) >> 3) - j0;
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int u = __shfl_up(incl, d);
+          if (lane >= d) incl += u;
+        }
+        const bool hit = q >= incl - c && q < incl;
+        const unsigned long long m = __ballot(hit);
+        if (m == 0) return;
+        tile = __shfl(gs0 / BM + j0 + (q - (incl - c)), __ffsll((long long)m) - 1);
+      }
+    }
+    f = a.tile_group[tile];
+    if (f < 0) return;
+    slot0 = tile * BM;
+    kbeg = 0;
+    kend = a.K;
+  }
+  const float* __restrict__ Bb = DW ? a.B : a.B + (int64_t)f * 32 * a.ldb;
+
+  f32x16 acc, cor;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = cor[r] = 0.f;
+
+  // this thread's chunk of each operand (coordinates inside the tile never change)
+  int atr, atc, btr, btc;
+  OpA::coords(threadIdx.x, atr, atc);
+  OpB::coords(threadIdx.x, btr, btc);
+  const bool a_mine = !OpA::PARTIAL || threadIdx.x < OpA::TOTAL;
+  const bool b_mine = !OpB::PARTIAL || threadIdx.x < OpB::TOTAL;
+  int64_t arow = 0;
+  bool arow_ok = false;
+  if (!DW) {
+    const int row = a.rowmap[slot0 + atr];
+    arow_ok = row >= 0;
+    arow = (int64_t)(row >= 0 ? row : 0) * a.lda + atc;
+  }
+  OpA la[2];
+  OpB lb[2];
+  int bnext = -1;                                    // DW: rowmap entry of this thread's row of the next tile to load
+#define MAPX_GX_ROW(t) (DW ? ((kbeg + (t) * kXBK + btr) < kend ? a.rowmap[kbeg + (t) * kXBK + btr] : -1) : 0)
+#define MAPX_GX_LOAD(SET, t, BROW)                                                                   \
+  do {                                                                                               \
+    const int k0 = kbeg + (t) * kXBK;                                                                \
+    if (a_mine) {                                                                                    \
+      const float* q;                                                                                \
+      if (DW) {                                                                                      \
+        la[SET].ok[0] = (k0 + atr) < kend;                                                           \
+        q = a.A + (la[SET].ok[0] ? (int64_t)(k0 + atr) * a.lda + atc : 0);                           \
+      } else {                                                                                       \
+        la[SET].ok[0] = arow_ok && (k0 + atc) < kend;                                                \
+        q = a.A + (la[SET].ok[0] ? arow + k0 : 0);                                                   \
+      }                                                                                              \
+      la[SET].r[0][0] = *reinterpret_cast<const float4*>(q);                                         \
+      la[SET].r[0][1] = *reinterpret_cast<const float4*>(q + 4);                                     \
+    }                                                                                                \
+    if (b_mine) {                                                                                    \
+      const float* q;                                                                                \
+      if (DW) {                                                                                      \
+        const int row = (BROW);                                                                      \
+        lb[SET].ok[0] = row >= 0 && (n0 + btc) < a.N;                                                \
+        q = Bb + (lb[SET].ok[0] ? (int64_t)row * a.ldb + n0 + btc : 0);                              \
+      } else {                                                                                       \
+        lb[SET].ok[0] = (k0 + btc) < kend;                                                           \
+        q = Bb + (int64_t)btr * a.ldb + (lb[SET].ok[0] ? k0 + btc : 0);                              \
+      }                                                                                              \
+      lb[SET].r[0][0] = *reinterpret_cast<const float4*>(q);                                         \
+      lb[SET].r[0][1] = *reinterpret_cast<const float4*>(q + 4);                                     \
+    }                                                                                                \
+  } while (0)
+#define MAPX_GX_STORE(SET, buf)                                                                      \
+  do {                                                                                               \
+    la[SET].template store<true>(smem + (buf) * kBuf);                                               \
+    lb[SET].template store<true>(smem + (buf) * kBuf + OpA::LDS_ELEMS);                              \
+  } while (0)
+  const int nk = (kend - kbeg + kXBK - 1) / kXBK;
+  if (nk > 0) MAPX_GX_LOAD(0, 0, MAPX_GX_ROW(0));
+  if (nk > 1) MAPX_GX_LOAD(1, 1, MAPX_GX_ROW(1));
+  if (nk > 0) MAPX_GX_STORE(0, 0);
+  if (nk > 2) MAPX_GX_LOAD(0, 2, MAPX_GX_ROW(2));
+  if (nk > 3) bnext = MAPX_GX_ROW(3);
+  __syncthreads();
+  // K-step kt on LDS buffer CUR = kt & 1 (literal): the wave's half of tile kt, then cut + store of tile
+  // kt+1 (register set CUR^1, landed), then the loads of tile kt+3 into that set and the row index of kt+4.
+#define MAPX_GX_KSTEP(CUR, kt, STEADY)                                                               \
+  do {                                                                                               \
+    const bf16_t* const As_cur = smem + (CUR) * kBuf;                                                \
+    const bf16_t* const Bs_cur = As_cur + OpA::LDS_ELEMS;                                            \
+    bf16x8 ah[1], am[1], al[1], bh[1], bm[1], bl[1];                                                 \
+    OpA::frags(As_cur, 0, abase, lane, half, ah);                                                    \
+    OpB::frags(Bs_cur, 0, bbase, lane, half, bh);                                                    \
+    OpA::frags(As_cur, 1, abase, lane, half, am);                                                    \
+    OpB::frags(Bs_cur, 1, bbase, lane, half, bm);                                                    \
+    OpA::frags(As_cur, 2, abase, lane, half, al);                                                    \
+    OpB::frags(Bs_cur, 2, bbase, lane, half, bl);                                                    \
+    cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[0], bh[0], cor, 0, 0, 0);                       \
+    cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0], bl[0], cor, 0, 0, 0);                       \
+    cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[0], bm[0], cor, 0, 0, 0);                       \
+    cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[0], bh[0], cor, 0, 0, 0);                       \
+    cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0], bm[0], cor, 0, 0, 0);                       \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0], bh[0], acc, 0, 0, 0);                       \
+    if ((STEADY) || (kt) + 1 < nk) MAPX_GX_STORE((CUR) ^ 1, (CUR) ^ 1);                              \
+    /* the row index of tile kt+4 is ISSUED before the loads of tile kt+3 (memory returns in order: */ \
+    /* the wait for it next step then leaves those loads in flight)                                  */ \
+    int bnew = -1;                                                                                   \
+    if (DW && ((STEADY) || (kt) + 4 < nk)) bnew = MAPX_GX_ROW((kt) + 4);                             \
+    if ((STEADY) || (kt) + 3 < nk) MAPX_GX_LOAD((CUR) ^ 1, (kt) + 3, bnext);                         \
+    bnext = bnew;                                                                                    \
+    __syncthreads();                                                                                 \
+  } while (0)
+  int kt = 0;
+  for (; kt + 5 < nk; kt += 2) {
+    MAPX_GX_KSTEP(0, kt, true);
+    MAPX_GX_KSTEP(1, kt + 1, true);
+  }
+  for (; kt < nk; kt += 2) {
+    MAPX_GX_KSTEP(0, kt, false);
+    if (kt + 1 < nk) MAPX_GX_KSTEP(1, kt + 1, false);
+  }
+#undef MAPX_GX_KSTEP
+#undef MAPX_GX_STORE
+#undef MAPX_GX_LOAD
+#undef MAPX_GX_ROW
+
+  // the second half's partial tiles go through LDS (every K-step ended on a barrier: the buffers are free)
+  float* const part = reinterpret_cast<float*>(smem_raw);      // [4 tiles][16 registers][64 lanes]
+  if (half == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[(w4 * 16 + r) * 64 + lane] = acc[r] + cor[r];
+  }
+  __syncthreads();
+  if (half == 1) return;
+  // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int n = (DW ? n0 : 0) + bbase + l31;
+  if (DW ? (n < a.N) : true) {
+    const float bn = DW ? 0.f : a.bias[f * 32 + n];
+    const float gs = (DW && a.gscale) ? *a.gscale : 1.f;
+    float* __restrict__ Cb = DW ? a.C + (int64_t)f * 32 * a.ldc : a.C + (int64_t)slot0 * a.ldc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = abase + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      const float v = (acc[r] + cor[r]) + part[(w4 * 16 + r) * 64 + lane];
+      Cb[(int64_t)m * a.ldc + n] = DW ? v * gs : v + bn;
+    }
+  }
+}
+
+template <bool DW>
+static hipError_t launch_grouped_x3(const GroupedArgs& g, dim3 grid, hipStream_t stream) {
+  constexpr int BM = DW ? 32 : 128, BN = DW ? 128 : 32;
+  using OpA = OperandX3<BM, 1, !DW, true, 512>;
+  using OpB = OperandX3<BN, 1, !DW, true, 512>;
+  constexpr size_t lds = (size_t)2 * (OpA::LDS_ELEMS + OpB::LDS_ELEMS) * sizeof(bf16_t);
+  static_assert(lds >= 4 * 16 * 64 * sizeof(float) && lds <= 160 * 1024, "LDS budget");
+  auto* fn = &gemm_grouped_x3_kernel<DW>;
+  static hipError_t raised =
+      hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (raised != hipSuccess) return raised;
+  hipLaunchKernelGGL(fn, grid, dim3(512), lds, stream, g);
+  return hipSuccess;
+}
+
+hipError_t enc_grouped_fwd_x3_launch(const GroupedArgs& g, int cap_slots, hipStream_t stream) {
+  return launch_grouped_x3<false>(g, dim3(cap_slots / 128), stream);
+}
+hipError_t enc_grouped_dw_x3_launch(const GroupedArgs& g, int F, hipStream_t stream) {
+  return launch_grouped_x3<true>(g, dim3(((g.N + 127) / 128) * F), stream);
 }
 
 }  // namespace mapx

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmapx_hip.so")
 
-MAPX_ABI_VERSION = 29
+MAPX_ABI_VERSION = 30
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_CROSS, EPI_ADD, EPI_RELU_MASK = range(6)
 
 _p, _i, _i64, _u64, _f, _d, _sz = (C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double,
@@ -77,7 +77,7 @@ SIGNATURES = {
     "mapx_layernorm_bwd": (_i, [_p, _p, _p, _p, _i64, _i, _p, _p, _p]),
     "mapx_sum_tasks": (_i, [_p, _i, _p]),
     "mapx_enc_group_layout": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
-    "mapx_enc_grouped_fwd": (_i, [_p, _i64, _i, _i, _p, _i64, _p, _p, _p, _i, _p, _p, _p]),
+    "mapx_enc_grouped_fwd": (_i, [_p, _i64, _i, _i, _p, _i64, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "mapx_enc_grouped_dw": (_i, [_p, _p, _i64, _i, _i, _p, _p, _i, _p, _p, _i64, _p]),
     "mapx_colsum_chunks": (_i, []),
     "mapx_colsum_workspace_bytes": (_sz, [_i]),

@@ -615,7 +615,8 @@ class EncGroups:
         B, L = masked_index.shape
         T, dev = B * L, masked_index.device
         self.T, self.L, self.F = T, L, F
-        self.cap = (T + 127 * F + 127) // 128 * 128
+        # >= T + 127 F (every group padded to 128); whole rounds of 8 tiles, one per XCD (enc_grouped_fwd's order)
+        self.cap = (T + 127 * F + 1023) // 1024 * 1024
         masked_index = masked_index.contiguous()
         i32 = dict(dtype=torch.int32, device=dev)
         self.rowmap = torch.empty(self.cap, **i32)
@@ -641,7 +642,8 @@ def enc_grouped_fwd(final, w, b, groups, zero_slots=None):
     with _timed("gemm_enc_grouped_fwd", 2.0 * groups.T * 32 * final.shape[1]):
         check(lib.mapx_enc_grouped_fwd(final.data_ptr(), final.stride(0), final.shape[0], final.shape[1],
                                        ptr(w), w.stride(0), ptr(b), ptr(groups.rowmap), ptr(groups.tile_group),
-                                       groups.cap, ptr(h), ptr(zero_slots), stream()))
+                                       ptr(groups.group_start), groups.F, groups.cap, ptr(h), ptr(zero_slots),
+                                       stream()))
     return h
 
 

@@ -36,13 +36,10 @@ def run(a_kc, b_kc, M, N, K, epi=EPI_NONE, nsplit=1, tile=-1):
 
 if __name__ == "__main__":
     print("mode", os.environ.get("MAPX_GEMM", "x3"))
-    if len(sys.argv) > 1 and sys.argv[1] == "ablate":
-        # needs a library built with the switches in:  make -C map-code_amd/csrc clean all EXTRA=-DMAPX_X3_ABLATE
-        print("ablation 4096 x 1000 x 4096 (128x128, 8 waves): us per K-step of 32")
-        for name, d in [("full", 0), ("no global loads", 1), ("no cut/store", 2), ("no loads, no cut", 3), ("no MFMA", 4),
-                        ("only MFMA+frags", 3), ("only loads+cut (no MFMA)", 4), ("nothing but frags", 7)]:
-            us, _ = run(True, True, 4096, 1000, 4096, epi=EPI_BIAS_RELU, tile=2 + (d << 8))
-            print(f"  {name:28s}: {us:7.1f} us   {(us - 10) / 128:5.2f} us/K-step")
+    if len(sys.argv) > 1 and sys.argv[1] == "ablate":       # one line per 128 x 128 layout; see tools/x3_ablate.sh
+        for tile in (2, 3):
+            us, _ = run(True, True, 4096, 1000, 4096, epi=EPI_BIAS_RELU, tile=tile)
+            print(f"  tile {tile}: {us:7.1f} us   {(us - 10) / 128:5.2f} us/K-step")
         sys.exit(0)
     print("NT 4096 x 1000 x K, bias+relu")
     for K in (32, 128, 512, 1024, 2048, 4096):

@@ -26,8 +26,11 @@ if __name__ == "__main__":
     bad = 0
     for (a_kc, b_kc, M, N, K) in [(1, 0, 777, 1248, 39), (1, 0, 64, 1248, 39), (1, 0, 777, 1248, 23), (1, 0, 777, 1248, 40),
                                   (1, 0, 4096, 736, 23), (1, 0, 777, 1248, 33), (1, 0, 9, 1248, 39), (1, 0, 137, 100, 39),
-                                  (1, 1, 777, 39, 1248), (0, 0, 39, 1248, 777), (0, 0, 1248, 1624, 777), (1, 0, 777, 1624, 1248)]:
-        for tile in (-1, 0, 1, 2):
+                                  (1, 1, 777, 39, 1248), (0, 0, 39, 1248, 777), (0, 0, 1248, 1624, 777), (1, 0, 777, 1624, 1248),
+                                  (1, 1, 4096, 1000, 368), (1, 1, 4096, 1000, 1000), (1, 0, 4096, 1000, 1000),
+                                  (1, 0, 4096, 1368, 736), (0, 0, 1000, 1000, 4096), (1, 1, 256, 128, 512),
+                                  (1, 1, 300, 200, 200), (0, 0, 300, 200, 520)]:
+        for tile in (-1, 0, 1, 2, 3):
             e = check(bool(a_kc), bool(b_kc), M, N, K, tile)
             flag = "" if e < 1e-6 else "   <-- BAD"
             bad += e >= 1e-6

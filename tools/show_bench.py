@@ -3,7 +3,7 @@
 import json
 import sys
 
-d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+d = json.loads((open(sys.argv[1]) if len(sys.argv) > 1 else sys.stdin).read().strip().splitlines()[-1])
 print(f"value {d['value']:.0f} {d['unit']}  ms/step {d['ms_per_step']:.3f}  n_gpus {d['n_gpus']}")
 tot = 0.0
 for k, v in sorted(d["kernels"].items(), key=lambda kv: -kv[1]["ms_per_step"]):
