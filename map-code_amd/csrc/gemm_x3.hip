@@ -314,10 +314,30 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
     la[SET].template store<MASK>(smem + (buf) * kBuf);                   \
     lb[SET].template store<MASK>(smem + (buf) * kBuf + OpA::LDS_ELEMS);  \
   } while (0)
-  if (nk > 0) MAPX_X_LOAD(0, 0);
-  if (nk > 1) MAPX_X_LOAD(1, 1);
-  if (nk > 0) MAPX_X_STORE(0, 0, true);
-  if (nk > 2) MAPX_X_LOAD(0, 2);
+  constexpr bool kWeave = (WR * WC == 4 && WMT * WNT == 4 && VEC);
+  // The woven layout wants every K-step of its loop alike.  So (nk >= 2) the K range's remainder goes
+  // FIRST: tile 0 is the partial one, [kbeg, kbeg + rem) with rem in 8..32, cut here with the bounds-
+  // checked load and the masked store; tiles 1.. are full ones starting at wk0 = kbeg + rem.  And where the
+  // loop would run out of tiles it repeats the last one: a cut into the LDS buffer nobody reads any more,
+  // loads of a tile that is in bounds.
+  // (nk >= 2 is the launcher's promise: it gives slabs of one K-step to the 8-wave layout.)
+  const int wk0 = kbeg + (kend - kbeg) - kXBK * (nk - 1);
+  if constexpr (kWeave) {
+    auto wload = [&](auto& oa, auto& ob, int t) __attribute__((always_inline)) {
+      const int tc = t < nk - 1 ? t : nk - 1, k0 = tc == 0 ? kbeg : wk0 + kXBK * (tc - 1);
+      oa.load(a.A, a.lda, m0, a.M, k0, tc == 0 ? wk0 : kend);
+      ob.load(a.B, a.ldb, n0, a.N, k0, tc == 0 ? wk0 : kend);
+    };
+    wload(la[0], lb[0], 0);
+    wload(la[1], lb[1], 1);
+    MAPX_X_STORE(0, 0, true);
+    wload(la[0], lb[0], 2);
+  } else {
+    if (nk > 0) MAPX_X_LOAD(0, 0);
+    if (nk > 1) MAPX_X_LOAD(1, 1);
+    if (nk > 0) MAPX_X_STORE(0, 0, true);
+    if (nk > 2) MAPX_X_LOAD(0, 2);
+  }
   __syncthreads();
   // K-step on LDS buffer CUR (= kt & 1, literal): at its start set CUR^1 holds tile kt+1 (landed),
   // set CUR holds tile kt+2 (in flight, issued one step ago)
@@ -328,7 +348,6 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
 #else
   constexpr int kDbg = 0;
 #endif
-  constexpr bool kWeave = (WR * WC == 4 && WMT * WNT == 4 && VEC);
 #define MAPX_X_COMPUTE(CUR)                                                                            \
   do {                                                                                                 \
     const bf16_t* const As_cur = smem + (CUR) * kBuf;                                                  \
@@ -395,15 +414,10 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
     const uint32_t* const w_ = (pl) == 0 ? cH[(c) & 1] : (pl) == 1 ? cM[(c) & 1] : cL[(c) & 1];        \
     *reinterpret_cast<uint4*>(d_) = make_uint4(w_[0], w_[1], w_[2], w_[3]);                            \
   } while (0)
-#define MAPX_X_WLOAD(CUR, kt, c, LD)                                                                   \
+#define MAPX_X_WLOAD(CUR, c)                                                                           \
   do {                                                                                                 \
     constexpr bool isA_ = (c) < OpA::NV;                                                               \
     constexpr int i_ = isA_ ? (c) : (c) - OpA::NV;                                                     \
-    if ((LD) == 2) {           /* the last tile: K bound checked, `ok` set for the masked cut */       \
-      if (isA_) la[(CUR) ^ 1].load_one(i_, a.A, a.lda, m0, a.M, kbeg + ((kt) + 3) * kXBK, kend);       \
-      else lb[(CUR) ^ 1].load_one(i_, a.B, a.ldb, n0, a.N, kbeg + ((kt) + 3) * kXBK, kend);            \
-      break;                                                                                           \
-    }                                                                                                  \
     const float* const q_ = isA_ ? wA + goffA[i_] : wB + goffB[i_];                                    \
     if (isA_) {                                                                                        \
       la[(CUR) ^ 1].r[i_][0] = *reinterpret_cast<const float4*>(q_);                                   \
@@ -413,15 +427,14 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
       lb[(CUR) ^ 1].r[i_][1] = *reinterpret_cast<const float4*>(q_ + 4);                               \
     }                                                                                                  \
   } while (0)
-#define MAPX_X_CUT_UNIT(CUR, kt, u, MK, LD)                                                                      \
+#define MAPX_X_CUT_UNIT(CUR, u)                                                                                  \
   do {                                                                                                 \
     constexpr int c_ = (u) / 12, e_ = ((u) % 12) / 3, st_ = (u) % 3;                                   \
     constexpr bool isA_ = c_ < OpA::NV;                                                                \
     constexpr int i_ = isA_ ? c_ : c_ - OpA::NV;                                                       \
     if (st_ == 0) {                                                                                    \
       const float4 v_ = isA_ ? la[(CUR) ^ 1].r[i_][e_ >> 1] : lb[(CUR) ^ 1].r[i_][e_ >> 1];            \
-      const bool keep_ = !(MK) || (isA_ ? la[(CUR) ^ 1].ok[i_] : lb[(CUR) ^ 1].ok[i_]);                \
-      piece(keep_ ? ((e_ & 1) ? v_.z : v_.x) : 0.f, keep_ ? ((e_ & 1) ? v_.w : v_.y) : 0.f, cH[c_ & 1][e_], cr0, cr1); \
+      piece((e_ & 1) ? v_.z : v_.x, (e_ & 1) ? v_.w : v_.y, cH[c_ & 1][e_], cr0, cr1);                 \
     } else if (st_ == 1) {                                                                             \
       float t0_, t1_;                                                                                  \
       piece(cr0, cr1, cM[c_ & 1][e_], t0_, t1_);                                                       \
@@ -429,10 +442,10 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
     } else {                                                                                           \
       cL[c_ & 1][e_] = pk_bf16(cr0, cr1);                                                              \
       if (c_ > 0 && e_ < 3) MAPX_X_WSTORE(CUR, (c_ > 0 ? c_ - 1 : 0), e_);                             \
-      if ((LD) != 0 && c_ > 0 && e_ == 3) MAPX_X_WLOAD(CUR, kt, (c_ > 0 ? c_ - 1 : 0), LD);            \
+      if (c_ > 0 && e_ == 3) MAPX_X_WLOAD(CUR, (c_ > 0 ? c_ - 1 : 0));                                 \
     }                                                                                                  \
   } while (0)
-#define MAPX_X_WSLOTS(CUR, kt, ST, MK, LD)                                                                          \
+#define MAPX_X_WSLOTS(CUR)                                                                                          \
   unroll_seq([&](auto zc) __attribute__((always_inline)) {                                             \
     constexpr int z = decltype(zc)::value;                                                             \
     constexpr int h = z / 24, t4 = (z % 24) / 6, i = t4 / 2, j = t4 % 2, term = z % 6;                 \
@@ -450,16 +463,14 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
       if (op == 0) fa[1][pl][t] = OpA::frag1(As_cur, pl, abase, lane, 1, t);                           \
       else fb[1][pl][t] = OpB::frag1(Bs_cur, pl, bbase, lane, 1, t);                                   \
     }                                                                                                  \
-    if ((ST) && !(kDbg & 2)) {                                                                         \
-      if constexpr (z < 42) MAPX_X_CUT_UNIT(CUR, kt, (z < 42 ? 6 + z : 0), MK, LD);                    \
+    if (!(kDbg & 2)) {                                                                                 \
+      if constexpr (z < 42) MAPX_X_CUT_UNIT(CUR, (z < 42 ? 6 + z : 0));                                \
       if constexpr (z >= 42 && z < 45) MAPX_X_WSTORE(CUR, 3, (z >= 42 && z < 45 ? z - 42 : 0));        \
-      if constexpr (z == 45) { if ((LD) != 0) MAPX_X_WLOAD(CUR, kt, 3, LD); }                          \
+      if constexpr (z == 45) MAPX_X_WLOAD(CUR, 3);                                                     \
     }                                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
   }, std::make_integer_sequence<int, 48>{})
-  // ST: tile kt+1 exists (cut + store it);  MK: it is the last, K-partial tile (zero-fill by its `ok` flags);
-  // LD: 0 no tile kt+3, 1 a full tile (steady loop), 2 the last tile (bounds-checked loads that set `ok`).
-#define MAPX_X_KSTEP_WEAVE(CUR, kt, ST, MK, LD)                                                                 \
+#define MAPX_X_KSTEP_WEAVE(CUR, kt)                                                                             \
   do {                                                                                                 \
     static_assert(OpA::NV == 2 && OpB::NV == 2 && WMT * WNT == 4, "weave: 4 chunks and 48 MFMAs per K-step"); \
     const bf16_t* const As_cur = smem + (CUR) * kBuf;                                                  \
@@ -472,15 +483,16 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
     }, std::make_integer_sequence<int, 12>{});                                                         \
     uint32_t cH[2][4], cM[2][4], cL[2][4];        /* [chunk parity][pair] */                           \
     float cr0 = 0.f, cr1 = 0.f;                                                                        \
-    const float* const wA = a.A + (int64_t)(kbeg + ((kt) + 3) * kXBK) * (A_KC ? 1 : a.lda);            \
-    const float* const wB = a.B + (int64_t)(kbeg + ((kt) + 3) * kXBK) * (B_KC ? 1 : a.ldb);            \
+    const int wk_ = wk0 + kXBK * (((kt) + 3 < nk - 1 ? (kt) + 3 : nk - 1) - 1);   /* tile min(kt+3, nk-1) */ \
+    const float* const wA = a.A + (int64_t)wk_ * (A_KC ? 1 : a.lda);                                   \
+    const float* const wB = a.B + (int64_t)wk_ * (B_KC ? 1 : a.ldb);                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
-    if ((ST) && !(kDbg & 2)) {                                                                         \
-      MAPX_X_CUT_UNIT(CUR, kt, 0, MK, LD); MAPX_X_CUT_UNIT(CUR, kt, 1, MK, LD); MAPX_X_CUT_UNIT(CUR, kt, 2, MK, LD); \
-      MAPX_X_CUT_UNIT(CUR, kt, 3, MK, LD); MAPX_X_CUT_UNIT(CUR, kt, 4, MK, LD); MAPX_X_CUT_UNIT(CUR, kt, 5, MK, LD); \
+    if (!(kDbg & 2)) {                                                                                 \
+      MAPX_X_CUT_UNIT(CUR, 0); MAPX_X_CUT_UNIT(CUR, 1); MAPX_X_CUT_UNIT(CUR, 2);                       \
+      MAPX_X_CUT_UNIT(CUR, 3); MAPX_X_CUT_UNIT(CUR, 4); MAPX_X_CUT_UNIT(CUR, 5);                       \
     }                                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
-    MAPX_X_WSLOTS(CUR, kt, ST, MK, LD);                                                                             \
+    MAPX_X_WSLOTS(CUR);                                                                                             \
     __syncthreads();                                                                                   \
   } while (0)
 #define MAPX_X_LOOPS(LATE)                                                                             \
@@ -533,35 +545,12 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
       OpB::coords(threadIdx.x + i * NT, tr, tc);
       soffB[i] = OpA::LDS_ELEMS + tr * OpB::LD + tc;
     }
-    // K-steps 0 .. nk-5 are steady (tile kt+3 is a full one); the last four are the same woven body with
-    // the last tile's special cases switched in by literals.  kt is even after the loop and 4 or 5 K-steps
-    // remain (nk >= 4), so the tail exists in two parities.
-#define MAPX_X_TAIL4(C0, C1, k0)                                                                       \
-  do {                                                                                                 \
-    MAPX_X_KSTEP_WEAVE(C0, (k0), true, false, 2);          /* loads the last tile */                   \
-    MAPX_X_KSTEP_WEAVE(C1, (k0) + 1, true, false, 0);                                                  \
-    MAPX_X_KSTEP_WEAVE(C0, (k0) + 2, true, true, 0);       /* cuts the last tile */                    \
-    MAPX_X_KSTEP_WEAVE(C1, (k0) + 3, false, false, 0);                                                 \
-  } while (0)
-    if (nk >= 4) {
-      int kt = 0;
-      for (; kt + 5 < nk; kt += 2) {
-        MAPX_X_KSTEP_WEAVE(0, kt, true, false, 1);
-        MAPX_X_KSTEP_WEAVE(1, kt + 1, true, false, 1);
-      }
-      if (nk - kt == 5) {
-        MAPX_X_KSTEP_WEAVE(0, kt, true, false, 1);
-        MAPX_X_TAIL4(1, 0, kt + 1);
-      } else {
-        MAPX_X_TAIL4(0, 1, kt);
-      }
-    } else {
-      for (int kt = 0; kt < nk; kt += 2) {
-        MAPX_X_KSTEP(0, kt, false, true, false);
-        if (kt + 1 < nk) MAPX_X_KSTEP(1, kt + 1, false, true, false);
-      }
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      MAPX_X_KSTEP_WEAVE(0, kt);
+      MAPX_X_KSTEP_WEAVE(1, kt + 1);
     }
-#undef MAPX_X_TAIL4
+    if (kt < nk) MAPX_X_KSTEP_WEAVE(0, kt);
   } else {
     MAPX_X_LOOPS(false);
   }
@@ -688,6 +677,7 @@ int gemm_f32x3_launch(int a_kc, int b_kc, int M, int N, int K, const float* A, i
   const int cls = (a_kc && b_kc) ? 0 : a_kc ? 1 : 2;
   int tile = (big >= 160) ? (cls == 0 ? big_tile / 100 : cls == 1 ? big_tile / 10 % 10 : big_tile % 10) : 0;
   if (tile_hint >= 0 && (tile_hint & 255) <= 3) tile = tile_hint & 255;
+  if (tile == 3 && (!vec || K - (int64_t)g.k_chunk * (nsplit - 1) <= kXBK)) tile = 2;   // the woven layout: vector loads, >= 2 K-steps per slab
   hipError_t e;
   if (a_kc && b_kc) e = launch_layout_x3<true, true>(g, vec, tile, nsplit, stream);
   else if (a_kc) e = launch_layout_x3<true, false>(g, vec, tile, nsplit, stream);
