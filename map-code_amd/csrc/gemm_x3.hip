@@ -55,12 +55,16 @@ template <class F, int... Z>
 __device__ __forceinline__ void unroll_seq(F&& f, std::integer_sequence<int, Z...>) {
   (f(std::integral_constant<int, Z>{}), ...);
 }
-// order in which a k16 half's 12 fragments are read = order in which the MFMAs first need them
-// (tiles (0,0) (0,1) (1,0) (1,1); per tile lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi): {operand, plane, tile}
-__host__ __device__ constexpr int frag_order(int q, int what) {
-  constexpr int order[12][3] = {{0, 2, 0}, {1, 0, 0}, {0, 0, 0}, {1, 2, 0}, {0, 1, 0}, {1, 1, 0},
-                                {1, 0, 1}, {1, 2, 1}, {1, 1, 1}, {0, 2, 1}, {0, 0, 1}, {0, 1, 1}};
-  return order[q][what];
+// order in which a k16 half's 3 (WMT + WNT) fragments are read = order in which the MFMAs first need them
+// (tiles (0,0) (0,1) .. row-major; per tile lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi):
+// what = 0: operand (0 A, 1 B), 1: plane (0 hi, 1 mid, 2 lo), 2: tile of the operand
+__host__ __device__ constexpr int frag_order(int q, int what, int wnt) {
+  constexpr int first[6][2] = {{0, 2}, {1, 0}, {0, 0}, {1, 2}, {0, 1}, {1, 1}};   // tile (0,0): {operand, plane}
+  constexpr int later[3] = {0, 2, 1};                                            // a new row / column: planes in use order
+  if (q < 6) return what == 0 ? first[q][0] : what == 1 ? first[q][1] : 0;
+  const int r = (q - 6) / 3, pl = later[(q - 6) % 3];
+  const bool isB = r < wnt - 1;                 // columns 1 .. WNT-1 of B come first (tiles (0, j)), then rows of A
+  return what == 0 ? (isB ? 1 : 0) : what == 1 ? pl : (isB ? r + 1 : r - (wnt - 1) + 1);
 }
 
 // Cut of 8 fp32 values into three planes of 8 bf16, each piece ROUNDED to nearest (v_cvt_pk_bf16_f32)
@@ -314,7 +318,10 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
     la[SET].template store<MASK>(smem + (buf) * kBuf);                   \
     lb[SET].template store<MASK>(smem + (buf) * kBuf + OpA::LDS_ELEMS);  \
   } while (0)
-  constexpr bool kWeave = (WR * WC == 4 && WMT * WNT == 4 && VEC);
+  constexpr bool kWeave = (WR * WC == 4 && VEC);
+  // the woven K-step (below): MFMA slots, units of the cut, fragments per k16 half, slots that carry units
+  constexpr int kNM = 12 * WMT * WNT, kNCH = OpA::NV + OpB::NV, kU = 12 * kNCH, kFR = 3 * (WMT + WNT);
+  constexpr int kPre = 6, kS = kNM - 4;
   // The woven layout wants every K-step of its loop alike.  So (nk >= 2) the K range's remainder goes
   // FIRST: tile 0 is the partial one, [kbeg, kbeg + rem) with rem in 8..32, cut here with the bounds-
   // checked load and the masked store; tiles 1.. are full ones starting at wk0 = kbeg + rem.  And where the
@@ -392,20 +399,22 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
     }                                                                                                  \
     __syncthreads();                                                                                   \
   } while (0)
-  // One wave per SIMD (kWeave: 4 waves, wave tile 64 x 64): nothing but the ORDER of the wave's own
-  // instructions can put the cut of tile kt+1 into the shadow of tile kt's MFMAs, and left alone the
-  // compiler emits the 48 MFMAs, then the whole cut.  An MFMA holds the SIMD's vector issue for 8 of its 32
-  // cycles and every other instruction costs about 4 (MI355X_MICROARCH.md, 'vector-instruction ISSUE
-  // cost'): 5 instructions per MFMA gap hide.  So the steady-state K-step is 48 slots fenced by
-  // sched_barrier(0); slot z = MFMA z + at most one UNIT of the cut (4 chunks x 4 pairs x 3 pieces = 48
-  // units of 5, 5 and 1 VALU) + at most one memory instruction:
-  //   before MFMA 0   the first half's 12 fragment reads, then units 0..5 under their latency
+  // One wave per SIMD (kWeave: the 4-wave layouts): nothing but the ORDER of the wave's own instructions
+  // can put the cut of tile kt+1 into the shadow of tile kt's MFMAs, and left alone the compiler emits all
+  // MFMAs, then the whole cut.  An MFMA holds the SIMD's vector issue for 8 of its 32 cycles and every
+  // other instruction costs about 4 (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost'): 5 instructions
+  // per MFMA gap hide.  So a K-step is kNM = 12 WMT WNT slots fenced by sched_barrier(0); slot z = MFMA z +
+  // its share of the cut's UNITS (chunks x 4 pairs x 3 pieces, of 5, 5 and 1 VALU) + at most one memory
+  // instruction.  For the 128 x 128 tile (48 MFMAs, 4 chunks = 48 units):
+  //   before MFMA 0   the first k16 half's 12 fragment reads, then units 0..5 under their latency
   //   slots 0..41     unit 6 + z;  even slots < 24: a fragment of the second k16 half (for MFMAs 24..47);
   //                   the 1-VALU units of chunk c carry chunk c-1's three LDS stores and its two global loads
   //   slots 42..45    the last chunk's stores and loads
+  // (128 x 64: 24 slots for 36 units, 1 or 2 per slot; 64 x 64: 12 slots for 24 units — those two are bound
+  // by the cut's issue slots, not by the MFMAs.)
   // Out-of-range rows / columns of an edge tile are not masked here: their addresses are clamped to the
   // operand's first row / column and what they contribute lands in outputs the epilogue does not store
-  // (only the K bound needs zeros, and the steady loop never meets it).
+  // (only the K bound needs zeros, and the prologue has dealt with it).
 #define MAPX_X_WSTORE(CUR, c, pl)                                                                      \
   do {                                                                                                 \
     constexpr bool isA_ = (c) < OpA::NV;                                                               \
@@ -445,10 +454,10 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
       if (c_ > 0 && e_ == 3) MAPX_X_WLOAD(CUR, (c_ > 0 ? c_ - 1 : 0));                                 \
     }                                                                                                  \
   } while (0)
-#define MAPX_X_WSLOTS(CUR)                                                                                          \
+#define MAPX_X_WSLOTS(CUR)                                                                             \
   unroll_seq([&](auto zc) __attribute__((always_inline)) {                                             \
     constexpr int z = decltype(zc)::value;                                                             \
-    constexpr int h = z / 24, t4 = (z % 24) / 6, i = t4 / 2, j = t4 % 2, term = z % 6;                 \
+    constexpr int h = z / (kNM / 2), t4 = (z % (kNM / 2)) / 6, i = t4 / WNT, j = t4 % WNT, term = z % 6; \
     if (!(kDbg & 4)) {                                                                                 \
     if (term == 0) cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][2][i], fb[h][0][j], cor[i][j], 0, 0, 0); \
     if (term == 1) cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][0][i], fb[h][2][j], cor[i][j], 0, 0, 0); \
@@ -458,35 +467,44 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
     if (term == 5) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][0][i], fb[h][0][j], acc[i][j], 0, 0, 0); \
     }                                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
-    if constexpr (z < 24 && z % 2 == 0) {                                                              \
-      constexpr int q = z / 2, op = frag_order(q, 0), pl = frag_order(q, 1), t = frag_order(q, 2);     \
-      if (op == 0) fa[1][pl][t] = OpA::frag1(As_cur, pl, abase, lane, 1, t);                           \
-      else fb[1][pl][t] = OpB::frag1(Bs_cur, pl, bbase, lane, 1, t);                                   \
+    if constexpr (z < kNM / 2) {                                                                       \
+      constexpr int q0 = z * kFR / (kNM / 2), q1 = (z + 1) * kFR / (kNM / 2);                          \
+      if constexpr (q0 < q1) {                                                                         \
+        constexpr int op = frag_order(q0, 0, WNT), pl = frag_order(q0, 1, WNT), t = frag_order(q0, 2, WNT); \
+        if (op == 0) fa[1][pl][t] = OpA::frag1(As_cur, pl, abase, lane, 1, t);                         \
+        else fb[1][pl][t] = OpB::frag1(Bs_cur, pl, bbase, lane, 1, t);                                 \
+      }                                                                                                \
     }                                                                                                  \
     if (!(kDbg & 2)) {                                                                                 \
-      if constexpr (z < 42) MAPX_X_CUT_UNIT(CUR, (z < 42 ? 6 + z : 0));                                \
-      if constexpr (z >= 42 && z < 45) MAPX_X_WSTORE(CUR, 3, (z >= 42 && z < 45 ? z - 42 : 0));        \
-      if constexpr (z == 45) MAPX_X_WLOAD(CUR, 3);                                                     \
+      if constexpr (z < kS) {                                                                          \
+        constexpr int u0 = kPre + z * (kU - kPre) / kS, u1 = kPre + (z + 1) * (kU - kPre) / kS;        \
+        if constexpr (u0 < u1) MAPX_X_CUT_UNIT(CUR, u0);                                               \
+        if constexpr (u0 + 1 < u1) MAPX_X_CUT_UNIT(CUR, (u0 + 1 < u1 ? u0 + 1 : 0));                   \
+        if constexpr (u0 + 2 < u1) MAPX_X_CUT_UNIT(CUR, (u0 + 2 < u1 ? u0 + 2 : 0));                   \
+        static_assert(u1 - u0 <= 3, "at most three units of the cut per slot");                        \
+      }                                                                                                \
+      if constexpr (z >= kS && z < kS + 3) MAPX_X_WSTORE(CUR, kNCH - 1, (z >= kS && z < kS + 3 ? z - kS : 0)); \
+      if constexpr (z == kS + 3) MAPX_X_WLOAD(CUR, kNCH - 1);                                          \
     }                                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
-  }, std::make_integer_sequence<int, 48>{})
+  }, std::make_integer_sequence<int, kNM>{})
 #define MAPX_X_KSTEP_WEAVE(CUR, kt)                                                                             \
   do {                                                                                                 \
-    static_assert(OpA::NV == 2 && OpB::NV == 2 && WMT * WNT == 4, "weave: 4 chunks and 48 MFMAs per K-step"); \
     const bf16_t* const As_cur = smem + (CUR) * kBuf;                                                  \
     const bf16_t* const Bs_cur = As_cur + OpA::LDS_ELEMS;                                              \
     bf16x8 fa[2][3][WMT], fb[2][3][WNT];          /* [k16 half][plane hi/mid/lo][tile] */              \
     unroll_seq([&](auto qc) __attribute__((always_inline)) {                                           \
-      constexpr int q = decltype(qc)::value, op = frag_order(q, 0), pl = frag_order(q, 1), t = frag_order(q, 2); \
+      constexpr int q = decltype(qc)::value, op = frag_order(q, 0, WNT), pl = frag_order(q, 1, WNT), t = frag_order(q, 2, WNT); \
       if (op == 0) fa[0][pl][t] = OpA::frag1(As_cur, pl, abase, lane, 0, t);                           \
       else fb[0][pl][t] = OpB::frag1(Bs_cur, pl, bbase, lane, 0, t);                                   \
-    }, std::make_integer_sequence<int, 12>{});                                                         \
+    }, std::make_integer_sequence<int, kFR>{});                                                        \
     uint32_t cH[2][4], cM[2][4], cL[2][4];        /* [chunk parity][pair] */                           \
     float cr0 = 0.f, cr1 = 0.f;                                                                        \
     const int wk_ = wk0 + kXBK * (((kt) + 3 < nk - 1 ? (kt) + 3 : nk - 1) - 1);   /* tile min(kt+3, nk-1) */ \
     const float* const wA = a.A + (int64_t)wk_ * (A_KC ? 1 : a.lda);                                   \
     const float* const wB = a.B + (int64_t)wk_ * (B_KC ? 1 : a.ldb);                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
+    static_assert(kPre == 6 && kU >= 12, "the units before the first MFMA are written out");           \
     if (!(kDbg & 2)) {                                                                                 \
       MAPX_X_CUT_UNIT(CUR, 0); MAPX_X_CUT_UNIT(CUR, 1); MAPX_X_CUT_UNIT(CUR, 2);                       \
       MAPX_X_CUT_UNIT(CUR, 3); MAPX_X_CUT_UNIT(CUR, 4); MAPX_X_CUT_UNIT(CUR, 5);                       \
@@ -677,7 +695,8 @@ int gemm_f32x3_launch(int a_kc, int b_kc, int M, int N, int K, const float* A, i
   const int cls = (a_kc && b_kc) ? 0 : a_kc ? 1 : 2;
   int tile = (big >= 160) ? (cls == 0 ? big_tile / 100 : cls == 1 ? big_tile / 10 % 10 : big_tile % 10) : 0;
   if (tile_hint >= 0 && (tile_hint & 255) <= 3) tile = tile_hint & 255;
-  if (tile == 3 && (!vec || K - (int64_t)g.k_chunk * (nsplit - 1) <= kXBK)) tile = 2;   // the woven layout: vector loads, >= 2 K-steps per slab
+  // the woven K loop (4-wave layouts with vector loads) wants >= 2 K-steps in every slab
+  if (tile != 2 && vec && K - (int64_t)g.k_chunk * (nsplit - 1) <= kXBK) tile = 2;
   hipError_t e;
   if (a_kc && b_kc) e = launch_layout_x3<true, true>(g, vec, tile, nsplit, stream);
   else if (a_kc) e = launch_layout_x3<true, false>(g, vec, tile, nsplit, stream);

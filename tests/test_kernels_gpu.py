@@ -760,12 +760,14 @@ def test_dropout_mask_is_regenerated_not_stored(ops):
     backward pass regenerates the very mask of the forward pass from (seed, offset); another offset
     gives another mask; the device-side offset adds to the host one (graph replay)."""
     n, p = 1_000_003, 0.3
-    x = torch.randn(n, device=DEV)
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    sign = lambda: torch.where(torch.rand(n, device=DEV, generator=gen) < 0.5, -1.0, 1.0)
+    x = (torch.rand(n, device=DEV, generator=gen) + 0.25) * sign()        # never 0: "kept" is visible as y != 0
     y = ops.dropout(x, p, 42, 7)
     keep = y != 0
     assert abs(float(keep.float().mean()) - (1 - p)) < 3e-3
     assert torch.allclose(y[keep], x[keep] / (1 - p), rtol=1e-6)
-    g = torch.randn(n, device=DEV)
+    g = (torch.rand(n, device=DEV, generator=gen) + 0.25) * sign()
     assert torch.equal(ops.dropout(g, p, 42, 7) != 0, keep)                       # same mask in backward
     assert not torch.equal(ops.dropout(x, p, 42, 8) != 0, keep)
     dev = torch.tensor([3], dtype=torch.int32, device=DEV)
