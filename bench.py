@@ -28,7 +28,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = {"f32": 157.3,     # v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
-                    "bf16": 2500.0}   # v_mfma_f32_32x32x16_bf16, dense bf16 peak (no 2:1 sparsity)
+                    "bf16": 2500.0,   # v_mfma_f32_32x32x16_bf16, dense bf16 peak (no 2:1 sparsity)
+                    # fp32 products formed from six bf16 MFMAs (csrc/gemm_x3.hip: operands cut into three bf16
+                    # pieces): the instruction-level ceiling of that algorithm in fp32-equivalent flop/s
+                    "f32x3": 2500.0 / 6}
 ROUND = "r02"                # profiles/<ROUND>_pmc_hbm_traffic[_bf16].json is this round's PMC summary
 
 WORKLOADS = {
@@ -40,12 +43,14 @@ WORKLOADS = {
 
 # kernel class (ops.Timers name) -> substrings of the rocprof kernel names it launches
 PMC_MAP = {
-    "gemm_fwd_nt": [["gemm_f32_kernel<", ", true, true, true,"], ["gemm_bf16_kernel<", ", true, true, "]],
-    "gemm_dx_nn": [["gemm_f32_kernel<", ", true, false, true,"], ["gemm_bf16_kernel<", ", true, false, "]],
+    "gemm_fwd_nt": [["gemm_f32_kernel<", ", true, true, true,"], ["gemm_f32x3_kernel<", ", true, true, true>"],
+                    ["gemm_bf16_kernel<", ", true, true, "]],
+    "gemm_dx_nn": [["gemm_f32_kernel<", ", true, false, true,"], ["gemm_f32x3_kernel<", ", true, false, true>"],
+                   ["gemm_bf16_kernel<", ", true, false, "]],
     "gemm_dw_tn": [["gemm_f32_kernel<", ", false, false, true,"], ["gemm_tn_deep_kernel"],
-                   ["gemm_bf16_kernel<", ", false, false, "]],
-    "gemm_enc_grouped_fwd": ["gemm_grouped_kernel<false>"],
-    "gemm_enc_grouped_dw": ["gemm_grouped_kernel<true>"],
+                   ["gemm_f32x3_kernel<", ", false, false, true>"], ["gemm_bf16_kernel<", ", false, false, "]],
+    "gemm_enc_grouped_fwd": [["gemm_grouped_kernel<false>"], ["gemm_grouped_x3_kernel<false>"]],
+    "gemm_enc_grouped_dw": [["gemm_grouped_kernel<true>"], ["gemm_grouped_x3_kernel<true>"]],
     "nce_fwd": ["nce_fwd_"],
     "nce_table_grad": ["seg_reduce_pass_a<8, true"],
     "seg_reduce_rows": ["seg_reduce_pass_a<4, false"],
@@ -452,7 +457,8 @@ def main():
     # committed PMC passes measured per launch
     data_dependent = ("table_adam_update", "table_adam_catchup", "nce_table_grad", "seg_reduce_rows")
     # the grouped feat_encoder kernels compute in fp32 in either mode; the dense GEMM classes follow --dtype
-    mfma_peak = lambda name: MFMA_PEAK_TFLOPS["f32" if "grouped" in name else args.dtype]
+    f32_kind = "f32x3" if ops.GEMM_X3 else "f32"
+    mfma_peak = lambda name: MFMA_PEAK_TFLOPS[f32_kind if ("grouped" in name or args.dtype == "f32") else args.dtype]
     gemm_flops = 0.0
     for name, s in ksum.items():
         per_launch = s["work"] / s["launches"]
@@ -464,6 +470,11 @@ def main():
             gemm_flops += s["work"] / ksteps
             kernels[name] = dict(bound="mfma", achieved=rate / 1e12, peak=mfma_peak(name), unit="TFLOP/s",
                                  frac=rate / 1e12 / mfma_peak(name))
+            if mfma_peak(name) == MFMA_PEAK_TFLOPS["f32x3"]:
+                # algorithmic fp32 flop/s; `peak` = bf16 dense peak / 6 MFMAs per product; for comparison the
+                # same rate against the fp32 MFMA instruction's own peak (what gemm.hip's kernels are bound by)
+                kernels[name].update(peak_is="bf16 dense MFMA peak / 6 (three-piece bf16 split, six MFMAs per product)",
+                                     frac_of_f32_mfma_peak=rate / 1e12 / MFMA_PEAK_TFLOPS["f32"])
         else:
             kernels[name] = dict(bound="hbm", achieved=rate / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                                  frac=rate / 1e9 / HBM_PEAK_GBS)
@@ -472,7 +483,9 @@ def main():
                              algorithmic_per_launch=per_launch,
                              bytes_from="pmc" if measured else "model")
     dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
-    roofline = dict(kernel=dominant, **{k: kernels[dominant][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")})
+    roofline = dict(kernel=dominant, **{k: kernels[dominant][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                                         "peak_is", "frac_of_f32_mfma_peak")
+                                        if k in kernels[dominant]})
     hbm_name = "nce_fwd"
     out = {
         "metric": "pretrain samples/sec (DCNv2+MFP, Avazu, bs4096)", "value": world * B * args.steps / dt,
@@ -483,7 +496,9 @@ def main():
                                f"({'uniform' if args.uniform else 'Zipf(1.1)'} per field), F={cfg.num_fields}, "
                                f"V={cfg.input_size}, E=16, H=1000x3, cross x3, P=32, K=25, mask_ratio 0.3"
                                + (", bf16 GEMM operands / activations over fp32 master weights, tables and optimizer"
-                                  if args.dtype == "bf16" else ""),
+                                  if args.dtype == "bf16" else
+                                  ", fp32 GEMMs as six bf16 MFMAs per product (operands cut into three bf16 pieces, fp32 accumulation)"
+                                  if ops.GEMM_X3 else ""),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "launch": ("eager" if not tr.use_graph else
                               "hipGraph replay of mask + forward + backward; pack and merge + optimizer replayed per message size, RCCL calls eager"
@@ -495,7 +510,7 @@ def main():
         # all GEMM flops of a step over the whole step's time, against the dtype's dense MFMA peak:
         # what the step as a whole makes of the matrix cores (the per-kernel `roofline.frac` is a
         # kernel running alone)
-        "step_mfma_frac": gemm_flops / (dt / args.steps) / 1e12 / MFMA_PEAK_TFLOPS[args.dtype],
+        "step_mfma_frac": gemm_flops / (dt / args.steps) / 1e12 / MFMA_PEAK_TFLOPS[f32_kind if args.dtype == "f32" else args.dtype],
         "step_gemm_gflop": gemm_flops / 1e9,
         "traffic_stale": pmc_stale(args.dtype), "traffic_from": os.path.relpath(pmc_file(args.dtype), ROOT),
         "kernels": kernels, "final_loss": final_loss,
