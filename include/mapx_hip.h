@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 30
+#define MAPX_ABI_VERSION 31
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -324,8 +324,11 @@ int mapx_dynamic_mask_mfp(const int64_t* ids, int64_t B, int F, int L,
 /* mapx_dynamic_mask_mfp on batch rows that are still in the HBM-resident split: batch row b is row
  * sel[b] (0 <= sel[b] < N, caller-checked) of split_ids [N,F].  Replaces the DataLoader's collate of
  * trainer.py:51-58, 306-313 (and the row-gather + copy launches a resident split otherwise needs in
- * front of every step).  Same outputs as mapx_dynamic_mask_mfp(split_ids[sel], ...). */
-int mapx_dynamic_mask_mfp_rows(const int64_t* split_ids, int64_t N, const int64_t* sel, int64_t B, int F, int L,
+ * front of every step).  Same outputs as mapx_dynamic_mask_mfp(split_ids[sel], ...).
+ * sel_cursor_dev_opt (device int64, may be NULL): the batch is sel[*cursor .. *cursor + B) — `sel` is then a
+ * whole epoch's permutation and a captured step walks it by itself (the caller advances the cursor). */
+int mapx_dynamic_mask_mfp_rows(const int64_t* split_ids, int64_t N, const int64_t* sel,
+                               const int64_t* sel_cursor_dev_opt, int64_t B, int F, int L,
                                const int64_t* masked_index_in, uint64_t seed, uint64_t offset,
                                const int32_t* offset_dev, int64_t* ids_out, int64_t* labels,
                                int64_t* masked_index_out, int32_t* keys_out_opt, hipStream_t stream);

@@ -68,10 +68,14 @@ __global__ void __launch_bounds__(256) mask_mfp_kernel(const int64_t* __restrict
                                                        int64_t* __restrict__ labels,
                                                        int64_t* __restrict__ mi_out,
                                                        int32_t* __restrict__ keys_out,
-                                                       const int64_t* __restrict__ sel) {
+                                                       const int64_t* __restrict__ sel,
+                                                       const int64_t* __restrict__ sel_cursor) {
   // sel (optional): batch row b is row sel[b] of `ids` — the batch is cut out of the HBM-resident
   // split here instead of by two index kernels and two copies in front of every step
   if (offset_dev) offset += (uint64_t)(uint32_t)*offset_dev;   // graph-replay safe stream offset
+  // sel_cursor (optional): `sel` is a whole epoch's permutation and the batch starts at *sel_cursor — a
+  // captured step then walks the epoch by itself, with no copy of row numbers in front of each replay
+  if (sel && sel_cursor) sel += *sel_cursor;
   for (int64_t b0 = (int64_t)blockIdx.x * kMaskRows; b0 < B; b0 += (int64_t)gridDim.x * kMaskRows) {
     const int64_t rows = (B - b0) < kMaskRows ? (B - b0) : kMaskRows;
     for (int64_t i = threadIdx.x; i < rows * F; i += blockDim.x) {
@@ -202,11 +206,12 @@ extern "C" int mapx_dynamic_mask_mfp(const int64_t* ids, int64_t B, int F, int L
   if (B == 0) return MAPX_OK;
   hipLaunchKernelGGL(mask_mfp_kernel, dim3(grid_for(B, kMaskRows)), dim3(256), 0, stream, ids, B, F, L,
                      masked_index_in, seed, offset, offset_dev, ids_out, labels, masked_index_out, keys_out_opt,
-                     (const int64_t*)nullptr);
+                     (const int64_t*)nullptr, (const int64_t*)nullptr);
   return check_launch("dynamic_mask_mfp");
 }
 
-extern "C" int mapx_dynamic_mask_mfp_rows(const int64_t* split_ids, int64_t N, const int64_t* sel, int64_t B, int F,
+extern "C" int mapx_dynamic_mask_mfp_rows(const int64_t* split_ids, int64_t N, const int64_t* sel,
+                                          const int64_t* sel_cursor_dev_opt, int64_t B, int F,
                                           int L, const int64_t* masked_index_in, uint64_t seed, uint64_t offset,
                                           const int32_t* offset_dev, int64_t* ids_out, int64_t* labels,
                                           int64_t* masked_index_out, int32_t* keys_out_opt, hipStream_t stream) {
@@ -215,7 +220,8 @@ extern "C" int mapx_dynamic_mask_mfp_rows(const int64_t* split_ids, int64_t N, c
                "dynamic_mask_mfp_rows: bad arguments");
   if (B == 0) return MAPX_OK;
   hipLaunchKernelGGL(mask_mfp_kernel, dim3(grid_for(B, kMaskRows)), dim3(256), 0, stream, split_ids, B, F, L,
-                     masked_index_in, seed, offset, offset_dev, ids_out, labels, masked_index_out, keys_out_opt, sel);
+                     masked_index_in, seed, offset, offset_dev, ids_out, labels, masked_index_out, keys_out_opt, sel,
+                     sel_cursor_dev_opt);
   return check_launch("dynamic_mask_mfp_rows");
 }
 

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmapx_hip.so")
 
-MAPX_ABI_VERSION = 30
+MAPX_ABI_VERSION = 31
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_CROSS, EPI_ADD, EPI_RELU_MASK = range(6)
 
 _p, _i, _i64, _u64, _f, _d, _sz = (C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double,
@@ -91,7 +91,7 @@ SIGNATURES = {
     "mapx_eval_metrics_workspace_bytes": (_sz, [_i64]),
     "mapx_eval_metrics": (_i, [_p, _p, _i64, _p, _p, _sz, _p]),
     "mapx_dynamic_mask_mfp": (_i, [_p, _i64, _i, _i, _p, _u64, _u64, _p, _p, _p, _p, _p, _p]),
-    "mapx_dynamic_mask_mfp_rows": (_i, [_p, _i64, _p, _i64, _i, _i, _p, _u64, _u64, _p, _p, _p, _p, _p, _p]),
+    "mapx_dynamic_mask_mfp_rows": (_i, [_p, _i64, _p, _p, _i64, _i, _i, _p, _u64, _u64, _p, _p, _p, _p, _p, _p]),
     "mapx_dynamic_mask_rfd": (_i, [_p, _i64, _i, _i, _p, _p, _p, _i64, _i, _p, _p, _i64, _u64, _u64, _p, _p, _p,
                                   _p, _p]),
     "mapx_adamw_dense": (_i, [_p, _p, _p, _p, _i64, _p, _i, _p, _d, _d, _d, _d, _p]),

@@ -198,6 +198,10 @@ COLSUM_CHUNKS = lib.mapx_colsum_chunks()
 # at all) was also slower (1.49 vs 1.42 ms): the slabs are cold by then, whereas a reduce right
 # behind the GEMM finds them in L2 / Infinity Cache.
 DEFER = os.environ.get("MAPX_DEFER", "0") == "1"
+# the bias gradients' row-chunk partials alone (7 tiny second-stage launches per step on the GEMM chains,
+# 128 x N floats each: nothing to go cold)
+# measured: 0.943 / 0.950 vs 0.952 / 0.954 ms per step, same box: on by default
+DEFER_COLSUM = DEFER or os.environ.get("MAPX_DEFER_COLSUM", "1") == "1"
 
 
 def defer_sum(dst, src, stride, nsplit, n):
@@ -850,7 +854,7 @@ def colsum(x, out=None, defer=False):
         ws = scratch(lib.mapx_colsum_bf16_workspace_bytes(Nn), x.device)
         check(lib.mapx_colsum_bf16(x.data_ptr(), x.stride(0), M, Nn, ptr(out), ptr(ws), ws.numel(), stream()))
         return out
-    defer = DEFER and defer and out is not None
+    defer = DEFER_COLSUM and defer and out is not None
     if out is None:
         out = torch.empty(Nn, dtype=torch.float32, device=x.device)
     ws = _partials(Nn, x.device, defer)
@@ -917,7 +921,7 @@ def relu_mask_colsum(dy, y, db=None, defer=False):
         y = y.contiguous()
     M, Nn = dy.shape
     dz = torch.empty(M, Nn, dtype=torch.float32, device=dy.device)
-    defer = DEFER and defer and db is not None
+    defer = DEFER_COLSUM and defer and db is not None
     if db is None:
         db = torch.empty(Nn, dtype=torch.float32, device=dy.device)
     ws = _partials(Nn, dy.device, defer)
@@ -953,7 +957,7 @@ def cross_bwd_pre_colsum(g, x0, u, dx0=None, db=None, defer=False, plus_g=False)
     acc = dx0 is not None
     if dx0 is None:
         dx0 = torch.empty(M, Nn, dtype=torch.float32, device=g.device)
-    defer = DEFER and defer and db is not None
+    defer = DEFER_COLSUM and defer and db is not None
     if db is None:
         db = torch.empty(Nn, dtype=torch.float32, device=g.device)
     ws = _partials(Nn, g.device, defer)
@@ -1042,21 +1046,24 @@ def eval_metrics(logits, labels):
     return dict(auc=auc, logloss=ll, avg_logits=ml, avg_probs=mp, positives=int(npos), negatives=int(nneg))
 
 
-def dynamic_mask_mfp(ids, L, masked_index=None, seed=0, offset=0, offset_dev=None, sel=None):
+def dynamic_mask_mfp(ids, L, masked_index=None, seed=0, offset=0, offset_dev=None, sel=None, sel_cursor=None,
+                     batch=None):
     """-> (masked ids [B,F], labels [B,L], masked_index [B,L])  (trainer.py:217-232).
-    `sel` int64 [B]: `ids` is the whole HBM-resident split [N,F] and the batch is its rows sel."""
+    `sel` int64 [B]: `ids` is the whole HBM-resident split [N,F] and the batch is its rows sel.
+    `sel_cursor` (device int64 scalar) + `batch`: sel is a whole epoch's permutation and the batch is
+    sel[*cursor : *cursor + batch] (a captured step walks the epoch without host copies)."""
     require_gpu(ids)
     ids = ids.contiguous()
     if sel is not None:
         require_gpu(sel)
         sel = sel.contiguous()
-        B, F = sel.numel(), ids.shape[1]
+        B, F = (sel.numel() if sel_cursor is None else int(batch)), ids.shape[1]
         out = torch.empty(B, F, dtype=torch.int64, device=ids.device)
         labels = torch.empty(B, L, dtype=torch.int64, device=ids.device)
         mi_out = torch.empty(B, L, dtype=torch.int64, device=ids.device)
         mi_in = masked_index.contiguous() if masked_index is not None else None
         keys = torch.empty(B * F, dtype=torch.int32, device=ids.device)
-        check(lib.mapx_dynamic_mask_mfp_rows(ptr(ids), ids.shape[0], ptr(sel), B, F, L, ptr(mi_in), seed, offset,
+        check(lib.mapx_dynamic_mask_mfp_rows(ptr(ids), ids.shape[0], ptr(sel), ptr(sel_cursor), B, F, L, ptr(mi_in), seed, offset,
                                              ptr(offset_dev), ptr(out), ptr(labels), ptr(mi_out), ptr(keys), stream()))
         _keys_of[0], _keys_of[1] = out, keys
         return out, labels, mi_out

@@ -33,12 +33,17 @@ class RowsRef:
     gather of X and Y and no copy of them into a captured step's static buffers — only the 32 KB of
     row numbers.  Quacks like the (X, Y) tensors where the step loop touches them."""
 
-    def __init__(self, split, sel):
+    def __init__(self, split, sel, order=None, start=0, stride=0, cursor=None, batch=None):
         self.split, self.sel = split, sel
+        # where the rows come from: sel == order[start : start + B], the same rank's next batch starts
+        # `stride` later.  A captured step (GraphedStep) keeps its own copy of `order` and a device-side
+        # cursor instead of receiving 32 KB of row numbers in front of every replay: then `sel` is the
+        # whole permutation and the batch is sel[*cursor : *cursor + batch].
+        self.order, self.start, self.stride, self.cursor, self.batch = order, start, stride, cursor, batch
 
     @property
     def shape(self):
-        return (self.sel.shape[0], self.split.X.shape[1])
+        return (self.batch if self.cursor is not None else self.sel.shape[0], self.split.X.shape[1])
 
     @property
     def is_cuda(self):
@@ -94,7 +99,7 @@ class DeviceSplit:
             else:
                 sel = order[s:s + batch_size]
                 if rows:
-                    ref = RowsRef(self, sel)
+                    ref = RowsRef(self, sel, order=order, start=s, stride=w * batch_size)
                     yield ref, ref
                 else:
                     yield self.X[sel], self.Y[sel]
@@ -144,20 +149,43 @@ class GraphedStep:
 
     def __init__(self, trainer, step_fn, X, Y):
         self.trainer = _weak(trainer)       # no trainer <-> graph cycle: both die by reference count
-        self.X, self.Y = X.clone(), Y.clone()
+        # Batches that are rows of the resident split in an epoch's permutation (RowsRef with `order`): the
+        # graph owns a copy of the permutation and a device-side cursor that it advances itself, so a replay
+        # is preceded by no copy at all (before: two 5-us copies + launch gaps in front of every step).
+        self.walk = (isinstance(X, RowsRef) and X.order is not None and X.stride > 0 and Y is X
+                     and os.environ.get("MAPX_WALK", "1") == "1")
+        if self.walk:
+            self.order = X.order.clone()
+            self.cursor = torch.full((1,), X.start, dtype=torch.int64, device=X.device)
+            self.stride, self._src, self._expect = X.stride, X.order, X.start
+            self.X = self.Y = RowsRef(X.split, self.order, cursor=self.cursor, batch=X.shape[0])
+        else:
+            self.X = X.clone()
+            self.Y = self.X if Y is X else Y.clone()
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         gs, sd = trainer.global_step, trainer.optimizer.steps_done
         try:
             with _capture(self.graph):
                 self.out = step_fn(self.X, self.Y)
+                if self.walk:
+                    self.cursor.add_(self.stride)
         finally:
             # the capture pass ran the Python bookkeeping but no kernel
             trainer.global_step, trainer.optimizer.steps_done = gs, sd
 
     def __call__(self, X, Y):
-        self.X.copy_(X)
-        self.Y.copy_(Y)
+        if self.walk:
+            if X.order is not self._src:               # a new epoch's permutation
+                self.order.copy_(X.order)
+                self._src, self._expect = X.order, None
+            if X.start != self._expect:                # (first batch of an epoch, or a caller that skips around)
+                self.cursor.fill_(X.start)
+            self._expect = X.start + self.stride
+        else:
+            self.X.copy_(X)
+            if self.Y is not self.X:
+                self.Y.copy_(Y)
         self.graph.replay()
         # the step's host-side effects (a replay runs no Python)
         opt = self.trainer.optimizer
@@ -217,6 +245,9 @@ class GraphedBackward:
         try:
             with _capture(self.graph):
                 self.out = fwd_bwd_fn(self.X, self.Y)
+                # deferred partial sums (bias gradients) belong to this graph: the list that names them
+                # exists only while the capture runs, a replay would leave them unsummed for the tail
+                ops.flush_deferred()
         finally:
             if self.early:
                 layers.plan_observers.remove(publish)
@@ -502,10 +533,12 @@ class Trainer:
     # ------------------------------------------------------------------ masking (a1, a2)
     def dynamic_mask(self, inputs, sampling_method="normal", masked_index=None, replace_feat=None):
         ids = inputs["input_ids"]
-        sel = None
+        sel = sel_cursor = batch = None
         if isinstance(ids, RowsRef):                   # rows of the resident split
             if self.args.pt_type == "MFP":
-                ids, sel = ids.split.X, ids.sel
+                ref = ids
+                ids, sel = ref.split.X, ref.sel
+                sel_cursor, batch = ref.cursor, ref.shape[0]
             else:
                 ids = ids.X
         F = self.model_config.num_fields
@@ -520,13 +553,14 @@ class Trainer:
             offset, offset_dev = (self.rank << 40) + (3 << 36) + self._mask_calls, None
         if masked_index is None:
             if sampling_method == "normal":        # L distinct fields per row (trainer.py:222)
-                masked_index = torch.rand(ids.shape[0] if sel is None else sel.shape[0], F, device=ids.device,
+                masked_index = torch.rand(ids.shape[0] if sel is None else batch, F, device=ids.device,
                                           generator=self._generator()).argsort(1)[:, :L].contiguous()
             elif sampling_method != "randint":
                 raise NotImplementedError(sampling_method)
         if self.args.pt_type == "MFP":
             inputs["input_ids"], inputs["labels"], inputs["masked_index"] = ops.dynamic_mask_mfp(
-                ids, L, masked_index=masked_index, seed=seed, offset=offset, offset_dev=offset_dev, sel=sel)
+                ids, L, masked_index=masked_index, seed=seed, offset=offset, offset_dev=offset_dev, sel=sel,
+                sel_cursor=sel_cursor, batch=batch)
         elif self.args.pt_type == "RFD":
             x_train = self._split(self.train_dataset).X
             cfg = self.model_config
