@@ -784,7 +784,7 @@ __global__ void __launch_bounds__(256) sum_tasks_kernel(SumTasks tasks) {
 }
 
 // column sums of X [M,N] (bias gradients): stage 1 = 32 row chunks -> partial[32][N]
-constexpr int kColChunks = 64;
+constexpr int kColChunks = 128;
 __global__ void __launch_bounds__(256) colsum_stage1_kernel(const float* __restrict__ x, int64_t ld,
                                                             int M, int N, float* __restrict__ part) {
   // block = 64 columns x 4 row lanes
@@ -839,23 +839,27 @@ __global__ void __launch_bounds__(256) cross_bwd_pre_kernel(const float* __restr
 //   OP 0 (ReLU layer):   dz = y > 0 ? dy : 0                      db = colsum(dz)
 //   OP 1 (cross layer):  t = g * x0 ; dx0 (+)= g * u (+ g)        db = colsum(t)
 //                        accumulate bit 0: add to the dx0 already there; bit 1: also add g
-// Block = 64 columns x 4 row lanes over one of kColChunks row chunks; stage 2 adds the chunks.
-template <int OP>
+// Block = CL column lanes (x float4) x 256 / CL row lanes over one of kColChunks row chunks; stage 2 adds the
+// chunks.  CL = 64 or 32, whichever wastes fewer lanes on the last column block (N = 368: 92 float4 columns
+// are 2 blocks of 64 with 28 % of the lanes idle, or 3 blocks of 32 with 4 %).
+template <int OP, int CL>
 __global__ void __launch_bounds__(256) ew_colsum_kernel(const float* __restrict__ a, int64_t lda,
                                                         const float* __restrict__ b, int64_t ldb,
                                                         const float* __restrict__ c, int M, int N,
                                                         float* __restrict__ o1, float* __restrict__ o2,
                                                         int accumulate, float* __restrict__ part) {
-  // 64 lanes x float4 = 256 columns per block row; 4 row lanes; N % 4 == 0, lda % 4 == 0 (host-checked)
-  const int col = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-  const int rl = threadIdx.x >> 6;
+  // CL lanes x float4 columns per block row; RL row lanes; N % 4 == 0, lda % 4 == 0 (host-checked)
+  constexpr int RL = 256 / CL;
+  const int cl = threadIdx.x % CL;
+  const int col = (blockIdx.x * CL + cl) * 4;
+  const int rl = threadIdx.x / CL;
   const int rows_per = (M + kColChunks - 1) / kColChunks;
   const int r0 = blockIdx.y * rows_per;
   const int r1 = (r0 + rows_per < M) ? r0 + rows_per : M;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (col < N) {
 #pragma unroll 4
-    for (int r = r0 + rl; r < r1; r += 4) {
+    for (int r = r0 + rl; r < r1; r += RL) {
       const int64_t i = ((int64_t)r * N + col) >> 2;
       const float4 av = reinterpret_cast<const float4*>(a)[((int64_t)r * lda + col) >> 2];   // a may be a column slice
       const float4 bv = reinterpret_cast<const float4*>(b)[((int64_t)r * ldb + col) >> 2];
@@ -881,18 +885,24 @@ __global__ void __launch_bounds__(256) ew_colsum_kernel(const float* __restrict_
       }
     }
   }
-  __shared__ float4 s[4][64];
-  s[rl][threadIdx.x & 63] = v;
+  __shared__ float4 s[RL][CL];
+  s[rl][cl] = v;
   __syncthreads();
   if (rl == 0 && col < N) {
-    float4 t = s[0][threadIdx.x];
+    float4 t = s[0][cl];
 #pragma unroll
-    for (int k = 1; k < 4; ++k) {
-      const float4 q = s[k][threadIdx.x];
+    for (int k = 1; k < RL; ++k) {       // fixed order: bit-reproducible
+      const float4 q = s[k][cl];
       t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
     }
     *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * N + col) = t;
   }
+}
+
+// 32 instead of 64 column lanes per block when that leaves fewer lanes of the last column block idle
+static inline bool ew_narrow_lanes(int N) {
+  const int c4 = (N + 3) / 4;
+  return ((c4 + 31) / 32) * 32 < ((c4 + 63) / 64) * 64;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1286,8 +1296,12 @@ extern "C" int mapx_relu_mask_colsum(const float* dy, int64_t ld_dy, const float
     return MAPX_EWORKSPACE;
   }
   float* part = static_cast<float*>(ws);
-  hipLaunchKernelGGL(ew_colsum_kernel<0>, dim3((N + 255) / 256, kColChunks), dim3(256), 0, stream, dy, ld_dy, y,
-                     ld_y, (const float*)nullptr, M, N, dz, (float*)nullptr, 0, part);
+  if (ew_narrow_lanes(N))
+    hipLaunchKernelGGL((ew_colsum_kernel<0, 32>), dim3((N + 127) / 128, kColChunks), dim3(256), 0, stream, dy, ld_dy, y,
+                       ld_y, (const float*)nullptr, M, N, dz, (float*)nullptr, 0, part);
+  else
+    hipLaunchKernelGGL((ew_colsum_kernel<0, 64>), dim3((N + 255) / 256, kColChunks), dim3(256), 0, stream, dy, ld_dy, y,
+                       ld_y, (const float*)nullptr, M, N, dz, (float*)nullptr, 0, part);
   if (db) hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, db);
   return check_launch("relu_mask_colsum");
 }
@@ -1304,8 +1318,12 @@ extern "C" int mapx_cross_bwd_pre_colsum(const float* g, int64_t ld_g, const flo
     return MAPX_EWORKSPACE;
   }
   float* part = static_cast<float*>(ws);
-  hipLaunchKernelGGL(ew_colsum_kernel<1>, dim3((N + 255) / 256, kColChunks), dim3(256), 0, stream, g, ld_g, x0,
-                     (int64_t)N, u, M, N, t, dx0, accumulate, part);
+  if (ew_narrow_lanes(N))
+    hipLaunchKernelGGL((ew_colsum_kernel<1, 32>), dim3((N + 127) / 128, kColChunks), dim3(256), 0, stream, g, ld_g, x0,
+                       (int64_t)N, u, M, N, t, dx0, accumulate, part);
+  else
+    hipLaunchKernelGGL((ew_colsum_kernel<1, 64>), dim3((N + 255) / 256, kColChunks), dim3(256), 0, stream, g, ld_g, x0,
+                       (int64_t)N, u, M, N, t, dx0, accumulate, part);
   if (db) hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, db);
   return check_launch("cross_bwd_pre_colsum");
 }
