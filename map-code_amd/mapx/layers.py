@@ -140,7 +140,7 @@ class PlanSlot:
                 t.record_stream(self.origin)
 
     @staticmethod
-    def start_many(slots, implied=()):
+    def start_many(slots, implied=(), after=None):
         """Build the plans of several tables' slots with ONE chain of launches (ops.SegPlan.build_many:
         both sorts of a step cost one sort's chain of dependent kernels).  The side stream waits for
         every slot's keys; slots that were started already are left alone."""
@@ -155,6 +155,13 @@ class PlanSlot:
         # caller's stream order guarantees it): the side stream then forks from one point of the step
         # instead of joining two streams (measured: no difference, 0.756 vs 0.757 ms in bf16 mode)
         forked = [(s not in implied) and ops.stream_wait_event(side, s.ready, s.origin) for s in slots]
+        if after is not None:
+            # also behind what `after` (a stream) has enqueued so far: the graph runtime runs a side chain
+            # AHEAD of later-captured work of the queue it lands on, so the caller names the kernels the
+            # chain must not delay (bf16 mode: the deep tower's GEMMs waited 140 us behind the sort)
+            with torch.cuda.stream(after):
+                ev = ops.record_event()
+            ops.stream_wait_event(side, ev, after)
         with torch.cuda.stream(side):
             plans = ops.SegPlan.build_many(keys, [s.table.num_rows for s in slots])
             for s, plan in zip(slots, plans):

@@ -26,6 +26,9 @@ NCE_EARLY = os.environ.get("MAPX_NCE_EARLY", "1") == "1"
 # with the old single-table kernels back to back: 1.39 ms) unbalance them.  "auto": off for fp32, fwd
 # for bf16, where the GEMMs are short and the sort is the longest chain of the step.
 JOINT_PLAN = os.environ.get("MAPX_JOINT_PLAN", "auto")
+# the joint plan in forward waits for the deep tower's GEMMs to be on their way (bf16 mode: 0.690 vs 0.744 ms;
+# without it the graph runtime ran the sort chain ahead of them on the queue they share)
+PLAN_AFTER_DNN = os.environ.get("MAPX_PLAN_AFTER_DNN", "1") == "1"
 
 _OTHER_BACKBONES = ("trans", "fignn", "fgcnn")
 
@@ -226,7 +229,8 @@ class DCNV2(BaseModel):
                 # (the tower stream forked from the main one behind the gather: the sampled ids' event
                 # implies that the embedding's keys are final)
                 PlanSlot.start_many([self.embed.table.plan, self.mfp_criterion.table.plan],
-                                    implied=[self.embed.table.plan] if IMPLIED else ())
+                                    implied=[self.embed.table.plan] if IMPLIED else (),
+                                    after=main if PLAN_AFTER_DNN else None)
             elif nce_idx is not None and mode == "bwd" and self.mfp_criterion.table.plan is not None:
                 # the head's backward node starts both (PlanSlot.start_many from IndexLinear's partner list)
                 self.mfp_criterion.table.plan.partners = [self.embed.table.plan]
