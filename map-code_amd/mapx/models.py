@@ -24,7 +24,9 @@ NCE_EARLY = os.environ.get("MAPX_NCE_EARLY", "1") == "1"
 # side chain is appended to one of them, and the fp32 step's two queues are balanced with the small
 # embedding sort in forward and the sampled ids' sort in backward; the same two sorts as one lump (also
 # with the old single-table kernels back to back: 1.39 ms) unbalance them.  "auto": off for fp32, fwd
-# for bf16, where the GEMMs are short and the sort is the longest chain of the step.
+# for bf16, where the GEMMs are short and the sort is the longest chain of the step.  (Round 2, fp32: the
+# embedding's sort started by the head's backward node right behind the sampled ids' sort — so that the
+# head's backward no longer waits 34 us for the latter — 1.13 vs 0.96 ms.)
 JOINT_PLAN = os.environ.get("MAPX_JOINT_PLAN", "auto")
 # the joint plan in forward waits for the deep tower's GEMMs to be on their way (bf16 mode: 0.690 vs 0.744 ms;
 # without it the graph runtime ran the sort chain ahead of them on the queue they share)
