@@ -258,6 +258,60 @@ __device__ inline void epilogue_rows_x3(const GemmX3Args& a, float* __restrict__
   }
 }
 
+// The same pass for 16-byte-aligned operands, without control flow between a load and its use: a thread's
+// column never changes (NT is a multiple of BN / 4), so the bias is fetched once; rows go in batches of
+// four whose auxiliary operands are all requested before the first of them is used; rows past M re-read
+// row m0 and are simply not stored.  (With the loads inside `if (m < M)` blocks every iteration paid a
+// full L2 round trip: 2.4 us per launch on the 128 x 128 tile with bias + ReLU.)
+template <int EPI, int BM, int BN, int NT>
+__device__ inline void epilogue_rows_x3_vec(const GemmX3Args& a, float* __restrict__ C, const float* __restrict__ tile,
+                                            int m0, int n0) {
+  constexpr int LDT = BN + 4, CPR = BN / 4, RPI = NT / CPR, NIT = BM / RPI, U = NIT < 4 ? NIT : 4;
+  static_assert(NT % CPR == 0 && BM % RPI == 0 && NIT % U == 0, "epilogue tiling");
+  constexpr bool kBias = EPI >= MAPX_EPI_BIAS && EPI <= MAPX_EPI_BIAS_CROSS;
+  constexpr bool kAux1 = EPI == MAPX_EPI_BIAS_CROSS || EPI == MAPX_EPI_ADD || EPI == MAPX_EPI_RELU_MASK;
+  constexpr bool kAux2 = EPI == MAPX_EPI_BIAS_CROSS;
+  const int c0 = (threadIdx.x % CPR) * 4, r0 = threadIdx.x / CPR;
+  const int n = n0 + c0;
+  const bool ncol = n < a.N;
+  const int ns = ncol ? n : 0;
+  float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (kBias) b0 = *reinterpret_cast<const float4*>(a.bias + ns);
+#pragma unroll
+  for (int it0 = 0; it0 < NIT; it0 += U) {
+    float4 t[U], p1[U], p2[U];
+    bool ok[U];
+    int64_t mrow[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = r0 + (it0 + u) * RPI, m = m0 + row;
+      ok[u] = ncol && m < a.M;
+      mrow[u] = m < a.M ? m : m0;
+      t[u] = *reinterpret_cast<const float4*>(tile + row * LDT + c0);
+      if (kAux1) p1[u] = *reinterpret_cast<const float4*>(a.aux1 + mrow[u] * a.ld1 + ns);
+      if (kAux2) p2[u] = *reinterpret_cast<const float4*>(a.aux2 + mrow[u] * a.ld2 + ns);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float v[4] = {t[u].x + b0.x, t[u].y + b0.y, t[u].z + b0.z, t[u].w + b0.w};
+      const float x1[4] = {p1[u].x, p1[u].y, p1[u].z, p1[u].w}, x2[4] = {p2[u].x, p2[u].y, p2[u].z, p2[u].w};
+      float w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (EPI == MAPX_EPI_BIAS_RELU) v[e] = fmaxf(v[e], 0.f);
+        w[e] = v[e];
+        if (EPI == MAPX_EPI_BIAS_CROSS) v[e] = x1[e] + x2[e] * v[e];
+        if (EPI == MAPX_EPI_ADD) v[e] += x1[e];
+        if (EPI == MAPX_EPI_RELU_MASK) v[e] = x1[e] > 0.f ? v[e] : 0.f;
+      }
+      if (ok[u]) {
+        *reinterpret_cast<float4*>(C + mrow[u] * a.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+        if (kAux2) *reinterpret_cast<float4*>(a.out2 + mrow[u] * a.ldo2 + n) = make_float4(w[0], w[1], w[2], w[3]);
+      }
+    }
+  }
+}
+
 // WR x WC waves, each owning WMT x WNT MFMA tiles of 32 x 32: block tile (32 WMT WR) x (32 WNT WC).
 // 8 waves (two per SIMD) on a 128 x 128 tile: while one wave of a SIMD cuts and stores its share of
 // the next tile (VALU + LDS), its partner's MFMAs keep the matrix pipe busy — the overlap that one
@@ -597,6 +651,17 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
   auto al16 = [](const void* p, int64_t ld) { return p == nullptr || ((uintptr_t)p % 16 == 0 && ld % 4 == 0); };
   const bool vio = a.N % 4 == 0 && al16(C, a.ldc) && al16(a.aux1, a.ld1) && al16(a.aux2, a.ld2) && al16(a.out2, a.ldo2) &&
                    al16(a.bias, 0);
+  if (vio) {
+    switch (a.epi) {
+      case MAPX_EPI_BIAS: epilogue_rows_x3_vec<MAPX_EPI_BIAS, BM, BN, NT>(a, C, tile, m0, n0); break;
+      case MAPX_EPI_BIAS_RELU: epilogue_rows_x3_vec<MAPX_EPI_BIAS_RELU, BM, BN, NT>(a, C, tile, m0, n0); break;
+      case MAPX_EPI_BIAS_CROSS: epilogue_rows_x3_vec<MAPX_EPI_BIAS_CROSS, BM, BN, NT>(a, C, tile, m0, n0); break;
+      case MAPX_EPI_ADD: epilogue_rows_x3_vec<MAPX_EPI_ADD, BM, BN, NT>(a, C, tile, m0, n0); break;
+      case MAPX_EPI_RELU_MASK: epilogue_rows_x3_vec<MAPX_EPI_RELU_MASK, BM, BN, NT>(a, C, tile, m0, n0); break;
+      default: epilogue_rows_x3_vec<MAPX_EPI_NONE, BM, BN, NT>(a, C, tile, m0, n0); break;
+    }
+    return;
+  }
   switch (a.epi) {
     case MAPX_EPI_BIAS: epilogue_rows_x3<MAPX_EPI_BIAS, BM, BN, NT>(a, C, tile, m0, n0, vio); break;
     case MAPX_EPI_BIAS_RELU: epilogue_rows_x3<MAPX_EPI_BIAS_RELU, BM, BN, NT>(a, C, tile, m0, n0, vio); break;

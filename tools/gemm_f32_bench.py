@@ -34,7 +34,7 @@ def run(a_kc, b_kc, M, N, K, epi=EPI_NONE, nsplit=1, tile=-1):
     return us, 2.0 * M * N * K / us / 1e6
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "fixed"):
     print("mode", os.environ.get("MAPX_GEMM", "x3"))
     if len(sys.argv) > 1 and sys.argv[1] == "ablate":       # one line per 128 x 128 layout; see tools/x3_ablate.sh
         for tile in (2, 3):
@@ -60,3 +60,44 @@ if __name__ == "__main__":
         for tile in ((-1, 0, 1, 2, 3) if os.environ.get('MAPX_GEMM', 'x3') == 'x3' else (-1,)):
             us, tf = run(a[0], a[1], a[2], a[3], a[4], epi=a[5], nsplit=a[6], tile=tile)
             print(f"  {name:26s} tile {tile:2d}: {us:7.1f} us  {tf:7.1f} TF")
+
+
+def graph_time(fn, n=50, reps=10):
+    """us per call with n dependent calls captured in one hipGraph (no host launch gaps)."""
+    fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        g.replay()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / (reps * n)
+
+
+def fixed_cost():
+    """K-independent cost of a launch inside a graph: time at K = 32 .. 512 per tile layout and epilogue."""
+    for (M, N) in ((4096, 1000), (4096, 368)):
+        for epi in (EPI_NONE, EPI_BIAS_RELU):
+            for tile in (0, 1, 3, 2):
+                row = []
+                for K in (32, 64, 128, 256, 512):
+                    A = torch.randn(M, K, device="cuda")
+                    B = torch.randn(N, K, device="cuda")
+                    bias = torch.randn(N, device="cuda") if epi != EPI_NONE else None
+                    out = torch.empty(M, N, device="cuda")
+                    us = graph_time(lambda: ops.gemm(A, B, True, True, M, N, K, out=out, epi=epi, bias=bias, tile=tile))
+                    row.append(f"K{K}: {us:5.1f}")
+                print(f"{M}x{N} epi {epi} tile {tile}: " + "  ".join(row))
+    x = torch.zeros(256, device="cuda")
+    print(f"empty-ish kernel (x.add_(1) on 256 floats) in the same graph harness: {graph_time(lambda: x.add_(1)):.2f} us")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "fixed":
+    fixed_cost()
