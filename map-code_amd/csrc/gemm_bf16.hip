@@ -236,6 +236,87 @@ __device__ inline void epilogue_rows_h(const GemmHArgs& a, void* __restrict__ C,
   }
 }
 
+// The same pass for the all-aligned case (vio), without control flow between a load and its use — see
+// epilogue_rows_x3_vec (gemm_x3.hip): bias once per thread (its 8 columns never change), rows in batches
+// of four with every auxiliary load of the batch requested first, rows past M re-read row m0 and are not stored.
+template <int EPI, bool C_F32, bool AUX_F32, int BM, int BN>
+__device__ inline void epilogue_rows_h_vec(const GemmHArgs& a, void* __restrict__ C, const float* __restrict__ tile,
+                                           int m0, int n0) {
+  constexpr int LDT = BN + 4, CPR = BN / 8, RPI = 256 / CPR, NIT = BM / RPI, U = NIT < 4 ? NIT : 4;
+  static_assert(256 % CPR == 0 && BM % RPI == 0 && NIT % U == 0, "epilogue tiling");
+  constexpr bool kBias = EPI >= MAPX_EPI_BIAS && EPI <= MAPX_EPI_BIAS_CROSS;
+  constexpr bool kAux1 = EPI == MAPX_EPI_BIAS_CROSS || EPI == MAPX_EPI_ADD || EPI == MAPX_EPI_RELU_MASK;
+  constexpr bool kAux2 = EPI == MAPX_EPI_BIAS_CROSS;
+  const int c0 = (threadIdx.x % CPR) * 8, r0 = threadIdx.x / CPR;
+  const int n = n0 + c0;
+  const bool ncol = n < a.N;
+  const int ns = ncol ? n : 0;
+  float b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (kBias) {
+    const float4 b0 = *reinterpret_cast<const float4*>(a.bias + ns), b1 = *reinterpret_cast<const float4*>(a.bias + ns + 4);
+    b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+  }
+#pragma unroll
+  for (int it0 = 0; it0 < NIT; it0 += U) {
+    float4 t0[U], t1[U], q0[U], q1[U];
+    bf16x8 h1[U], h2[U];
+    bool ok[U];
+    int64_t mrow[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = r0 + (it0 + u) * RPI, m = m0 + row;
+      ok[u] = ncol && m < a.M;
+      mrow[u] = m < a.M ? m : m0;
+      t0[u] = *reinterpret_cast<const float4*>(tile + row * LDT + c0);
+      t1[u] = *reinterpret_cast<const float4*>(tile + row * LDT + c0 + 4);
+      if (kAux1) {
+        if (AUX_F32) {
+          const float* p = reinterpret_cast<const float*>(a.aux1) + mrow[u] * a.ld1 + ns;
+          q0[u] = *reinterpret_cast<const float4*>(p);
+          q1[u] = *reinterpret_cast<const float4*>(p + 4);
+        } else {
+          h1[u] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(a.aux1) + mrow[u] * a.ld1 + ns);
+        }
+      }
+      if (kAux2) h2[u] = *reinterpret_cast<const bf16x8*>(a.aux2 + mrow[u] * a.ld2 + ns);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float v[8] = {t0[u].x, t0[u].y, t0[u].z, t0[u].w, t1[u].x, t1[u].y, t1[u].z, t1[u].w}, w[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] += b[e];
+        float x1 = 0.f, x2 = 0.f;
+        if (kAux1) x1 = AUX_F32 ? (e < 4 ? (&q0[u].x)[e] : (&q1[u].x)[e - 4]) : (float)h1[u][e];
+        if (kAux2) x2 = (float)h2[u][e];
+        if (EPI == MAPX_EPI_BIAS_RELU) v[e] = fmaxf(v[e], 0.f);
+        w[e] = v[e];
+        if (EPI == MAPX_EPI_BIAS_CROSS) v[e] = x1 + x2 * v[e];
+        if (EPI == MAPX_EPI_ADD) v[e] += x1;
+        if (EPI == MAPX_EPI_RELU_MASK) v[e] = x1 > 0.f ? v[e] : 0.f;
+      }
+      if (ok[u]) {
+        if (C_F32) {
+          float* c = reinterpret_cast<float*>(C) + mrow[u] * a.ldc + n;
+          *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(C) + mrow[u] * a.ldc + n) = o;
+        }
+        if (kAux2) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16_t)w[e];
+          *reinterpret_cast<bf16x8*>(a.out2 + mrow[u] * a.ldo2 + n) = o;
+        }
+      }
+    }
+  }
+}
+
 template <int WMT, int WNT, bool A_KC, bool B_KC, bool VEC>
 __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmHArgs a, int c_f32, int aux1_f32) {
   constexpr int BM = 64 * WMT, BN = 64 * WNT;
@@ -371,7 +452,11 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmHArgs a, int c_f32, 
   };
   const bool vio = a.N % 8 == 0 && al(C, a.ldc, c_f32 ? 4 : 2) && al(a.aux1, a.ld1, aux1_f32 ? 4 : 2) &&
                    al(a.aux2, a.ld2, 2) && al(a.out2, a.ldo2, 2) && al(a.bias, 0, 4);
-#define MAPX_EPI_CASE(E, CF, AF) epilogue_rows_h<E, CF, AF, BM, BN>(a, C, tile, m0, n0, vio)
+#define MAPX_EPI_CASE(E, CF, AF)                                                          \
+  do {                                                                                   \
+    if (vio) epilogue_rows_h_vec<E, CF, AF, BM, BN>(a, C, tile, m0, n0);                 \
+    else epilogue_rows_h<E, CF, AF, BM, BN>(a, C, tile, m0, n0, vio);                    \
+  } while (0)
   if (a.dbg & 1) return;
   if (c_f32) {
     switch (a.epi) {       // fp32 outputs: logits of the heads, weight-gradient slabs
