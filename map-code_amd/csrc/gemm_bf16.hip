@@ -29,6 +29,7 @@
 // round trip), LDS stores one K-step ahead.
 #include "../../include/mapx_hip.h"
 #include "common.h"
+#include <utility>
 
 namespace mapx {
 
@@ -36,6 +37,7 @@ typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmHArgs {
   const bf16_t* A; int64_t lda;
@@ -54,6 +56,12 @@ struct GemmHArgs {
 };
 
 constexpr int kHBK = 64;
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a constant expression
+template <class F, int... Z>
+__device__ __forceinline__ void unroll_seq_h(F&& f, std::integer_sequence<int, Z...>) {
+  (f(std::integral_constant<int, Z>{}), ...);
+}
 
 // One operand's staging: global tile -> registers (16-byte chunks of 8 bf16) -> LDS, and LDS -> fragments.
 // VEC requires: leading dimension % 8 == 0, 16-B aligned base, contiguous extent % 8 == 0: a chunk is
@@ -112,25 +120,21 @@ struct OperandH {
     }
   }
 
-  // fragments of k16-step s4 (k = 16 s4 + 8 (lane >> 5) + j) for this wave's T tiles
-  __device__ static inline void frags(const bf16_t* __restrict__ s, int base, int lane, int s4, bf16x8 (&f)[T]) {
+  // fragment of k16-step s4 (k = 16 s4 + 8 (lane >> 5) + j) for this wave's tile t
+  __device__ static inline bf16x8 frag1(const bf16_t* __restrict__ s, int base, int lane, int s4, int t) {
     const int l31 = lane & 31, kh = lane >> 5;
+    if (KC) return *reinterpret_cast<const bf16x8*>(s + (base + 32 * t + l31) * LD + 16 * s4 + 8 * kh);
+    // transposing read: lane 4q+p of a 16-lane group addresses block row q, columns 4p..4p+3, and
+    // receives column (lane & 15) of the block's 4 rows
+    const int q = (lane >> 2) & 3, p = lane & 3, half = (lane >> 4) & 1;
+    const bf16_t* a0 = s + (16 * s4 + 8 * kh + q) * LD + base + 32 * t + 16 * half + 4 * p;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0 + 4 * LD));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+  __device__ static inline void frags(const bf16_t* __restrict__ s, int base, int lane, int s4, bf16x8 (&f)[T]) {
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      if (KC) {
-        f[t] = *reinterpret_cast<const bf16x8*>(s + (base + 32 * t + l31) * LD + 16 * s4 + 8 * kh);
-      } else {
-        // transposing read: lane 4q+p of a 16-lane group addresses block row q, columns 4p..4p+3, and
-        // receives column (lane & 15) of the block's 4 rows
-        const int q = (lane >> 2) & 3, p = lane & 3, half = (lane >> 4) & 1;
-        const bf16_t* a0 = s + (16 * s4 + 8 * kh + q) * LD + base + 32 * t + 16 * half + 4 * p;
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-            (__attribute__((address_space(3))) bf16x4*)(a0));
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-            (__attribute__((address_space(3))) bf16x4*)(a0 + 4 * LD));
-        f[t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-      }
-    }
+    for (int t = 0; t < T; ++t) f[t] = frag1(s, base, lane, s4, t);
   }
 };
 
@@ -317,7 +321,8 @@ __device__ inline void epilogue_rows_h_vec(const GemmHArgs& a, void* __restrict_
   }
 }
 
-template <int WMT, int WNT, bool A_KC, bool B_KC, bool VEC>
+// WEAVE (needs VEC and >= 2 K-steps in every slab): the K loop as hand-ordered slots, see below.
+template <int WMT, int WNT, bool A_KC, bool B_KC, bool VEC, bool WEAVE>
 __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmHArgs a, int c_f32, int aux1_f32) {
   constexpr int BM = 64 * WMT, BN = 64 * WNT;
   using OpA = OperandH<BM, WMT, A_KC, VEC>;
@@ -379,54 +384,170 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmHArgs a, int c_f32, 
   // block-uniform: every chunk of every FULL K-step of this tile is inside the matrix (a K tail
   // only touches the last tile, which the epilogue loop below stores with its predicates)
   const bool interior = VEC && (m0 + BM <= a.M) && (n0 + BN <= a.N);
-  if (nk > 0) MAPX_H_LOAD(0, 0);
-  if (nk > 1) MAPX_H_LOAD(1, 1);
-  if (nk > 0) MAPX_H_STORE(0, 0);
-  if (nk > 2) MAPX_H_LOAD(0, 2);
-  __syncthreads();
-  // one K-step on LDS buffer CUR (= kt & 1, a literal: the loop is unrolled by two so that the
-  // register sets are indexed statically — a runtime index would send them to scratch)
-#define MAPX_H_KSTEP(CUR, kt, STEADY, MASK)                                                            \
+  if constexpr (WEAVE) {
+    // One wave per SIMD: only the order of the wave's own instructions can keep the matrix pipe fed, and
+    // hipcc's order — all fragment reads, all MFMAs, then the LDS stores and global loads — leaves it idle
+    // for a third of a K-step (0.84 us per K-step of 64 where 16 MFMAs take 0.35).  As in gemm_x3.hip the
+    // K-step is a sequence of slots fenced by sched_barrier(0): slot z = MFMA z + a fragment of the k16 step
+    // after the next + (even slots) the LDS store of one chunk of tile kt+1 / (odd slots) the global load that
+    // refills a stored chunk with tile kt+3.  Every K-step is the same body: the K remainder goes first
+    // (tile 0 is the partial one, handled by the bounds-checked loads and the masked store below), edge
+    // tiles clamp their out-of-range rows / columns to the first one (they only feed outputs that are
+    // not stored), and past the last tile the loop re-loads the last tile.
+    constexpr int kNM = 4 * WMT * WNT, kNCH = OpA::NV + OpB::NV, kFR = WMT + WNT, kPre = 2;
+    static_assert(kNCH >= kPre && kNCH - kPre <= kNM / 2, "one stored chunk per even slot");
+    const int wk0 = kbeg + (kend - kbeg) - kHBK * (nk - 1);        // start of tile 1
+    auto wload = [&](auto& oa, auto& ob, int t) __attribute__((always_inline)) {
+      const int tc = t < nk - 1 ? t : nk - 1, k0 = tc == 0 ? kbeg : wk0 + kHBK * (tc - 1);
+      oa.load(a.A, a.lda, m0, a.M, k0, tc == 0 ? wk0 : kend);
+      ob.load(a.B, a.ldb, n0, a.N, k0, tc == 0 ? wk0 : kend);
+    };
+    wload(la[0], lb[0], 0);
+    wload(la[1], lb[1], 1);
+    MAPX_H_STORE(0, 0);
+    wload(la[0], lb[0], 2);
+    __syncthreads();
+    int64_t goffA[OpA::NV], goffB[OpB::NV];      // chunk's element offset from the K-step's operand base (edges clamped)
+    int soffA[OpA::NV], soffB[OpB::NV];          // chunk's element offset inside an LDS buffer
+#pragma unroll
+    for (int i = 0; i < OpA::NV; ++i) {
+      int tr, tc;
+      OpA::coords(threadIdx.x + i * 256, tr, tc);
+      const bool in = (A_KC ? m0 + tr : m0 + tc) < a.M;
+      goffA[i] = A_KC ? (int64_t)(in ? m0 + tr : 0) * a.lda + tc : (int64_t)tr * a.lda + (in ? m0 + tc : 0);
+      soffA[i] = tr * OpA::LD + tc;
+    }
+#pragma unroll
+    for (int i = 0; i < OpB::NV; ++i) {
+      int tr, tc;
+      OpB::coords(threadIdx.x + i * 256, tr, tc);
+      const bool in = (B_KC ? n0 + tr : n0 + tc) < a.N;
+      goffB[i] = B_KC ? (int64_t)(in ? n0 + tr : 0) * a.ldb + tc : (int64_t)tr * a.ldb + (in ? n0 + tc : 0);
+      soffB[i] = OpA::LDS_ELEMS + tr * OpB::LD + tc;
+    }
+    // the loop's chunk registers: an ext-vector array (an array of HIP's uint4 structs, indexed from inside
+    // the slot lambdas, went to scratch — a scratch store behind every global load, each with vmcnt(0))
+    u32x4 rr[2][kNCH];
+#pragma unroll
+    for (int set = 0; set < 2; ++set) {
+#pragma unroll
+      for (int i = 0; i < OpA::NV; ++i) rr[set][i] = u32x4{la[set].r[i].x, la[set].r[i].y, la[set].r[i].z, la[set].r[i].w};
+#pragma unroll
+      for (int i = 0; i < OpB::NV; ++i)
+        rr[set][OpA::NV + i] = u32x4{lb[set].r[i].x, lb[set].r[i].y, lb[set].r[i].z, lb[set].r[i].w};
+    }
+#define MAPX_H_WSTORE(CUR, c)                                                                          \
+  do {                                                                                                 \
+    constexpr bool isA_ = (c) < OpA::NV;                                                               \
+    constexpr int i_ = isA_ ? (c) : (c) - OpA::NV;                                                     \
+    *reinterpret_cast<u32x4*>(smem + ((CUR) ^ 1) * kBuf + (isA_ ? soffA[i_] : soffB[i_])) = rr[(CUR) ^ 1][c]; \
+  } while (0)
+#define MAPX_H_WLOAD(CUR, c)                                                                           \
+  do {                                                                                                 \
+    constexpr bool isA_ = (c) < OpA::NV;                                                               \
+    constexpr int i_ = isA_ ? (c) : (c) - OpA::NV;                                                     \
+    rr[(CUR) ^ 1][c] = *reinterpret_cast<const u32x4*>(isA_ ? wA + goffA[i_] : wB + goffB[i_]);        \
+  } while (0)
+#define MAPX_H_KSTEP_WEAVE(CUR, kt)                                                                    \
   do {                                                                                                 \
     const bf16_t* const As_cur = smem + (CUR) * kBuf;                                                  \
     const bf16_t* const Bs_cur = As_cur + OpA::LDS_ELEMS;                                              \
-    bf16x8 af[2][WMT], bf[2][WNT];                                                                     \
-    OpA::frags(As_cur, abase, lane, 0, af[0]);                                                         \
-    OpB::frags(Bs_cur, bbase, lane, 0, bf[0]);                                                         \
-    _Pragma("unroll") for (int s4 = 0; s4 < kHBK / 16; ++s4) {                                         \
-      const int c = s4 & 1;                                                                            \
-      if (s4 + 1 < kHBK / 16) {                                                                        \
-        OpA::frags(As_cur, abase, lane, s4 + 1, af[c ^ 1]);                                            \
-        OpB::frags(Bs_cur, bbase, lane, s4 + 1, bf[c ^ 1]);                                            \
+    bf16x8 fa[kHBK / 16][WMT], fb[kHBK / 16][WNT];   /* [k16 step][tile]: read two k16 steps ahead of use */ \
+    OpA::frags(As_cur, abase, lane, 0, fa[0]);                                                         \
+    OpB::frags(Bs_cur, bbase, lane, 0, fb[0]);                                                         \
+    OpA::frags(As_cur, abase, lane, 1, fa[1]);                                                         \
+    OpB::frags(Bs_cur, bbase, lane, 1, fb[1]);                                                         \
+    const int wk_ = wk0 + kHBK * (((kt) + 3 < nk - 1 ? (kt) + 3 : nk - 1) - 1);   /* tile min(kt+3, nk-1) */ \
+    const bf16_t* const wA = a.A + (int64_t)wk_ * (A_KC ? 1 : a.lda);                                  \
+    const bf16_t* const wB = a.B + (int64_t)wk_ * (B_KC ? 1 : a.ldb);                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    MAPX_H_WSTORE(CUR, 0); MAPX_H_WSTORE(CUR, 1);    /* under the latency of the first fragments */   \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    unroll_seq_h([&](auto zc) __attribute__((always_inline)) {                                         \
+      constexpr int z = decltype(zc)::value, s4 = z / (WMT * WNT), t = z % (WMT * WNT), i = t / WNT, j = t % WNT; \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s4][i], fb[s4][j], acc[i][j], 0, 0, 0);     \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+      if constexpr (s4 + 2 < kHBK / 16) {          /* the fragments of k16 step s4 + 2, spread over this step's slots */ \
+        constexpr int q0 = t * kFR / (WMT * WNT), q1 = (t + 1) * kFR / (WMT * WNT);                    \
+        unroll_seq_h([&](auto qc) __attribute__((always_inline)) {                                     \
+          constexpr int q = q0 + decltype(qc)::value;                                                  \
+          if constexpr (q < WMT) fa[s4 + 2][q] = OpA::frag1(As_cur, abase, lane, s4 + 2, q);           \
+          else fb[s4 + 2][q - WMT] = OpB::frag1(Bs_cur, bbase, lane, s4 + 2, q - WMT);                 \
+        }, std::make_integer_sequence<int, q1 - q0>{});                                                \
       }                                                                                                \
-      _Pragma("unroll") for (int i = 0; i < WMT; ++i)                                                  \
-        _Pragma("unroll") for (int j = 0; j < WNT; ++j)                                                \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c][i], bf[c][j], acc[i][j], 0, 0, 0); \
-    }                                                                                                  \
-    if ((STEADY) && !(MASK)) MAPX_H_STORE_I((CUR) ^ 1, (CUR) ^ 1);  /* tile kt+1: loaded two steps ago */ \
-    else if ((STEADY) || (kt) + 1 < nk) MAPX_H_STORE((CUR) ^ 1, (CUR) ^ 1);                            \
-    if ((STEADY) || (kt) + 3 < nk) MAPX_H_LOAD((CUR) ^ 1, (kt) + 3);                                   \
-    /* (a sched_group_barrier pattern spreading LDS reads / stores / global loads between the MFMAs */ \
-    /*  was measured: 59.5 vs 55.2 us at K = 4096 — the compiler's own order is the better one)       */ \
+      if constexpr (z % 2 == 0) {                                                                      \
+        constexpr int c = kPre + z / 2;                                                                \
+        if constexpr (c < kNCH) MAPX_H_WSTORE(CUR, c);                                                 \
+      } else {                                                                                         \
+        constexpr int c0 = (z / 2) * kNCH / (kNM / 2), c1 = (z / 2 + 1) * kNCH / (kNM / 2);            \
+        unroll_seq_h([&](auto cc) __attribute__((always_inline)) {                                     \
+          constexpr int c = c0 + decltype(cc)::value;                                                  \
+          MAPX_H_WLOAD(CUR, c);                                                                        \
+        }, std::make_integer_sequence<int, c1 - c0>{});                                                \
+      }                                                                                                \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+    }, std::make_integer_sequence<int, kNM>{});                                                        \
     __syncthreads();                                                                                   \
   } while (0)
-  // steady state (STEADY literal: tiles kt+1 .. kt+4 exist): a branch-free body, so that the
-  // compiler counts the loads in flight exactly instead of draining them at every join
-  int kt = 0;
-  if (interior) {
-    for (; kt + 4 < nk; kt += 2) {
-      MAPX_H_KSTEP(0, kt, true, false);
-      MAPX_H_KSTEP(1, kt + 1, true, false);
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      MAPX_H_KSTEP_WEAVE(0, kt);
+      MAPX_H_KSTEP_WEAVE(1, kt + 1);
     }
+    if (kt < nk) MAPX_H_KSTEP_WEAVE(0, kt);
+#undef MAPX_H_KSTEP_WEAVE
+#undef MAPX_H_WLOAD
+#undef MAPX_H_WSTORE
   } else {
-    for (; kt + 4 < nk; kt += 2) {
-      MAPX_H_KSTEP(0, kt, true, true);
-      MAPX_H_KSTEP(1, kt + 1, true, true);
+    if (nk > 0) MAPX_H_LOAD(0, 0);
+    if (nk > 1) MAPX_H_LOAD(1, 1);
+    if (nk > 0) MAPX_H_STORE(0, 0);
+    if (nk > 2) MAPX_H_LOAD(0, 2);
+    __syncthreads();
+    // one K-step on LDS buffer CUR (= kt & 1, a literal: the loop is unrolled by two so that the
+    // register sets are indexed statically — a runtime index would send them to scratch)
+  #define MAPX_H_KSTEP(CUR, kt, STEADY, MASK)                                                            \
+    do {                                                                                                 \
+      const bf16_t* const As_cur = smem + (CUR) * kBuf;                                                  \
+      const bf16_t* const Bs_cur = As_cur + OpA::LDS_ELEMS;                                              \
+      bf16x8 af[2][WMT], bf[2][WNT];                                                                     \
+      OpA::frags(As_cur, abase, lane, 0, af[0]);                                                         \
+      OpB::frags(Bs_cur, bbase, lane, 0, bf[0]);                                                         \
+      _Pragma("unroll") for (int s4 = 0; s4 < kHBK / 16; ++s4) {                                         \
+        const int c = s4 & 1;                                                                            \
+        if (s4 + 1 < kHBK / 16) {                                                                        \
+          OpA::frags(As_cur, abase, lane, s4 + 1, af[c ^ 1]);                                            \
+          OpB::frags(Bs_cur, bbase, lane, s4 + 1, bf[c ^ 1]);                                            \
+        }                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < WMT; ++i)                                                  \
+          _Pragma("unroll") for (int j = 0; j < WNT; ++j)                                                \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c][i], bf[c][j], acc[i][j], 0, 0, 0); \
+      }                                                                                                  \
+      if ((STEADY) && !(MASK)) MAPX_H_STORE_I((CUR) ^ 1, (CUR) ^ 1);  /* tile kt+1: loaded two steps ago */ \
+      else if ((STEADY) || (kt) + 1 < nk) MAPX_H_STORE((CUR) ^ 1, (CUR) ^ 1);                            \
+      if ((STEADY) || (kt) + 3 < nk) MAPX_H_LOAD((CUR) ^ 1, (kt) + 3);                                   \
+      /* (a sched_group_barrier pattern spreading LDS reads / stores / global loads between the MFMAs */ \
+      /*  was measured: 59.5 vs 55.2 us at K = 4096 — the compiler's own order is the better one)       */ \
+      __syncthreads();                                                                                   \
+    } while (0)
+    // steady state (STEADY literal: tiles kt+1 .. kt+4 exist): a branch-free body, so that the
+    // compiler counts the loads in flight exactly instead of draining them at every join
+    int kt = 0;
+    if (interior) {
+      for (; kt + 4 < nk; kt += 2) {
+        MAPX_H_KSTEP(0, kt, true, false);
+        MAPX_H_KSTEP(1, kt + 1, true, false);
+      }
+    } else {
+      for (; kt + 4 < nk; kt += 2) {
+        MAPX_H_KSTEP(0, kt, true, true);
+        MAPX_H_KSTEP(1, kt + 1, true, true);
+      }
     }
-  }
-  for (; kt < nk; kt += 2) {
-    MAPX_H_KSTEP(0, kt, false, true);
-    if (kt + 1 < nk) MAPX_H_KSTEP(1, kt + 1, false, true);
+    for (; kt < nk; kt += 2) {
+      MAPX_H_KSTEP(0, kt, false, true);
+      if (kt + 1 < nk) MAPX_H_KSTEP(1, kt + 1, false, true);
+    }
   }
 #undef MAPX_H_KSTEP
 #undef MAPX_H_LOAD
@@ -501,13 +622,13 @@ __global__ void __launch_bounds__(256) splitk_reduce_h1_kernel(const float* __re
   }
 }
 
-template <int WMT, int WNT, bool A_KC, bool B_KC, bool VEC>
+template <int WMT, int WNT, bool A_KC, bool B_KC, bool VEC, bool WEAVE>
 static hipError_t launch_one_h(const GemmHArgs& a, int nsplit, int c_f32, int aux1_f32, hipStream_t stream) {
   using OpA = OperandH<64 * WMT, WMT, A_KC, VEC>;
   using OpB = OperandH<64 * WNT, WNT, B_KC, VEC>;
   constexpr size_t lds = (size_t)2 * (OpA::LDS_ELEMS + OpB::LDS_ELEMS) * sizeof(bf16_t);
   static_assert(lds >= (size_t)(64 * WMT) * (64 * WNT + 4) * sizeof(float), "the epilogue's fp32 tile must fit the operand buffers");
-  auto* fn = &gemm_bf16_kernel<WMT, WNT, A_KC, B_KC, VEC>;
+  auto* fn = &gemm_bf16_kernel<WMT, WNT, A_KC, B_KC, VEC, WEAVE>;
   static hipError_t raised = lds > 65536
       ? hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
       : hipSuccess;
@@ -518,8 +639,12 @@ static hipError_t launch_one_h(const GemmHArgs& a, int nsplit, int c_f32, int au
 
 template <int WMT, int WNT, bool A_KC, bool B_KC>
 static hipError_t launch_tile_h(const GemmHArgs& a, bool vec, int nsplit, int c_f32, int aux1_f32, hipStream_t stream) {
-  return vec ? launch_one_h<WMT, WNT, A_KC, B_KC, true>(a, nsplit, c_f32, aux1_f32, stream)
-             : launch_one_h<WMT, WNT, A_KC, B_KC, false>(a, nsplit, c_f32, aux1_f32, stream);
+  // the woven K loop: vector loads and at least two K-steps in every split-K slab
+  static const bool weave_on = [] { const char* e = getenv("MAPX_BF16_WEAVE"); return !e || atoi(e) != 0; }();
+  const bool weave = weave_on && vec && (int64_t)a.K - (int64_t)a.k_chunk * (nsplit - 1) > kHBK;
+  if (weave) return launch_one_h<WMT, WNT, A_KC, B_KC, true, true>(a, nsplit, c_f32, aux1_f32, stream);
+  return vec ? launch_one_h<WMT, WNT, A_KC, B_KC, true, false>(a, nsplit, c_f32, aux1_f32, stream)
+             : launch_one_h<WMT, WNT, A_KC, B_KC, false, false>(a, nsplit, c_f32, aux1_f32, stream);
 }
 
 template <bool A_KC, bool B_KC>
