@@ -19,17 +19,15 @@ NCE_EARLY = os.environ.get("MAPX_NCE_EARLY", "1") == "1"
 # both tables' segment plans from one chain of launches (8 launches instead of 16, 0.112 instead of
 # 0.19 ms of sorting per step): "fwd" = started in forward behind the towers, "bwd" = started by the
 # head's backward node (where the sampled ids' sort alone starts otherwise), "off" = one chain per
-# table.  Measured (one MI355X, 200 steps): bf16 0.793 (off) / 0.752 (fwd) / 0.761 (bwd) ms per step;
-# fp32 1.200 (off) / 1.306 (fwd) / 1.305 (bwd) — the replayed graph runs on two hardware queues, a
-# side chain is appended to one of them, and the fp32 step's two queues are balanced with the small
-# embedding sort in forward and the sampled ids' sort in backward; the same two sorts as one lump (also
-# with the old single-table kernels back to back: 1.39 ms) unbalance them.  "auto": off for fp32, fwd
-# for bf16, where the GEMMs are short and the sort is the longest chain of the step.  (Round 2, fp32: the
+# table; "auto" = fwd.  What decided it was WHERE the graph runtime runs the chain: captured as a branch
+# of its own it was run ahead of the deep tower's GEMMs on the queue the two share, and the joint chain
+# lost in fp32 (1.306 fwd / 1.305 bwd vs 1.200 off) and won only a little in bf16 (0.752 vs 0.793).  Made
+# to wait for the deep tower's GEMMs (PLAN_AFTER_DNN below) it wins in both: fp32 0.908 / 0.912 vs 0.935 /
+# 0.937 ms (off), bf16 0.690 vs 0.744 (fwd without the wait) vs 0.783 (off).  (Also measured in fp32: the
 # embedding's sort started by the head's backward node right behind the sampled ids' sort — so that the
 # head's backward no longer waits 34 us for the latter — 1.13 vs 0.96 ms.)
 JOINT_PLAN = os.environ.get("MAPX_JOINT_PLAN", "auto")
-# the joint plan in forward waits for the deep tower's GEMMs to be on their way (bf16 mode: 0.690 vs 0.744 ms;
-# without it the graph runtime ran the sort chain ahead of them on the queue they share)
+# the joint plan in forward waits for the deep tower's GEMMs to be on their way (see above)
 PLAN_AFTER_DNN = os.environ.get("MAPX_PLAN_AFTER_DNN", "1") == "1"
 
 _OTHER_BACKBONES = ("trans", "fignn", "fgcnn")
@@ -224,7 +222,7 @@ class DCNV2(BaseModel):
             # ids' sort as a chain of its own ahead of the embedding's cost 1.375 vs 1.21 ms.)
             mode = JOINT_PLAN
             if mode == "auto":
-                mode = "off" if self.embed.compute_dtype == torch.float32 else "fwd"
+                mode = "fwd"
             if nce_idx is not None and mode == "fwd":
                 from .layers import PlanSlot
                 from .layers import IMPLIED
