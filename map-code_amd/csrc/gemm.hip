@@ -1105,7 +1105,7 @@ extern "C" int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   if (M == 0 || N == 0) return MAPX_OK;
   MAPX_REQUIRE(A && B && C, "gemm_f32: null operand");
   MAPX_REQUIRE(!(a_kc == 0 && b_kc != 0), "gemm_f32: layout (A m-contiguous, B k-contiguous) unused");
-  MAPX_REQUIRE(epi >= MAPX_EPI_NONE && epi <= MAPX_EPI_RELU_MASK, "gemm_f32: bad epilogue %d", epi);
+  MAPX_REQUIRE(epi >= MAPX_EPI_NONE && epi <= MAPX_EPI_RELU_MASK_COLSUM, "gemm_f32: bad epilogue %d", epi);
   {   // the epilogue addresses every output / auxiliary operand with 32-bit element offsets
     const int64_t lim = (int64_t)1 << 31, rows = M > 0 ? M : 1;
     MAPX_REQUIRE(rows * ldc < lim && rows * ld1 < lim && rows * ld2 < lim && rows * ldo2 < lim,
@@ -1113,7 +1113,13 @@ extern "C" int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   }
   if (epi >= MAPX_EPI_BIAS && epi <= MAPX_EPI_BIAS_CROSS) MAPX_REQUIRE(bias, "gemm_f32: bias missing");
   if (epi == MAPX_EPI_BIAS_CROSS) MAPX_REQUIRE(aux1 && aux2 && out2, "gemm_f32: cross operands missing");
-  if (epi == MAPX_EPI_ADD || epi == MAPX_EPI_RELU_MASK) MAPX_REQUIRE(aux1, "gemm_f32: aux missing");
+  if (epi == MAPX_EPI_ADD || epi == MAPX_EPI_RELU_MASK || epi == MAPX_EPI_RELU_MASK_COLSUM)
+    MAPX_REQUIRE(aux1, "gemm_f32: aux missing");
+  MAPX_REQUIRE(epi >= MAPX_EPI_NONE && epi <= MAPX_EPI_RELU_MASK_COLSUM, "gemm_f32: unknown epilogue %d", epi);
+  if (epi == MAPX_EPI_RELU_MASK_COLSUM && gemm_mode() != 1) {
+    set_error("gemm_f32: EPI_RELU_MASK_COLSUM exists in the MAPX_GEMM=x3 family only");
+    return MAPX_EINVAL;
+  }
   if (nsplit < 1) nsplit = 1;
   MAPX_REQUIRE(nsplit == 1 || epi == MAPX_EPI_NONE, "gemm_f32: split-K needs EPI_NONE");
   if (gemm_mode() == 1)

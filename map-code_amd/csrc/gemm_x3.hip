@@ -269,9 +269,11 @@ __device__ inline void epilogue_rows_x3_vec(const GemmX3Args& a, float* __restri
   constexpr int LDT = BN + 4, CPR = BN / 4, RPI = NT / CPR, NIT = BM / RPI, U = NIT < 4 ? NIT : 4;
   static_assert(NT % CPR == 0 && BM % RPI == 0 && NIT % U == 0, "epilogue tiling");
   constexpr bool kBias = EPI >= MAPX_EPI_BIAS && EPI <= MAPX_EPI_BIAS_CROSS;
-  constexpr bool kAux1 = EPI == MAPX_EPI_BIAS_CROSS || EPI == MAPX_EPI_ADD || EPI == MAPX_EPI_RELU_MASK;
+  constexpr bool kColsum = EPI == MAPX_EPI_RELU_MASK_COLSUM;
+  constexpr bool kAux1 = EPI == MAPX_EPI_BIAS_CROSS || EPI == MAPX_EPI_ADD || EPI == MAPX_EPI_RELU_MASK || kColsum;
   constexpr bool kAux2 = EPI == MAPX_EPI_BIAS_CROSS;
   const int c0 = (threadIdx.x % CPR) * 4, r0 = threadIdx.x / CPR;
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);        // kColsum: this thread's 4 columns over its rows
   const int n = n0 + c0;
   const bool ncol = n < a.N;
   const int ns = ncol ? n : 0;
@@ -302,12 +304,29 @@ __device__ inline void epilogue_rows_x3_vec(const GemmX3Args& a, float* __restri
         w[e] = v[e];
         if (EPI == MAPX_EPI_BIAS_CROSS) v[e] = x1[e] + x2[e] * v[e];
         if (EPI == MAPX_EPI_ADD) v[e] += x1[e];
-        if (EPI == MAPX_EPI_RELU_MASK) v[e] = x1[e] > 0.f ? v[e] : 0.f;
+        if (EPI == MAPX_EPI_RELU_MASK || kColsum) v[e] = x1[e] > 0.f ? v[e] : 0.f;
       }
+      if (kColsum && ok[u]) { csum.x += v[0]; csum.y += v[1]; csum.z += v[2]; csum.w += v[3]; }
       if (ok[u]) {
         *reinterpret_cast<float4*>(C + mrow[u] * a.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
         if (kAux2) *reinterpret_cast<float4*>(a.out2 + mrow[u] * a.ldo2 + n) = make_float4(w[0], w[1], w[2], w[3]);
       }
+    }
+  }
+  if (kColsum) {
+    // column sums of the tile's (masked) rows: the RPI threads of a column group meet in LDS behind the
+    // fp32 tile and are added in a fixed order; one partial row per 128-row tile, summed later
+    float4* const red = reinterpret_cast<float4*>(const_cast<float*>(tile) + BM * LDT);
+    red[r0 * CPR + threadIdx.x % CPR] = csum;
+    __syncthreads();
+    if (r0 == 0 && ncol) {
+      float4 t = red[threadIdx.x % CPR];
+#pragma unroll
+      for (int k = 1; k < RPI; ++k) {
+        const float4 q = red[k * CPR + threadIdx.x % CPR];
+        t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+      }
+      *reinterpret_cast<float4*>(a.out2 + (int64_t)(m0 / 128) * a.ldo2 + n) = t;
     }
   }
 }
@@ -658,6 +677,9 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
       case MAPX_EPI_BIAS_CROSS: epilogue_rows_x3_vec<MAPX_EPI_BIAS_CROSS, BM, BN, NT>(a, C, tile, m0, n0); break;
       case MAPX_EPI_ADD: epilogue_rows_x3_vec<MAPX_EPI_ADD, BM, BN, NT>(a, C, tile, m0, n0); break;
       case MAPX_EPI_RELU_MASK: epilogue_rows_x3_vec<MAPX_EPI_RELU_MASK, BM, BN, NT>(a, C, tile, m0, n0); break;
+      case MAPX_EPI_RELU_MASK_COLSUM:
+        if constexpr (BM == 128) epilogue_rows_x3_vec<MAPX_EPI_RELU_MASK_COLSUM, BM, BN, NT>(a, C, tile, m0, n0);
+        break;
       default: epilogue_rows_x3_vec<MAPX_EPI_NONE, BM, BN, NT>(a, C, tile, m0, n0); break;
     }
     return;
@@ -760,6 +782,14 @@ int gemm_f32x3_launch(int a_kc, int b_kc, int M, int N, int K, const float* A, i
   const int cls = (a_kc && b_kc) ? 0 : a_kc ? 1 : 2;
   int tile = (big >= 160) ? (cls == 0 ? big_tile / 100 : cls == 1 ? big_tile / 10 % 10 : big_tile % 10) : 0;
   if (tile_hint >= 0 && (tile_hint & 255) <= 3) tile = tile_hint & 255;
+  if (epi == MAPX_EPI_RELU_MASK_COLSUM) {
+    auto al16 = [](const void* p, int64_t ld) { return p && (uintptr_t)p % 16 == 0 && ld % 4 == 0; };
+    if (!(N % 4 == 0 && nsplit <= 1 && al16(C, ldc) && al16(aux1, ld1) && al16(out2, ldo2))) {
+      set_error("gemm_f32: EPI_RELU_MASK_COLSUM needs N %% 4 == 0, no split-K, 16-byte aligned C / aux1 / out2");
+      return MAPX_EINVAL;
+    }
+    if (tile == 0) tile = 1;          // one partial row per 128-row tile
+  }
   // the woven K loop (4-wave layouts with vector loads) wants >= 2 K-steps in every slab
   if (tile != 2 && vec && K - (int64_t)g.k_chunk * (nsplit - 1) <= kXBK) tile = 2;
   hipError_t e;

@@ -411,9 +411,19 @@ def _weight_grads(ctx, dz, x, sw, sb, need=None):
     return (None if sw is not None else dw), (None if sb is not None else db)
 
 
+class _ReluLink:
+    """Between a ReLU layer and the ONE Linear that consumes its output (MLPBlock's chain): the consumer's
+    input-gradient GEMM can apply the producer's ReLU mask (its saved input IS the producer's output) and
+    form the producer's bias gradient in its epilogue; it then sets `premasked` and the producer's backward
+    finds dZ instead of dY — one elementwise + column-sum launch less per layer on the backward chain."""
+
+    def __init__(self):
+        self.premasked, self.sb = False, None
+
+
 class _Linear(Function):
     @staticmethod
-    def forward(ctx, x, w, b, relu, out=None, out_f32=False):
+    def forward(ctx, x, w, b, relu, out=None, out_f32=False, link_in=None, link_out=None):
         x = x.contiguous()
         half = ops.is_bf16(x)
         if half and relu and out_f32:
@@ -422,6 +432,9 @@ class _Linear(Function):
         y = ops.linear_fwd(x, wop, b, relu=relu, out=out, out_dtype=torch.float32 if (half and out_f32) else None)
         ctx.relu, ctx.half = relu, half
         ctx.slots = (_grad_slot(w), _grad_slot(b))
+        ctx.link_in, ctx.link_out = link_in, (link_out if relu else None)
+        if ctx.link_out is not None:
+            ctx.link_out.sb = ctx.slots[1]
         ctx.save_for_backward(x, wop, y if relu else None)
         return y
 
@@ -431,15 +444,27 @@ class _Linear(Function):
         sw, sb = ctx.slots
         if ctx.half and gy.dtype == torch.float32:
             gy = ops.cast_bf16(gy)                 # the fp32 gradient of a head's logits enters the bf16 trunk
-        if ctx.relu and (ctx.half or gy.shape[1] % 4 == 0):      # ReLU mask and bias gradient in one pass over dY
+        if ctx.relu and ctx.link_out is not None and ctx.link_out.premasked:
+            # the consumer's dX GEMM has applied this layer's mask and queued its bias gradient (_ReluLink)
+            dz, db = gy.contiguous(), None
+            dw = ops.linear_bwd_weight(dz, x, out=sw, defer=True) if ctx.needs_input_grad[1] else None
+            dw = None if sw is not None else dw
+        elif ctx.relu and (ctx.half or gy.shape[1] % 4 == 0):      # ReLU mask and bias gradient in one pass over dY
             dz, db = ops.relu_mask_colsum(gy, y, db=sb, defer=True)      # gy may be a slice of d(concat)
             dw = ops.linear_bwd_weight(dz, x, out=sw, defer=True) if ctx.needs_input_grad[1] else None
             dw, db = (None if sw is not None else dw), (None if sb is not None else db)
         else:
             dz = ops.relu_mask(gy.contiguous(), y.contiguous()) if ctx.relu else gy.contiguous()
             dw, db = _weight_grads(ctx, dz, x, sw, sb)
-        dx = ops.linear_bwd_input(dz, w) if ctx.needs_input_grad[0] else None
-        return dx, dw, db, None, None, None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            link = ctx.link_in
+            if link is not None and link.sb is not None and ops.fused_mask_colsum_ok(dz, x):
+                dx = ops.linear_bwd_input(dz, w, relu_of=x, colsum_to=link.sb)     # x = the producer's ReLU output
+                link.premasked = True
+            else:
+                dx = ops.linear_bwd_input(dz, w)
+        return dx, dw, db, None, None, None, None, None
 
 
 class HipLinear(nn.Module):
@@ -458,9 +483,10 @@ class HipLinear(nn.Module):
             self.weight.uniform_(-bound, bound)
             self.bias.uniform_(-bound, bound)
 
-    def forward(self, x, out=None):
-        """`out`: optional pre-allocated destination (ops.alias_cols of a wider buffer)."""
-        return _Linear.apply(x, self.weight, self.bias, self.relu, out, self.out_fp32)
+    def forward(self, x, out=None, link_in=None, link_out=None):
+        """`out`: optional pre-allocated destination (ops.alias_cols of a wider buffer).  link_in / link_out:
+        _ReluLink objects of a chain in which this layer's input / output has exactly one consumer."""
+        return _Linear.apply(x, self.weight, self.bias, self.relu, out, self.out_fp32, link_in, link_out)
 
 
 class MLPBlock(nn.Module):
@@ -483,6 +509,7 @@ class MLPBlock(nn.Module):
     def forward(self, x, out=None):
         layers = [m for m in self.dnn.values() if isinstance(m, HipLinear)]
         drops = [m for m in self.dnn.values() if isinstance(m, HipDropout)]
+        link = None
         for i, layer in enumerate(layers):
             last = i == len(layers) - 1
             if drops:
@@ -490,7 +517,10 @@ class MLPBlock(nn.Module):
                     raise NotImplementedError("hidden_dropout_rate > 0 is built for compute_dtype=fp32")
                 x = drops[i](layer(x), out=out if last else None)
             else:
-                x = layer(x, out=out if last else None)
+                # layer i's output feeds layer i+1 and nothing else: their backward passes are linked
+                link_out = None if last else _ReluLink()
+                x = layer(x, out=out if last else None, link_in=link, link_out=link_out)
+                link = link_out
         return x
 
 

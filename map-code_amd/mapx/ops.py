@@ -784,17 +784,36 @@ def linear_fwd(x, w, b, relu=False, out=None, out_dtype=None):
                 bias=b, out_dtype=out_dtype)
 
 
-def linear_bwd_input(dy, w, out=None, add=None, relu_of=None):
+RELU_LINK = os.environ.get("MAPX_RELU_LINK", "1") == "1"
+
+
+def fused_mask_colsum_ok(dy, relu_of):
+    """Can linear_bwd_input also apply the upstream ReLU's mask and form its bias gradient?  (fp32 on
+    the bf16-matrix-core family, 16-byte rows, deferred partial sums on.)"""
+    return (RELU_LINK and GEMM_X3 and DEFER_COLSUM and dy.dtype == torch.float32 and relu_of.dtype == torch.float32
+            and relu_of.dim() == 2 and relu_of.shape[1] % 4 == 0 and row_sliceable(relu_of))
+
+
+def linear_bwd_input(dy, w, out=None, add=None, relu_of=None, colsum_to=None):
     """dX = dY W  (+ add)  or masked by relu_of > 0.  dy [M,N], w [N,K] -> [M,K] (dtype of dy;
-    bf16: `add` may be fp32 — the cross tower's running dL/dX0)."""
+    bf16: `add` may be fp32 — the cross tower's running dL/dX0).
+    colsum_to (with relu_of; see fused_mask_colsum_ok): the masked result is the upstream ReLU layer's dZ,
+    and its column sums — that layer's bias gradient — leave the same epilogue as one partial row per
+    128-row tile, summed into `colsum_to` by flush_deferred()."""
     M, Nn = dy.shape
     K = w.shape[1]
-    epi, aux = N.EPI_NONE, None
+    epi, aux, out2 = N.EPI_NONE, None, None
     if add is not None:
         epi, aux = N.EPI_ADD, add
+    elif relu_of is not None and colsum_to is not None:
+        epi, aux = N.EPI_RELU_MASK_COLSUM, relu_of
+        out2 = torch.empty((M + 127) // 128, K, dtype=torch.float32, device=dy.device)
     elif relu_of is not None:
         epi, aux = N.EPI_RELU_MASK, relu_of
-    return gemm(dy, w, True, False, M, K, Nn, out=out, epi=epi, aux1=aux)
+    dx = gemm(dy, w, True, False, M, K, Nn, out=out, epi=epi, aux1=aux, out2=out2)
+    if out2 is not None:
+        defer_sum(colsum_to, out2, K, out2.shape[0], K)
+    return dx
 
 
 GEMM_X3 = lib.mapx_gemm_f32_mode() == 1      # fp32 GEMMs as 3 x bf16 split products (csrc/gemm_x3.hip)
