@@ -230,8 +230,10 @@ int mapx_scale_inplace(float* x, int64_t n, const float* g, hipStream_t stream);
 #define MAPX_EPI_ADD 4
 #define MAPX_EPI_RELU_MASK 5
 /* RELU_MASK plus the column sums of the masked result, one partial row per 128-row tile: out2 [ceil(M/128)][ldo2]
- * fp32 (the upstream layer's bias gradient: add the rows with mapx_sum_tasks).  The fp32-on-bf16-matrix-core
- * family only (mapx_gemm_f32_mode() == 1), 16-byte aligned operands; else MAPX_EINVAL. */
+ * fp32 (the upstream layer's bias gradient: add the rows with mapx_sum_tasks).  mapx_gemm_f32: the
+ * fp32-on-bf16-matrix-core family only (mapx_gemm_f32_mode() == 1); mapx_gemm_bf16: `out2` then points to
+ * those FP32 partial rows (ldo2 in floats) and the sums are those of the bf16 values stored.  16-byte aligned
+ * operands, no split-K; else MAPX_EINVAL. */
 #define MAPX_EPI_RELU_MASK_COLSUM 6
 /* nsplit_deferred != NULL: the split-K slabs stay in `ws` ([nsplit][M*N], dense) and
  * *nsplit_deferred receives the slab count (0 = C already final): the caller sums them later

@@ -249,9 +249,11 @@ __device__ inline void epilogue_rows_h_vec(const GemmHArgs& a, void* __restrict_
   constexpr int LDT = BN + 4, CPR = BN / 8, RPI = 256 / CPR, NIT = BM / RPI, U = NIT < 4 ? NIT : 4;
   static_assert(256 % CPR == 0 && BM % RPI == 0 && NIT % U == 0, "epilogue tiling");
   constexpr bool kBias = EPI >= MAPX_EPI_BIAS && EPI <= MAPX_EPI_BIAS_CROSS;
-  constexpr bool kAux1 = EPI == MAPX_EPI_BIAS_CROSS || EPI == MAPX_EPI_ADD || EPI == MAPX_EPI_RELU_MASK;
+  constexpr bool kColsum = EPI == MAPX_EPI_RELU_MASK_COLSUM;
+  constexpr bool kAux1 = EPI == MAPX_EPI_BIAS_CROSS || EPI == MAPX_EPI_ADD || EPI == MAPX_EPI_RELU_MASK || kColsum;
   constexpr bool kAux2 = EPI == MAPX_EPI_BIAS_CROSS;
   const int c0 = (threadIdx.x % CPR) * 8, r0 = threadIdx.x / CPR;
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // kColsum: this thread's 8 columns over its rows
   const int n = n0 + c0;
   const bool ncol = n < a.N;
   const int ns = ncol ? n : 0;
@@ -297,7 +299,8 @@ __device__ inline void epilogue_rows_h_vec(const GemmHArgs& a, void* __restrict_
         w[e] = v[e];
         if (EPI == MAPX_EPI_BIAS_CROSS) v[e] = x1 + x2 * v[e];
         if (EPI == MAPX_EPI_ADD) v[e] += x1;
-        if (EPI == MAPX_EPI_RELU_MASK) v[e] = x1 > 0.f ? v[e] : 0.f;
+        if (EPI == MAPX_EPI_RELU_MASK || kColsum) v[e] = x1 > 0.f ? v[e] : 0.f;
+        if (kColsum && ok[u]) csum[e] += C_F32 ? v[e] : (float)(bf16_t)v[e];     // the column sum of what is stored
       }
       if (ok[u]) {
         if (C_F32) {
@@ -317,6 +320,31 @@ __device__ inline void epilogue_rows_h_vec(const GemmHArgs& a, void* __restrict_
           *reinterpret_cast<bf16x8*>(a.out2 + mrow[u] * a.ldo2 + n) = o;
         }
       }
+    }
+  }
+  if (kColsum) {
+    // column sums of the tile's masked rows, fixed order: lanes of a wave that share their columns (xor CPR,
+    // 2 CPR, ...), then the four waves through LDS behind the fp32 tile; out2 holds FP32 partial rows here,
+    // one per 128-row tile (ldo2 in floats)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = CPR; d < 64; d <<= 1)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) csum[e] += __shfl_xor(csum[e], d);
+    float* const red = const_cast<float*>(tile) + BM * LDT;       // [4 waves][CPR][8]
+    if (lane < CPR) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[(wave * CPR + lane) * 8 + e] = csum[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < CPR && ncol) {
+      float t[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = (red[threadIdx.x * 8 + e] + red[(CPR + threadIdx.x) * 8 + e]) +
+                                         (red[(2 * CPR + threadIdx.x) * 8 + e] + red[(3 * CPR + threadIdx.x) * 8 + e]);
+      float* const dst = reinterpret_cast<float*>(a.out2) + (int64_t)(m0 / 128) * a.ldo2 + n;
+      *reinterpret_cast<float4*>(dst) = make_float4(t[0], t[1], t[2], t[3]);
+      *reinterpret_cast<float4*>(dst + 4) = make_float4(t[4], t[5], t[6], t[7]);
     }
   }
 }
@@ -595,6 +623,9 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmHArgs a, int c_f32, 
         else MAPX_EPI_CASE(MAPX_EPI_ADD, false, false);
         break;
       case MAPX_EPI_RELU_MASK: MAPX_EPI_CASE(MAPX_EPI_RELU_MASK, false, false); break;
+      case MAPX_EPI_RELU_MASK_COLSUM:       /* (launcher: 128-row tiles, aligned operands) */
+        if constexpr (BM == 128) epilogue_rows_h_vec<MAPX_EPI_RELU_MASK_COLSUM, false, false, BM, BN>(a, C, tile, m0, n0);
+        break;
       default: MAPX_EPI_CASE(MAPX_EPI_NONE, false, false); break;
     }
   }
@@ -838,7 +869,7 @@ extern "C" int mapx_gemm_bf16(int a_kc, int b_kc, int M, int N, int K, const map
   if (M == 0 || N == 0) return MAPX_OK;
   MAPX_REQUIRE(A && B && C, "gemm_bf16: null operand");
   MAPX_REQUIRE(!(a_kc == 0 && b_kc != 0), "gemm_bf16: layout (A m-contiguous, B k-contiguous) unused");
-  MAPX_REQUIRE(epi >= MAPX_EPI_NONE && epi <= MAPX_EPI_RELU_MASK, "gemm_bf16: bad epilogue %d", epi);
+  MAPX_REQUIRE(epi >= MAPX_EPI_NONE && epi <= MAPX_EPI_RELU_MASK_COLSUM, "gemm_bf16: bad epilogue %d", epi);
   {
     const int64_t lim = (int64_t)1 << 31, rows = M > 0 ? M : 1;
     MAPX_REQUIRE(rows * ldc < lim && rows * ld1 < lim && rows * ld2 < lim && rows * ldo2 < lim,
@@ -846,8 +877,12 @@ extern "C" int mapx_gemm_bf16(int a_kc, int b_kc, int M, int N, int K, const map
   }
   if (epi >= MAPX_EPI_BIAS && epi <= MAPX_EPI_BIAS_CROSS) MAPX_REQUIRE(bias, "gemm_bf16: bias missing");
   if (epi == MAPX_EPI_BIAS_CROSS) MAPX_REQUIRE(aux1 && aux2 && out2 && !c_f32, "gemm_bf16: cross operands missing / fp32 output");
-  if (epi == MAPX_EPI_ADD || epi == MAPX_EPI_RELU_MASK)
+  if (epi == MAPX_EPI_ADD || epi == MAPX_EPI_RELU_MASK || epi == MAPX_EPI_RELU_MASK_COLSUM)
     MAPX_REQUIRE(aux1 && !c_f32, "gemm_bf16: aux missing, or fp32 output with ADD / RELU_MASK");
+  if (epi == MAPX_EPI_RELU_MASK_COLSUM)      // out2 = fp32 partial rows [ceil(M/128)][ldo2 floats]
+    MAPX_REQUIRE(out2 && N % 8 == 0 && nsplit <= 1 && (uintptr_t)C % 16 == 0 && ldc % 8 == 0 && (uintptr_t)aux1 % 16 == 0 &&
+                     ld1 % 8 == 0 && (uintptr_t)out2 % 16 == 0 && ldo2 % 4 == 0,
+                 "gemm_bf16: EPI_RELU_MASK_COLSUM needs N %% 8 == 0, no split-K, 16-byte aligned C / aux1 / out2");
   MAPX_REQUIRE(!aux1_f32 || epi == MAPX_EPI_ADD, "gemm_bf16: an fp32 auxiliary operand is built for EPI_ADD only");
   if (nsplit < 1) nsplit = 1;
   MAPX_REQUIRE(nsplit == 1 || (epi == MAPX_EPI_NONE && c_f32), "gemm_bf16: split-K needs EPI_NONE and an fp32 output");
@@ -882,6 +917,7 @@ extern "C" int mapx_gemm_bf16(int a_kc, int b_kc, int M, int N, int K, const map
   g.dbg = tile_hint >= 0 ? (tile_hint >> 8) : 0;
   if (tile_hint >= 0) tile_hint &= 255;
   if (tile_hint >= 0 && tile_hint <= 2) tile = tile_hint;
+  if (epi == MAPX_EPI_RELU_MASK_COLSUM && tile == 0) tile = 1;       // one partial row per 128-row tile
   hipError_t lerr;
   if (a_kc && b_kc) lerr = launch_layout_h<true, true>(g, vec, tile, nsplit, c_f32, aux1_f32, stream);
   else if (a_kc) lerr = launch_layout_h<true, false>(g, vec, tile, nsplit, c_f32, aux1_f32, stream);

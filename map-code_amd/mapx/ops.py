@@ -695,6 +695,9 @@ def scale_(x, g):
 
 
 # --------------------------------------------------------------------------- dense
+_EPI_RELU_MASK_COLSUM = N.EPI_RELU_MASK_COLSUM      # (gemm_bf16's N is a size)
+
+
 def gemm_bf16(a, b, a_kc, b_kc, M, N, K, out=None, out_dtype=BF16, ldc=None, epi=N.EPI_NONE, bias=None,
               aux1=None, aux2=None, out2=None, nsplit=1, lda=None, ldb=None, tile=-1):
     """The bf16-operand GEMM (include/mapx_hip.h: mapx_gemm_bf16): a, b, aux2, out2 bf16; C bf16 or
@@ -720,8 +723,8 @@ def gemm_bf16(a, b, a_kc, b_kc, M, N, K, out=None, out_dtype=BF16, ldc=None, epi
         raise TypeError("gemm_bf16: the bias stays fp32")
     aux1_f32 = aux1 is not None and aux1.dtype == torch.float32
     for t_ in (aux2, out2):
-        if t_ is not None and not is_bf16(t_):
-            raise TypeError("gemm_bf16: aux2 / out2 are bf16")
+        if t_ is not None and not is_bf16(t_) and not (t_ is out2 and epi == _EPI_RELU_MASK_COLSUM):
+            raise TypeError("gemm_bf16: aux2 / out2 are bf16 (out2 of EPI_RELU_MASK_COLSUM: fp32 partial rows)")
     kind = "gemm_fwd_nt" if (a_kc and b_kc) else ("gemm_dx_nn" if a_kc else "gemm_dw_tn")
     with _timed(kind, 2.0 * M * N * K):
         check(lib.mapx_gemm_bf16(int(a_kc), int(b_kc), M, N, K, a.data_ptr(), lda, b.data_ptr(), ldb,
@@ -790,8 +793,12 @@ RELU_LINK = os.environ.get("MAPX_RELU_LINK", "1") == "1"
 def fused_mask_colsum_ok(dy, relu_of):
     """Can linear_bwd_input also apply the upstream ReLU's mask and form its bias gradient?  (fp32 on
     the bf16-matrix-core family, 16-byte rows, deferred partial sums on.)"""
-    return (RELU_LINK and GEMM_X3 and DEFER_COLSUM and dy.dtype == torch.float32 and relu_of.dtype == torch.float32
-            and relu_of.dim() == 2 and relu_of.shape[1] % 4 == 0 and row_sliceable(relu_of))
+    if not (RELU_LINK and DEFER_COLSUM and relu_of.dim() == 2 and dy.dtype == relu_of.dtype):
+        return False
+    if is_bf16(dy):
+        return relu_of.shape[1] % 8 == 0 and relu_of.stride(1) == 1 and relu_of.stride(0) % 8 == 0 \
+            and relu_of.data_ptr() % 16 == 0
+    return GEMM_X3 and dy.dtype == torch.float32 and relu_of.shape[1] % 4 == 0 and row_sliceable(relu_of)
 
 
 def linear_bwd_input(dy, w, out=None, add=None, relu_of=None, colsum_to=None):
