@@ -771,7 +771,16 @@ __global__ void __launch_bounds__(256) sum_tasks_kernel(SumTasks tasks) {
        i += (int64_t)gridDim.x * blockDim.x) {
     float v = 0.f;
     int s = 0;
-    for (; s + 8 <= tk.nsplit; s += 8) {        // 8 loads in flight, added in slab order
+    // The kernel is a latency chain (a column has one thread, a task a few blocks): 32 loads in flight per
+    // round trip — 128 row-chunk partials of a bias gradient are 4 round trips, not 16 — added in slab order.
+    for (; s + 32 <= tk.nsplit; s += 32) {
+      float x[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) x[u] = tk.src[(s + u) * tk.stride + i];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) v += x[u];
+    }
+    for (; s + 8 <= tk.nsplit; s += 8) {
       float x[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) x[u] = tk.src[(s + u) * tk.stride + i];
