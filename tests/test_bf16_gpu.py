@@ -416,3 +416,23 @@ def test_bf16_graph_replay_equals_eager_bitwise_and_checkpoint_is_fp32():
         assert all(v.dtype != BF for v in ck.values()) and set(ck) == set(out[-1])
     for k in out[0]:
         assert torch.equal(out[0][k], out[1][k]), k
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 1000, 1000), (300, 368, 200)])
+def test_gemm_bf16_relu_mask_colsum_epilogue(M, N, K):
+    """EPI_RELU_MASK_COLSUM on the bf16 family: masked bf16 result + fp32 partial rows (one per 128-row tile)
+    whose sum is the column sum of the bf16 values stored; and the woven K loop against hipcc's own order."""
+    from mapx import ops
+    from mapx.native import EPI_RELU_MASK_COLSUM
+    g = torch.Generator().manual_seed(M + N)
+    dy, w = torch.randn(M, K, generator=g).to(BF), torch.randn(K, N, generator=g).to(BF)
+    y = torch.randn(M, N, generator=g).to(BF)
+    part = torch.full(((M + 127) // 128, N), 7.0, dtype=torch.float32, device=DEV)
+    dz = ops.gemm_bf16(dy.to(DEV), w.to(DEV), True, False, M, N, K, epi=EPI_RELU_MASK_COLSUM, aux1=y.to(DEV), out2=part)
+    ref = (dy.double() @ w.double()) * (y.double() > 0)
+    bound = dy.abs().double() @ w.abs().double()
+    d = (dz.double().cpu() - ref).abs()
+    assert bool((d <= 0.5 * EPS_BF * ref.abs() + 4e-6 * bound + 1e-30).all())
+    got, want = part.double().cpu().sum(0), dz.double().cpu().sum(0)
+    assert bool(((got - want).abs() <= 1e-6 * dz.double().cpu().abs().sum(0) + 1e-6).all())
+

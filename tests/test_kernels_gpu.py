@@ -284,6 +284,88 @@ def test_gemm_tn_deep_kernel(ops, M, N, K, ns):
         assert torch.equal(big[:, :N], out) and bool((big[:, N:] == 3.0).all())
 
 
+@pytest.mark.parametrize("a_kc,b_kc,M,N,K", [(1, 1, 4096, 1000, 368), (1, 1, 4096, 1000, 1000), (1, 0, 4096, 1368, 736),
+                                             (0, 0, 1000, 1000, 4096), (1, 1, 300, 200, 200), (0, 0, 300, 200, 520),
+                                             (1, 0, 777, 1624, 1248), (1, 1, 256, 128, 64), (1, 0, 130, 72, 40)])
+def test_gemm_every_tile_layout(ops, a_kc, b_kc, M, N, K):
+    """Every tile layout of the fp32 GEMM (hints 0-3: 64x64, 128x64, 128x128 by 8 waves, 128x128 by 4
+    waves with the hand-woven K-step) on the step's shapes and on the woven loop's corner cases: a K
+    remainder (the partial tile goes first), edge tiles in both dimensions (out-of-range rows are read from
+    row 0, not masked), K of exactly two K-steps, and K too short for the woven loop (falls back)."""
+    g = torch.Generator().manual_seed(M * 131 + N * 17 + K)
+    A = torch.randn((M, K) if a_kc else (K, M), generator=g)
+    B = torch.randn((N, K) if b_kc else (K, N), generator=g)
+    Am, Bm = (A if a_kc else A.t()), (B.t() if b_kc else B)
+    ref = Am.double() @ Bm.double()
+    bound = 2e-6 * (Am.abs().double() @ Bm.abs().double()) + 1e-6
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    for tile in (-1, 0, 1, 2, 3):
+        out = ops.gemm(Ad, Bd, bool(a_kc), bool(b_kc), M, N, K, tile=tile)
+        assert bool(((_cpu(out).double() - ref).abs() <= bound).all()), tile
+        assert torch.equal(out, ops.gemm(Ad, Bd, bool(a_kc), bool(b_kc), M, N, K, tile=tile)), tile
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 1000, 1000), (300, 368, 200), (129, 72, 1000)])
+def test_gemm_relu_mask_colsum_epilogue(ops, M, N, K):
+    """EPI_RELU_MASK_COLSUM (an MLP layer's dX GEMM doing the upstream layer's ReLU backward): the masked
+    product, and one partial row of its column sums per 128-row tile that add up to the bias gradient."""
+    from mapx.native import EPI_RELU_MASK_COLSUM
+    if not ops.GEMM_X3:
+        pytest.skip("the fp32-MFMA family has no such epilogue")
+    g = torch.Generator().manual_seed(M + N + K)
+    dy, w, y = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g), torch.randn(M, N, generator=g)
+    part = torch.full(((M + 127) // 128, N), 7.0, device=DEV)
+    dz = ops.gemm(dy.to(DEV), w.to(DEV), True, False, M, N, K, epi=EPI_RELU_MASK_COLSUM, aux1=y.to(DEV), out2=part)
+    ref = (dy.double() @ w.double()) * (y > 0)
+    bound = 2e-6 * (dy.abs().double() @ w.abs().double()) + 1e-6
+    assert bool(((_cpu(dz).double() - ref).abs() <= bound).all())
+    # the partial rows are exactly the fp32 sums of the stored tile rows, tile by tile, in a fixed order
+    got = _cpu(part).double().sum(0)
+    want = _cpu(dz).double().sum(0)
+    assert bool(((got - want).abs() <= 1e-6 * _cpu(dz).double().abs().sum(0) + 1e-6).all())
+    again = torch.empty_like(part)
+    ops.gemm(dy.to(DEV), w.to(DEV), True, False, M, N, K, epi=EPI_RELU_MASK_COLSUM, aux1=y.to(DEV), out2=again)
+    assert torch.equal(part, again)
+
+
+def test_mlp_backward_link_equals_unlinked(ops, monkeypatch):
+    """layers._ReluLink: the MLP's gradients with the ReLU mask + bias gradient folded into the consumer's dX
+    epilogue agree with the plain chain (same math, different summation order of the bias gradient)."""
+    from mapx import layers
+    torch.manual_seed(3)
+    x = torch.randn(512, 368, device=DEV)
+    outs = []
+    for link in (True, False):
+        monkeypatch.setattr(ops, "RELU_LINK", link)
+        torch.manual_seed(7)
+        mlp = layers.MLPBlock(368, hidden_size=1000, num_hidden_layers=3, hidden_dropout_rate=0.0).to(DEV)
+        slots = {id(p): torch.zeros_like(p) for p in mlp.parameters()}
+        monkeypatch.setattr(layers, "_grad_slot", lambda p: slots.get(id(p)))
+        xin = x.clone().requires_grad_(True)
+        mlp(xin).square().sum().backward()
+        ops.flush_deferred()
+        outs.append(([slots[id(p)].clone() for p in mlp.parameters()], xin.grad.clone()))
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6
+    assert float((outs[0][1] - outs[1][1]).abs().max()) <= 2e-5 * float(outs[1][1].abs().max())
+
+
+def test_mask_rows_with_device_cursor(ops):
+    """mapx_dynamic_mask_mfp_rows with a device-side cursor (a captured step walking an epoch's permutation)
+    == the same call on the slice of row numbers."""
+    g = torch.Generator().manual_seed(0)
+    N_, F, B, L = 5000, 23, 256, 6
+    split = torch.randint(10, 1000, (N_, F), generator=g).to(DEV)
+    order = torch.randperm(N_, generator=g).to(DEV)
+    mi = torch.stack([torch.randperm(F, generator=g)[:L] for _ in range(B)]).to(DEV)
+    for start in (0, 256, 4096):
+        cur = torch.tensor([start], dtype=torch.int64, device=DEV)
+        a = ops.dynamic_mask_mfp(split, L, masked_index=mi, sel=order, sel_cursor=cur, batch=B)
+        b = ops.dynamic_mask_mfp(split, L, masked_index=mi, sel=order[start:start + B].contiguous())
+        for x_, y_ in zip(a, b):
+            assert torch.equal(x_, y_)
+
+
 def test_gemm_writes_into_column_slice(ops):
     x, w, b = torch.randn(50, 64, device=DEV), torch.randn(40, 64, device=DEV), torch.randn(40, device=DEV)
     final = torch.full((50, 100), 7.0, device=DEV)
