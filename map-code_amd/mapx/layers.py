@@ -8,7 +8,7 @@ import torch
 from torch import nn
 from torch.autograd import Function
 
-from . import ops
+from . import ops, parallel
 
 
 def compute_dtype_of(config):
@@ -203,6 +203,10 @@ class _Gather(Function):
     def backward(ctx, g):
         if ctx.plan is None:
             raise RuntimeError("embedding backward without a segment plan")
+        if getattr(ctx.table, "mark_dense_ready", False) and ops.TAIL_OVERLAP and not parallel.exchanging():
+            # this node is the model's last: every dense gradient is enqueued (the towers' streams are joined
+            # in the gradient this node receives) — the optimizer's dense half need not wait for the table's
+            ops.dense_ready[0], ops.dense_ready[1] = ops.record_event(), torch.cuda.current_stream()
         plan = ctx.plan.get()
         g = g.contiguous().view(-1, ctx.width)           # bf16 rows in bf16 mode: summed in fp32
         ctx.table.sparse_grad = (plan, ops.seg_reduce_rows(plan, g, ctx.width), None)

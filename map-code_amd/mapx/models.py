@@ -164,6 +164,7 @@ class DCNV2(BaseModel):
         super().__init__(model_name="DCNV2", config=config)
         self.embed = Embeddings(config)
         self.embed.defer_plan = True                 # forward() picks the fork point of the sort
+        self.embed.table.mark_dense_ready = True     # the gather's backward node is this model's last one
         input_dim = config.num_fields * config.embed_size
         self.cross_net = CrossNetV2(input_dim, config.num_cross_layers)
         final_dim = input_dim

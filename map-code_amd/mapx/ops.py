@@ -105,6 +105,10 @@ def aux_stream(name, device, high=False):
 # side-stream chain that has slack (the cross tower's backward) — the same placement that works in
 # forward for the NCE sampling; whatever is still queued when the optimizer starts runs there.
 _side_tasks = []
+# "every dense gradient of this backward pass is final": an event recorded by the model's LAST backward node
+# (the embedding gather of a tower model) before its own kernels; the optimizer's dense half may start there
+dense_ready = [None, None]        # [event, stream it was recorded on]
+TAIL_OVERLAP = os.environ.get("MAPX_TAIL_OVERLAP", "1") == "1"
 
 
 def add_side_task(fn):
@@ -211,8 +215,12 @@ def defer_sum(dst, src, stride, nsplit, n):
 def flush_deferred():
     """Launch the pending slab sums (32 tasks per launch)."""
     global _deferred
+    cur = torch.cuda.current_stream() if torch.cuda.is_available() else None
     while _deferred:
         batch, _deferred = _deferred[:32], _deferred[32:]
+        if cur is not None:
+            for (_, src, _, _, _) in batch:       # partial buffers die with this list: keep them from being
+                src.record_stream(cur)            # recycled while another stream than their own still reads them
         arr = (N.SumTask * len(batch))()
         for i, (dst, src, stride, nsplit, n) in enumerate(batch):
             arr[i].dst, arr[i].src = dst.data_ptr(), src.data_ptr()

@@ -207,12 +207,30 @@ class MapxOptimizer:
     def step(self):
         ops.run_side_tasks()            # early table updates nobody picked up
         self.collect_torch_grads()
-        ops.flush_deferred()            # split-K slabs / colsum partials of this backward pass
-        if self.max_grad_norm > 0:
-            self.clip_grad_norm_()
-        self._dense_update()
-        for t in self.tables:
-            t.update()
+        ev, ev_stream = ops.dense_ready
+        ops.dense_ready[0] = ops.dense_ready[1] = None
+        main = torch.cuda.current_stream() if torch.cuda.is_available() else None
+        from . import parallel
+        if ev is not None and self.max_grad_norm <= 0 and ev_stream == main and not parallel.exchanging():
+            # The dense half (partial sums + dense AdamW, HBM-bound, ~30 us) beside the tables' half (the
+            # embedding gradient's reduction + row updates, ~30 us) instead of behind it: it forks from the
+            # point where the dense gradients were final, on the tower stream, which is idle by then.
+            side = ops.aux_stream("tower", self.done.device)
+            forked = ops.stream_wait_event(side, ev, main)
+            with torch.cuda.stream(side):
+                ops.flush_deferred()
+                self._dense_update()
+            for t in self.tables:
+                t.update()
+            if forked:
+                ops.stream_wait(main, side)
+        else:
+            ops.flush_deferred()            # split-K slabs / colsum partials of this backward pass
+            if self.max_grad_norm > 0:
+                self.clip_grad_norm_()
+            self._dense_update()
+            for t in self.tables:
+                t.update()
         ops.step_advance(self.done)
         self.steps_done += 1
         for t in self.tables:
@@ -230,6 +248,7 @@ class MapxOptimizer:
         the sparse side channel needs clearing."""
         for t in self.tables:
             t.table.sparse_grad = None
+        ops.dense_ready[0] = ops.dense_ready[1] = None
 
     def flush(self):
         """Materialise reference-equivalent table weights (before eval / checkpoint)."""
