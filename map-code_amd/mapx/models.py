@@ -214,7 +214,9 @@ class DCNV2(BaseModel):
                         and (groups is not None or self.embed.compute_dtype != torch.float32):
                     # the NCE head's sampling and the lazy catch-up of the sampled rows need only
                     # the targets: HBM-bound kernels that run beside the deep tower's first GEMMs
-                    # instead of alone between the towers and the loss (same branch, no new one)
+                    # instead of alone between the towers and the loss (same branch, no new one).  (Round 2: BEHIND
+                    # the cross tower's GEMMs instead, the trunk joining at the cross tower's end and only the
+                    # loss kernel waiting for the sampling: 1.02 vs 0.91 ms fp32, 0.72 vs 0.66 bf16.)
                     nce_idx = self.mfp_criterion.sample_ids(labels, noise_samples)
                 cross_output = self.cross_net(feat_embed, out=ops.alias_cols(final_buf, 0, D) if direct else None)
             dnn_output = self.parallel_dnn(feat_embed, out=ops.alias_cols(final_buf, D, H) if direct else None)
