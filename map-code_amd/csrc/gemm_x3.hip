@@ -422,7 +422,8 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
   // K-step on LDS buffer CUR (= kt & 1, literal): at its start set CUR^1 holds tile kt+1 (landed),
   // set CUR holds tile kt+2 (in flight, issued one step ago)
   // Timing experiments (tools/x3_ablate.sh): -DMAPX_X3_ABLATE=<bits> builds the K loop without some of its
-  // phases (1 no global loads, 2 no cut / LDS stores / loads, 4 no MFMAs); results are then wrong.
+  // phases (1 no global loads, 2 no cut / LDS stores / loads, 4 no MFMAs; woven loop only: 8 B's cut
+  // skipped as if B came pre-split, 16 no LDS stores, 32 no global loads); results are then wrong.
 #ifdef MAPX_X3_ABLATE
   constexpr int kDbg = MAPX_X3_ABLATE;       // compile-time: a run-time switch would put branches into the slots
 #else
@@ -490,6 +491,7 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
   // (only the K bound needs zeros, and the prologue has dealt with it).
 #define MAPX_X_WSTORE(CUR, c, pl)                                                                      \
   do {                                                                                                 \
+    if (kDbg & 16) break;                                                                              \
     constexpr bool isA_ = (c) < OpA::NV;                                                               \
     constexpr int i_ = isA_ ? (c) : (c) - OpA::NV, plane_ = isA_ ? OpA::PLANE : OpB::PLANE;            \
     bf16_t* const d_ = smem + ((CUR) ^ 1) * kBuf + (isA_ ? soffA[i_] : soffB[i_]) + (pl) * plane_;     \
@@ -498,6 +500,7 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
   } while (0)
 #define MAPX_X_WLOAD(CUR, c)                                                                           \
   do {                                                                                                 \
+    if (kDbg & 32) break;                                                                              \
     constexpr bool isA_ = (c) < OpA::NV;                                                               \
     constexpr int i_ = isA_ ? (c) : (c) - OpA::NV;                                                     \
     const float* const q_ = isA_ ? wA + goffA[i_] : wB + goffB[i_];                                    \
@@ -514,7 +517,12 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
     constexpr int c_ = (u) / 12, e_ = ((u) % 12) / 3, st_ = (u) % 3;                                   \
     constexpr bool isA_ = c_ < OpA::NV;                                                                \
     constexpr int i_ = isA_ ? c_ : c_ - OpA::NV;                                                       \
-    if (st_ == 0) {                                                                                    \
+    if ((kDbg & 8) && !isA_) {      /* ablation: B as if it came pre-split (no VALU; wrong results) */   \
+      const float4 v_ = lb[(CUR) ^ 1].r[i_][e_ >> 1];                                                  \
+      if (st_ == 0) cH[c_ & 1][e_] = __float_as_uint(v_.x);                                            \
+      if (st_ == 1) cM[c_ & 1][e_] = __float_as_uint(v_.y);                                            \
+      if (st_ == 2) cL[c_ & 1][e_] = __float_as_uint(v_.z);                                            \
+    } else if (st_ == 0) {                                                                             \
       const float4 v_ = isA_ ? la[(CUR) ^ 1].r[i_][e_ >> 1] : lb[(CUR) ^ 1].r[i_][e_ >> 1];            \
       piece((e_ & 1) ? v_.z : v_.x, (e_ & 1) ? v_.w : v_.y, cH[c_ & 1][e_], cr0, cr1);                 \
     } else if (st_ == 1) {                                                                             \
@@ -523,6 +531,8 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
       cr0 = t0_; cr1 = t1_;                                                                            \
     } else {                                                                                           \
       cL[c_ & 1][e_] = pk_bf16(cr0, cr1);                                                              \
+    }                                                                                                  \
+    if (st_ == 2) {                                                                                    \
       if (c_ > 0 && e_ < 3) MAPX_X_WSTORE(CUR, (c_ > 0 ? c_ - 1 : 0), e_);                             \
       if (c_ > 0 && e_ == 3) MAPX_X_WLOAD(CUR, (c_ > 0 ? c_ - 1 : 0));                                 \
     }                                                                                                  \
