@@ -105,6 +105,7 @@ def aux_stream(name, device, high=False):
 # side-stream chain that has slack (the cross tower's backward) — the same placement that works in
 # forward for the NCE sampling; whatever is still queued when the optimizer starts runs there.
 _side_tasks = []
+pending_joins = []                # (waiting stream, side stream) left open by a backward node; the optimizer joins
 # "every dense gradient of this backward pass is final": an event recorded by the model's LAST backward node
 # (the embedding gather of a tower model) before its own kernels; the optimizer's dense half may start there
 dense_ready = [None, None]        # [event, stream it was recorded on]
