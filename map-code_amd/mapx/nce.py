@@ -59,6 +59,10 @@ class AliasMultinomial(nn.Module):
         return ops.alias_draw(self.packed(), targets, K, seed, offset, offset_dev)
 
 
+def _head_side():
+    return HEAD_SIDE
+
+
 class _NceLoss(Function):
     @staticmethod
     def forward(ctx, enc, emb_w, bias_w, logq, masked_index, idx, crit, F, P, want_logits):
@@ -81,6 +85,19 @@ class _NceLoss(Function):
         if ctx.plan is None:
             raise RuntimeError("NCE backward without a segment plan")
         plan = ctx.plan.get()
+        lazy = ctx.crit.table.lazy
+        if lazy is not None and getattr(lazy, "early_now", False) and _head_side() and dh.is_cuda:
+            # as in _EncNceLoss.backward: the table's gradient and row update leave the main chain
+            main, side = torch.cuda.current_stream(), ops.aux_stream("tower", dh.device)
+            if ops.stream_wait(side, main):
+                with torch.cuda.stream(side):
+                    ge, gb = ops.nce_table_grad(plan, dlogit, h, ctx.K, ctx.P, gscale=gl)
+                    ctx.crit.table.sparse_grad = (plan, ge, gb)
+                    lazy.update()
+                for t in (ge, gb, dlogit, h, gl) + tuple(plan.tensors()):
+                    t.record_stream(side)
+                ops.pending_joins.append((main, side))
+                return denc, None, None, None, None, None, None, None, None, None
         ge, gb = ops.nce_table_grad(plan, dlogit, h, ctx.K, ctx.P, gscale=gl)
         ctx.crit.table.sparse_grad = (plan, ge, gb)
         return denc, None, None, None, None, None, None, None, None, None
