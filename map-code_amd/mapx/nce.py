@@ -146,7 +146,8 @@ class _EncNceLoss(Function):
             # The table's gradient reduction and row update need nothing of this backward pass but the loss
             # scale; the trunk's backward needs only dfinal.  They go to the tower stream (idle between the
             # towers' forward and backward), forked behind the dX GEMM; the trunk's backward no longer waits
-            # for them on the main stream.
+            # for them on the main stream.  (The encoder's dW / db there as well, or on the plan stream: 0.888 /
+            # 0.883 vs 0.873 ms — the cross tower's backward queues behind whatever this stream holds.)
             plan = ctx.plan.get()
             main, side = torch.cuda.current_stream(), ops.aux_stream("tower", final.device)
             if ops.stream_wait(side, main):
