@@ -128,7 +128,7 @@ def parse():
     ap.add_argument("--preroll", type=int, default=400,
                     help="untimed real training steps before the warm-up, so that the lazy table optimizer "
                          "carries a realistic replay debt (rows re-touched after long gaps)")
-    ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=14)
     ap.add_argument("--fake-world", type=int, default=0, metavar="N",
                     help="data-parallel tail rehearsal on ONE GPU: N real forward/backward passes on different "
                          "batches give N ranks' sparse-gradient messages; the merge (gather exchange and "
