@@ -142,7 +142,9 @@ class _EncNceLoss(Function):
             raise RuntimeError("NCE backward without a segment plan")
         lazy = ctx.crit.table.lazy
         early = lazy is not None and getattr(lazy, "early_now", False)
-        if early and HEAD_SIDE and final.is_cuda:
+        # (with a gradient exchange or a clipping norm ahead the row update has to wait; the reduction need not)
+        aside = HEAD_SIDE and final.is_cuda and (early or ops.HEAD_SIDE_REDUCE_ONLY)
+        if aside:
             # The table's gradient reduction and row update need nothing of this backward pass but the loss
             # scale; the trunk's backward needs only dfinal.  They go to the tower stream (idle between the
             # towers' forward and backward), forked behind the dX GEMM; the trunk's backward no longer waits
@@ -154,7 +156,8 @@ class _EncNceLoss(Function):
                 with torch.cuda.stream(side):
                     ge, gb = ops.nce_table_grad(plan, dlogit, h, ctx.K, ctx.P, gscale=gl)
                     ctx.crit.table.sparse_grad = (plan, ge, gb)
-                    lazy.update()
+                    if early:
+                        lazy.update()
                 for t in (ge, gb, dlogit, h, gl) + tuple(plan.tensors()):
                     t.record_stream(side)
                 ops.pending_joins.append((main, side))

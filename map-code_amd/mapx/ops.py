@@ -106,6 +106,15 @@ def aux_stream(name, device, high=False):
 # forward for the NCE sampling; whatever is still queued when the optimizer starts runs there.
 _side_tasks = []
 pending_joins = []                # (waiting stream, side stream) left open by a backward node; the optimizer joins
+HEAD_SIDE_REDUCE_ONLY = os.environ.get("MAPX_HEAD_SIDE_DP", "1") == "1"
+
+
+def join_pending():
+    """Join the side streams that backward nodes forked and left open (optimizer.step, or the end of a captured
+    forward + backward whose tail runs elsewhere)."""
+    while pending_joins:
+        waiter, side = pending_joins.pop()
+        stream_wait(waiter, side)
 # "every dense gradient of this backward pass is final": an event recorded by the model's LAST backward node
 # (the embedding gather of a tower model) before its own kernels; the optimizer's dense half may start there
 dense_ready = [None, None]        # [event, stream it was recorded on]

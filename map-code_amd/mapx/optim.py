@@ -205,9 +205,7 @@ class MapxOptimizer:
                 p.grad = None
 
     def step(self):
-        while ops.pending_joins:        # side work a backward node forked and left open
-            waiter, side = ops.pending_joins.pop()
-            ops.stream_wait(waiter, side)
+        ops.join_pending()              # side work a backward node forked and left open
         ops.run_side_tasks()            # early table updates nobody picked up
         self.collect_torch_grads()
         ev, ev_stream = ops.dense_ready

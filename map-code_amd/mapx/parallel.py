@@ -286,6 +286,7 @@ def sync_dense(optimizer):
     """Mean over ranks of the dense gradients: one all-reduce per flat group."""
     from . import ops
     optimizer.collect_torch_grads()
+    ops.join_pending()                  # side streams of the backward pass (table gradients)
     ops.flush_deferred()                # dense gradients must be final before the all-reduce
     if exchanging() and dist.get_backend() == "nccl" and len(optimizer.groups) > 1:
         opts = dist.AllreduceCoalescedOptions()

@@ -248,6 +248,7 @@ class GraphedBackward:
                 # deferred partial sums (bias gradients) belong to this graph: the list that names them
                 # exists only while the capture runs, a replay would leave them unsummed for the tail
                 ops.flush_deferred()
+                ops.join_pending()        # side streams a backward node forked: joined inside this graph
         finally:
             if self.early:
                 layers.plan_observers.remove(publish)
