@@ -163,7 +163,7 @@ class _EncNceLoss(Function):
                 ops.pending_joins.append((main, side))
                 early = None
         dw = ops.enc_grouped_dw(dh_slots, final, ctx.groups, out=sw, gscale=gl)
-        db = ops.colsum(denc, out=sb)
+        db = ops.colsum(denc, out=sb, defer=True)      # second stage with the other deferred partial sums
         if early is not None:
             plan = ctx.plan.get()
             ge, gb = ops.nce_table_grad(plan, dlogit, h, ctx.K, ctx.P, gscale=gl)
