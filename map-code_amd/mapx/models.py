@@ -28,6 +28,7 @@ NCE_EARLY = os.environ.get("MAPX_NCE_EARLY", "1") == "1"
 # head's backward no longer waits 34 us for the latter — 1.13 vs 0.96 ms.)
 JOINT_PLAN = os.environ.get("MAPX_JOINT_PLAN", "auto")
 # the joint plan in forward waits for the deep tower's GEMMs to be on their way (see above)
+LAYOUT_ON_MAIN = os.environ.get("MAPX_LAYOUT_ON_MAIN", "1") == "1"     # 0.869 / 0.873 vs 0.876 / 0.882 ms
 PLAN_AFTER_DNN = os.environ.get("MAPX_PLAN_AFTER_DNN", "1") == "1"
 
 _OTHER_BACKBONES = ("trans", "fignn", "fgcnn")
@@ -205,8 +206,12 @@ class DCNV2(BaseModel):
             D, H = feat_embed.shape[1], self.config.hidden_size
             direct = self.config.num_cross_layers > 0
             final_buf = torch.empty(feat_embed.shape[0], D + H, dtype=feat_embed.dtype, device=feat_embed.device)
+            if LAYOUT_ON_MAIN and self._grouped_head(masked_index):
+                # the grouped encoder's slot layout (one 15-us launch) ahead of the deep tower, which by now
+                # has ~45 us of slack against the cross tower's stream (round 1 had it the other way round)
+                groups = ops.EncGroups(masked_index, self.config.num_fields)
             with torch.cuda.stream(tower):
-                if self._grouped_head(masked_index):
+                if self._grouped_head(masked_index) and groups is None:
                     # the cross tower has ~70 us of slack against the deep one: the slot layout of
                     # the grouped encoder (one single-workgroup launch) rides on its stream
                     groups = ops.EncGroups(masked_index, self.config.num_fields)
