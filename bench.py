@@ -457,7 +457,7 @@ def main():
     # committed PMC passes measured per launch
     data_dependent = ("table_adam_update", "table_adam_catchup", "nce_table_grad", "seg_reduce_rows")
     # the grouped feat_encoder kernels compute in fp32 in either mode; the dense GEMM classes follow --dtype
-    f32_kind = "f32x3" if ops.GEMM_X3 else "f32"
+    f32_kind = "f32x3"
     mfma_peak = lambda name: MFMA_PEAK_TFLOPS[f32_kind if ("grouped" in name or args.dtype == "f32") else args.dtype]
     gemm_flops = 0.0
     for name, s in ksum.items():
@@ -497,8 +497,7 @@ def main():
                                f"V={cfg.input_size}, E=16, H=1000x3, cross x3, P=32, K=25, mask_ratio 0.3"
                                + (", bf16 GEMM operands / activations over fp32 master weights, tables and optimizer"
                                   if args.dtype == "bf16" else
-                                  ", fp32 GEMMs as six bf16 MFMAs per product (operands cut into three bf16 pieces, fp32 accumulation)"
-                                  if ops.GEMM_X3 else ""),
+                                  ", fp32 GEMMs as six bf16 MFMAs per product (operands cut into three bf16 pieces, fp32 accumulation)"),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "launch": ("eager" if not tr.use_graph else
                               "hipGraph replay of mask + forward + backward; pack and merge + optimizer replayed per message size, RCCL calls eager"

@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 32
+#define MAPX_ABI_VERSION 33
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -230,8 +230,7 @@ int mapx_scale_inplace(float* x, int64_t n, const float* g, hipStream_t stream);
 #define MAPX_EPI_ADD 4
 #define MAPX_EPI_RELU_MASK 5
 /* RELU_MASK plus the column sums of the masked result, one partial row per 128-row tile: out2 [ceil(M/128)][ldo2]
- * fp32 (the upstream layer's bias gradient: add the rows with mapx_sum_tasks).  mapx_gemm_f32: the
- * fp32-on-bf16-matrix-core family only (mapx_gemm_f32_mode() == 1); mapx_gemm_bf16: `out2` then points to
+ * fp32 (the upstream layer's bias gradient: add the rows with mapx_sum_tasks).  mapx_gemm_bf16: `out2` then points to
  * those FP32 partial rows (ldo2 in floats) and the sums are those of the bf16 values stored.  16-byte aligned
  * operands, no split-K; else MAPX_EINVAL. */
 #define MAPX_EPI_RELU_MASK_COLSUM 6
@@ -239,11 +238,6 @@ int mapx_scale_inplace(float* x, int64_t n, const float* g, hipStream_t stream);
  * *nsplit_deferred receives the slab count (0 = C already final): the caller sums them later
  * with mapx_sum_tasks, together with every other deferred sum of the backward pass. */
 size_t mapx_gemm_splitk_workspace_bytes(int M, int N, int nsplit);
-/* Which kernel family mapx_gemm_f32 runs on: 1 = fp32 operands cut into three bf16 pieces, six
- * v_mfma_f32_32x32x16_bf16 per product, fp32 accumulation (csrc/gemm_x3.hip; default), 0 = the exact
- * fp32 FMA chain of v_mfma_f32_32x32x2_f32 (environment MAPX_GEMM=mfma32).  Callers use it to pick
- * split-K factors (the two families prefer different tile shapes). */
-int mapx_gemm_f32_mode(void);
 int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, int64_t lda,
                   const float* B, int64_t ldb, float* C, int64_t ldc, int epi, const float* bias,
                   const float* aux1, int64_t ld1, const float* aux2, int64_t ld2, float* out2,

@@ -69,18 +69,24 @@ __global__ void __launch_bounds__(256) mask_mfp_kernel(const int64_t* __restrict
                                                        int64_t* __restrict__ mi_out,
                                                        int32_t* __restrict__ keys_out,
                                                        const int64_t* __restrict__ sel,
-                                                       const int64_t* __restrict__ sel_cursor) {
+                                                       const int64_t* __restrict__ sel_cursor, int64_t nrows) {
   // sel (optional): batch row b is row sel[b] of `ids` — the batch is cut out of the HBM-resident
   // split here instead of by two index kernels and two copies in front of every step
   if (offset_dev) offset += (uint64_t)(uint32_t)*offset_dev;   // graph-replay safe stream offset
   // sel_cursor (optional): `sel` is a whole epoch's permutation and the batch starts at *sel_cursor — a
   // captured step then walks the epoch by itself, with no copy of row numbers in front of each replay
   if (sel && sel_cursor) sel += *sel_cursor;
+  // (row numbers outside the split — a cursor walked past its permutation, a corrupt selection — are clamped:
+  // the caller checks its cursor on the host, GraphedStep.__call__; a stray row must not become a page fault)
+  auto row_of = [&](int64_t b) {
+    const int64_t r = sel[b];
+    return r < 0 ? (int64_t)0 : (r < nrows ? r : nrows - 1);
+  };
   for (int64_t b0 = (int64_t)blockIdx.x * kMaskRows; b0 < B; b0 += (int64_t)gridDim.x * kMaskRows) {
     const int64_t rows = (B - b0) < kMaskRows ? (B - b0) : kMaskRows;
     for (int64_t i = threadIdx.x; i < rows * F; i += blockDim.x) {
       const int64_t b = b0 + i / F;
-      ids_out[b0 * F + i] = sel ? ids[sel[b] * F + i % F] : ids[b0 * F + i];
+      ids_out[b0 * F + i] = sel ? ids[row_of(b) * F + i % F] : ids[b0 * F + i];
     }
     __threadfence_block();
     __syncthreads();
@@ -94,7 +100,7 @@ __global__ void __launch_bounds__(256) mask_mfp_kernel(const int64_t* __restrict
         f = bounded(r.x, (uint32_t)F);
       }
       if (mi_out) mi_out[b * L + l] = f;
-      labels[b * L + l] = ids[(sel ? sel[b] : b) * F + f];
+      labels[b * L + l] = ids[(sel ? row_of(b) : b) * F + f];
       ids_out[b * F + f] = 3;  // '<mask>' (duplicates of f write the same value)
     }
     __threadfence_block();
@@ -206,7 +212,7 @@ extern "C" int mapx_dynamic_mask_mfp(const int64_t* ids, int64_t B, int F, int L
   if (B == 0) return MAPX_OK;
   hipLaunchKernelGGL(mask_mfp_kernel, dim3(grid_for(B, kMaskRows)), dim3(256), 0, stream, ids, B, F, L,
                      masked_index_in, seed, offset, offset_dev, ids_out, labels, masked_index_out, keys_out_opt,
-                     (const int64_t*)nullptr, (const int64_t*)nullptr);
+                     (const int64_t*)nullptr, (const int64_t*)nullptr, (int64_t)0);
   return check_launch("dynamic_mask_mfp");
 }
 
@@ -221,7 +227,7 @@ extern "C" int mapx_dynamic_mask_mfp_rows(const int64_t* split_ids, int64_t N, c
   if (B == 0) return MAPX_OK;
   hipLaunchKernelGGL(mask_mfp_kernel, dim3(grid_for(B, kMaskRows)), dim3(256), 0, stream, split_ids, B, F, L,
                      masked_index_in, seed, offset, offset_dev, ids_out, labels, masked_index_out, keys_out_opt, sel,
-                     sel_cursor_dev_opt);
+                     sel_cursor_dev_opt, N);
   return check_launch("dynamic_mask_mfp_rows");
 }
 

@@ -92,7 +92,7 @@ class BaseModel(nn.Module):
         if (is_pretrain is None and cfg.pretrain) or is_pretrain:
             if cfg.pt_type == "MFP":
                 crit = self.mfp_criterion
-                if (GROUPED_ENCODER and crit.supports_grouped_encoder() and inputs.shape[1] % 4 == 0
+                if (GROUPED_ENCODER and crit.supports_grouped_encoder() and inputs.shape[1] % 8 == 0
                         and inputs.dtype == torch.float32):
                     # only the L masked fields' blocks of feat_encoder are computed (26 %)
                     loss, _logits, _idx = crit.forward_with_encoder(labels, inputs, self.feat_encoder,
@@ -186,7 +186,7 @@ class DCNV2(BaseModel):
     def _grouped_head(self, masked_index):
         return (self._mfp_head(masked_index) and self.embed.compute_dtype == torch.float32
                 and GROUPED_ENCODER and self.mfp_criterion.supports_grouped_encoder()
-                and self.feat_encoder.in_features % 4 == 0)
+                and self.feat_encoder.in_features % 8 == 0)
 
     def forward(self, input_ids, labels=None, masked_index=None, noise_samples=None):
         groups, nce_idx = None, None

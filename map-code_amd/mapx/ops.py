@@ -136,11 +136,18 @@ def clear_side_tasks():
 
 
 def reset_aux_streams():
-    """Forget the named side streams (new ones are made on demand): after a failed graph capture
-    the old ones may be stuck in the invalidated capture."""
+    """Forget the named side streams (new ones are made on demand) and everything a backward pass may have
+    left queued on them: after a failed graph capture the streams may be stuck in the invalidated capture,
+    and the per-backward lists (joins left open, deferred partial sums, side tasks, the dense-ready event)
+    still name that capture's streams, events and partial buffers — an eager retry that found them would
+    wait on a dead stream in optimizer.step() or sum stale partials into the bias gradients."""
     _aux_streams.clear()
     _scratch_retired.extend(_scratch.values())
     _scratch.clear()
+    pending_joins.clear()
+    _deferred.clear()
+    _side_tasks.clear()
+    dense_ready[0] = dense_ready[1] = None
 
 
 def _capturing(st):
@@ -809,14 +816,14 @@ RELU_LINK = os.environ.get("MAPX_RELU_LINK", "1") == "1"
 
 
 def fused_mask_colsum_ok(dy, relu_of):
-    """Can linear_bwd_input also apply the upstream ReLU's mask and form its bias gradient?  (fp32 on
-    the bf16-matrix-core family, 16-byte rows, deferred partial sums on.)"""
+    """Can linear_bwd_input also apply the upstream ReLU's mask and form its bias gradient?  (16-byte rows,
+    deferred partial sums on.)"""
     if not (RELU_LINK and DEFER_COLSUM and relu_of.dim() == 2 and dy.dtype == relu_of.dtype):
         return False
     if is_bf16(dy):
         return relu_of.shape[1] % 8 == 0 and relu_of.stride(1) == 1 and relu_of.stride(0) % 8 == 0 \
             and relu_of.data_ptr() % 16 == 0
-    return GEMM_X3 and dy.dtype == torch.float32 and relu_of.shape[1] % 4 == 0 and row_sliceable(relu_of)
+    return dy.dtype == torch.float32 and relu_of.shape[1] % 4 == 0 and row_sliceable(relu_of)
 
 
 def linear_bwd_input(dy, w, out=None, add=None, relu_of=None, colsum_to=None):
@@ -841,9 +848,6 @@ def linear_bwd_input(dy, w, out=None, add=None, relu_of=None, colsum_to=None):
     return dx
 
 
-GEMM_X3 = lib.mapx_gemm_f32_mode() == 1      # fp32 GEMMs as 3 x bf16 split products (csrc/gemm_x3.hip)
-
-
 def _splits_wide_tiles(M, Nn, Kred):
     """split-K factor for the bf16-MFMA kernels (bf16 operands, or fp32 cut into three bf16 pieces):
     128 x 128 tiles, split over K until they cover the 256 CUs, K chunk >= 256."""
@@ -854,26 +858,12 @@ def _splits_wide_tiles(M, Nn, Kred):
     return ns
 
 
-def _splits_for(M, Nn, Kred):
-    """split-K factor for weight-gradient GEMMs (output [M,Nn] small, reduction Kred = batch
-    long): aim at ~1024 blocks of 64x64 (4 per CU), power of two, K chunk >= 256
-    (tools/gemm_bench.py sweep on MI355X)."""
-    tiles = math.ceil(M / 64) * math.ceil(Nn / 64)
-    if tiles >= 256:          # one 64x64 tile per CU already: 84.6 us unsplit vs 80.0 us + a 9-13 us slab sum
-        return 1
-    want = max(1.0, 1024.0 / tiles)
-    ns = min(16, 2 ** int(round(math.log2(want))))
-    while ns > 1 and Kred // ns < 256:
-        ns //= 2
-    return ns
-
-
 def linear_bwd_weight(dy, x, out=None, defer=False):
     """dW = dY^T X.  dy [B,N], x [B,K] -> [N,K].  defer: leave split-K slabs for flush_deferred()."""
     Bn, Nn = dy.shape
     K = x.shape[1]
     # the bf16-MFMA kernels want 128 x 128 tiles (half the L2 -> LDS bytes per flop of 64 x 64 ones)
-    ns = _splits_wide_tiles(Nn, K, Bn) if (is_bf16(dy) or GEMM_X3) else _splits_for(Nn, K, Bn)
+    ns = _splits_wide_tiles(Nn, K, Bn)
     if out is not None and out.stride(0) != K:
         ns = 1
     if is_bf16(dy):                          # fp32 gradient from bf16 operands

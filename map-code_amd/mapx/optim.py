@@ -146,9 +146,12 @@ class MapxOptimizer:
         for t in self.tables:
             t.early_now = bool(open_) and t.early_ok
 
+    FLAT_PAD = 8          # elements every parameter's slot of a flat buffer is rounded up to (saved with the state)
+
     @staticmethod
     def _flatten(members, wd, dev, bf16=False):
-        sizes = [(p.numel() + 7) // 8 * 8 for _, p in members]      # keep every view 16-B aligned (fp32 and bf16)
+        pad = MapxOptimizer.FLAT_PAD
+        sizes = [(p.numel() + pad - 1) // pad * pad for _, p in members]   # every view 16-B aligned (fp32 and bf16)
         total = sum(sizes)
         flat_p = torch.zeros(total, device=dev)
         flat_g = torch.zeros(total, device=dev)
@@ -163,7 +166,7 @@ class MapxOptimizer:
             p._mapx_bf16 = flat_h[off:off + p.numel()].view_as(p) if bf16 else None
             off += sz
         return dict(p=flat_p, g=flat_g, m=torch.zeros_like(flat_p), v=torch.zeros_like(flat_p), wd=wd,
-                    names=[n for n, _ in members], h=flat_h)
+                    names=[n for n, _ in members], numels=[p.numel() for _, p in members], h=flat_h)
 
     def refresh_bf16(self):
         """Re-derive the bf16 weight shadows from the fp32 master weights: after anything other than
@@ -199,20 +202,26 @@ class MapxOptimizer:
     def collect_torch_grads(self):
         """Parameters that a model uses through plain torch ops (e.g. DeepFM's one-element LR bias)
         get their gradient in `.grad`, not in the flat buffer the fused kernels write: move it."""
+        moved = 0
         for p in self.dense_params:
             if p.grad is not None:
                 p._mapx_grad.copy_(p.grad)
                 p.grad = None
+                moved += 1
+        return moved
 
     def step(self):
         ops.join_pending()              # side work a backward node forked and left open
         ops.run_side_tasks()            # early table updates nobody picked up
-        self.collect_torch_grads()
+        moved = self.collect_torch_grads()
         ev, ev_stream = ops.dense_ready
         ops.dense_ready[0] = ops.dense_ready[1] = None
         main = torch.cuda.current_stream() if torch.cuda.is_available() else None
         from . import parallel
-        if ev is not None and self.max_grad_norm <= 0 and ev_stream == main and not parallel.exchanging():
+        # (the copies collect_torch_grads enqueued on the main stream come AFTER the dense-ready event: a side
+        # stream that waits for that event alone could read the flat gradient before they land)
+        if ev is not None and moved == 0 and self.max_grad_norm <= 0 and ev_stream == main \
+                and not parallel.exchanging():
             # The dense half (partial sums + dense AdamW, HBM-bound, ~30 us) beside the tables' half (the
             # embedding gradient's reduction + row updates, ~30 us) instead of behind it: it forks from the
             # point where the dense gradients were final, on the tower stream, which is idle by then.
@@ -261,7 +270,7 @@ class MapxOptimizer:
         """Everything needed to continue training bit-exactly: dense and table Adam moments, the
         per-row replay clocks, the update counter.  (The reference saves model weights only and
         cannot resume mid-run: trainer.py:517-519.)"""
-        return dict(steps_done=self.steps_done, done=self.done.cpu(),
+        return dict(steps_done=self.steps_done, done=self.done.cpu(), flat_pad=self.FLAT_PAD,
                     groups=[dict(names=g["names"], m=g["m"].cpu(), v=g["v"].cpu()) for g in self.groups],
                     tables=[dict(name=t.table.name, m0=t.m0.cpu(), v0=t.v0.cpu(),
                                  m1=None if t.m1 is None else t.m1.cpu(),
@@ -271,8 +280,23 @@ class MapxOptimizer:
     def load_state_dict(self, sd):
         self.steps_done = int(sd["steps_done"])
         self.done.copy_(sd["done"])
+        pad = int(sd.get("flat_pad", 4))      # (states written before the key existed used slots of 4 elements)
         for g, s in zip(self.groups, sd["groups"]):
-            assert g["names"] == s["names"], "parameter layout changed since the state was saved"
+            if g["names"] != s["names"]:
+                raise ValueError("optimizer state: the parameter list changed since the state was saved")
+            if pad != self.FLAT_PAD or s["m"].numel() != g["m"].numel():
+                # another slot size: the flat moments do not line up — re-pack them parameter by parameter
+                sizes = g["numels"]
+                src_off = dst_off = 0
+                for n in sizes:
+                    for key in ("m", "v"):
+                        g[key][dst_off:dst_off + n].copy_(s[key][src_off:src_off + n])
+                    src_off += (n + pad - 1) // pad * pad
+                    dst_off += (n + self.FLAT_PAD - 1) // self.FLAT_PAD * self.FLAT_PAD
+                if src_off != s["m"].numel():
+                    raise ValueError(f"optimizer state: flat moments of {s['m'].numel()} elements do not match the "
+                                     f"parameters at a slot size of {pad}")
+                continue
             g["m"].copy_(s["m"])
             g["v"].copy_(s["v"])
         for t, s in zip(self.tables, sd["tables"]):

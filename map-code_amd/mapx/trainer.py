@@ -176,6 +176,12 @@ class GraphedStep:
 
     def __call__(self, X, Y):
         if self.walk:
+            if not (isinstance(X, RowsRef) and X.order is not None and Y is X):
+                raise TypeError("this captured step walks an epoch's permutation: it takes the RowsRef batches of "
+                                "DeviceSplit.batches(rows=True), not tensors (run_step keys its graphs by input kind)")
+            if X.start + X.shape[0] > X.order.numel():
+                raise IndexError(f"batch rows [{X.start}, {X.start + X.shape[0]}) run past the epoch's "
+                                 f"{X.order.numel()} rows")
             if X.order is not self._src:               # a new epoch's permutation
                 self.order.copy_(X.order)
                 self._src, self._expect = X.order, None
@@ -497,7 +503,8 @@ class Trainer:
                      and (kind == "ctr" or self.args.sampling_method == "randint"))
         if not graphable:
             return fn(X, Y)
-        key = (kind, tuple(X.shape))
+        # (a step captured on row references walks the permutation by itself and cannot take tensor batches)
+        key = (kind, tuple(X.shape), isinstance(X, RowsRef) and X.order is not None)
         g = self._graphs.get(key, 0)
         if isinstance(g, int):
             if g < self.GRAPH_AFTER:

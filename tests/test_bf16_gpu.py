@@ -257,6 +257,8 @@ def test_bf16_model_vs_golden_and_oracle(case, mode):
     loss_ref, _, _ = _oracle_grads(mode, cfg, params, inp, preacts=pre)
     assert abs(loss_ref - float(z["out/loss"])) <= 1e-5 * abs(loss_ref)       # the oracle IS the golden path
     flips = _check_pattern(masks, pre, f"{case}/{mode}")
+    from util import note_golden
+    note_golden(f"bf16/DCNv2/{mode}/{case}", "bf16-pattern", flips)      # bf16 mode is always compared on its own pattern
     _, _, ref_grads = _oracle_grads(mode, cfg, params, inp, relu_masks=masks)
     worst = _grads_vs(model, ref_grads, 1e-2, f"{case}/{mode}")
     print(f"[bf16 {case} {mode}] loss {float(loss.detach()):.6f} vs {float(z['out/loss']):.6f}; {flips} of "
@@ -264,16 +266,16 @@ def test_bf16_model_vs_golden_and_oracle(case, mode):
           f"worst gradient {worst[1]:.2e} of scale at {worst[0]}")
 
 
-@pytest.mark.parametrize("mode", ["MFP", "RFD", "CTR"])
-def test_bf16_full_batch_vs_fp32_oracle(mode):
-    """BASELINE batch (4096 x 23, K = 25, P = 32, H = 1000) in bf16 mode against the fp32 oracle on the
-    step's own masks / negatives / replacements: loss, logits, every gradient within 1e-2."""
+@pytest.mark.parametrize("mode,B,F", [("MFP", 4096, 23), ("RFD", 4096, 23), ("CTR", 4096, 23), ("MFP", 777, 39)])
+def test_bf16_full_batch_vs_fp32_oracle(mode, B, F):
+    """BASELINE batch (4096 x 23, K = 25, P = 32, H = 1000; and a ragged 777 x 39 Criteo-width batch) in bf16
+    mode against the fp32 oracle on the step's own masks / negatives / replacements: loss, logits, every
+    gradient within 1e-2."""
     from mapx import ops
     from mapx.dataset import synth_table
     from mapx.models import BaseModel
     from oracle import ref_model as R
     from util import make_config
-    B, F = 4096, 23
     cfg = dict(F=F, V=60000, E=16, H=1000, NL=3, NC=3, P=32, K=25)
     ids_np, y_np, _, _ = synth_table(B, F, cfg["V"], seed=1)
     cnt = np.bincount(ids_np.reshape(-1), minlength=cfg["V"]).astype(np.float32)

@@ -263,10 +263,10 @@ def test_gemm_backward_products(ops, M, N, K):
 
 @pytest.mark.parametrize("M,N,K,ns", [(128, 192, 512, 1), (128, 192, 512, 2), (1000, 1000, 256, 1), (1000, 1000, 4096, 1),
                                       (64, 64, 384, 1), (100, 68, 256, 1), (1000, 368, 2048, 2)])
-def test_gemm_tn_deep_kernel(ops, M, N, K, ns):
-    """Shapes that take the deep-K weight-gradient kernel (64x64x128 tiles, LDS-DMA staging: K and
-    the split chunks multiples of 128, one round of blocks): edge tiles (1000 = 15 x 64 + 40,
-    100 x 68), split-K slabs, and bit-reproducibility."""
+def test_gemm_weight_gradient_shapes(ops, M, N, K, ns):
+    """Weight-gradient products (both operands k-strided) with K a multiple of 128: edge tiles
+    (1000 = 7 x 128 + 104, 100 x 68), split-K slabs, padded leading dimensions, an output with a row stride of its
+    own, and bit-reproducibility."""
     g = torch.Generator().manual_seed(M + N + K + ns)
     a, b = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
     ad, bd = a.to(DEV), b.to(DEV)
@@ -305,13 +305,55 @@ def test_gemm_every_tile_layout(ops, a_kc, b_kc, M, N, K):
         assert torch.equal(out, ops.gemm(Ad, Bd, bool(a_kc), bool(b_kc), M, N, K, tile=tile)), tile
 
 
+def test_gemm_x3_operand_magnitudes(ops):
+    """The six-product arithmetic of the fp32 GEMM (three bf16 pieces per operand, csrc/gemm_x3.hip) away from
+    randn operands: what it guarantees and where it stops, as measured by
+    tools/micro/x3_magnitude_probe.py and stated in DESIGN 4.1:
+    * exponents spread over 2^-30 .. 2^30 inside a row, rows scaled to 2^+-100: the error stays below 1e-6 of
+      sum_k |a_k b_k| (randn: 8e-8) — the pieces carry the fp32 exponent range, nothing is scaled per tensor;
+    * |x| < 2^-110: the lower pieces are bf16 subnormals and are lost, the precision falls off towards bf16's 8 bits
+      at 2^-126 and below (bounded by 2^-7 here) — fp32 training values are 25 orders of magnitude above that;
+    * |x| > 3.3895e38 (the largest bf16): the leading piece rounds to infinity and the residual is NaN, so that
+      output ROW is NaN where fp32 arithmetic would be finite; infinities and NaNs make their rows non-finite
+      (an infinity gives NaN, not +-inf); other rows are untouched."""
+    g = torch.Generator().manual_seed(0)
+    M, N, K = 256, 128, 512
+
+    def spread(shape, lo, hi):
+        mant = 1 + torch.rand(shape, generator=g)
+        e = torch.randint(lo, hi + 1, shape, generator=g).float()
+        return torch.where(torch.rand(shape, generator=g) < 0.5, -1.0, 1.0) * mant * torch.exp2(e)
+
+    def worst(A, B):
+        out = _cpu(ops.gemm(A.to(DEV), B.to(DEV), True, True, M, N, K))
+        ref, mag = A.double() @ B.double().t(), A.abs().double() @ B.abs().double().t()
+        return out, float(((out.double() - ref).abs() / mag).max())
+
+    assert worst(spread((M, K), -30, 30), spread((N, K), -30, 30))[1] <= 1e-6
+    assert worst(spread((M, K), -3, 3) * 2.0 ** 100, spread((N, K), -3, 3) * 2.0 ** -100)[1] <= 1e-6
+    assert worst(spread((M, K), -100, -100), spread((N, K), 60, 60))[1] <= 1e-6
+    out, err = worst(spread((M, K), 0, 0) * 2.0 ** -125, spread((N, K), 20, 20))       # lower pieces subnormal in bf16
+    assert bool(torch.isfinite(out).all()) and err <= 2.0 ** -7
+    A = torch.randn(M, K, generator=g)
+    A[3, 7] = 3.40e38                                      # between the largest bf16 and the largest fp32
+    out, _ = worst(A, torch.randn(N, K, generator=g) * 1e-3)
+    assert bool(torch.isnan(out[3]).all()) and bool(torch.isfinite(out[:3]).all()) and bool(torch.isfinite(out[4:]).all())
+    A = torch.randn(M, K, generator=g)
+    A[5, 1], A[6, 2] = float("inf"), float("nan")
+    B = torch.randn(N, K, generator=g)
+    out = _cpu(ops.gemm(A.to(DEV), B.to(DEV), True, True, M, N, K))
+    assert bool(torch.isnan(out[5]).all()) and bool(torch.isnan(out[6]).all())
+    keep = torch.ones(M, dtype=torch.bool)
+    keep[5] = keep[6] = False
+    ref = A[keep].double() @ B.double().t()
+    assert bool(((out[keep].double() - ref).abs() <= 1e-6 * (A[keep].abs().double() @ B.abs().double().t())).all())
+
+
 @pytest.mark.parametrize("M,N,K", [(4096, 1000, 1000), (300, 368, 200), (129, 72, 1000)])
 def test_gemm_relu_mask_colsum_epilogue(ops, M, N, K):
     """EPI_RELU_MASK_COLSUM (an MLP layer's dX GEMM doing the upstream layer's ReLU backward): the masked
     product, and one partial row of its column sums per 128-row tile that add up to the bias gradient."""
     from mapx.native import EPI_RELU_MASK_COLSUM
-    if not ops.GEMM_X3:
-        pytest.skip("the fp32-MFMA family has no such epilogue")
     g = torch.Generator().manual_seed(M + N + K)
     dy, w, y = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g), torch.randn(M, N, generator=g)
     part = torch.full(((M + 127) // 128, N), 7.0, device=DEV)

@@ -110,3 +110,26 @@ def oracle_case_grads(mode, cfg, params, inp, relu_masks=None, preacts=None):
         loss, out = R.ctr_head(P, R.trunk(P, ids, cfg["NC"], cfg["NL"], **kw), t(inp["y"]))
     loss.backward()
     return float(loss), out.detach().numpy(), {k: v.grad.numpy() for k, v in P.items()}
+
+
+# ----------------------------------------------------------------------------- what a golden check compared
+# tests/test_model_gpu.py::_check_grads compares every gradient with the fixture of the real reference and, when
+# that fails because a hidden unit sits on the ReLU's kink, with the oracle re-run on the step's own pattern.
+# Which of the two happened is recorded here per test case, printed in the terminal summary (conftest.py) and
+# checked against tests/golden/pattern_fallback_allowed.json: a case that passes directly today may not start
+# to need the fallback unnoticed.
+GOLDEN_LOG = []
+
+
+def note_golden(tag, how, flips=0):
+    GOLDEN_LOG.append((tag, how, int(flips)))
+
+
+def fallback_allowed(tag):
+    import json
+    import os
+    if os.environ.get("MAPX_GOLDEN_ALLOW_ALL") == "1":
+        return True
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pattern_fallback_allowed.json")
+    with open(path) as f:
+        return tag in json.load(f)["allowed"]
