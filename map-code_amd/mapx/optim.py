@@ -287,15 +287,15 @@ class MapxOptimizer:
             if pad != self.FLAT_PAD or s["m"].numel() != g["m"].numel():
                 # another slot size: the flat moments do not line up — re-pack them parameter by parameter
                 sizes = g["numels"]
+                if sum((n + pad - 1) // pad * pad for n in sizes) != s["m"].numel() or s["v"].numel() != s["m"].numel():
+                    raise ValueError(f"optimizer state: flat moments of {s['m'].numel()} elements do not match the "
+                                     f"parameters at a slot size of {pad}")
                 src_off = dst_off = 0
                 for n in sizes:
                     for key in ("m", "v"):
                         g[key][dst_off:dst_off + n].copy_(s[key][src_off:src_off + n])
                     src_off += (n + pad - 1) // pad * pad
                     dst_off += (n + self.FLAT_PAD - 1) // self.FLAT_PAD * self.FLAT_PAD
-                if src_off != s["m"].numel():
-                    raise ValueError(f"optimizer state: flat moments of {s['m'].numel()} elements do not match the "
-                                     f"parameters at a slot size of {pad}")
                 continue
             g["m"].copy_(s["m"])
             g["v"].copy_(s["v"])
