@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 33
+#define MAPX_ABI_VERSION 34
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -243,6 +243,30 @@ int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, int64
                   const float* aux1, int64_t ld1, const float* aux2, int64_t ld2, float* out2,
                   int64_t ldo2, int nsplit, int tile_hint, void* ws, size_t ws_bytes,
                   int* nsplit_deferred, hipStream_t stream);
+/* The input-gradient GEMM  v = dY W (+ add)  (a_kc = 1, b_kc = 0: dY [M,K], W [K,N]) whose epilogue also does the
+ * elementwise backward that follows it in DCNv2's backward pass, on the tile while it is still in LDS:
+ *   columns n >= c0:  v = mask[m,n] > 0 ? v : 0        ReLU backward of the layer whose OUTPUT `mask` is
+ *                                                       (MLPBlock, layers.py:173-188)
+ *   columns n <  c0:  t[m,n] = v x0[m,n];  dx0[m,n] = (accumulate ? dx0[m,n] : 0) + v u[m,n] (+ v if plus_v)
+ *                                                       the cross layer's backward (layers.py:200:
+ *                                                       X_{i+1} = X_i + X0 * u, u = W X_i + b)
+ *   C[m,n] = v;  part[m / 128][n] = sum over the 128-row tile of (n >= c0 ? v : t[m,n])  (bias gradients: add the
+ *   rows with mapx_sum_tasks).
+ * c0 = 0: a ReLU layer's dZ only; c0 = N: a cross layer only; 0 < c0 < N: the concatenated input of the heads
+ * (models.py:316-318), cross tower left of c0, deep tower right of it.  N, c0 % 4 == 0, 16-byte aligned operands. */
+int mapx_gemm_f32_bwd_fused(int M, int N, int K, const float* dY, int64_t lda, const float* W, int64_t ldw,
+                            float* C, int64_t ldc, const float* add_opt, int64_t ld_add, const float* mask_opt,
+                            int64_t ld_mask, int c0, const float* x0, int64_t ld_x0, const float* u, int64_t ld_u,
+                            float* t, int64_t ld_t, float* dx0, int64_t ld_dx0, int accumulate, int plus_v,
+                            float* part, int64_t ld_part, hipStream_t stream);
+/* `count` (<= 4) products of ONE shape in one launch (the cross layers' weight gradients, layers.py:197-201:
+ * three 368 x 368 x 4096 products fill the GPU together, none of them alone): C[z] [M,N] dense = A[z] . B[z],
+ * operands described as in mapx_gemm_f32 (a_kc / b_kc, lda, ldb).  nsplit > 1: split-K through `ws`
+ * (count * mapx_gemm_splitk_workspace_bytes(M, N, nsplit) bytes), the slabs of all problems summed by one launch.
+ * The pointer arrays are HOST memory. */
+int mapx_gemm_f32_batched(int count, int a_kc, int b_kc, int M, int N, int K, const float* const* A,
+                          int64_t lda, const float* const* B, int64_t ldb, float* const* C, int nsplit,
+                          void* ws, size_t ws_bytes, hipStream_t stream);
 /* dst[i] = sum_{s < nsplit} src[s*stride + i], i < n, for up to 32 tasks in ONE launch.  The
  * task list is HOST memory (copied into the kernel arguments). */
 typedef struct mapx_sum_task {

@@ -14,6 +14,7 @@
 #include "../../include/mapx_hip.h"
 #include "common.h"
 #include "gemm_grouped.h"
+#include "gemm_x3_common.h"
 
 namespace mapx {
 
@@ -364,7 +365,7 @@ static inline bool ew_narrow_lanes(int N) {
 int gemm_f32x3_launch(int a_kc, int b_kc, int M, int N, int K, const float* A, int64_t lda, const float* B,
                       int64_t ldb, float* C, int64_t ldc, int epi, const float* bias, const float* aux1, int64_t ld1,
                       const float* aux2, int64_t ld2, float* out2, int64_t ldo2, int nsplit, int tile_hint, void* ws,
-                      size_t ws_bytes, int* nsplit_deferred, hipStream_t stream);
+                      size_t ws_bytes, int* nsplit_deferred, hipStream_t stream, const GemmX3Extra* ex = nullptr);
 
 }  // namespace mapx
 
@@ -397,6 +398,73 @@ extern "C" int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   MAPX_REQUIRE(nsplit == 1 || epi == MAPX_EPI_NONE, "gemm_f32: split-K needs EPI_NONE");
   return gemm_f32x3_launch(a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, epi, bias, aux1, ld1, aux2, ld2, out2, ldo2,
                            nsplit, tile_hint, ws, ws_bytes, nsplit_deferred, stream);
+}
+
+extern "C" int mapx_gemm_f32_bwd_fused(int M, int N, int K, const float* dY, int64_t lda, const float* W, int64_t ldw,
+                                       float* C, int64_t ldc, const float* add_opt, int64_t ld_add,
+                                       const float* mask_opt, int64_t ld_mask, int c0, const float* x0, int64_t ld_x0,
+                                       const float* u, int64_t ld_u, float* t, int64_t ld_t, float* dx0,
+                                       int64_t ld_dx0, int accumulate, int plus_v, float* part, int64_t ld_part,
+                                       hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(M >= 0 && N > 0 && K > 0 && dY && W && C && part, "gemm_f32_bwd_fused: bad arguments");
+  if (M == 0) return MAPX_OK;
+  MAPX_REQUIRE(c0 >= 0 && c0 <= N && c0 % 4 == 0 && N % 4 == 0, "gemm_f32_bwd_fused: N and c0 must be multiples of 4");
+  MAPX_REQUIRE(c0 == N || mask_opt, "gemm_f32_bwd_fused: columns >= c0 need the ReLU output");
+  MAPX_REQUIRE(c0 == 0 || (x0 && u && t && dx0), "gemm_f32_bwd_fused: columns < c0 need x0, u, t and dx0");
+  auto al16 = [](const void* p, int64_t ld) { return p == nullptr || ((uintptr_t)p % 16 == 0 && ld % 4 == 0); };
+  MAPX_REQUIRE(al16(C, ldc) && al16(add_opt, ld_add) && al16(mask_opt, ld_mask) && al16(x0, ld_x0) && al16(u, ld_u) &&
+                   al16(t, ld_t) && al16(dx0, ld_dx0) && al16(part, ld_part) && ld_part >= N,
+               "gemm_f32_bwd_fused: every operand must be 16-byte aligned with a leading dimension %% 4 == 0");
+  {
+    const int64_t lim = (int64_t)1 << 31;
+    MAPX_REQUIRE((int64_t)M * ldc < lim && (int64_t)M * ld_add < lim && (int64_t)M * ld_mask < lim,
+                 "gemm_f32_bwd_fused: an operand spans 2^31 elements or more");
+  }
+  GemmX3Extra ex{};
+  ex.aux3 = u; ex.ld3 = ld_u; ex.mask = mask_opt; ex.ldm = ld_mask; ex.out3 = t; ex.ldo3 = ld_t; ex.out4 = dx0;
+  ex.ldo4 = ld_dx0; ex.c0 = c0; ex.flags = (accumulate ? 1 : 0) | (plus_v ? 2 : 0); ex.batch = 1;
+  return gemm_f32x3_launch(1, 0, M, N, K, dY, lda, W, ldw, C, ldc, MAPX_EPI_BWD_FUSED, nullptr, add_opt, ld_add, x0,
+                           ld_x0, part, ld_part, 1, -1, nullptr, 0, nullptr, stream, &ex);
+}
+
+extern "C" int mapx_gemm_f32_batched(int count, int a_kc, int b_kc, int M, int N, int K, const float* const* A,
+                                     int64_t lda, const float* const* B, int64_t ldb, float* const* C, int nsplit,
+                                     void* ws, size_t ws_bytes, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(count >= 1 && count <= 4 && A && B && C, "gemm_f32_batched: 1 to 4 problems");
+  MAPX_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_f32_batched: empty problem");
+  MAPX_REQUIRE(!(a_kc == 0 && b_kc != 0), "gemm_f32_batched: layout (A m-contiguous, B k-contiguous) unused");
+  if (nsplit < 1) nsplit = 1;
+  GemmX3Extra ex{};
+  ex.batch = count;
+  for (int z = 0; z < count; ++z) {
+    MAPX_REQUIRE(A[z] && B[z] && C[z], "gemm_f32_batched: null operand");
+    ex.Az[z] = A[z]; ex.Bz[z] = B[z]; ex.Cz[z] = C[z];
+  }
+  if (count == 1)
+    return gemm_f32x3_launch(a_kc, b_kc, M, N, K, A[0], lda, B[0], ldb, C[0], N, MAPX_EPI_NONE, nullptr, nullptr, 0,
+                             nullptr, 0, nullptr, 0, nsplit, -1, ws, ws_bytes, nullptr, stream, nullptr);
+  int got = 0;
+  // every problem with the vector-load conditions of problem 0 (same shapes and leading dimensions; bases checked)
+  for (int z = 1; z < count; ++z)
+    MAPX_REQUIRE(((uintptr_t)A[z] % 16 == 0) == ((uintptr_t)A[0] % 16 == 0) &&
+                     ((uintptr_t)B[z] % 16 == 0) == ((uintptr_t)B[0] % 16 == 0),
+                 "gemm_f32_batched: operands of one launch must share their alignment");
+  const int st = gemm_f32x3_launch(a_kc, b_kc, M, N, K, A[0], lda, B[0], ldb, C[0], N, MAPX_EPI_NONE, nullptr, nullptr, 0,
+                                   nullptr, 0, nullptr, 0, nsplit, -1, ws, ws_bytes, &got, stream, &ex);
+  if (st != MAPX_OK) return st;
+  if (got > 1) {            // slabs of problem z: ws + z * nsplit * M * N, `got` of them in use
+    SumTasks t;
+    memset(&t, 0, sizeof(t));
+    for (int z = 0; z < count; ++z) {
+      t.t[z].dst = C[z];
+      t.t[z].src = static_cast<const float*>(ws) + (int64_t)z * nsplit * M * N;
+      t.t[z].stride = (int64_t)M * N; t.t[z].n = (int64_t)M * N; t.t[z].nsplit = got;
+    }
+    hipLaunchKernelGGL(sum_tasks_kernel, dim3(96, count), dim3(256), 0, stream, t);
+  }
+  return check_launch("gemm_f32_batched");
 }
 
 extern "C" int mapx_enc_group_layout(const int64_t* masked_index, int T, int L, int F, int cap_slots,

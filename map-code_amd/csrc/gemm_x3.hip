@@ -124,8 +124,14 @@ struct OperandX3 {
 // the next tile (VALU + LDS), its partner's MFMAs keep the matrix pipe busy — the overlap that one
 // wave per SIMD only gets from a perfect instruction interleave.
 template <int WR, int WC, int WMT, int WNT, bool A_KC, bool B_KC, bool VEC>
-__global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) {
+__global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a_in) {
   constexpr int BM = 32 * WMT * WR, BN = 32 * WNT * WC, NT = 64 * WR * WC;
+  GemmX3Args a = a_in;
+  if (gridDim.z > 1) {                        // batched: problem blockIdx.z of gridDim.z equal-shaped ones
+    a.A = a_in.Az[blockIdx.z];
+    a.B = a_in.Bz[blockIdx.z];
+    a.C = a_in.Cz[blockIdx.z] + (int64_t)blockIdx.z * a_in.batch_slabs;
+  }
   using OpA = OperandX3<BM, WMT, A_KC, VEC, NT>;
   using OpB = OperandX3<BN, WNT, B_KC, VEC, NT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -478,6 +484,9 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
       case MAPX_EPI_RELU_MASK_COLSUM:
         if constexpr (BM == 128) epilogue_rows_x3_vec<MAPX_EPI_RELU_MASK_COLSUM, BM, BN, NT>(a, C, tile, m0, n0);
         break;
+      case MAPX_EPI_BWD_FUSED:
+        if constexpr (BM == 128) epilogue_bwd_fused<BM, BN, NT>(a, C, tile, m0, n0);
+        break;
       default: epilogue_rows_x3_vec<MAPX_EPI_NONE, BM, BN, NT>(a, C, tile, m0, n0); break;
     }
     return;
@@ -493,7 +502,7 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a) 
 }
 
 template <int WR, int WC, int WMT, int WNT, bool A_KC, bool B_KC, bool VEC>
-static hipError_t launch_one_x3(const GemmX3Args& a, int nsplit, hipStream_t stream) {
+static hipError_t launch_one_x3(const GemmX3Args& a, int nsplit, hipStream_t stream, int batch = 1) {
   constexpr int BM = 32 * WMT * WR, BN = 32 * WNT * WC, NT = 64 * WR * WC;
   using OpA = OperandX3<BM, WMT, A_KC, VEC, NT>;
   using OpB = OperandX3<BN, WNT, B_KC, VEC, NT>;
@@ -505,7 +514,7 @@ static hipError_t launch_one_x3(const GemmX3Args& a, int nsplit, hipStream_t str
       ? hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
       : hipSuccess;
   if (raised != hipSuccess) return raised;
-  hipLaunchKernelGGL(fn, dim3(a.tiles_m * a.tiles_n, nsplit), dim3(NT), lds, stream, a);
+  hipLaunchKernelGGL(fn, dim3(a.tiles_m * a.tiles_n, nsplit, batch), dim3(NT), lds, stream, a);
   return hipSuccess;
 }
 
@@ -513,9 +522,9 @@ static hipError_t launch_one_x3(const GemmX3Args& a, int nsplit, hipStream_t str
 // accumulator registers for the two sets and measured 15 % slower with one); tile 1: 128 x 64 by 4
 // waves; tile 0: 64 x 64 by 4 waves
 template <bool A_KC, bool B_KC>
-static hipError_t launch_layout_x3(GemmX3Args& a, bool vec, int tile, int nsplit, hipStream_t stream) {
-#define MAPX_X3(WR_, WC_, WM, WN) (vec ? launch_one_x3<WR_, WC_, WM, WN, A_KC, B_KC, true>(a, nsplit, stream) \
-                                       : launch_one_x3<WR_, WC_, WM, WN, A_KC, B_KC, false>(a, nsplit, stream))
+static hipError_t launch_layout_x3(GemmX3Args& a, bool vec, int tile, int nsplit, hipStream_t stream, int batch = 1) {
+#define MAPX_X3(WR_, WC_, WM, WN) (vec ? launch_one_x3<WR_, WC_, WM, WN, A_KC, B_KC, true>(a, nsplit, stream, batch) \
+                                       : launch_one_x3<WR_, WC_, WM, WN, A_KC, B_KC, false>(a, nsplit, stream, batch))
   // (128x128 by 4 waves with 64x64 wave tiles — 2/3 of the LDS fragment reads per MFMA — measured 8-14 %
   // slower on every shape of the step: one wave per SIMD leaves the cut nothing to hide behind.)
   if (tile == 3) {
@@ -561,28 +570,36 @@ __global__ void __launch_bounds__(256) splitk_reduce_x3_v4_kernel(const float* _
 int gemm_f32x3_launch(int a_kc, int b_kc, int M, int N, int K, const float* A, int64_t lda, const float* B,
                       int64_t ldb, float* C, int64_t ldc, int epi, const float* bias, const float* aux1, int64_t ld1,
                       const float* aux2, int64_t ld2, float* out2, int64_t ldo2, int nsplit, int tile_hint, void* ws,
-                      size_t ws_bytes, int* nsplit_deferred, hipStream_t stream) {
-  GemmX3Args g;
+                      size_t ws_bytes, int* nsplit_deferred, hipStream_t stream, const GemmX3Extra* ex) {
+  GemmX3Args g{};
+  const int batch = ex && ex->batch > 1 ? ex->batch : 1;
+  if (ex) {
+    g.aux3 = ex->aux3; g.ld3 = ex->ld3; g.mask = ex->mask; g.ldm = ex->ldm; g.out3 = ex->out3; g.ldo3 = ex->ldo3;
+    g.out4 = ex->out4; g.ldo4 = ex->ldo4; g.c0 = ex->c0; g.flags = ex->flags;
+    for (int z = 0; z < batch && batch > 1; ++z) { g.Az[z] = ex->Az[z]; g.Bz[z] = ex->Bz[z]; g.Cz[z] = ex->Cz[z]; }
+  }
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
   g.M = M; g.N = N; g.K = K; g.epi = epi; g.bias = bias;
   g.aux1 = aux1; g.ld1 = ld1; g.aux2 = aux2; g.ld2 = ld2; g.out2 = out2; g.ldo2 = ldo2;
   g.k_chunk = K > 0 ? K : kXBK; g.slab_stride = 0;
   if (nsplit > 1) {
-    const size_t need = (size_t)nsplit * M * N * sizeof(float);
+    const size_t need = (size_t)batch * nsplit * M * N * sizeof(float);
     if (!ws || ws_bytes < need) {
       set_error("gemm_f32: split-K workspace %zu < %zu", ws_bytes, need);
       return MAPX_EWORKSPACE;
     }
     const int kc = (int)ceil_div(ceil_div(K, nsplit), 64) * 64;
     g.k_chunk = kc;
+    g.batch_slabs = (int64_t)nsplit * M * N;      // (the requested count: the caller's slab layout)
     nsplit = (int)ceil_div(K, kc);
     g.C = static_cast<float*>(ws);
+    for (int z = 0; z < batch && batch > 1; ++z) g.Cz[z] = static_cast<float*>(ws);
     g.ldc = N;
     g.slab_stride = (int64_t)M * N;
   }
   const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) &&
                    (g.k_chunk % 8 == 0) && (a_kc ? (K % 8 == 0) : (M % 8 == 0)) && (b_kc ? (K % 8 == 0) : (N % 8 == 0));
-  auto blocks = [&](int bm, int bn) { return ceil_div(M, bm) * ceil_div(N, bn) * nsplit; };
+  auto blocks = [&](int bm, int bn) { return ceil_div(M, bm) * ceil_div(N, bn) * nsplit * batch; };
   const int64_t big = blocks(128, 128);
   // 128 x 128 layout of the NT / NN / TN products, three digits (3: 4 waves, hand-woven K-step; 2: 8 waves).
   // Alone the two are within 5 % of each other; inside the step's graph the 4-wave layout is worth 10 % of
@@ -593,6 +610,7 @@ int gemm_f32x3_launch(int a_kc, int b_kc, int M, int N, int K, const float* A, i
   const int cls = (a_kc && b_kc) ? 0 : a_kc ? 1 : 2;
   int tile = (big >= 160) ? (cls == 0 ? big_tile / 100 : cls == 1 ? big_tile / 10 % 10 : big_tile % 10) : 0;
   if (tile_hint >= 0 && (tile_hint & 255) <= 3) tile = tile_hint & 255;
+  if (epi == MAPX_EPI_BWD_FUSED && tile == 0) tile = 1;       // one partial row per 128-row tile
   if (epi == MAPX_EPI_RELU_MASK_COLSUM) {
     auto al16 = [](const void* p, int64_t ld) { return p && (uintptr_t)p % 16 == 0 && ld % 4 == 0; };
     if (!(N % 4 == 0 && nsplit <= 1 && al16(C, ldc) && al16(aux1, ld1) && al16(out2, ldo2))) {
@@ -604,10 +622,14 @@ int gemm_f32x3_launch(int a_kc, int b_kc, int M, int N, int K, const float* A, i
   // the woven K loop (4-wave layouts with vector loads) wants >= 2 K-steps in every slab
   if (tile != 2 && vec && K - (int64_t)g.k_chunk * (nsplit - 1) <= kXBK) tile = 2;
   hipError_t e;
-  if (a_kc && b_kc) e = launch_layout_x3<true, true>(g, vec, tile, nsplit, stream);
-  else if (a_kc) e = launch_layout_x3<true, false>(g, vec, tile, nsplit, stream);
-  else e = launch_layout_x3<false, false>(g, vec, tile, nsplit, stream);
+  if (a_kc && b_kc) e = launch_layout_x3<true, true>(g, vec, tile, nsplit, stream, batch);
+  else if (a_kc) e = launch_layout_x3<true, false>(g, vec, tile, nsplit, stream, batch);
+  else e = launch_layout_x3<false, false>(g, vec, tile, nsplit, stream, batch);
   MAPX_HIP(e);
+  if (batch > 1) {            // the caller sums the slabs of all problems with one launch (mapx_gemm_f32_batched)
+    if (nsplit_deferred) *nsplit_deferred = nsplit > 1 ? nsplit : 0;
+    return check_launch("gemm_f32 (3 x bf16, batched)");
+  }
   if (nsplit_deferred) *nsplit_deferred = nsplit > 1 ? nsplit : 0;
   if (nsplit > 1 && !nsplit_deferred) {
     MAPX_REQUIRE(ldc == N, "gemm_f32: split-K output must be dense (ldc == N)");

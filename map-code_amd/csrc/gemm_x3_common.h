@@ -26,7 +26,36 @@ struct GemmX3Args {
   int k_chunk;
   int64_t slab_stride;
   int tiles_m, tiles_n;
+  // MAPX_EPI_BWD_FUSED (mapx_gemm_f32_bwd_fused): aux1 = add (optional), aux2 = x0, aux3 = u, mask = ReLU output,
+  // out2 = column-sum partial rows, out3 = t, out4 = dx0;  c0 = first ReLU-masked column;  flags: 1 accumulate
+  // into dx0, 2 add v itself to dx0
+  const float* aux3; int64_t ld3;
+  const float* mask; int64_t ldm;
+  float* out3; int64_t ldo3;
+  float* out4; int64_t ldo4;
+  int c0, flags;
+  // batched launch (gridDim.z problems of one shape: mapx_gemm_f32_batched): operands of problem z; split-K slabs
+  // of problem z start z * batch_slabs floats into the workspace
+  const float* Az[4];
+  const float* Bz[4];
+  float* Cz[4];
+  int64_t batch_slabs;
 };
+
+// what the plain mapx_gemm_f32 contract does not carry (fused backward epilogue, batched launch)
+struct GemmX3Extra {
+  const float* aux3; int64_t ld3;
+  const float* mask; int64_t ldm;
+  float* out3; int64_t ldo3;
+  float* out4; int64_t ldo4;
+  int c0, flags;
+  int batch;
+  const float* Az[4];
+  const float* Bz[4];
+  float* Cz[4];
+};
+
+#define MAPX_EPI_BWD_FUSED 7        // internal to the library: reached through mapx_gemm_f32_bwd_fused only
 
 constexpr int kXBK = 32;
 
@@ -216,6 +245,89 @@ __device__ inline void epilogue_rows_x3_vec(const GemmX3Args& a, float* __restri
       }
       *reinterpret_cast<float4*>(a.out2 + (int64_t)(m0 / 128) * a.ldo2 + n) = t;
     }
+  }
+}
+
+
+// Epilogue of mapx_gemm_f32_bwd_fused (include/mapx_hip.h): the elementwise backward that follows a dX GEMM in
+// DCNv2's backward pass, done on the tile while it is in LDS instead of by one more launch on the chain:
+//   v = acc (+ add);   n >= c0:  v = mask > 0 ? v : 0 (ReLU backward);   n < c0:  t = v x0, dx0 (+)= v u (+ v)
+//   C = v;  one partial row per 128-row tile of the column sums of (n >= c0 ? v : t).
+// Same row pass as epilogue_rows_x3_vec (a thread's four columns never change, rows in batches of four whose
+// operands are all requested before the first is used); 16-byte aligned operands, N and c0 multiples of 4.
+template <int BM, int BN, int NT>
+__device__ inline void epilogue_bwd_fused(const GemmX3Args& a, float* __restrict__ C, const float* __restrict__ tile,
+                                          int m0, int n0) {
+  constexpr int LDT = BN + 4, CPR = BN / 4, RPI = NT / CPR, NIT = BM / RPI, U = NIT < 4 ? NIT : 4;
+  static_assert(NT % CPR == 0 && BM % RPI == 0 && NIT % U == 0 && BM == 128, "epilogue tiling");
+  const int c0 = (threadIdx.x % CPR) * 4, r0 = threadIdx.x / CPR;
+  const int n = n0 + c0;
+  const bool ncol = n < a.N;
+  const int ns = ncol ? n : 0;
+  const bool relu = ns >= a.c0;                       // this thread's four columns: ReLU-masked, or the cross layer's
+  const bool has_add = a.aux1 != nullptr, accum = (a.flags & 1) != 0, plus_v = (a.flags & 2) != 0;
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int it0 = 0; it0 < NIT; it0 += U) {
+    float4 t[U], pa[U], p1[U], p2[U], p3[U];
+    bool ok[U];
+    int64_t mrow[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = r0 + (it0 + u) * RPI, m = m0 + row;
+      ok[u] = ncol && m < a.M;
+      mrow[u] = m < a.M ? m : m0;
+      t[u] = *reinterpret_cast<const float4*>(tile + row * LDT + c0);
+      pa[u] = has_add ? *reinterpret_cast<const float4*>(a.aux1 + mrow[u] * a.ld1 + ns) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (relu) {
+        p1[u] = *reinterpret_cast<const float4*>(a.mask + mrow[u] * a.ldm + ns);
+      } else {
+        p1[u] = *reinterpret_cast<const float4*>(a.aux2 + mrow[u] * a.ld2 + ns);                       // x0
+        p2[u] = *reinterpret_cast<const float4*>(a.aux3 + mrow[u] * a.ld3 + ns);                       // u
+        p3[u] = accum ? *reinterpret_cast<const float4*>(a.out4 + mrow[u] * a.ldo4 + ns) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float v[4] = {t[u].x + pa[u].x, t[u].y + pa[u].y, t[u].z + pa[u].z, t[u].w + pa[u].w};
+      const float q1[4] = {p1[u].x, p1[u].y, p1[u].z, p1[u].w};
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = q1[e] > 0.f ? v[e] : 0.f;
+        if (ok[u]) {
+          csum.x += v[0]; csum.y += v[1]; csum.z += v[2]; csum.w += v[3];
+          *reinterpret_cast<float4*>(C + mrow[u] * a.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      } else {
+        const float q2[4] = {p2[u].x, p2[u].y, p2[u].z, p2[u].w}, q3[4] = {p3[u].x, p3[u].y, p3[u].z, p3[u].w};
+        float tt[4], d[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          tt[e] = v[e] * q1[e];
+          // the order of the unfused kernels (ew_colsum_kernel<1>): dx0 + g * u, then + g
+          d[e] = accum ? q3[e] + v[e] * q2[e] : v[e] * q2[e];
+          if (plus_v) d[e] += v[e];
+        }
+        if (ok[u]) {
+          csum.x += tt[0]; csum.y += tt[1]; csum.z += tt[2]; csum.w += tt[3];
+          *reinterpret_cast<float4*>(C + mrow[u] * a.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(a.out3 + mrow[u] * a.ldo3 + n) = make_float4(tt[0], tt[1], tt[2], tt[3]);
+          *reinterpret_cast<float4*>(a.out4 + mrow[u] * a.ldo4 + n) = make_float4(d[0], d[1], d[2], d[3]);
+        }
+      }
+    }
+  }
+  float4* const red = reinterpret_cast<float4*>(const_cast<float*>(tile) + BM * LDT);
+  red[r0 * CPR + threadIdx.x % CPR] = csum;
+  __syncthreads();
+  if (r0 == 0 && ncol) {
+    float4 s = red[threadIdx.x % CPR];
+#pragma unroll
+    for (int k = 1; k < RPI; ++k) {
+      const float4 q = red[k * CPR + threadIdx.x % CPR];
+      s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+    }
+    *reinterpret_cast<float4*>(a.out2 + (int64_t)(m0 / 128) * a.ldo2 + n) = s;
   }
 }
 

@@ -425,6 +425,40 @@ class _ReluLink:
         self.premasked, self.sb = False, None
 
 
+class _JoinLink:
+    """Between the two towers of DCNv2 and the ONE layer that consumes their concatenated output (the heads'
+    first Linear, or the grouped feat_encoder): that layer's input-gradient GEMM can do both towers' first
+    backward step in its epilogue (ops.gemm_bwd_fused) — the deep tower's last ReLU mask + bias gradient on the
+    columns right of D, the last cross layer's t = g X0, dX0 = g u and bias gradient left of it — instead of
+    three elementwise launches at the head of the two backward chains.  The towers fill in what the consumer
+    needs in forward (x0, u, bias-gradient slots); the consumer leaves t / dx0 for the cross tower and marks the
+    ReLU layer `premasked` (as _ReluLink does inside the MLP)."""
+
+    def __init__(self, D):
+        self.D = D
+        self.relu = _ReluLink()              # the deep tower's last layer
+        self.x0 = self.u = self.sb_cross = None
+        self.plus_v = False                  # a single cross layer: X_i IS X0, g joins dX0 at once
+        self.t = self.dx0 = None
+
+    def usable(self, dz, final):
+        return (ops.JOIN_FUSE and ops.DEFER_COLSUM and dz.dtype == torch.float32 and final.dtype == torch.float32
+                and self.relu.sb is not None and self.sb_cross is not None and self.x0 is not None
+                and self.D % 4 == 0 and final.shape[1] % 4 == 0 and final.shape[1] > self.D
+                and ops.row_sliceable(final) and self.x0.is_contiguous() and self.u.is_contiguous())
+
+
+def join_bwd_input(dz, w, final, link):
+    """dL/d(final) = dz W with both towers' first backward step in the epilogue (see _JoinLink)."""
+    D, Nn = link.D, final.shape[1]
+    C, t, dx0, part = ops.gemm_bwd_fused(dz, w, D, mask=final, x0=link.x0, u=link.u, plus_v=link.plus_v)
+    ops.defer_part_rows(link.sb_cross, part, 0, D)
+    ops.defer_part_rows(link.relu.sb, part, D, Nn - D)
+    link.t, link.dx0 = t, dx0
+    link.relu.premasked = True
+    return C
+
+
 class _Linear(Function):
     @staticmethod
     def forward(ctx, x, w, b, relu, out=None, out_f32=False, link_in=None, link_out=None):
@@ -463,7 +497,9 @@ class _Linear(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             link = ctx.link_in
-            if link is not None and link.sb is not None and ops.fused_mask_colsum_ok(dz, x):
+            if isinstance(link, _JoinLink):
+                dx = join_bwd_input(dz, w, x, link) if link.usable(dz, x) else ops.linear_bwd_input(dz, w)
+            elif link is not None and link.sb is not None and ops.fused_mask_colsum_ok(dz, x):
                 dx = ops.linear_bwd_input(dz, w, relu_of=x, colsum_to=link.sb)     # x = the producer's ReLU output
                 link.premasked = True
             else:
@@ -510,7 +546,9 @@ class MLPBlock(nn.Module):
                 self.dnn[str(3 * i + 2)] = HipDropout(self.p_drop)
             input_dim = hidden_size
 
-    def forward(self, x, out=None):
+    def forward(self, x, out=None, link_last=None):
+        """`link_last`: the _ReluLink of the block's last layer when its output has exactly one consumer that
+        can apply its ReLU mask (DCNv2: _JoinLink.relu)."""
         layers = [m for m in self.dnn.values() if isinstance(m, HipLinear)]
         drops = [m for m in self.dnn.values() if isinstance(m, HipDropout)]
         link = None
@@ -522,7 +560,7 @@ class MLPBlock(nn.Module):
                 x = drops[i](layer(x), out=out if last else None)
             else:
                 # layer i's output feeds layer i+1 and nothing else: their backward passes are linked
-                link_out = None if last else _ReluLink()
+                link_out = link_last if last else _ReluLink()
                 x = layer(x, out=out if last else None, link_in=link, link_out=link_out)
                 link = link_out
         return x
@@ -536,7 +574,7 @@ class _CrossTower(Function):
     elementwise launches at the very end of the step."""
 
     @staticmethod
-    def forward(ctx, x0, out, *wb):
+    def forward(ctx, x0, out, link, *wb):
         x0 = x0.contiguous()
         n = len(wb) // 2
         wops = [ops.bf16_weight(w) for w in wb[0::2]] if ops.is_bf16(x0) else list(wb[0::2])
@@ -547,6 +585,9 @@ class _CrossTower(Function):
             us.append(u)
         ctx.n = n
         ctx.slots = [(_grad_slot(wb[2 * i]), _grad_slot(wb[2 * i + 1])) for i in range(n)]
+        ctx.link = link
+        if link is not None:                 # what the consumer of the towers' output needs (see _JoinLink)
+            link.x0, link.u, link.sb_cross, link.plus_v = x0, us[-1], ctx.slots[n - 1][1], n == 1
         ctx.save_for_backward(x0, *xs[1:], *us, *wops)
         return xi
 
@@ -562,20 +603,50 @@ class _CrossTower(Function):
             g = g.contiguous()                   # else read in place: a slice of d(concat) costs no copy
         ops.run_side_tasks()                     # this chain has slack against the deep tower's
         grads = [None] * (2 * n)
-        dx0 = None
+        D = x0.shape[1]
+        t = dx0 = None
+        link = ctx.link
+        if link is not None and link.t is not None:
+            # the producer of g (the heads' first layer) has done the last layer's elementwise backward in its
+            # GEMM's epilogue and queued the bias gradient (_JoinLink)
+            t, dx0, link.t, link.dx0 = link.t, link.dx0, None, None
+            if t.is_cuda:
+                cur = torch.cuda.current_stream()
+                t.record_stream(cur)
+                dx0.record_stream(cur)
+        f32 = g.dtype == torch.float32 and x0.dtype == torch.float32
+        have_slots = all(sw is not None and sb is not None for sw, sb in ctx.slots)
+        # fused epilogues / one launch for all weight gradients: fp32, optimizer-owned gradient slots, 16-byte rows
+        fuse = ops.JOIN_FUSE and ops.DEFER_COLSUM and f32 and have_slots and D % 4 == 0 and n <= 4
+        pend = []
         for i in range(n - 1, -1, -1):
             sw, sb = ctx.slots[i]
             first = i == 0
-            # width D = F * embed_size is a multiple of 4 (Embeddings enforces embed_size % 4 == 0)
-            t, dx0, db = ops.cross_bwd_pre_colsum(g, x0, us[i], dx0=dx0, db=sb, defer=True, plus_g=first)
-            dw = ops.linear_bwd_weight(t, xs[i], out=sw, defer=True)                # t^T X_i
-            if ctx.needs_input_grad[2 + 2 * i]:
-                grads[2 * i] = None if sw is not None else dw
-            if ctx.needs_input_grad[3 + 2 * i]:
-                grads[2 * i + 1] = None if sb is not None else db
+            if t is None:
+                # width D = F * embed_size is a multiple of 4 (Embeddings enforces embed_size % 4 == 0)
+                t, dx0, db = ops.cross_bwd_pre_colsum(g, x0, us[i], dx0=dx0, db=sb, defer=True, plus_g=first)
+                if ctx.needs_input_grad[4 + 2 * i]:
+                    grads[2 * i + 1] = None if sb is not None else db
+            if fuse:
+                pend.append((t, xs[i], sw))                                         # t^T X_i, all layers in one launch
+            else:
+                dw = ops.linear_bwd_weight(t, xs[i], out=sw, defer=True)            # t^T X_i
+                if ctx.needs_input_grad[3 + 2 * i]:
+                    grads[2 * i] = None if sw is not None else dw
             # dL/dX_i = g + t W_i; for layer 0 that is part of dL/dX0 and g is already inside dx0
-            g = ops.linear_bwd_input(t, ws[i], add=dx0 if first else g)
-        return (g, None, *grads)
+            if first:
+                g = ops.linear_bwd_input(t, ws[i], add=dx0)
+                t = None
+            elif fuse:
+                # ... and the NEXT layer's t = dX_i X0, dX0 += dX_i u_{i-1} (+ dX_i), bias-gradient partials
+                g, t, dx0, part = ops.gemm_bwd_fused(t, ws[i], D, add=g, x0=x0, u=us[i - 1], dx0=dx0, plus_v=i == 1)
+                ops.defer_part_rows(ctx.slots[i - 1][1], part, 0, D)
+            else:
+                g = ops.linear_bwd_input(t, ws[i], add=g)
+                t = None
+        if pend:
+            ops.linear_bwd_weight_batched([p[0] for p in pend], [p[1] for p in pend], [p[2] for p in pend])
+        return (g, None, None, *grads)
 
 
 class CrossNetV2(nn.Module):
@@ -587,12 +658,13 @@ class CrossNetV2(nn.Module):
         self.num_layers = num_cross_layers
         self.cross_layers = nn.ModuleList(HipLinear(input_dim, input_dim) for _ in range(num_cross_layers))
 
-    def forward(self, x0, out=None):
-        """`out`: optional pre-allocated destination of the last layer (ops.alias_cols)."""
+    def forward(self, x0, out=None, link=None):
+        """`out`: optional pre-allocated destination of the last layer (ops.alias_cols); `link`: the _JoinLink to
+        the consumer of the towers' concatenated output."""
         if self.num_layers == 0:
             return x0
         wb = [p for layer in self.cross_layers for p in (layer.weight, layer.bias)]
-        return _CrossTower.apply(x0, out, *wb)
+        return _CrossTower.apply(x0, out, link, *wb)
 
 
 class _SelfAttention(Function):

@@ -41,8 +41,8 @@ class _RfdPredictor(nn.ModuleDict):
     def __init__(self, input_dim, hidden, out):
         super().__init__({"0": HipLinear(input_dim, hidden, relu=True), "2": HipLinear(hidden, out, out_fp32=True)})
 
-    def forward(self, x):
-        return self["2"](self["0"](x))
+    def forward(self, x, link_in=None):
+        return self["2"](self["0"](x, link_in=link_in))
 
 
 class BaseModel(nn.Module):
@@ -82,12 +82,13 @@ class BaseModel(nn.Module):
 
     # ------------------------------------------------------------------ heads
     def get_outputs(self, inputs, labels=None, masked_index=None, is_pretrain=None, noise_samples=None,
-                    groups=None, nce_idx=None):
+                    groups=None, nce_idx=None, join=None):
         """MFP -> (loss, #signals, #targets ranked first)            (models.py:71-78)
         RFD -> (loss, #signals, accuracy, positive ratio)            (models.py:79-85)
         CTR -> (loss, logits) or (logits,)                           (models.py:88-93)
         `#targets ranked first` is a device scalar (no host sync per step); the reference
-        returns a Python int after `.item()`."""
+        returns a Python int after `.item()`.  `join`: the layers._JoinLink of a two-tower trunk whose output
+        `inputs` is (the head's first layer then does both towers' first backward step in its dX epilogue)."""
         cfg = self.config
         if (is_pretrain is None and cfg.pretrain) or is_pretrain:
             if cfg.pt_type == "MFP":
@@ -97,16 +98,16 @@ class BaseModel(nn.Module):
                     # only the L masked fields' blocks of feat_encoder are computed (26 %)
                     loss, _logits, _idx = crit.forward_with_encoder(labels, inputs, self.feat_encoder,
                                                                     masked_index, noise_samples=noise_samples,
-                                                                    groups=groups, idx=nce_idx)
+                                                                    groups=groups, idx=nce_idx, join=join)
                 else:
                     # (bf16 mode: the dense encoder GEMM — 16x the MFMA rate makes computing all F blocks
                     # cheaper than the grouped GEMM's gathers; its output and the whole NCE head stay fp32)
-                    enc = self.feat_encoder(inputs)
+                    enc = self.feat_encoder(inputs, link_in=join)
                     loss, _logits, _idx = crit(labels, enc, masked_index=masked_index,
                                                noise_samples=noise_samples, idx=nce_idx)
                 return (loss, labels.shape[0] * labels.shape[1], self.mfp_criterion.last_acc)
             if cfg.pt_type == "RFD":
-                logits = self.pred_rfd(inputs)
+                logits = self.pred_rfd(inputs, link_in=join)
                 loss, stats = bce_with_logits(logits, labels)
                 return (loss, labels.shape[0] * labels.shape[1], stats[1], stats[2])
             raise NotImplementedError(cfg.pt_type)
@@ -189,7 +190,7 @@ class DCNV2(BaseModel):
                 and self.feat_encoder.in_features % 8 == 0)
 
     def forward(self, input_ids, labels=None, masked_index=None, noise_samples=None):
-        groups, nce_idx = None, None
+        groups, nce_idx, join = None, None, None
         feat_embed = self.embed(input_ids).flatten(start_dim=1)
         if self.config.num_hidden_layers > 0:
             # Three independent chains leave the gather: the cross tower (small D x D GEMMs on a
@@ -205,6 +206,10 @@ class DCNV2(BaseModel):
             # both towers write their last layer straight into the concatenated buffer
             D, H = feat_embed.shape[1], self.config.hidden_size
             direct = self.config.num_cross_layers > 0
+            if (direct and torch.is_grad_enabled() and feat_embed.dtype == torch.float32
+                    and not (self.parallel_dnn.p_drop > 0 and self.training)):
+                from .layers import _JoinLink
+                join = _JoinLink(D)            # towers -> the head's first layer (fused backward epilogue)
             final_buf = torch.empty(feat_embed.shape[0], D + H, dtype=feat_embed.dtype, device=feat_embed.device)
             if LAYOUT_ON_MAIN and self._grouped_head(masked_index):
                 # the grouped encoder's slot layout (one 15-us launch) ahead of the deep tower, which by now
@@ -223,8 +228,10 @@ class DCNV2(BaseModel):
                     # the cross tower's GEMMs instead, the trunk joining at the cross tower's end and only the
                     # loss kernel waiting for the sampling: 1.02 vs 0.91 ms fp32, 0.72 vs 0.66 bf16.)
                     nce_idx = self.mfp_criterion.sample_ids(labels, noise_samples)
-                cross_output = self.cross_net(feat_embed, out=ops.alias_cols(final_buf, 0, D) if direct else None)
-            dnn_output = self.parallel_dnn(feat_embed, out=ops.alias_cols(final_buf, D, H) if direct else None)
+                cross_output = self.cross_net(feat_embed, out=ops.alias_cols(final_buf, 0, D) if direct else None,
+                                              link=join)
+            dnn_output = self.parallel_dnn(feat_embed, out=ops.alias_cols(final_buf, D, H) if direct else None,
+                                           link_last=join.relu if join is not None else None)
             # Both tables' segment plans from ONE chain of launches (8 instead of 8 + 8), when the
             # sampled ids exist already (drawn early on the tower stream).  (Round 1 note: the sampled
             # ids' sort as a chain of its own ahead of the embedding's cost 1.375 vs 1.21 ms.)
@@ -262,8 +269,8 @@ class DCNV2(BaseModel):
             self.embed.table.start_plan()
         if self.config.pretrain:
             return self.get_outputs(final_output, labels, masked_index, noise_samples=noise_samples, groups=groups,
-                                    nce_idx=nce_idx)
-        return self.get_outputs(self.fc_out(final_output), labels)
+                                    nce_idx=nce_idx, join=join)
+        return self.get_outputs(self.fc_out(final_output, link_in=join), labels)
 
 
 class DNN(BaseModel):

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmapx_hip.so")
 
-MAPX_ABI_VERSION = 33
+MAPX_ABI_VERSION = 34
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_CROSS, EPI_ADD, EPI_RELU_MASK, EPI_RELU_MASK_COLSUM = range(7)
 
 _p, _i, _i64, _u64, _f, _d, _sz = (C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double,
@@ -59,6 +59,9 @@ SIGNATURES = {
     "mapx_gemm_splitk_workspace_bytes": (_sz, [_i, _i, _i]),
     "mapx_gemm_f32": (_i, [_i, _i, _i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _i, _p, _p, _i64, _p,
                            _i64, _p, _i64, _i, _i, _p, _sz, _p, _p]),
+    "mapx_gemm_f32_bwd_fused": (_i, [_i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i, _p, _i64, _p, _i64,
+                                     _p, _i64, _p, _i64, _i, _i, _p, _i64, _p]),
+    "mapx_gemm_f32_batched": (_i, [_i, _i, _i, _i, _i, _i, _p, _i64, _p, _i64, _p, _i, _p, _sz, _p]),
     "mapx_gemm_bf16": (_i, [_i, _i, _i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _i, _i, _p, _p, _i64, _i, _p, _i64,
                             _p, _i64, _i, _i, _p, _sz, _p]),
     "mapx_cast_f32_bf16": (_i, [_p, _i64, _p, _p]),

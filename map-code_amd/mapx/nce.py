@@ -113,13 +113,13 @@ class _EncNceLoss(Function):
 
     @staticmethod
     def forward(ctx, final, w_enc, b_enc, emb_w, bias_w, logq, masked_index, idx, crit, F, P, want_logits,
-                groups):
+                groups, join=None):
         final = final.contiguous()
         dh_slots = torch.empty(groups.cap, P, dtype=torch.float32, device=final.device)
         h_slots = ops.enc_grouped_fwd(final, w_enc, b_enc, groups, zero_slots=dh_slots)
         o = ops.nce_fwd(h_slots, masked_index, idx, emb_w, bias_w.view(-1), logq, F, P,
                         want_logits=want_logits, hpos=groups.hpos, dh_slots=dh_slots)
-        ctx.crit, ctx.F, ctx.P, ctx.K, ctx.groups = crit, F, P, idx.shape[1] - 1, groups
+        ctx.crit, ctx.F, ctx.P, ctx.K, ctx.groups, ctx.join = crit, F, P, idx.shape[1] - 1, groups, join
         ctx.plan = crit.table.plan
         ctx.slots = (getattr(w_enc, "_mapx_grad", None), getattr(b_enc, "_mapx_grad", None))
         ctx.save_for_backward(final, w_enc, o["dlogit"], o["dh"], o["h"], masked_index, dh_slots)
@@ -135,7 +135,14 @@ class _EncNceLoss(Function):
         sw, sb = ctx.slots
         gl = gl.contiguous().float()
         denc = ops.nce_scatter_dh(dh, mi, ctx.F, ctx.P, gscale=gl)          # dense [B, F*P]
-        dfinal = ops.linear_bwd_input(denc, w_enc) if ctx.needs_input_grad[0] else None
+        dfinal = None
+        if ctx.needs_input_grad[0]:
+            join = ctx.join
+            if join is not None and join.usable(denc, final):
+                from .layers import join_bwd_input
+                dfinal = join_bwd_input(denc, w_enc, final, join)      # + both towers' first backward step
+            else:
+                dfinal = ops.linear_bwd_input(denc, w_enc)
         if ctx.plan is not None:
             ctx.plan.start()         # sort of the sampled ids: forks from the draw, enqueued behind the dX GEMM
         if ctx.plan is None:
@@ -180,7 +187,7 @@ class _EncNceLoss(Function):
                 lazy.update()
             ops.add_side_task(update_rows)
         return (dfinal, None if sw is not None else dw, None if sb is not None else db,
-                None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None)
 
 
 class IndexLinear(nn.Module):
@@ -267,7 +274,7 @@ class IndexLinear(nn.Module):
         return idx
 
     def forward_with_encoder(self, target, final, encoder, masked_index, noise_samples=None, groups=None,
-                             idx=None):
+                             idx=None, join=None):
         """The MFP head from the trunk output: `encoder` (feat_encoder) is applied only to the
         field blocks that `masked_index` selects.  Same returns as forward()."""
         B, L = target.shape
@@ -278,7 +285,7 @@ class IndexLinear(nn.Module):
             groups = ops.EncGroups(masked_index, F)       # one launch: counting sort of the targets by field
         loss, acc, logits = _EncNceLoss.apply(final, encoder.weight, encoder.bias, self.emb.weight,
                                               self.bias.weight, self.logprob_noise, masked_index, idx, self,
-                                              F, P, self.return_logits, groups)
+                                              F, P, self.return_logits, groups, join)
         self.last_acc = acc
         if self.return_logits:
             logits = logits.view(B, L, -1)

@@ -1003,6 +1003,64 @@ def cross_bwd_pre_colsum(g, x0, u, dx0=None, db=None, defer=False, plus_g=False)
     return t, dx0, db
 
 
+JOIN_FUSE = os.environ.get("MAPX_JOIN_FUSE", "1") == "1"      # fused backward epilogues + batched cross dW (A/B switch)
+
+
+def gemm_bwd_fused(dy, w, c0, add=None, mask=None, x0=None, u=None, dx0=None, plus_v=False, out=None):
+    """v = dy W (+ add) with the elementwise backward that follows it done in the GEMM's epilogue
+    (include/mapx_hip.h: mapx_gemm_f32_bwd_fused): columns >= c0 masked by `mask` > 0 (the ReLU layer whose output
+    `mask` is), columns < c0 the cross layer's  t = v x0,  dx0 (+)= v u (+ v).  fp32.
+    -> (C [M,N], t [M,c0] | None, dx0 [M,c0] | None, part [ceil(M/128), N]: partial rows of the bias gradients)."""
+    require_gpu(dy, w)
+    M, K = dy.shape
+    Nn = w.shape[1]
+    dev = dy.device
+    C = out if out is not None else torch.empty(M, Nn, dtype=torch.float32, device=dev)
+    t = torch.empty(M, c0, dtype=torch.float32, device=dev) if c0 > 0 else None
+    accumulate = dx0 is not None
+    if c0 > 0 and dx0 is None:
+        dx0 = torch.empty(M, c0, dtype=torch.float32, device=dev)
+    part = torch.empty((M + 127) // 128, Nn, dtype=torch.float32, device=dev)
+    sd = lambda x: (x.data_ptr(), x.stride(0)) if x is not None else (None, 0)
+    with _timed("gemm_dx_nn", 2.0 * M * Nn * K):
+        check(lib.mapx_gemm_f32_bwd_fused(M, Nn, K, dy.data_ptr(), dy.stride(0), w.data_ptr(), w.stride(0),
+                                          C.data_ptr(), C.stride(0), *sd(add), *sd(mask), c0, *sd(x0), *sd(u), *sd(t),
+                                          *sd(dx0), int(accumulate), int(plus_v), part.data_ptr(), part.stride(0),
+                                          stream()))
+    return C, t, dx0, part
+
+
+def defer_part_rows(dst, part, col0, ncols):
+    """Queue dst[0:ncols] = column sums of part[:, col0 : col0 + ncols] (partial rows of a fused epilogue)."""
+    defer_sum(dst, part.view(-1)[col0:], part.stride(0), part.shape[0], ncols)
+
+
+def linear_bwd_weight_batched(dys, xs, outs):
+    """dW_z = dy_z^T x_z for up to four equal-shaped layers in ONE launch (+ one slab sum): dy_z [B,N],
+    x_z [B,K] -> outs[z] [N,K] (dense fp32, written in place).  The cross layers' weight gradients."""
+    import ctypes as C
+    cnt = len(dys)
+    Bn, Nn = dys[0].shape
+    K = xs[0].shape[1]
+    for d, x, o in zip(dys, xs, outs):
+        require_gpu(d, x, o)
+        if d.shape != (Bn, Nn) or x.shape != (Bn, K) or o.shape != (Nn, K) or not (d.is_contiguous() and x.is_contiguous()
+                                                                                   and o.is_contiguous()):
+            raise ValueError("linear_bwd_weight_batched: equal shapes, contiguous operands")
+    tiles = math.ceil(Nn / 128) * math.ceil(K / 128) * cnt
+    ns = 1
+    while ns < 16 and tiles * ns * 2 <= 288 and Bn // (ns * 2) >= 256:
+        ns *= 2
+    ws = scratch(cnt * lib.mapx_gemm_splitk_workspace_bytes(Nn, K, ns), dys[0].device) if ns > 1 else None
+    PP = C.c_void_p * cnt
+    with _timed("gemm_dw_tn", 2.0 * cnt * Nn * K * Bn):
+        check(lib.mapx_gemm_f32_batched(cnt, 0, 0, Nn, K, Bn, PP(*[d.data_ptr() for d in dys]), Nn,
+                                        PP(*[x.data_ptr() for x in xs]), K, PP(*[o.data_ptr() for o in outs]), ns,
+                                        ws.data_ptr() if ws is not None else None,
+                                        ws.numel() if ws is not None else 0, stream()))
+    return outs
+
+
 def relu_mask(dy, y):
     out = torch.empty_like(dy)
     fn = lib.mapx_relu_mask_bf16 if is_bf16(dy) else lib.mapx_relu_mask

@@ -305,6 +305,79 @@ def test_gemm_every_tile_layout(ops, a_kc, b_kc, M, N, K):
         assert torch.equal(out, ops.gemm(Ad, Bd, bool(a_kc), bool(b_kc), M, N, K, tile=tile)), tile
 
 
+@pytest.mark.parametrize("M,N,K,c0", [(4096, 1368, 736, 368), (300, 432, 96, 368), (129, 368, 368, 368),
+                                      (260, 1000, 200, 0), (64, 72, 40, 40)])
+@pytest.mark.parametrize("add,accumulate,plus_v", [(False, False, False), (True, True, False), (True, True, True)])
+def test_gemm_bwd_fused_epilogue(ops, M, N, K, c0, add, accumulate, plus_v):
+    """mapx_gemm_f32_bwd_fused: the dX GEMM whose epilogue does the ReLU backward right of column c0 and the
+    cross layer's backward (t = v x0, dx0 (+)= v u (+ v)) left of it, plus one partial row of the bias
+    gradients per 128-row tile — against fp64 on the step's shapes (the heads' concatenated input: N = D + H,
+    c0 = D), a cross layer alone (c0 = N), a ReLU layer alone (c0 = 0), ragged rows and edge tiles."""
+    g = torch.Generator().manual_seed(M + N + K + c0)
+    rn = lambda *sh: torch.randn(*sh, generator=g)
+    dy, w = rn(M, K), rn(K, N)
+    addv = rn(M, N) if add else None
+    mask, x0, u, dx0_in = rn(M, N), rn(M, max(c0, 4)), rn(M, max(c0, 4)), rn(M, max(c0, 4))
+    d = lambda x: None if x is None else x.to(DEV)
+    dx0_dev = dx0_in[:, :c0].contiguous().to(DEV) if (accumulate and c0 > 0) else None
+    C, t, dx0, part = ops.gemm_bwd_fused(d(dy), d(w), c0, add=d(addv), mask=d(mask) if c0 < N else None,
+                                         x0=d(x0[:, :c0].contiguous()) if c0 else None,
+                                         u=d(u[:, :c0].contiguous()) if c0 else None, dx0=dx0_dev, plus_v=plus_v)
+    v = dy.double() @ w.double() + (addv.double() if add else 0)
+    bound = 2e-6 * (dy.abs().double() @ w.abs().double() + (addv.abs().double() if add else 0)) + 1e-6
+    vr = v.clone()
+    vr[:, c0:] = v[:, c0:] * (mask[:, c0:] > 0)
+    assert bool(((_cpu(C).double() - vr).abs() <= bound).all())
+    col_ref = torch.zeros(N, dtype=torch.float64)
+    col_ref[c0:] = _cpu(C).double()[:, c0:].sum(0)
+    if c0:
+        Cc = _cpu(C).double()[:, :c0]
+        # t and dx0 are formed from the stored v: exact products up to one fp32 rounding each
+        assert bool(((_cpu(t).double() - Cc * x0[:, :c0].double()).abs() <= 1e-6 * (Cc * x0[:, :c0].double()).abs() + 1e-12).all())
+        want = Cc * u[:, :c0].double() + (dx0_in[:, :c0].double() if accumulate else 0) + (Cc if plus_v else 0)
+        mag = (Cc * u[:, :c0].double()).abs() + (dx0_in[:, :c0].abs().double() if accumulate else 0) + (Cc.abs() if plus_v else 0)
+        assert bool(((_cpu(dx0).double() - want).abs() <= 3e-7 * mag + 1e-12).all())
+        col_ref[:c0] = _cpu(t).double().sum(0)
+    assert part.shape == ((M + 127) // 128, N)
+    got = _cpu(part).double().sum(0)
+    absum = torch.zeros(N, dtype=torch.float64)
+    absum[c0:] = _cpu(C).double()[:, c0:].abs().sum(0)
+    if c0:
+        absum[:c0] = _cpu(t).double().abs().sum(0)
+    assert bool(((got - col_ref).abs() <= 1e-6 * absum + 1e-6).all())
+    # reproducible, and the partial rows feed mapx_sum_tasks as the bias gradients
+    C2, t2, dx02, part2 = ops.gemm_bwd_fused(d(dy), d(w), c0, add=d(addv), mask=d(mask) if c0 < N else None,
+                                            x0=d(x0[:, :c0].contiguous()) if c0 else None,
+                                            u=d(u[:, :c0].contiguous()) if c0 else None,
+                                            dx0=dx0_in[:, :c0].contiguous().to(DEV) if (accumulate and c0 > 0) else None,
+                                            plus_v=plus_v)
+    assert torch.equal(C, C2) and torch.equal(part, part2) and (c0 == 0 or (torch.equal(t, t2) and torch.equal(dx0, dx02)))
+    if c0 and c0 < N:
+        dst_a, dst_b = torch.zeros(c0, device=DEV), torch.zeros(N - c0, device=DEV)
+        ops.defer_part_rows(dst_a, part, 0, c0)
+        ops.defer_part_rows(dst_b, part, c0, N - c0)
+        ops.flush_deferred()
+        assert bool(((_cpu(dst_a).double() - col_ref[:c0]).abs() <= 1e-6 * absum[:c0] + 1e-6).all())
+        assert bool(((_cpu(dst_b).double() - col_ref[c0:]).abs() <= 1e-6 * absum[c0:] + 1e-6).all())
+
+
+@pytest.mark.parametrize("cnt,Bn,Nn,K", [(3, 4096, 368, 368), (2, 777, 72, 40), (4, 512, 128, 136), (1, 300, 64, 64)])
+def test_linear_bwd_weight_batched(ops, cnt, Bn, Nn, K):
+    """mapx_gemm_f32_batched: the cross layers' weight gradients (equal shapes) from one launch + one slab sum."""
+    g = torch.Generator().manual_seed(cnt + Bn + Nn + K)
+    dys = [torch.randn(Bn, Nn, generator=g) for _ in range(cnt)]
+    xs = [torch.randn(Bn, K, generator=g) for _ in range(cnt)]
+    outs = [torch.full((Nn, K), 7.0, device=DEV) for _ in range(cnt)]
+    ops.linear_bwd_weight_batched([t.to(DEV) for t in dys], [t.to(DEV) for t in xs], outs)
+    for dy, x, o in zip(dys, xs, outs):
+        ref = dy.double().t() @ x.double()
+        bound = 4e-6 * (dy.abs().double().t() @ x.abs().double()) + 1e-6
+        assert bool(((_cpu(o).double() - ref).abs() <= bound).all())
+    again = [torch.empty(Nn, K, device=DEV) for _ in range(cnt)]
+    ops.linear_bwd_weight_batched([t.to(DEV) for t in dys], [t.to(DEV) for t in xs], again)
+    assert all(torch.equal(a, b) for a, b in zip(outs, again))
+
+
 def test_gemm_x3_operand_magnitudes(ops):
     """The six-product arithmetic of the fp32 GEMM (three bf16 pieces per operand, csrc/gemm_x3.hip) away from
     randn operands: what it guarantees and where it stops, as measured by

@@ -756,3 +756,50 @@ def test_optimizer_state_with_another_flat_slot_size_is_repacked(tmp_path):
     bad["groups"] = [dict(names=s["names"], m=s["m"][:-4], v=s["v"][:-4]) for s in old["groups"]]
     with pytest.raises(ValueError):
         opt.load_state_dict(bad)
+
+
+@pytest.mark.parametrize("pt", ["MFP", "RFD"])
+def test_fused_backward_epilogues_equal_the_unfused_chain(tmp_path, pt):
+    """The heads' dX GEMM doing both towers' first backward step, the cross layers' dX GEMMs doing the next
+    layer's elementwise backward, and the cross layers' weight gradients from one launch (ops.JOIN_FUSE) against
+    the chain of separate launches they replace: same parameters after 6 steps up to the order of the sums
+    (bias gradients are added tile by tile instead of chunk by chunk, split-K slabs are cut differently)."""
+    from mapx import ops
+    from mapx.arguments import TrainingArguments
+    from mapx.dataset import OurDataset, synth_table
+    from mapx.models import BaseModel
+    from mapx.trainer import Trainer
+    from util import make_config
+    cfg = dict(F=23, V=3000, E=16, H=64, NL=3, NC=3, P=32, K=25)
+    ids, labels, _, _ = synth_table(512 * 6, 23, cfg["V"], seed=3)
+    cnt = np.bincount(ids.reshape(-1), minlength=cfg["V"]).astype(np.float32)
+    out, calls = [], []
+    real = ops.gemm_bwd_fused
+    for fuse in (True, False):
+        ops.JOIN_FUSE = fuse
+        try:
+            if fuse:
+                ops.gemm_bwd_fused = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+            torch.manual_seed(5)
+            config = make_config(cfg, pt, cnt if pt == "MFP" else None)
+            model = BaseModel.from_config(config)
+            targs = TrainingArguments(output_dir=str(tmp_path), per_gpu_train_batch_size=512,
+                                      per_gpu_eval_batch_size=512, learning_rate=1e-3, lr_sched="cosine",
+                                      weight_decay=5e-2, num_train_epochs=1, pretrain=True, pt_type=pt,
+                                      RFD_replace="Unigram", sampling_method="randint", mask_ratio=0.3, seed=11)
+            targs._device = torch.device(DEV)
+            ds = OurDataset(ids, labels)
+            tr = Trainer(model, config, targs, ds, ds)
+            tr.use_graph = False
+            train = tr._begin("test")
+            model.train()
+            for X, Y in train.batches(512, True, tr._generator(), (0, 1)):
+                tr.run_step(pt.lower(), X, Y)
+            tr.optimizer.flush()
+            out.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+        finally:
+            ops.JOIN_FUSE, ops.gemm_bwd_fused = True, real
+    assert len(calls) == 6 * 3          # per step: the head's dX GEMM + two of the three cross layers'
+    for k in out[0]:
+        if out[0][k].dtype.is_floating_point:
+            np.testing.assert_allclose(out[0][k].numpy(), out[1][k].numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
