@@ -1,6 +1,7 @@
 """DCNv2 building blocks over the gfx950 kernels (host mirror of reference code/layers.py:
 Embeddings :83-102, MLPBlock :173-188, CrossNetV2 :191-201).  autograd.Function = glue only:
 every forward/backward body is a C-ABI call (mapx.ops)."""
+import contextlib
 import math
 import os
 
@@ -427,19 +428,24 @@ class _ReluLink:
 
 class _JoinLink:
     """Between the two towers of DCNv2 and the ONE layer that consumes their concatenated output (the heads'
-    first Linear, or the grouped feat_encoder): that layer's input-gradient GEMM can do both towers' first
-    backward step in its epilogue (ops.gemm_bwd_fused) — the deep tower's last ReLU mask + bias gradient on the
-    columns right of D, the last cross layer's t = g X0, dX0 = g u and bias gradient left of it — instead of
-    three elementwise launches at the head of the two backward chains.  The towers fill in what the consumer
-    needs in forward (x0, u, bias-gradient slots); the consumer leaves t / dx0 for the cross tower and marks the
-    ReLU layer `premasked` (as _ReluLink does inside the MLP)."""
+    first Linear, or the grouped feat_encoder).  That layer's input gradient is formed as TWO products, one per
+    tower, each on its tower's stream and each doing the tower's first backward step in its epilogue:
+      deep tower (columns D.. of the weight, main stream): dZ = ReLU mask of the last MLP layer applied, its bias
+        gradient's partial rows queued (EPI_RELU_MASK_COLSUM) — 4096 x 1000 outputs are exactly one round of
+        128 x 128 tiles, where the joint 4096 x 1368 product ran 1.4 rounds;
+      cross tower (columns ..D, tower stream): g, t = g X0, dX0 = g u and the bias gradient's partial rows
+        (ops.gemm_bwd_fused).
+    Both backward chains start from their own GEMM instead of waiting for one joint GEMM plus three elementwise
+    launches.  The towers fill in what the consumer needs in forward (x0, u, bias-gradient slots); the consumer
+    leaves g / dz / t / dx0 here and returns a placeholder as dL/d(final); _JoinColumns.backward hands the two
+    tensors to the towers (as _ReluLink does for the mask inside the MLP)."""
 
     def __init__(self, D):
         self.D = D
         self.relu = _ReluLink()              # the deep tower's last layer
         self.x0 = self.u = self.sb_cross = None
         self.plus_v = False                  # a single cross layer: X_i IS X0, g joins dX0 at once
-        self.t = self.dx0 = None
+        self.t = self.dx0 = self.g = self.dz = None
 
     def usable(self, dz, final):
         return (ops.JOIN_FUSE and ops.DEFER_COLSUM and dz.dtype == torch.float32 and final.dtype == torch.float32
@@ -449,14 +455,21 @@ class _JoinLink:
 
 
 def join_bwd_input(dz, w, final, link):
-    """dL/d(final) = dz W with both towers' first backward step in the epilogue (see _JoinLink)."""
+    """dL/d(final) = dz W as one product per tower (see _JoinLink) -> a placeholder of dL/d(final)'s shape."""
     D, Nn = link.D, final.shape[1]
-    C, t, dx0, part = ops.gemm_bwd_fused(dz, w, D, mask=final, x0=link.x0, u=link.u, plus_v=link.plus_v)
-    ops.defer_part_rows(link.sb_cross, part, 0, D)
-    ops.defer_part_rows(link.relu.sb, part, D, Nn - D)
-    link.t, link.dx0 = t, dx0
+    main = torch.cuda.current_stream() if dz.is_cuda else None
+    side = ops.aux_stream("tower", dz.device) if dz.is_cuda else None
+    forked = ops.stream_wait(side, main) if dz.is_cuda else False
+    with (torch.cuda.stream(side) if forked else contextlib.nullcontext()):
+        g, t, dx0, part = ops.gemm_bwd_fused(dz, w[:, :D], D, x0=link.x0, u=link.u, plus_v=link.plus_v)
+        ops.defer_part_rows(link.sb_cross, part, 0, D)
+    if forked:
+        dz.record_stream(side)
+        ops.pending_joins.append((main, side))
+    dzr = ops.linear_bwd_input(dz, w[:, D:], relu_of=final[:, D:], colsum_to=link.relu.sb)
     link.relu.premasked = True
-    return C
+    link.t, link.dx0, link.g, link.dz = t, dx0, g, dzr
+    return torch.empty(1, 1, dtype=final.dtype, device=final.device).expand(final.shape[0], Nn)    # never read
 
 
 class _Linear(Function):
@@ -484,7 +497,7 @@ class _Linear(Function):
             gy = ops.cast_bf16(gy)                 # the fp32 gradient of a head's logits enters the bf16 trunk
         if ctx.relu and ctx.link_out is not None and ctx.link_out.premasked:
             # the consumer's dX GEMM has applied this layer's mask and queued its bias gradient (_ReluLink)
-            dz, db = gy.contiguous(), None
+            dz, db = (gy if ops.row_sliceable(gy) else gy.contiguous()), None
             dw = ops.linear_bwd_weight(dz, x, out=sw, defer=True) if ctx.needs_input_grad[1] else None
             dw = None if sw is not None else dw
         elif ctx.relu and (ctx.half or gy.shape[1] % 4 == 0):      # ReLU mask and bias gradient in one pass over dY
@@ -646,6 +659,7 @@ class _CrossTower(Function):
                 t = None
         if pend:
             ops.linear_bwd_weight_batched([p[0] for p in pend], [p[1] for p in pend], [p[2] for p in pend])
+        ops.run_late_tasks()                     # what only the optimizer waits for (the encoder's dW / db)
         return (g, None, None, *grads)
 
 
@@ -835,13 +849,18 @@ class _JoinColumns(Function):
     `buf` (ops.alias_cols): no copy forward, two slices backward."""
 
     @staticmethod
-    def forward(ctx, a, b, buf):
-        ctx.split = a.shape[1]
+    def forward(ctx, a, b, buf, link=None):
+        ctx.split, ctx.link = a.shape[1], link
         return buf
 
     @staticmethod
     def backward(ctx, g):
-        return g[:, :ctx.split], g[:, ctx.split:], None
+        link = ctx.link
+        if link is not None and link.g is not None:
+            # the consumer formed the two towers' gradients separately (_JoinLink); `g` is a placeholder
+            gc, gd, link.g, link.dz = link.g, link.dz, None, None
+            return gc, gd, None, None
+        return g[:, :ctx.split], g[:, ctx.split:], None, None
 
 
 class _Bce(Function):

@@ -262,7 +262,7 @@ class DCNV2(BaseModel):
                 if nce_idx is not None:
                     labels.record_stream(tower)
                     nce_idx.record_stream(main)
-            final_output = _JoinColumns.apply(cross_output, dnn_output, final_buf) if direct \
+            final_output = _JoinColumns.apply(cross_output, dnn_output, final_buf, join) if direct \
                 else torch.cat([cross_output, dnn_output], dim=-1)
         else:
             final_output = self.cross_net(feat_embed)

@@ -104,6 +104,7 @@ class _NceLoss(Function):
 
 
 HEAD_SIDE = os.environ.get("MAPX_HEAD_SIDE", "1") == "1"     # 0.871 vs 0.900 ms per step
+LATE_TABLE = os.environ.get("MAPX_LATE_TABLE", "1") == "1"
 
 
 class _EncNceLoss(Function):
@@ -135,12 +136,13 @@ class _EncNceLoss(Function):
         sw, sb = ctx.slots
         gl = gl.contiguous().float()
         denc = ops.nce_scatter_dh(dh, mi, ctx.F, ctx.P, gscale=gl)          # dense [B, F*P]
-        dfinal = None
+        dfinal, joined = None, False
         if ctx.needs_input_grad[0]:
             join = ctx.join
             if join is not None and join.usable(denc, final):
                 from .layers import join_bwd_input
-                dfinal = join_bwd_input(denc, w_enc, final, join)      # + both towers' first backward step
+                dfinal = join_bwd_input(denc, w_enc, final, join)      # one product per tower, each on its stream
+                joined = True
             else:
                 dfinal = ops.linear_bwd_input(denc, w_enc)
         if ctx.plan is not None:
@@ -151,7 +153,25 @@ class _EncNceLoss(Function):
         early = lazy is not None and getattr(lazy, "early_now", False)
         # (with a gradient exchange or a clipping norm ahead the row update has to wait; the reduction need not)
         aside = HEAD_SIDE and final.is_cuda and (early or ops.HEAD_SIDE_REDUCE_ONLY)
-        if aside:
+        if aside and joined and LATE_TABLE:
+            # with one product per tower the cross tower's chain starts at once on the tower stream; the table's
+            # gradient reduction and row update (HBM-bound, ~70 us) go BEHIND it (ops.run_late_tasks) instead of in
+            # front of it, beside the deep tower's remaining MFMA-bound GEMMs
+            crit, K, P, do_update = ctx.crit, ctx.K, ctx.P, early
+            plan = ctx.plan.get()        # (joined here, on the main stream: a tower <- plan join inside a capture
+                                         # is the one that crashed hipStreamEndCapture in round 1)
+
+            def table_work():
+                ge, gb = ops.nce_table_grad(plan, dlogit, h, K, P, gscale=gl)
+                crit.table.sparse_grad = (plan, ge, gb)
+                if do_update:
+                    lazy.update()
+                cur = torch.cuda.current_stream()
+                for t in (dlogit, h, gl) + tuple(plan.tensors()):
+                    t.record_stream(cur)
+            ops.add_late_task(table_work)
+            early = None
+        elif aside:
             # The table's gradient reduction and row update need nothing of this backward pass but the loss
             # scale; the trunk's backward needs only dfinal.  They go to the tower stream (idle between the
             # towers' forward and backward), forked behind the dX GEMM; the trunk's backward no longer waits
@@ -169,8 +189,22 @@ class _EncNceLoss(Function):
                     t.record_stream(side)
                 ops.pending_joins.append((main, side))
                 early = None
-        dw = ops.enc_grouped_dw(dh_slots, final, ctx.groups, out=sw, gscale=gl)
-        db = ops.colsum(denc, out=sb, defer=True)      # second stage with the other deferred partial sums
+        if joined and sw is not None and sb is not None:
+            # nothing but the optimizer waits for the encoder's own gradients, and both towers' backward passes
+            # wait for this node to return: they go to the end of the cross tower's chain (ops.run_late_tasks)
+            groups = ctx.groups
+
+            def encoder_grads():
+                cur = torch.cuda.current_stream()
+                for t in (dh_slots, final, denc, gl) + tuple(groups.tensors()):
+                    t.record_stream(cur)
+                ops.enc_grouped_dw(dh_slots, final, groups, out=sw, gscale=gl)
+                ops.colsum(denc, out=sb, defer=True)
+            ops.add_late_task(encoder_grads)
+            dw = db = None
+        else:
+            dw = ops.enc_grouped_dw(dh_slots, final, ctx.groups, out=sw, gscale=gl)
+            db = ops.colsum(denc, out=sb, defer=True)      # second stage with the other deferred partial sums
         if early is not None:
             plan = ctx.plan.get()
             ge, gb = ops.nce_table_grad(plan, dlogit, h, ctx.K, ctx.P, gscale=gl)

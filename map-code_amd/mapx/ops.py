@@ -130,9 +130,25 @@ def run_side_tasks():
         _side_tasks.pop(0)()
 
 
+# Late tasks: work of a backward node that nothing but the optimizer waits for (the grouped encoder's weight and
+# bias gradients), queued instead of run on the chain that the towers' backward passes wait behind; the cross
+# tower's backward node runs them at its END (its chain is the shorter one), optimizer.step() whatever is left.
+_late_tasks = []
+
+
+def add_late_task(fn):
+    _late_tasks.append(fn)
+
+
+def run_late_tasks():
+    while _late_tasks:
+        _late_tasks.pop(0)()
+
+
 def clear_side_tasks():
     """Drop tasks that an aborted backward pass left behind."""
     _side_tasks.clear()
+    _late_tasks.clear()
 
 
 def reset_aux_streams():
@@ -147,6 +163,7 @@ def reset_aux_streams():
     pending_joins.clear()
     _deferred.clear()
     _side_tasks.clear()
+    _late_tasks.clear()
     dense_ready[0] = dense_ready[1] = None
 
 

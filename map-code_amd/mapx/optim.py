@@ -213,6 +213,7 @@ class MapxOptimizer:
     def step(self):
         ops.join_pending()              # side work a backward node forked and left open
         ops.run_side_tasks()            # early table updates nobody picked up
+        ops.run_late_tasks()            # optimizer-only gradients nobody picked up
         moved = self.collect_torch_grads()
         ev, ev_stream = ops.dense_ready
         ops.dense_ready[0] = ops.dense_ready[1] = None

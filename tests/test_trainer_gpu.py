@@ -799,7 +799,7 @@ def test_fused_backward_epilogues_equal_the_unfused_chain(tmp_path, pt):
             out.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
         finally:
             ops.JOIN_FUSE, ops.gemm_bwd_fused = True, real
-    assert len(calls) == 6 * 3          # per step: the head's dX GEMM + two of the three cross layers'
+    assert len(calls) == 6 * 3          # per step: the cross half of the head's dX + two of the three cross layers'
     for k in out[0]:
         if out[0][k].dtype.is_floating_point:
             np.testing.assert_allclose(out[0][k].numpy(), out[1][k].numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
