@@ -481,6 +481,12 @@ def test_full_vocabulary_step_properties(F, V, pt, dtype):
                     assert torch.equal(nplan.uniq[:nplan.count()].long(), torch.unique(idx.long()))
                 for t in tr.optimizer.tables:
                     t.table.sparse_grad = None
+                # this backward pass had no optimizer.step(): sum what it queued NOW — left in the list, its partial
+                # sums would share one launch with the real step's and race them for the same gradient slots
+                from mapx import ops
+                ops.join_pending()
+                ops.run_late_tasks()
+                ops.flush_deferred()
             tr.run_step(pt.lower(), X, Y)
         assert tr.global_step == steps
         tr.optimizer.flush()
