@@ -403,6 +403,7 @@ def main():
     for g in graphed:
         g.host_s = [0.0] * len(g.host_s)
         g.poll_s = 0.0
+        g.spin_s = 0.0
     captures0 = sum(g.captures for g in graphed)
     parallel.barrier()
     torch.cuda.synchronize()
@@ -420,7 +421,10 @@ def main():
         names = ("launch", "counts", "tail_capture", "dense_allreduce", "tail")
         dp_info = {"host_us_per_step": {n: round(1e6 * sum(g.host_s[i] for g in graphed) / args.steps, 1)
                                         for i, n in enumerate(names)},
+                   # host time between the replay's launch and its segment counts: mostly asleep (wait), the
+                   # last part polling the mailbox with a back-off (spin)
                    "poll_us_per_step": round(1e6 * sum(g.poll_s for g in graphed) / args.steps, 1),
+                   "spin_us_per_step": round(1e6 * sum(g.spin_s for g in graphed) / args.steps, 1),
                    "tail_captures_in_timed_region": sum(g.captures for g in graphed) - captures0,
                    "message_sizes": sorted({sz for g in graphed for sz in g.tails})}
     if world > 1:                                       # the slowest rank sets the time

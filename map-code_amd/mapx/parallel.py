@@ -111,14 +111,22 @@ def pack_table(table, maxc):
 
 
 def gather_buffers(keys, rows):
+    """Receive buffers of one table's all-gather, on the messages' device (a captured merge reads them in place)."""
     w = world()
-    return (torch.empty(w * keys.shape[0], dtype=torch.int32, device=_staged(keys).device),
-            torch.empty(w * rows.shape[0], rows.shape[1], dtype=torch.float32, device=_staged(rows).device))
+    return (torch.empty(w * keys.shape[0], dtype=torch.int32, device=keys.device),
+            torch.empty(w * rows.shape[0], rows.shape[1], dtype=torch.float32, device=rows.device))
 
 
 def all_gather_table(keys, rows, k_all, r_all):
-    dist.all_gather_into_tensor(k_all, _staged(keys))
-    dist.all_gather_into_tensor(r_all, _staged(rows))
+    if dist.get_backend() == "gloo" and keys.is_cuda:        # gloo moves host memory only: staged both ways
+        ks, rs = torch.empty(k_all.shape, dtype=k_all.dtype), torch.empty(r_all.shape, dtype=r_all.dtype)
+        dist.all_gather_into_tensor(ks, keys.cpu())
+        dist.all_gather_into_tensor(rs, rows.cpu())
+        k_all.copy_(ks)
+        r_all.copy_(rs)
+        return
+    dist.all_gather_into_tensor(k_all, keys)
+    dist.all_gather_into_tensor(r_all, rows)
 
 
 def all_gather_tables(msgs, gathered):
@@ -155,7 +163,7 @@ def _sync_table_grad_hip(table, maxc):
     keys, rows = pack_table(table, maxc)
     k_all, r_all = gather_buffers(keys, rows)
     all_gather_table(keys, rows, k_all, r_all)
-    merge_table(table, k_all.to(dev), r_all.to(dev))
+    merge_table(table, k_all, r_all)
 
 
 def sync_table_grad(table, maxc, merge_fn=hip_merge):

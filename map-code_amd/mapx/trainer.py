@@ -224,12 +224,15 @@ class GraphedBackward:
         from . import layers
         self.trainer = _weak(trainer)       # no trainer <-> graph cycle: both die by reference count
         self.X, self.Y = X.clone(), Y.clone()
-        # (gloo stages every message through host memory: its exchange stays eager)
+        # (gloo stages every message through host memory and synchronises the device doing so: its exchange stays
+        # eager unless MAPX_DP_GLOO_GRAPH=1 asks for the captured tail — the 2-rank test on one GPU does)
         self.early = (parallel.exchanging() and parallel.EXCHANGE == "gather" and X.is_cuda
-                      and torch.distributed.get_backend() == "nccl")
+                      and (torch.distributed.get_backend() == "nccl"
+                           or os.environ.get("MAPX_DP_GLOO_GRAPH", "0") == "1"))
         self.replays = 0
         self.sizes_floor = None
-        self.tails, self.captures, self.poll_s = {}, 0, 0.0
+        self.tails, self.captures, self.poll_s, self.spin_s = {}, 0, 0.0, 0.0
+        self._arrival = None            # seconds after the replay's launch at which the counts usually land
         self.host_s = [0.0] * 5         # launch | counts | tail capture | dense all-reduce | tail
         tables = [t.table for t in trainer.optimizer.tables]
         if self.early:                  # nothing below may be allocated while a stream is capturing
@@ -266,14 +269,21 @@ class GraphedBackward:
             self.published = with_grad
 
     def _max_counts(self):
-        """Spin until this replay's counts have landed, then MAX over ranks on a side stream (the
-        main stream is still busy with the graph)."""
+        """Wait until this replay's counts have landed, then MAX over ranks on a side stream (the main stream is
+        still busy with the graph).  The counts land a fixed part of the way into the replay (behind the segment
+        plans): the host SLEEPS up to shortly before the time they took on earlier replays and only then polls,
+        with a back-off from 20 us; `poll_s` is the whole wait, `spin_s` the part of it spent polling."""
         a, t0 = self.pinned_np, time.perf_counter()
+        landed = lambda i: int(a[i, 1]) == self.replays and int(a[i, 0]) + int(a[i, 1]) == int(a[i, 2])
+        if self._arrival is not None and self._arrival > 150e-6 and not all(landed(i) for i in self.published):
+            time.sleep(self._arrival - 100e-6)
+        t1 = time.perf_counter()
+        pause = 20e-6
         for i in self.published:
-            while not (int(a[i, 1]) == self.replays and int(a[i, 0]) + int(a[i, 1]) == int(a[i, 2])):
+            while not landed(i):
                 waited = time.perf_counter() - t0
-                if waited > 1e-3:
-                    time.sleep(0 if waited < 0.05 else 1e-3)     # past a step's length: stop burning the core
+                time.sleep(pause)
+                pause = min(pause * 1.5, 1e-3)
                 if waited > 60.0:
                     seen = {j: tuple(int(x) for x in a[j, :3]) for j in self.published}
                     try:
@@ -286,6 +296,10 @@ class GraphedBackward:
                                        f"(count, stamp, check) per table = {seen}, expected stamp {self.replays} "
                                        "(a stalled collective on another rank keeps the previous tail, and so "
                                        "this replay, from running)")
+        now = time.perf_counter()
+        self.spin_s += now - t1
+        took = now - self._t_launch
+        self._arrival = took if self._arrival is None else 0.8 * self._arrival + 0.2 * took
         self.poll_s += time.perf_counter() - t0
         T = len(self.published)
         for k, i in enumerate(self.published):
@@ -298,6 +312,7 @@ class GraphedBackward:
         t = [time.perf_counter()]
         self.X.copy_(X)
         self.Y.copy_(Y)
+        self._t_launch = time.perf_counter()
         self.graph.replay()
         self.replays += 1
         for tb, sg in zip(self.trainer.optimizer.tables, self.sparse):

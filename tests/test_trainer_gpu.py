@@ -259,6 +259,29 @@ def test_one_rank_rccl_exchange_equals_plain_step(tmp_path):
         assert torch.equal(outs["plain"][k], outs["dp_graph"][k]), ("graphed exchange", k)
 
 
+def test_two_ranks_graphed_exchange_equals_eager(tmp_path):
+    """the GRAPHED data-parallel step at world size 2 — GraphedBackward (mask + forward + backward
+    replayed, segment counts published to the host mid-graph, MAX over ranks) and GraphedExchangeTail (pack graph,
+    all-gathers, merge + optimizer graph) — with two gloo ranks on this one GPU, each on its own rows, masks and
+    negatives: replicas bit-identical, and bit-identical to the same two ranks stepping eagerly (which
+    test_data_parallel_two_ranks_equal_single_process ties to the single-process step)."""
+    worker = os.path.join(ROOT, "tests", "dp_graph_worker.py")
+    env = dict(os.environ, MAPX_DP_GLOO_GRAPH="1",
+               PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "map-code_amd"), os.path.join(ROOT, "tests"),
+                                           os.path.join(ROOT, "tests", "golden")]))
+    outs = {}
+    for mode, port in (("eager", "29547"), ("graph", "29549")):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                            "--master-addr", "127.0.0.1", "--master-port", port, worker, str(tmp_path / f"{mode}.pt"),
+                            mode], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (mode, r.stderr[-3000:])
+        outs[mode] = [torch.load(str(tmp_path / f"{mode}.pt.{k}")) for k in (0, 1)]
+    for k in outs["eager"][0]:
+        assert torch.equal(outs["graph"][0][k], outs["graph"][1][k]), f"graphed replicas diverged on {k}"
+        assert torch.equal(outs["eager"][0][k], outs["eager"][1][k]), f"eager replicas diverged on {k}"
+        assert torch.equal(outs["graph"][0][k], outs["eager"][0][k]), f"graphed exchange != eager exchange on {k}"
+
+
 @pytest.mark.parametrize("max_grad_norm,backbone,full,epochs",
                          [(0.0, "DCNv2", 9, 2), (0.5, "DCNv2", 9, 2), (0.0, "DeepFM", 9, 2),
                           # GRAPH_AFTER full batches per epoch: the step is captured right after the
