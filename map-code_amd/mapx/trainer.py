@@ -271,20 +271,30 @@ class GraphedBackward:
     def _max_counts(self):
         """Wait until this replay's counts have landed, then MAX over ranks on a side stream (the main stream is
         still busy with the graph).  The counts land a fixed part of the way into the replay (behind the segment
-        plans): the host SLEEPS up to shortly before the time they took on earlier replays and only then polls,
-        with a back-off from 20 us; `poll_s` is the whole wait, `spin_s` the part of it spent polling."""
+        plans).  The host sleeps through the first 60 % of the time they took on earlier replays — an estimate
+        that only replays whose landing was SEEN by a poll update, and that shrinks whenever the counts were
+        already there on waking (a sleep may overshoot by more than it was asked for) — then polls: busily for
+        at most 300 us, with 50-us sleeps after that.  `poll_s` is the whole wait, `spin_s` the busy part."""
         a, t0 = self.pinned_np, time.perf_counter()
         landed = lambda i: int(a[i, 1]) == self.replays and int(a[i, 0]) + int(a[i, 1]) == int(a[i, 2])
-        if self._arrival is not None and self._arrival > 150e-6 and not all(landed(i) for i in self.published):
-            time.sleep(self._arrival - 100e-6)
+        all_landed = lambda: all(landed(i) for i in self.published)
+        if self._arrival is not None and not all_landed():
+            nap = self._t_launch + 0.6 * self._arrival - time.perf_counter()
+            if nap > 50e-6:
+                time.sleep(nap)
         t1 = time.perf_counter()
-        pause = 20e-6
+        seen_landing = not all_landed()
+        if not seen_landing and self._arrival is not None:
+            self._arrival *= 0.9                                  # overslept, or an idle GPU: sleep less next time
+        busy = 0.0
         for i in self.published:
             while not landed(i):
-                waited = time.perf_counter() - t0
-                time.sleep(pause)
-                pause = min(pause * 1.5, 1e-3)
-                if waited > 60.0:
+                now = time.perf_counter()
+                if now - t1 > 300e-6:
+                    time.sleep(50e-6)
+                else:
+                    busy = now - t1
+                if now - t0 > 60.0:
                     seen = {j: tuple(int(x) for x in a[j, :3]) for j in self.published}
                     try:
                         torch.cuda.synchronize()                 # surface the HIP error behind a dead replay
@@ -297,9 +307,10 @@ class GraphedBackward:
                                        "(a stalled collective on another rank keeps the previous tail, and so "
                                        "this replay, from running)")
         now = time.perf_counter()
-        self.spin_s += now - t1
-        took = now - self._t_launch
-        self._arrival = took if self._arrival is None else 0.8 * self._arrival + 0.2 * took
+        self.spin_s += min(busy, now - t1) if seen_landing else 0.0
+        if seen_landing:
+            took = now - self._t_launch
+            self._arrival = took if self._arrival is None else 0.8 * self._arrival + 0.2 * took
         self.poll_s += time.perf_counter() - t0
         T = len(self.published)
         for k, i in enumerate(self.published):
