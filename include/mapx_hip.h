@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 34
+#define MAPX_ABI_VERSION 35
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -90,11 +90,13 @@ int mapx_seg_plan_merge(const int32_t* keys, int lists, int64_t len, void* ws, s
                         int32_t* seg_start, int32_t* n_uniq, hipStream_t stream);
 
 /* out[u,:] = sum_{j in run u} src[perm[j],:]  (W floats per row, W % 4 == 0).  Embedding
- * table gradient: src = dL/dX0 viewed [B*F, E], plan over input_ids.flatten(). */
+ * table gradient: src = dL/dX0 viewed [B*F, E], plan over input_ids.flatten().  src2_opt: a second
+ * tensor of the same shape added to src element by element on the fly (DCNv2, models.py:308-317: X0 feeds
+ * the cross tower and the deep tower, autograd adds their two dL/dX0 with an elementwise kernel). */
 size_t mapx_seg_reduce_workspace_bytes(int64_t n, int W);
 int mapx_seg_reduce_rows(int64_t n, const int32_t* perm, const int32_t* rank,
-                         const int32_t* seg_start, const float* src, int W, float* out, void* ws,
-                         size_t ws_bytes, int32_t* zeroed_counter_opt, hipStream_t stream);
+                         const int32_t* seg_start, const float* src, const float* src2_opt, int W, float* out,
+                         void* ws, size_t ws_bytes, int32_t* zeroed_counter_opt, hipStream_t stream);
 
 /* Same with one extra scalar per run: out_extra[u] = sum_{j in run u} extra[(perm[j] / group) *
  * extra_stride]; src rows have stride ld_src >= W.  DeepFM: the LR weight w[V,1]
@@ -371,7 +373,10 @@ int mapx_dynamic_mask_rfd(const int64_t* ids, int64_t B, int F, int L,
 int mapx_adamw_dense(float* p, const float* g, float* m, float* v, int64_t n, const float* sched,
                      int sched_len, const int32_t* done, double beta1, double beta2, double eps,
                      double weight_decay, hipStream_t stream);
-int mapx_step_advance(int32_t* done, hipStream_t stream);
+/* *done += 1 (scheduler.step(), trainer.py:141,329,453); cursor_opt: the device-side batch cursor of a
+ * step that walks the epoch's permutation (the DataLoader's next batch, trainer.py:306), moved by
+ * cursor_stride rows in the same launch. */
+int mapx_step_advance(int32_t* done, int64_t* cursor_opt, int64_t cursor_stride, hipStream_t stream);
 /* Lazy exact row-sparse AdamW on a table group {p0 [V,W0] (+ optional p1 [V])} sharing
  * last[V].  rows NULL: rows row_begin..row_begin+n_rows-1 (flush / sweep); else rows[i],
  * i < *n_rows_dev (or n_rows if NULL); negative entries of rows[] are skipped (padding).  grad0 NULL: catch-up to *done only; else catch-up
@@ -413,8 +418,8 @@ int mapx_emb_gather_fwd_bf16(const int64_t* ids, int64_t n, const float* table, 
                              mapx_bf16* out, int* err_flag, hipStream_t stream);
 /* mapx_seg_reduce_rows over bf16 gradient rows (fp32 sums, fp32 output). */
 int mapx_seg_reduce_rows_bf16(int64_t n, const int32_t* perm, const int32_t* rank, const int32_t* seg_start,
-                              const mapx_bf16* src, int W, float* out, void* ws, size_t ws_bytes,
-                              int32_t* zeroed_counter_opt, hipStream_t stream);
+                              const mapx_bf16* src, const mapx_bf16* src2_opt, int W, float* out, void* ws,
+                              size_t ws_bytes, int32_t* zeroed_counter_opt, hipStream_t stream);
 /* bf16 counterparts of mapx_colsum / mapx_relu_mask_colsum / mapx_cross_bwd_pre_colsum /
  * mapx_relu_mask: activations and their gradients bf16, column sums (bias gradients) and the running
  * dL/dX0 of the cross tower fp32.  Any N and leading dimensions. */

@@ -139,14 +139,25 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a_i
   constexpr int kBuf = OpA::LDS_ELEMS + OpB::LDS_ELEMS;
 
   const int nb = a.tiles_m * a.tiles_n;
-  int lin = blockIdx.x;
-  const int per = nb / 8;
-  if (lin < per * 8) lin = (lin % 8) * per + lin / 8;      // XCD-aware tile order (see gemm.hip)
+  int lin = blockIdx.x, ks = blockIdx.y;
+  if (a.xcd_slices) {
+    // Split-K: workgroups reach the XCDs round-robin in launch order (x fastest), so XCD c = L % 8.  Dealing
+    // the tiles as below gave every XCD all K of 1/8 of the tiles: its L2 fetched one operand WHOLE (8 x 16 MB
+    // for the 1000 x 1000 x 4096 weight gradient, PMC: 138 MB per launch for 36 MB of operands and output).
+    // Here XCD c takes k-slice c % nsplit of the tiles of group c / nsplit: 1/nsplit of both operands' k range,
+    // the rows / columns of 1/(8/nsplit) of the tiles.
+    const int L = blockIdx.x + blockIdx.y * nb, c = L & 7, slot = L >> 3, ns = gridDim.y;
+    ks = c % ns;
+    lin = (c / ns) * (nb / (8 / ns)) + slot;
+  } else {
+    const int per = nb / 8;
+    if (lin < per * 8) lin = (lin % 8) * per + lin / 8;      // XCD-aware tile order (see gemm.hip)
+  }
   const int tm = lin / a.tiles_n, tn = lin % a.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int kbeg = blockIdx.y * a.k_chunk;
+  const int kbeg = ks * a.k_chunk;
   const int kend = (kbeg + a.k_chunk < a.K) ? kbeg + a.k_chunk : a.K;
-  float* __restrict__ C = a.C + (int64_t)blockIdx.y * a.slab_stride;
+  float* __restrict__ C = a.C + (int64_t)ks * a.slab_stride;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave / WC, wc = wave % WC;
@@ -489,15 +500,15 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a_i
         break;
       default: epilogue_rows_x3_vec<MAPX_EPI_NONE, BM, BN, NT>(a, C, tile, m0, n0); break;
     }
-    return;
-  }
-  switch (a.epi) {
-    case MAPX_EPI_BIAS: epilogue_rows_x3<MAPX_EPI_BIAS, BM, BN, NT>(a, C, tile, m0, n0, vio); break;
-    case MAPX_EPI_BIAS_RELU: epilogue_rows_x3<MAPX_EPI_BIAS_RELU, BM, BN, NT>(a, C, tile, m0, n0, vio); break;
-    case MAPX_EPI_BIAS_CROSS: epilogue_rows_x3<MAPX_EPI_BIAS_CROSS, BM, BN, NT>(a, C, tile, m0, n0, vio); break;
-    case MAPX_EPI_ADD: epilogue_rows_x3<MAPX_EPI_ADD, BM, BN, NT>(a, C, tile, m0, n0, vio); break;
-    case MAPX_EPI_RELU_MASK: epilogue_rows_x3<MAPX_EPI_RELU_MASK, BM, BN, NT>(a, C, tile, m0, n0, vio); break;
-    default: epilogue_rows_x3<MAPX_EPI_NONE, BM, BN, NT>(a, C, tile, m0, n0, vio); break;
+  } else {
+    switch (a.epi) {
+      case MAPX_EPI_BIAS: epilogue_rows_x3<MAPX_EPI_BIAS, BM, BN, NT>(a, C, tile, m0, n0, vio); break;
+      case MAPX_EPI_BIAS_RELU: epilogue_rows_x3<MAPX_EPI_BIAS_RELU, BM, BN, NT>(a, C, tile, m0, n0, vio); break;
+      case MAPX_EPI_BIAS_CROSS: epilogue_rows_x3<MAPX_EPI_BIAS_CROSS, BM, BN, NT>(a, C, tile, m0, n0, vio); break;
+      case MAPX_EPI_ADD: epilogue_rows_x3<MAPX_EPI_ADD, BM, BN, NT>(a, C, tile, m0, n0, vio); break;
+      case MAPX_EPI_RELU_MASK: epilogue_rows_x3<MAPX_EPI_RELU_MASK, BM, BN, NT>(a, C, tile, m0, n0, vio); break;
+      default: epilogue_rows_x3<MAPX_EPI_NONE, BM, BN, NT>(a, C, tile, m0, n0, vio); break;
+    }
   }
 }
 
@@ -566,6 +577,11 @@ __global__ void __launch_bounds__(256) splitk_reduce_x3_v4_kernel(const float* _
   }
 }
 
+static bool xcd_slices_enabled() {
+  static const bool on = [] { const char* e = getenv("MAPX_XCD_SLICES"); return !e || atoi(e) != 0; }();
+  return on;
+}
+
 // Called by mapx_gemm_f32 (gemm.hip) when the split-bf16 path is selected.  Same contract.
 int gemm_f32x3_launch(int a_kc, int b_kc, int M, int N, int K, const float* A, int64_t lda, const float* B,
                       int64_t ldb, float* C, int64_t ldc, int epi, const float* bias, const float* aux1, int64_t ld1,
@@ -597,6 +613,7 @@ int gemm_f32x3_launch(int a_kc, int b_kc, int M, int N, int K, const float* A, i
     g.ldc = N;
     g.slab_stride = (int64_t)M * N;
   }
+
   const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) &&
                    (g.k_chunk % 8 == 0) && (a_kc ? (K % 8 == 0) : (M % 8 == 0)) && (b_kc ? (K % 8 == 0) : (N % 8 == 0));
   auto blocks = [&](int bm, int bn) { return ceil_div(M, bm) * ceil_div(N, bn) * nsplit * batch; };
@@ -621,6 +638,11 @@ int gemm_f32x3_launch(int a_kc, int b_kc, int M, int N, int K, const float* A, i
   }
   // the woven K loop (4-wave layouts with vector loads) wants >= 2 K-steps in every slab
   if (tile != 2 && vec && K - (int64_t)g.k_chunk * (nsplit - 1) <= kXBK) tile = 2;
+  if (nsplit > 1 && batch == 1 && xcd_slices_enabled()) {
+    const int bm = tile == 0 ? 64 : 128, bn = (tile == 0 || tile == 1) ? 64 : 128;
+    const int64_t nb1 = ceil_div(M, bm) * ceil_div(N, bn);
+    g.xcd_slices = (8 % nsplit == 0 && nb1 % (8 / nsplit) == 0 && (nb1 * nsplit) % 8 == 0) ? 1 : 0;
+  }
   hipError_t e;
   if (a_kc && b_kc) e = launch_layout_x3<true, true>(g, vec, tile, nsplit, stream, batch);
   else if (a_kc) e = launch_layout_x3<true, false>(g, vec, tile, nsplit, stream, batch);

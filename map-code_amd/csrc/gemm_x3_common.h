@@ -40,6 +40,7 @@ struct GemmX3Args {
   const float* Bz[4];
   float* Cz[4];
   int64_t batch_slabs;
+  int xcd_slices;        // split-K blocks dealt so that an XCD works on ONE k-slice (see the kernel's tile order)
 };
 
 // what the plain mapx_gemm_f32 contract does not carry (fused backward epilogue, batched launch)

@@ -187,7 +187,12 @@ __global__ void __launch_bounds__(256) adamw_dense_kernel(float* __restrict__ p,
   }
 }
 
-__global__ void step_advance_kernel(int32_t* done) { *done += 1; }
+// ... and, when the step walks an epoch's permutation by a device-side cursor (trainer.GraphedStep), the
+// cursor's move to the next batch: one launch at the end of a step instead of two.
+__global__ void step_advance_kernel(int32_t* done, int64_t* cursor, int64_t stride) {
+  *done += 1;
+  if (cursor) *cursor += stride;
+}
 
 // ---------------------------------------------------------------------------- lazy tables
 struct TableGroup {
@@ -399,9 +404,9 @@ extern "C" int mapx_adamw_dense_shadow(float* p, const float* g, float* m, float
   return check_launch("adamw_dense_shadow");
 }
 
-extern "C" int mapx_step_advance(int32_t* done, hipStream_t stream) {
+extern "C" int mapx_step_advance(int32_t* done, int64_t* cursor_opt, int64_t cursor_stride, hipStream_t stream) {
   MAPX_REQUIRE(done, "step_advance: null");
-  hipLaunchKernelGGL(mapx::step_advance_kernel, dim3(1), dim3(1), 0, stream, done);
+  hipLaunchKernelGGL(mapx::step_advance_kernel, dim3(1), dim3(1), 0, stream, done, cursor_opt, cursor_stride);
   return mapx::check_launch("step_advance");
 }
 

@@ -334,14 +334,21 @@ extern "C" size_t mapx_seg_reduce_workspace_bytes(int64_t n, int W) {
 }
 
 extern "C" int mapx_seg_reduce_rows(int64_t n, const int32_t* perm, const int32_t* rank,
-                                    const int32_t* seg_start, const float* src, int W, float* out,
-                                    void* ws, size_t ws_bytes, int32_t* zeroed_counter_opt, hipStream_t stream) {
+                                    const int32_t* seg_start, const float* src, const float* src2_opt, int W,
+                                    float* out, void* ws, size_t ws_bytes, int32_t* zeroed_counter_opt,
+                                    hipStream_t stream) {
   MAPX_REQUIRE(n >= 0, "seg_reduce_rows: n < 0");
   if (n == 0) return MAPX_OK;
   MAPX_REQUIRE(perm && rank && seg_start && src && out, "seg_reduce_rows: null pointer");
-  MAPX_REQUIRE(((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)ws % 16 == 0),
+  MAPX_REQUIRE(((uintptr_t)src % 16 == 0) && ((uintptr_t)src2_opt % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
+                   ((uintptr_t)ws % 16 == 0),
                "seg_reduce_rows: pointers must be 16-byte aligned");
   mapx::SegPlanView pl{n, perm, rank, seg_start};
+  if (src2_opt) {
+    mapx::Rows2Contrib c2{src, src2_opt, W};
+    return mapx::seg_reduce_launch<false>(pl, c2, W, out, nullptr, ws, ws_bytes, zeroed_counter_opt, stream,
+                                          "seg_reduce_rows");
+  }
   mapx::RowsContrib c{src, W};
   return mapx::seg_reduce_launch<false>(pl, c, W, out, nullptr, ws, ws_bytes, zeroed_counter_opt, stream,
                                         "seg_reduce_rows");
@@ -351,14 +358,21 @@ extern "C" int mapx_seg_reduce_rows(int64_t n, const int32_t* perm, const int32_
 // extra[position / group] (DeepFM: the LR weight shares the embedding's ids, its gradient
 // dL/dlr[b] is common to the F positions of batch row b).
 extern "C" int mapx_seg_reduce_rows_bf16(int64_t n, const int32_t* perm, const int32_t* rank,
-                                         const int32_t* seg_start, const mapx_bf16* src, int W, float* out, void* ws,
-                                         size_t ws_bytes, int32_t* zeroed_counter_opt, hipStream_t stream) {
+                                         const int32_t* seg_start, const mapx_bf16* src, const mapx_bf16* src2_opt,
+                                         int W, float* out, void* ws, size_t ws_bytes,
+                                         int32_t* zeroed_counter_opt, hipStream_t stream) {
   MAPX_REQUIRE(n >= 0, "seg_reduce_rows_bf16: n < 0");
   if (n == 0) return MAPX_OK;
   MAPX_REQUIRE(perm && rank && seg_start && src && out, "seg_reduce_rows_bf16: null pointer");
-  MAPX_REQUIRE((uintptr_t)src % 8 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)ws % 16 == 0,
+  MAPX_REQUIRE((uintptr_t)src % 8 == 0 && (uintptr_t)src2_opt % 8 == 0 && (uintptr_t)out % 16 == 0 &&
+                   (uintptr_t)ws % 16 == 0,
                "seg_reduce_rows_bf16: pointers must be 8 / 16-byte aligned");
   mapx::SegPlanView pl{n, perm, rank, seg_start};
+  if (src2_opt) {
+    mapx::Rows2Bf16Contrib c2{reinterpret_cast<const __bf16*>(src), reinterpret_cast<const __bf16*>(src2_opt), W};
+    return mapx::seg_reduce_launch<false>(pl, c2, W, out, nullptr, ws, ws_bytes, zeroed_counter_opt, stream,
+                                          "seg_reduce_rows_bf16");
+  }
   mapx::RowsBf16Contrib c{reinterpret_cast<const __bf16*>(src), W};
   return mapx::seg_reduce_launch<false>(pl, c, W, out, nullptr, ws, ws_bytes, zeroed_counter_opt, stream,
                                         "seg_reduce_rows_bf16");

@@ -41,6 +41,22 @@ struct RowsContrib {
   }
 };
 
+// Rows that reach the table as the SUM of two gradient tensors (DCNv2: dL/dX0 of the deep tower and of the
+// cross tower): a + b is formed here, element by element, instead of by an elementwise launch in front of
+// the reduction — the same fp32 additions in the same order, so the result is bit-identical.
+struct Rows2Contrib {
+  const float* src;   // [n, W]
+  const float* src2;  // [n, W]
+  int W;
+  __device__ inline void prepare() {}
+  __device__ inline float4 operator()(int32_t p, int sub, float& extra) const {
+    extra = 0.f;
+    const float4 a = *reinterpret_cast<const float4*>(src + (int64_t)p * W + 4 * sub);
+    const float4 b = *reinterpret_cast<const float4*>(src2 + (int64_t)p * W + 4 * sub);
+    return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+};
+
 // bf16 gradient rows (bf16 compute mode: dL/dX0 leaves the trunk's backward GEMMs in bf16);
 // the sums are fp32 like everything else here.
 struct RowsBf16Contrib {
@@ -52,6 +68,27 @@ struct RowsBf16Contrib {
     extra = 0.f;
     const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(src + (int64_t)p * W + 4 * sub);
     return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+  }
+};
+
+// Two bf16 gradient tensors summed on the fly; the sum is rounded to bf16 first, as the elementwise
+// bf16 addition it replaces would have done.
+struct Rows2Bf16Contrib {
+  const __bf16* src;
+  const __bf16* src2;
+  int W;
+  __device__ inline void prepare() {}
+  __device__ inline float4 operator()(int32_t p, int sub, float& extra) const {
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    extra = 0.f;
+    const bf16x4_t a = *reinterpret_cast<const bf16x4_t*>(src + (int64_t)p * W + 4 * sub);
+    const bf16x4_t b = *reinterpret_cast<const bf16x4_t*>(src2 + (int64_t)p * W + 4 * sub);
+    float4 r;
+    r.x = (float)(__bf16)((float)a[0] + (float)b[0]);
+    r.y = (float)(__bf16)((float)a[1] + (float)b[1]);
+    r.z = (float)(__bf16)((float)a[2] + (float)b[2]);
+    r.w = (float)(__bf16)((float)a[3] + (float)b[3]);
+    return r;
   }
 };
 

@@ -205,12 +205,28 @@ class _Gather(Function):
         if ctx.plan is None:
             raise RuntimeError("embedding backward without a segment plan")
         if getattr(ctx.table, "mark_dense_ready", False) and ops.TAIL_OVERLAP and not parallel.exchanging():
-            # this node is the model's last: every dense gradient is enqueued (the towers' streams are joined
-            # in the gradient this node receives) — the optimizer's dense half need not wait for the table's
+            # this node is the model's last: every dense gradient of THIS stream is enqueued (the tower stream's
+            # are behind it in that stream's own order, which is where the optimizer's dense half runs) — the
+            # optimizer's dense half need not wait for the table's
             ops.dense_ready[0], ops.dense_ready[1] = ops.record_event(), torch.cuda.current_stream()
         plan = ctx.plan.get()
         g = g.contiguous().view(-1, ctx.width)           # bf16 rows in bf16 mode: summed in fp32
-        ctx.table.sparse_grad = (plan, ops.seg_reduce_rows(plan, g, ctx.width), None)
+        g2, link = None, getattr(ctx.table, "x0_link", None)
+        if link is not None and link.g is not None:
+            # the cross tower's dL/dX0, left aside by its backward node (_X0Link): summed with the deep tower's
+            # inside the reduction; this stream waits for the cross chain's LAST GEMM only, not for what that
+            # stream runs behind it (the NCE table's gradient and update, the encoder's dW: ~120 us)
+            g2, ev, st, link.g = link.g.view(-1, ctx.width), link.event, link.stream, None
+            if g.is_cuda and ops.stream_wait_event(torch.cuda.current_stream(), ev, st):
+                g2.record_stream(torch.cuda.current_stream())
+            if g2.dtype != g.dtype or g2.shape != g.shape:
+                g, g2 = g + g2, None
+        ctx.table.sparse_grad = (plan, ops.seg_reduce_rows(plan, g, ctx.width, src2=g2), None)
+        lazy = ctx.table.lazy
+        if lazy is not None and getattr(lazy, "early_now", False) and getattr(ctx.table, "mark_dense_ready", False):
+            lazy.update()                 # nothing else of the step feeds this table: its rows move at once
+        if not ops.step_window[0]:
+            ops.join_pending()            # no optimizer.step() follows at once: leave nothing open behind backward()
         return None, None, None, None
 
 
@@ -426,6 +442,18 @@ class _ReluLink:
         self.premasked, self.sb = False, None
 
 
+class _X0Link:
+    """Between DCNv2's cross tower and the embedding gather, both of which autograd would join through an
+    elementwise add of the two towers' dL/dX0 in front of the gather's backward — a launch that also makes the
+    main stream wait for EVERYTHING the cross tower's stream holds when its node returns.  The cross tower's
+    node leaves its dL/dX0 here with an event recorded behind its last GEMM and returns None; the gather's
+    backward adds the two tensors inside the segment reduction (ops.seg_reduce_rows(src2=))."""
+
+    def __init__(self, consumer_stream):
+        self.g = self.event = self.stream = None
+        self.consumer_stream = consumer_stream
+
+
 class _JoinLink:
     """Between the two towers of DCNv2 and the ONE layer that consumes their concatenated output (the heads'
     first Linear, or the grouped feat_encoder).  That layer's input gradient is formed as TWO products, one per
@@ -587,7 +615,7 @@ class _CrossTower(Function):
     elementwise launches at the very end of the step."""
 
     @staticmethod
-    def forward(ctx, x0, out, link, *wb):
+    def forward(ctx, x0, out, link, x0_link, *wb):
         x0 = x0.contiguous()
         n = len(wb) // 2
         wops = [ops.bf16_weight(w) for w in wb[0::2]] if ops.is_bf16(x0) else list(wb[0::2])
@@ -598,7 +626,7 @@ class _CrossTower(Function):
             us.append(u)
         ctx.n = n
         ctx.slots = [(_grad_slot(wb[2 * i]), _grad_slot(wb[2 * i + 1])) for i in range(n)]
-        ctx.link = link
+        ctx.link, ctx.x0_link = link, x0_link
         if link is not None:                 # what the consumer of the towers' output needs (see _JoinLink)
             link.x0, link.u, link.sb_cross, link.plus_v = x0, us[-1], ctx.slots[n - 1][1], n == 1
         ctx.save_for_backward(x0, *xs[1:], *us, *wops)
@@ -638,13 +666,13 @@ class _CrossTower(Function):
             if t is None:
                 # width D = F * embed_size is a multiple of 4 (Embeddings enforces embed_size % 4 == 0)
                 t, dx0, db = ops.cross_bwd_pre_colsum(g, x0, us[i], dx0=dx0, db=sb, defer=True, plus_g=first)
-                if ctx.needs_input_grad[4 + 2 * i]:
+                if ctx.needs_input_grad[5 + 2 * i]:
                     grads[2 * i + 1] = None if sb is not None else db
             if fuse:
                 pend.append((t, xs[i], sw))                                         # t^T X_i, all layers in one launch
             else:
                 dw = ops.linear_bwd_weight(t, xs[i], out=sw, defer=True)            # t^T X_i
-                if ctx.needs_input_grad[3 + 2 * i]:
+                if ctx.needs_input_grad[4 + 2 * i]:
                     grads[2 * i] = None if sw is not None else dw
             # dL/dX_i = g + t W_i; for layer 0 that is part of dL/dX0 and g is already inside dx0
             if first:
@@ -657,10 +685,19 @@ class _CrossTower(Function):
             else:
                 g = ops.linear_bwd_input(t, ws[i], add=g)
                 t = None
+        xl = ctx.x0_link
+        if xl is not None and g.is_cuda and g.is_contiguous():
+            # dL/dX0 goes to the gather's backward through the link, with an event HERE: the gather waits for the
+            # dX chain above, not for the weight gradients and late tasks below
+            cur = torch.cuda.current_stream()
+            xl.g, xl.event, xl.stream = g, ops.record_event(), cur
+            if cur.cuda_stream != xl.consumer_stream.cuda_stream:
+                ops.pending_joins.append((xl.consumer_stream, cur))
+            g = None
         if pend:
             ops.linear_bwd_weight_batched([p[0] for p in pend], [p[1] for p in pend], [p[2] for p in pend])
         ops.run_late_tasks()                     # what only the optimizer waits for (the encoder's dW / db)
-        return (g, None, None, *grads)
+        return (g, None, None, None, *grads)
 
 
 class CrossNetV2(nn.Module):
@@ -672,13 +709,13 @@ class CrossNetV2(nn.Module):
         self.num_layers = num_cross_layers
         self.cross_layers = nn.ModuleList(HipLinear(input_dim, input_dim) for _ in range(num_cross_layers))
 
-    def forward(self, x0, out=None, link=None):
+    def forward(self, x0, out=None, link=None, x0_link=None):
         """`out`: optional pre-allocated destination of the last layer (ops.alias_cols); `link`: the _JoinLink to
-        the consumer of the towers' concatenated output."""
+        the consumer of the towers' concatenated output; `x0_link`: the _X0Link to the embedding gather."""
         if self.num_layers == 0:
             return x0
         wb = [p for layer in self.cross_layers for p in (layer.weight, layer.bias)]
-        return _CrossTower.apply(x0, out, link, *wb)
+        return _CrossTower.apply(x0, out, link, x0_link, *wb)
 
 
 class _SelfAttention(Function):

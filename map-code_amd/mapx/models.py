@@ -30,6 +30,7 @@ JOINT_PLAN = os.environ.get("MAPX_JOINT_PLAN", "auto")
 # the joint plan in forward waits for the deep tower's GEMMs to be on their way (see above)
 LAYOUT_ON_MAIN = os.environ.get("MAPX_LAYOUT_ON_MAIN", "1") == "1"     # 0.869 / 0.873 vs 0.876 / 0.882 ms
 PLAN_AFTER_DNN = os.environ.get("MAPX_PLAN_AFTER_DNN", "1") == "1"
+X0_LINK = os.environ.get("MAPX_X0_LINK", "1") == "1"       # A/B switch of layers._X0Link
 
 _OTHER_BACKBONES = ("trans", "fignn", "fgcnn")
 
@@ -210,6 +211,12 @@ class DCNV2(BaseModel):
                     and not (self.parallel_dnn.p_drop > 0 and self.training)):
                 from .layers import _JoinLink
                 join = _JoinLink(D)            # towers -> the head's first layer (fused backward epilogue)
+            x0_link = None
+            if (X0_LINK and direct and torch.is_grad_enabled() and self.embed.table.plan is not None
+                    and not self.embed.embed_norm and not (self.embed.dropout.p > 0 and self.training)):
+                from .layers import _X0Link
+                x0_link = _X0Link(main)        # cross tower -> the gather's backward (no elementwise add, no wait)
+            self.embed.table.x0_link = x0_link
             final_buf = torch.empty(feat_embed.shape[0], D + H, dtype=feat_embed.dtype, device=feat_embed.device)
             if LAYOUT_ON_MAIN and self._grouped_head(masked_index):
                 # the grouped encoder's slot layout (one 15-us launch) ahead of the deep tower, which by now
@@ -229,7 +236,7 @@ class DCNV2(BaseModel):
                     # loss kernel waiting for the sampling: 1.02 vs 0.91 ms fp32, 0.72 vs 0.66 bf16.)
                     nce_idx = self.mfp_criterion.sample_ids(labels, noise_samples)
                 cross_output = self.cross_net(feat_embed, out=ops.alias_cols(final_buf, 0, D) if direct else None,
-                                              link=join)
+                                              link=join, x0_link=x0_link)
             dnn_output = self.parallel_dnn(feat_embed, out=ops.alias_cols(final_buf, D, H) if direct else None,
                                            link_last=join.relu if join is not None else None)
             # Both tables' segment plans from ONE chain of launches (8 instead of 8 + 8), when the
@@ -265,6 +272,7 @@ class DCNV2(BaseModel):
             final_output = _JoinColumns.apply(cross_output, dnn_output, final_buf, join) if direct \
                 else torch.cat([cross_output, dnn_output], dim=-1)
         else:
+            self.embed.table.x0_link = None
             final_output = self.cross_net(feat_embed)
             self.embed.table.start_plan()
         if self.config.pretrain:

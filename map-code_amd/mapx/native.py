@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmapx_hip.so")
 
-MAPX_ABI_VERSION = 34
+MAPX_ABI_VERSION = 35
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_CROSS, EPI_ADD, EPI_RELU_MASK, EPI_RELU_MASK_COLSUM = range(7)
 
 _p, _i, _i64, _u64, _f, _d, _sz = (C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double,
@@ -29,7 +29,7 @@ SIGNATURES = {
     "mapx_seg_plan_multi": (_i, [_i, _p, _p, _p, _p, _sz, _p, _p, _p, _p, _p, _p, _p]),
     "mapx_seg_plan_merge": (_i, [_p, _i, _i64, _p, _sz, _p, _p, _p, _p, _p, _p, _p]),
     "mapx_seg_reduce_workspace_bytes": (_sz, [_i64, _i]),
-    "mapx_seg_reduce_rows": (_i, [_i64, _p, _p, _p, _p, _i, _p, _p, _sz, _p, _p]),
+    "mapx_seg_reduce_rows": (_i, [_i64, _p, _p, _p, _p, _p, _i, _p, _p, _sz, _p, _p]),
     "mapx_seg_reduce_rows_extra": (_i, [_i64, _p, _p, _p, _p, _i, _i64, _p, _i, _i64, _p, _p, _p, _sz, _p, _p]),
     "mapx_pack_sparse": (_i, [_p, _p, _i, _p, _p, _i64, _i64, _f, C.c_int32, _p, _p, _p]),
     "mapx_publish_i32": (_i, [_p, _i, _p, _p, _p]),
@@ -67,7 +67,7 @@ SIGNATURES = {
     "mapx_cast_f32_bf16": (_i, [_p, _i64, _p, _p]),
     "mapx_cast_bf16_f32": (_i, [_p, _i64, _p, _p]),
     "mapx_emb_gather_fwd_bf16": (_i, [_p, _i64, _p, _i64, _i, _p, _p, _p]),
-    "mapx_seg_reduce_rows_bf16": (_i, [_i64, _p, _p, _p, _p, _i, _p, _p, _sz, _p, _p]),
+    "mapx_seg_reduce_rows_bf16": (_i, [_i64, _p, _p, _p, _p, _p, _i, _p, _p, _sz, _p, _p]),
     "mapx_colsum_bf16_workspace_bytes": (_sz, [_i]),
     "mapx_colsum_bf16": (_i, [_p, _i64, _i, _i, _p, _p, _sz, _p]),
     "mapx_relu_mask_colsum_bf16": (_i, [_p, _i64, _p, _i64, _i, _i, _p, _p, _p, _sz, _p]),
@@ -97,7 +97,7 @@ SIGNATURES = {
     "mapx_dynamic_mask_rfd": (_i, [_p, _i64, _i, _i, _p, _p, _p, _i64, _i, _p, _p, _i64, _u64, _u64, _p, _p, _p,
                                   _p, _p]),
     "mapx_adamw_dense": (_i, [_p, _p, _p, _p, _i64, _p, _i, _p, _d, _d, _d, _d, _p]),
-    "mapx_step_advance": (_i, [_p, _p]),
+    "mapx_step_advance": (_i, [_p, _p, _i64, _p]),
     "mapx_table_adam": (_i, [_p, _p, _p, _i, _f, _p, _p, _p, _f, _p, _p, _i64, _i64, _p, _p, _p, _p,
                              _i, _p, _p, _i, _i, _d, _d, _d, _i, _p]),
 }

@@ -118,6 +118,9 @@ def join_pending():
 # "every dense gradient of this backward pass is final": an event recorded by the model's LAST backward node
 # (the embedding gather of a tower model) before its own kernels; the optimizer's dense half may start there
 dense_ready = [None, None]        # [event, stream it was recorded on]
+# True between MapxOptimizer.backward_window(True) and (False): optimizer.step() follows this backward pass at
+# once and joins what it left open; outside the window backward() joins its side streams itself
+step_window = [False]
 TAIL_OVERLAP = os.environ.get("MAPX_TAIL_OVERLAP", "1") == "1"
 
 
@@ -161,6 +164,7 @@ def reset_aux_streams():
     _scratch_retired.extend(_scratch.values())
     _scratch.clear()
     pending_joins.clear()
+    step_window[0] = False
     _deferred.clear()
     _side_tasks.clear()
     _late_tasks.clear()
@@ -413,16 +417,23 @@ class SegPlan:
         return self.n_uniq.data_ptr() + 4
 
 
-def seg_reduce_rows(plan, src, W):
-    """out[u,:] = sum of src rows whose key is plan.uniq[u]; out has capacity plan.n rows."""
+def seg_reduce_rows(plan, src, W, src2=None):
+    """out[u,:] = sum of src rows whose key is plan.uniq[u]; out has capacity plan.n rows.
+    `src2`: a second tensor like src, added to it element by element inside the kernel (the two towers'
+    dL/dX0 of DCNv2: no elementwise launch in front of the reduction)."""
     require_gpu(src)
+    if src2 is not None:
+        require_gpu(src2)
+        if src2.dtype != src.dtype or src2.shape != src.shape or not src2.is_contiguous():
+            raise ValueError("seg_reduce_rows: src2 must match src (dtype, shape, contiguous)")
     out = torch.empty(max(plan.n, 1), W, dtype=torch.float32, device=src.device)
     nb = lib.mapx_seg_reduce_workspace_bytes(plan.n, W)
     ws = scratch(nb, src.device)
     fn = lib.mapx_seg_reduce_rows_bf16 if is_bf16(src) else lib.mapx_seg_reduce_rows
-    with _timed("seg_reduce_rows", plan.n * (float(src.element_size()) * W + 8)):
+    nsrc = 2 if src2 is not None else 1
+    with _timed("seg_reduce_rows", plan.n * (float(src.element_size()) * W * nsrc + 8)):
         check(fn(plan.n, ptr(plan.perm), ptr(plan.rank), ptr(plan.seg_start),
-                 ptr(src), W, ptr(out), ptr(ws), ws.numel(), plan.take_counter(), stream()))
+                 ptr(src), ptr(src2), W, ptr(out), ptr(ws), ws.numel(), plan.take_counter(), stream()))
     return out
 
 
@@ -1268,8 +1279,12 @@ def adamw_dense(p, g, m, v, sched, done, beta1, beta2, eps, wd, shadow=None):
                                               stream()))
 
 
-def step_advance(done):
-    check(lib.mapx_step_advance(ptr(done), stream()))
+def step_advance(done, cursor=None, stride=0):
+    """*done += 1; `cursor` (int64 device scalar): += stride in the same launch (the batch cursor of a step
+    that walks the epoch's permutation, trainer.GraphedStep)."""
+    if cursor is not None and (cursor.dtype != torch.int64 or not cursor.is_cuda):
+        raise TypeError("step_advance: the cursor is an int64 device scalar")
+    check(lib.mapx_step_advance(ptr(done), ptr(cursor), int(stride), stream()))
 
 
 def table_adam(p0, m0, v0, wd0, last, sched, done, aux, beta1, beta2, eps, p1=None, m1=None, v1=None,

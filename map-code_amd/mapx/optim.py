@@ -136,6 +136,9 @@ class MapxOptimizer:
                  and not parallel.exchanging())
         for t in self.tables:
             t.early_ok, t.early_now = early, False
+        # (int64 device cursor, stride) of a captured step that walks the epoch's permutation: moved to the next
+        # batch by the launch that advances the update counter (trainer.GraphedStep sets it around its capture)
+        self.walk_cursor = None
 
     def backward_window(self, open_):
         """Between backward_window(True) and (False) — the Trainer brackets loss.backward() of a step
@@ -143,6 +146,7 @@ class MapxOptimizer:
         gradient is final.  Outside the window backward() never touches a parameter."""
         if open_:
             ops.clear_side_tasks()      # leftovers of a backward pass that raised
+        ops.step_window[0] = bool(open_)
         for t in self.tables:
             t.early_now = bool(open_) and t.early_ok
 
@@ -242,7 +246,7 @@ class MapxOptimizer:
             self._dense_update()
             for t in self.tables:
                 t.update()
-        ops.step_advance(self.done)
+        ops.step_advance(self.done, *(self.walk_cursor or ()))
         self.steps_done += 1
         for t in self.tables:
             t.sweep_some()

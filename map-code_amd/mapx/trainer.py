@@ -166,12 +166,13 @@ class GraphedStep:
         self.graph = torch.cuda.CUDAGraph()
         gs, sd = trainer.global_step, trainer.optimizer.steps_done
         try:
+            if self.walk:      # the step's last launch (update counter += 1) also moves the cursor to the next batch
+                trainer.optimizer.walk_cursor = (self.cursor, self.stride)
             with _capture(self.graph):
                 self.out = step_fn(self.X, self.Y)
-                if self.walk:
-                    self.cursor.add_(self.stride)
         finally:
             # the capture pass ran the Python bookkeeping but no kernel
+            trainer.optimizer.walk_cursor = None
             trainer.global_step, trainer.optimizer.steps_done = gs, sd
 
     def __call__(self, X, Y):
@@ -479,27 +480,33 @@ class Trainer:
         self.optimizer.step()                                # + scheduler.step() + zero_grad()
         self.global_step += 1
 
-    # forward + backward of one step (what a data-parallel graph captures); *_step adds the
-    # gradient exchange, the optimizer and the schedule
-    def _mfp_fwd_bwd(self, X, Y):
-        inputs = self.dynamic_mask({"input_ids": X, "labels": Y}, self.args.sampling_method)
-        loss, count, acc = self.model(**inputs)
+    def _backward(self, loss):
+        """loss.backward() of a step whose gradient exchange / optimizer.step() follows at once (see
+        MapxOptimizer.backward_window: tables may move their rows as soon as their gradient is final, side
+        streams are left for the optimizer to join)."""
         self.optimizer.backward_window(True)
         try:
             loss.backward(self._one.view(loss.shape))
         finally:
             self.optimizer.backward_window(False)
+
+    # forward + backward of one step (what a data-parallel graph captures); *_step adds the
+    # gradient exchange, the optimizer and the schedule
+    def _mfp_fwd_bwd(self, X, Y):
+        inputs = self.dynamic_mask({"input_ids": X, "labels": Y}, self.args.sampling_method)
+        loss, count, acc = self.model(**inputs)
+        self._backward(loss)
         return loss.detach(), self.model.mfp_criterion.last_acc_ratio      # = acc / count, from the loss kernel
 
     def _rfd_fwd_bwd(self, X, Y):
         inputs = self.dynamic_mask({"input_ids": X, "labels": Y}, self.args.sampling_method)
         loss, count, acc, pos_ratio = self.model(**inputs)
-        loss.backward(self._one.view(loss.shape))
+        self._backward(loss)
         return loss.detach(), acc
 
     def _ctr_fwd_bwd(self, X, Y):
         loss, logits = self.model(input_ids=X, labels=Y)
-        loss.backward(self._one.view(loss.shape))
+        self._backward(loss)
         return loss.detach(), logits.detach().view(-1)
 
     def _mfp_step(self, X, Y):

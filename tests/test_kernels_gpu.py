@@ -76,6 +76,14 @@ def test_seg_plan_and_reduce_rows(ops, n, V, W):
     # bit-reproducible: same inputs -> same bits
     out2 = ops.seg_reduce_rows(plan, src.to(DEV), W)
     assert torch.equal(out[:U], out2[:U])
+    # two sources summed inside the kernel == the reduction of their elementwise sum, bit for bit
+    # (DCNv2: the towers' two dL/dX0, layers._X0Link)
+    src_b = torch.randn(n, W, generator=torch.Generator().manual_seed(2))
+    both = ops.seg_reduce_rows(plan, src.to(DEV), W, src2=src_b.to(DEV))
+    assert torch.equal(both[:U], ops.seg_reduce_rows(plan, src.to(DEV) + src_b.to(DEV), W)[:U])
+    if W % 4 == 0 and n > 1:
+        ha, hb = src.to(DEV).bfloat16(), src_b.to(DEV).bfloat16()
+        assert torch.equal(ops.seg_reduce_rows(plan, ha, W, src2=hb)[:U], ops.seg_reduce_rows(plan, ha + hb, W)[:U])
 
 
 @pytest.mark.parametrize("lists,length,V", [(1, 1000, 5000), (2, 700, 900), (4, 5000, 100000), (8, 20000, 9_449_445),
@@ -622,6 +630,10 @@ def test_adamw_dense_trajectory_vs_oracle(ops, wd):
         ops.adamw_dense(p, grad.to(DEV), m, v, sched, done, 0.9, 0.999, 1e-8, wd)
         ops.step_advance(done)
     assert int(done) == T
+    cur = torch.tensor([5], dtype=torch.int64, device=DEV)       # the batch cursor rides on the same launch
+    done2 = done.clone()
+    ops.step_advance(done2, cur, 4096)
+    assert int(done2) == T + 1 and int(cur) == 4101
     np.testing.assert_allclose(_cpu(p).numpy(), p_ref.numpy(), rtol=2e-6, atol=1e-7)
     np.testing.assert_allclose(_cpu(m).numpy(), m_ref.numpy(), rtol=2e-6, atol=2e-8)
     np.testing.assert_allclose(_cpu(v).numpy(), v_ref.numpy(), rtol=2e-6, atol=1e-10)
