@@ -452,6 +452,40 @@ int mapx_layernorm_fwd(const float* x, int64_t R, int E, const float* w, const f
 int mapx_layernorm_bwd(const float* dy, const float* x, const float* w, const float* stats, int64_t R, int E,
                        float* dx, float* dy_xhat, hipStream_t stream);
 
+/* ------------------------------------------------------------------ vocabulary builders (f4)
+ * One categorical field of data_preprocess/proc_avazu.py:237-262 / proc_criteo.py:147-163:
+ *   for k, v in Counter(feat).most_common(): if v >= n_core: feat_map[name-k] = len(feat_map)
+ *   feat_map[name-<oov>] = len(feat_map);   feat_ids = [feat_map.get(name-f, oov) for f in feat]
+ * keys [n] i64 = the column's raw values (any 64-bit pattern but INT64_MIN).  Steps, each one launch:
+ *  table_init  an open-addressing table of `capacity` (power of two, >= 2 x distinct values) slots:
+ *              keys INT64_MIN, counts 0, first positions INT32_MAX;
+ *  count       every row finds / claims its value's slot: count += 1, first = min(first, row);
+ *              slot_of_row [n].  *err_flag |= 1: a key equals INT64_MIN; |= 2: table full;
+ *  compact     occupied slots -> entries (order unspecified): slot_entry [capacity], entry_keys /
+ *              entry_count / entry_first [>= distinct values]; n_entries_maxc [2] = {#entries, largest count};
+ *  (the caller sorts the entries by first position, then stably by the keys of rank_keys:
+ *   mapx_seg_plan twice -> by_first [U], by_count [U]: rank r holds entry by_first[by_count[r]])
+ *  rank_keys   keys2[r] = max_count - entry_count[by_first[r]];
+ *  assign      rank_of_entry [U]; ranked_keys / ranked_counts [U] = the values and counts in id order;
+ *              *n_kept = number of values with count >= n_core (they are ranks 0 .. n_kept-1);
+ *  map         ids_out[i * ld_out] = base + (rank < n_kept ? rank : n_kept)   (base + n_kept = <oov>). */
+int mapx_vocab_table_init(int64_t* table_keys, int32_t* table_count, int32_t* table_first, int64_t capacity,
+                          hipStream_t stream);
+int mapx_vocab_count(const int64_t* keys, int64_t n, int64_t* table_keys, int32_t* table_count,
+                     int32_t* table_first, int64_t capacity, int32_t* slot_of_row, int* err_flag,
+                     hipStream_t stream);
+int mapx_vocab_compact(const int64_t* table_keys, const int32_t* table_count, const int32_t* table_first,
+                       int64_t capacity, int32_t* slot_entry, int64_t* entry_keys, int32_t* entry_count,
+                       int32_t* entry_first, int32_t* n_entries_maxc, hipStream_t stream);
+int mapx_vocab_rank_keys(const int32_t* entry_count, const int32_t* by_first, int64_t n_entries, int32_t max_count,
+                         int32_t* keys2, hipStream_t stream);
+int mapx_vocab_assign(const int32_t* by_first, const int32_t* by_count, const int32_t* entry_count,
+                      const int64_t* entry_keys, int64_t n_entries, int32_t n_core, int32_t* rank_of_entry,
+                      int64_t* ranked_keys, int32_t* ranked_counts, int32_t* n_kept, hipStream_t stream);
+int mapx_vocab_map(const int32_t* slot_of_row, const int32_t* slot_entry, const int32_t* rank_of_entry,
+                   const int32_t* n_kept, int64_t n, int64_t base, int64_t* ids_out, int64_t ld_out,
+                   hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

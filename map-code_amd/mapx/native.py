@@ -98,6 +98,12 @@ SIGNATURES = {
                                   _p, _p]),
     "mapx_adamw_dense": (_i, [_p, _p, _p, _p, _i64, _p, _i, _p, _d, _d, _d, _d, _p]),
     "mapx_step_advance": (_i, [_p, _p, _i64, _p]),
+    "mapx_vocab_table_init": (_i, [_p, _p, _p, _i64, _p]),
+    "mapx_vocab_count": (_i, [_p, _i64, _p, _p, _p, _i64, _p, _p, _p]),
+    "mapx_vocab_compact": (_i, [_p, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
+    "mapx_vocab_rank_keys": (_i, [_p, _p, _i64, C.c_int32, _p, _p]),
+    "mapx_vocab_assign": (_i, [_p, _p, _p, _p, _i64, C.c_int32, _p, _p, _p, _p, _p]),
+    "mapx_vocab_map": (_i, [_p, _p, _p, _p, _i64, _i64, _p, _i64, _p]),
     "mapx_table_adam": (_i, [_p, _p, _p, _i, _f, _p, _p, _p, _f, _p, _p, _i64, _i64, _p, _p, _p, _p,
                              _i, _p, _p, _i, _i, _d, _d, _d, _i, _p]),
 }

@@ -161,3 +161,19 @@ def test_decay_groups():
     assert not R.decays("mfp_criterion.bias.weight")       # name contains "bias"
     assert not R.decays("cross_net.cross_layers.0.bias")
     assert R.decays("parallel_dnn.dnn.3.weight")
+
+
+# --------------------------------------------------------------------------- vocabulary builders
+@pytest.mark.parametrize("name", ["avazu", "criteo"])
+def test_vocab_oracle_matches_reference_preprocessing(golden_dir, name):
+    """oracle/vocab.py against the feat_map that the reference's own generate_dataset()
+    (data_preprocess/proc_avazu.py, proc_criteo.py) wrote for the fixture's columns: every key, every id, in order,
+    and every row's translation."""
+    import os
+    from oracle import vocab as V
+    z = np.load(os.path.join(golden_dir, f"vocab_{name}.npz"))
+    cols = {str(n): z[f"col/{n}"].tolist() for n in z["names"]}
+    feat_map, rows = V.build_feat_map(cols, int(z["n_core"]))
+    assert list(feat_map.keys()) == [str(k) for k in z["feat_map_keys"]]
+    assert list(feat_map.values()) == z["feat_map_ids"].tolist() == list(range(int(z["input_size"])))
+    assert np.array_equal(np.array(rows, dtype=np.int64), z["feat_ids"])
