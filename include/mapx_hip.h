@@ -388,9 +388,12 @@ int mapx_step_advance(int32_t* done, int64_t* cursor_opt, int64_t cursor_stride,
  * aux_rows = 17: a replay of any length is O(1) per element; aux_rows = 3: steps are replayed one
  * by one while the Adam term can still move p, the rest from rows 0-2.
  * rows_may_repeat (catch-up only): rows[] is the raw id list of the batch; one lane group per
- * stale row wins an atomicCAS on last[row], so no sort is needed before the forward pass. */
-int mapx_table_adam(float* p0, float* m0, float* v0, int W0, float wd0, float* p1, float* m1,
-                    float* v1, float wd1, int32_t* last, const int32_t* rows, int64_t row_begin,
+ * stale row wins an atomicCAS on last[row], so no sort is needed before the forward pass.
+ * ld_mv0 / ld_mv1: row strides (floats) of m0, v0 / m1, v1 — W0 / 1 for separate dense arrays; a row's two
+ * moments side by side in one record: v0 = m0 + W0 with ld_mv0 = 2 W0, v1 = m1 + 1 with ld_mv1 = 2 (random rows
+ * cost per access, not per byte: 2 random places per row instead of 3). */
+int mapx_table_adam(float* p0, float* m0, float* v0, int64_t ld_mv0, int W0, float wd0, float* p1, float* m1,
+                    float* v1, int64_t ld_mv1, float wd1, int32_t* last, const int32_t* rows, int64_t row_begin,
                     int64_t n_rows, const int32_t* n_rows_dev, const float* grad0,
                     const float* grad1, const float* sched, int sched_len, const int32_t* done,
                     const double* aux, int aux_len, int aux_rows, double beta1, double beta2, double eps,

@@ -195,10 +195,15 @@ __global__ void step_advance_kernel(int32_t* done, int64_t* cursor, int64_t stri
 }
 
 // ---------------------------------------------------------------------------- lazy tables
+// Row strides of the moments: a row's m and v may sit side by side in ONE record (m0 = base, v0 = base + W0,
+// ld_mv0 = 2 W0; the scalar table: m1 = base, v1 = base + 1, ld_mv1 = 2).  Random rows cost per ROW ACCESS, not per
+// byte — 86 k random 256-byte records read in the time of 86 k 128-byte rows (tools/micro/row_width.py: 21.5 vs
+// 21.0 us; two separate 128-byte rows: 42 us) — so the update touches 2 random places per row instead of 3.
 struct TableGroup {
   float* p0; float* m0; float* v0; int W0; float wd0;   // main table [V, W0], W0 % 4 == 0
   float* p1; float* m1; float* v1; float wd1;           // optional scalar-per-row table [V] or null
   int32_t* last;                                        // [V] updates applied to each row
+  int64_t ld_mv0, ld_mv1;                               // row stride (floats) of m0 / v0 and of m1 / v1
 };
 
 // Replay zero-gradient updates (from+1 .. to) on one float4 of a row.
@@ -238,23 +243,37 @@ constexpr int kRowBusy = -1;
 
 // One row's worth of work for one lane group: catch-up through `target` updates, then (grad0)
 // update target+1.  gi = index of the row's gradient in grad0/grad1.
-template <int LG>
+// LATE_FROM (the gradient update): `from` = last[r] is fetched HERE, together with the row's p, m, v and gradient
+// instead of ahead of them — the row id leads to ONE round of random loads, not to last[r] and then to the rows
+// (the kernels are chains of dependent misses: 3 round trips -> 2).
+template <int LG, bool LATE_FROM = false>
 __device__ inline void table_adam_row(const TableGroup& tg, int64_t r, int from, int target,
                                       int64_t gi, const float* __restrict__ grad0,
                                       const float* __restrict__ grad1,
                                       const float2* __restrict__ sched, int sched_len,
                                       const AdamHyper& h, const ReplayAux& ax, int lig) {
+  float4 gfirst = make_float4(0.f, 0.f, 0.f, 0.f);
+  float p1v = 0.f, m1v = 0.f, v1v = 0.f, g1v = 0.f;
+  if (LATE_FROM) {
+    if (lig * 4 < tg.W0) gfirst = *reinterpret_cast<const float4*>(grad0 + gi * tg.W0 + 4 * lig);
+    if (tg.p1 && lig == 0) {
+      p1v = tg.p1[r]; m1v = tg.m1[r * tg.ld_mv1]; v1v = tg.v1[r * tg.ld_mv1];
+      g1v = grad1[gi];
+    }
+  }
   for (int sub = lig; sub * 4 < tg.W0; sub += LG) {
     float* pp = tg.p0 + r * tg.W0 + 4 * sub;
-    float* pm = tg.m0 + r * tg.W0 + 4 * sub;
-    float* pv = tg.v0 + r * tg.W0 + 4 * sub;
+    float* pm = tg.m0 + r * tg.ld_mv0 + 4 * sub;
+    float* pv = tg.v0 + r * tg.ld_mv0 + 4 * sub;
     float4 p = *reinterpret_cast<float4*>(pp);
     float4 m = *reinterpret_cast<float4*>(pm);
     float4 v = *reinterpret_cast<float4*>(pv);
+    if (LATE_FROM && sub == lig) from = tg.last[r];
     replay4(p, m, v, from, target, sched, sched_len, tg.wd0, h, ax);
     if (grad0) {
       const float2 sc = sched[target < sched_len ? target : sched_len - 1];
-      const float4 g = *reinterpret_cast<const float4*>(grad0 + gi * tg.W0 + 4 * sub);
+      const float4 g = (LATE_FROM && sub == lig) ? gfirst
+                                                 : *reinterpret_cast<const float4*>(grad0 + gi * tg.W0 + 4 * sub);
       const float decay = sc.y * tg.wd0;
       adam_elem(p.x, m.x, v.x, g.x, sc.x, decay, h);
       adam_elem(p.y, m.y, v.y, g.y, sc.x, decay, h);
@@ -266,7 +285,9 @@ __device__ inline void table_adam_row(const TableGroup& tg, int64_t r, int from,
     *reinterpret_cast<float4*>(pv) = v;
   }
   if (tg.p1 && lig == 0) {
-    float p = tg.p1[r], m = tg.m1[r], v = tg.v1[r];
+    float p, m, v;
+    if (LATE_FROM) { p = p1v; m = m1v; v = v1v; }
+    else { p = tg.p1[r]; m = tg.m1[r * tg.ld_mv1]; v = tg.v1[r * tg.ld_mv1]; }
     int s = from;
     if (ax.rows > 3 && target < ax.len) {
       if (target > from) {
@@ -287,9 +308,9 @@ __device__ inline void table_adam_row(const TableGroup& tg, int64_t r, int from,
     }
     if (grad1) {
       const float2 sc = sched[target < sched_len ? target : sched_len - 1];
-      adam_elem(p, m, v, grad1[gi], sc.x, sc.y * tg.wd1, h);
+      adam_elem(p, m, v, LATE_FROM ? g1v : grad1[gi], sc.x, sc.y * tg.wd1, h);
     }
-    tg.p1[r] = p; tg.m1[r] = m; tg.v1[r] = v;
+    tg.p1[r] = p; tg.m1[r * tg.ld_mv1] = m; tg.v1[r * tg.ld_mv1] = v;
   }
   // the row's lanes sit in one wave and have all read `from` already (program order)
   if (lig == 0) tg.last[r] = grad0 ? target + 1 : target;
@@ -316,8 +337,12 @@ __global__ void __launch_bounds__(256) table_adam_kernel(TableGroup tg, const in
        i += ((int64_t)gridDim.x * blockDim.x) / LG) {
     const int64_t r = rows ? (int64_t)rows[i] : row_begin + i;
     if (r < 0) continue;                 // padding entry of a gathered gradient list (mapx.parallel)
+    if (grad0) {
+      table_adam_row<LG, true>(tg, r, 0, target, i, grad0, grad1, sched, sched_len, h, ax, lig);
+      continue;
+    }
     const int from = tg.last[r];
-    if (from >= target && !grad0) continue;
+    if (from >= target) continue;
     table_adam_row<LG>(tg, r, from, target, i, grad0, grad1, sched, sched_len, h, ax, lig);
   }
 }
@@ -410,8 +435,8 @@ extern "C" int mapx_step_advance(int32_t* done, int64_t* cursor_opt, int64_t cur
   return mapx::check_launch("step_advance");
 }
 
-extern "C" int mapx_table_adam(float* p0, float* m0, float* v0, int W0, float wd0, float* p1,
-                               float* m1, float* v1, float wd1, int32_t* last,
+extern "C" int mapx_table_adam(float* p0, float* m0, float* v0, int64_t ld_mv0, int W0, float wd0, float* p1,
+                               float* m1, float* v1, int64_t ld_mv1, float wd1, int32_t* last,
                                const int32_t* rows, int64_t row_begin, int64_t n_rows,
                                const int32_t* n_rows_dev, const float* grad0, const float* grad1,
                                const float* sched, int sched_len, const int32_t* done,
@@ -421,11 +446,15 @@ extern "C" int mapx_table_adam(float* p0, float* m0, float* v0, int W0, float wd
   MAPX_REQUIRE(p0 && m0 && v0 && last && sched && done && aux && aux_len > 1,
                "table_adam: null pointer");
   MAPX_REQUIRE(W0 > 0 && W0 % 4 == 0, "table_adam: row width %d must be a multiple of 4", W0);
+  MAPX_REQUIRE(ld_mv0 >= W0 && ld_mv0 % 4 == 0 && (uintptr_t)m0 % 16 == 0 && (uintptr_t)v0 % 16 == 0 &&
+                   (uintptr_t)p0 % 16 == 0,
+               "table_adam: moment rows must be 16-byte aligned (ld_mv0 %% 4 == 0, >= W0)");
+  MAPX_REQUIRE(!p1 || ld_mv1 >= 1, "table_adam: ld_mv1 < 1");
   MAPX_REQUIRE(!p1 || (m1 && v1), "table_adam: secondary state missing");
   MAPX_REQUIRE(!(grad0 && p1) || grad1, "table_adam: secondary gradient missing");
   MAPX_REQUIRE(!rows_may_repeat || (rows && !grad0), "table_adam: repeated rows only in catch-up mode");
   if (n_rows <= 0) return MAPX_OK;
-  TableGroup tg{p0, m0, v0, W0, wd0, p1, m1, v1, wd1, last};
+  TableGroup tg{p0, m0, v0, W0, wd0, p1, m1, v1, wd1, last, ld_mv0, ld_mv1};
   const int lg = (W0 <= 16) ? 4 : (W0 <= 32 ? 8 : 16);
   const int grid = grid_for(n_rows * lg, 256, 4096);
   const AdamHyper h = make_hyper(beta1, beta2, eps);

@@ -104,7 +104,7 @@ SIGNATURES = {
     "mapx_vocab_rank_keys": (_i, [_p, _p, _i64, C.c_int32, _p, _p]),
     "mapx_vocab_assign": (_i, [_p, _p, _p, _p, _i64, C.c_int32, _p, _p, _p, _p, _p]),
     "mapx_vocab_map": (_i, [_p, _p, _p, _p, _i64, _i64, _p, _i64, _p]),
-    "mapx_table_adam": (_i, [_p, _p, _p, _i, _f, _p, _p, _p, _f, _p, _p, _i64, _i64, _p, _p, _p, _p,
+    "mapx_table_adam": (_i, [_p, _p, _p, _i64, _i, _f, _p, _p, _p, _i64, _f, _p, _p, _i64, _i64, _p, _p, _p, _p,
                              _i, _p, _p, _i, _i, _d, _d, _d, _i, _p]),
 }
 

@@ -1296,8 +1296,24 @@ def table_adam(p0, m0, v0, wd0, last, sched, done, aux, beta1, beta2, eps, p1=No
         n_rows = rows.numel() if rows is not None else p0.shape[0] - row_begin
     kind = "table_adam_update" if grad0 is not None else ("table_adam_catchup" if rows is not None
                                                            else "table_adam_sweep")
+    # m0 / v0 (and m1 / v1) are dense arrays of their own, or the two halves of one record per row (row stride 2 W0 / 2)
+    def _rows(t, width):
+        if t.dim() == 1:
+            return t.data_ptr(), t.stride(0)
+        if t.stride(1) != 1 or t.shape[1] != width:
+            raise ValueError("table_adam: moment rows must be unit-stride rows of the table's width")
+        return t.data_ptr(), t.stride(0)
+    (pm0, ld0), (pv0, ldv0) = _rows(m0, W0), _rows(v0, W0)
+    if ld0 != ldv0:
+        raise ValueError("table_adam: m0 and v0 must share their row stride")
+    pm1 = pv1 = None
+    ld1 = 1
+    if p1 is not None:
+        (pm1, ld1), (pv1, ldv1) = _rows(m1, 1), _rows(v1, 1)
+        if ld1 != ldv1:
+            raise ValueError("table_adam: m1 and v1 must share their stride")
     with _timed(kind, float(n_rows) * (W0 + (1 if p1 is not None else 0)) * 4.0 * 7):
-        check(lib.mapx_table_adam(ptr(p0), ptr(m0), ptr(v0), W0, wd0, ptr(p1), ptr(m1), ptr(v1), wd1,
+        check(lib.mapx_table_adam(ptr(p0), pm0, pv0, ld0, W0, wd0, ptr(p1), pm1, pv1, ld1, wd1,
                                   ptr(last), ptr(rows), row_begin, n_rows, ptr(n_rows_dev), ptr(grad0),
                                   ptr(grad1), ptr(sched), sched.shape[0], ptr(done), ptr(aux),
                                   aux.shape[1], aux.shape[0], beta1, beta2, eps, int(rows_may_repeat), stream()))

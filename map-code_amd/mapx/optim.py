@@ -16,6 +16,7 @@ import torch
 from . import ops
 
 NO_DECAY = ("bias", "LayerNorm.weight")          # trainer.py:61
+PACK_MOMENTS = os.environ.get("MAPX_PACK_MOMENTS", "1") == "1"      # A/B switch: m | v of a table row in one record
 
 
 def decays(name):
@@ -43,9 +44,21 @@ class TableAdam:
         self.b1, self.b2, self.eps = hyper
         self.sched, self.done = sched, done
         p0, p1 = table.p0.data, (table.p1.data if table.p1 is not None else None)
-        self.m0, self.v0 = torch.zeros_like(p0), torch.zeros_like(p0)
-        self.m1 = torch.zeros(p1.shape[0], device=p1.device) if p1 is not None else None
-        self.v1 = torch.zeros(p1.shape[0], device=p1.device) if p1 is not None else None
+        # a row's two moments side by side in ONE record [V, 2 W] (m | v): the update reads and writes two random
+        # places per row (the parameter row and this record) instead of three — random rows cost per access, not
+        # per byte (csrc/optim.hip TableGroup).  m0 / v0 (m1 / v1) are views of the halves.
+        W = p0.shape[1]
+        self.mv0 = torch.zeros(p0.shape[0], 2 * W, dtype=p0.dtype, device=p0.device) if PACK_MOMENTS else None
+        if PACK_MOMENTS:
+            self.m0, self.v0 = self.mv0[:, :W], self.mv0[:, W:]
+        else:
+            self.m0, self.v0 = torch.zeros_like(p0), torch.zeros_like(p0)
+        self.m1 = self.v1 = self.mv1 = None
+        if p1 is not None and PACK_MOMENTS:
+            self.mv1 = torch.zeros(p1.shape[0], 2, device=p1.device)
+            self.m1, self.v1 = self.mv1[:, 0], self.mv1[:, 1]
+        elif p1 is not None:
+            self.m1, self.v1 = torch.zeros(p1.shape[0], device=p1.device), torch.zeros(p1.shape[0], device=p1.device)
         self.last = torch.zeros(p0.shape[0], dtype=torch.int32, device=p0.device)
         self.stale = False
         self.cursor = 0
@@ -277,9 +290,9 @@ class MapxOptimizer:
         cannot resume mid-run: trainer.py:517-519.)"""
         return dict(steps_done=self.steps_done, done=self.done.cpu(), flat_pad=self.FLAT_PAD,
                     groups=[dict(names=g["names"], m=g["m"].cpu(), v=g["v"].cpu()) for g in self.groups],
-                    tables=[dict(name=t.table.name, m0=t.m0.cpu(), v0=t.v0.cpu(),
-                                 m1=None if t.m1 is None else t.m1.cpu(),
-                                 v1=None if t.v1 is None else t.v1.cpu(), last=t.last.cpu(),
+                    tables=[dict(name=t.table.name, m0=t.m0.contiguous().cpu(), v0=t.v0.contiguous().cpu(),
+                                 m1=None if t.m1 is None else t.m1.contiguous().cpu(),
+                                 v1=None if t.v1 is None else t.v1.contiguous().cpu(), last=t.last.cpu(),
                                  stale=t.stale, cursor=t.cursor) for t in self.tables])
 
     def load_state_dict(self, sd):
