@@ -32,7 +32,7 @@ MFMA_PEAK_TFLOPS = {"f32": 157.3,     # v_mfma_f32_32x32x2_f32, dense fp32 matri
                     # fp32 products formed from six bf16 MFMAs (csrc/gemm_x3.hip: operands cut into three bf16
                     # pieces): the instruction-level ceiling of that algorithm in fp32-equivalent flop/s
                     "f32x3": 2500.0 / 6}
-ROUND = "r02"                # profiles/<ROUND>_pmc_hbm_traffic[_bf16].json is this round's PMC summary
+ROUND = "r03"                # profiles/<ROUND>_pmc_hbm_traffic[_bf16].json is this round's PMC summary
 
 WORKLOADS = {
     "avazu": dict(F=23, V=9449445),

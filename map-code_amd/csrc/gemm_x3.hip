@@ -12,10 +12,10 @@
 // feat_encoder / pred_rfd / fc_out models.py:74,119-124,304, and all their backward products) are
 // MFMA-bound, so this is where the fp32 step's time is.  Inputs, outputs, bias, epilogues and the
 // accumulation stay fp32; tensors in HBM are plain fp32 (the cut happens between the global load and
-// the LDS store, in the shadow of the MFMAs).  Measured error against fp64: see tests (same bound as
-// the fp32-MFMA kernel of gemm.hip, which stays selectable: MAPX_GEMM=mfma32).
+// the LDS store, in the shadow of the MFMAs).  Measured error against fp64: see tests (inside the bound the
+// fp32-MFMA instruction's own rounding chain gave; that kernel family, round 1's, was removed in round 3).
 //
-// Same interface as gemm.hip: operand storage flags (A_KC / B_KC), epilogues, split-K slabs.
+// Interface of mapx_gemm_f32 (gemm.hip): operand storage flags (A_KC / B_KC), epilogues, split-K slabs.
 // Tiling: 256 threads = 2x2 waves, block tile (64 WMT) x (64 WNT), BK = 32; per operand three bf16
 // planes in LDS, laid out like gemm_bf16.hip's single plane (k-contiguous: [row][32 + 8], one
 // ds_read_b128 per fragment, conflict-free at the 80-byte row stride; k-strided: [k][rows + 32], two

@@ -658,7 +658,8 @@ class _CrossTower(Function):
         f32 = g.dtype == torch.float32 and x0.dtype == torch.float32
         have_slots = all(sw is not None and sb is not None for sw, sb in ctx.slots)
         # fused epilogues / one launch for all weight gradients: fp32, optimizer-owned gradient slots, 16-byte rows
-        fuse = ops.JOIN_FUSE and ops.DEFER_COLSUM and f32 and have_slots and D % 4 == 0 and n <= 4
+        ok = ops.DEFER_COLSUM and f32 and have_slots and D % 4 == 0 and n <= 4
+        fuse, batch_dw = ops.CROSS_FUSE and ok, ops.DW_BATCH and ok
         pend = []
         for i in range(n - 1, -1, -1):
             sw, sb = ctx.slots[i]
@@ -668,7 +669,7 @@ class _CrossTower(Function):
                 t, dx0, db = ops.cross_bwd_pre_colsum(g, x0, us[i], dx0=dx0, db=sb, defer=True, plus_g=first)
                 if ctx.needs_input_grad[5 + 2 * i]:
                     grads[2 * i + 1] = None if sb is not None else db
-            if fuse:
+            if batch_dw:
                 pend.append((t, xs[i], sw))                                         # t^T X_i, all layers in one launch
             else:
                 dw = ops.linear_bwd_weight(t, xs[i], out=sw, defer=True)            # t^T X_i

@@ -28,7 +28,10 @@ NCE_EARLY = os.environ.get("MAPX_NCE_EARLY", "1") == "1"
 # head's backward no longer waits 34 us for the latter — 1.13 vs 0.96 ms.)
 JOINT_PLAN = os.environ.get("MAPX_JOINT_PLAN", "auto")
 # the joint plan in forward waits for the deep tower's GEMMs to be on their way (see above)
-LAYOUT_ON_MAIN = os.environ.get("MAPX_LAYOUT_ON_MAIN", "1") == "1"     # 0.869 / 0.873 vs 0.876 / 0.882 ms
+# the grouped encoder's slot layout ahead of the deep tower (main stream) or on the cross tower's stream.  Round 2: main
+# won (0.869 / 0.873 vs 0.876 / 0.882 ms); round 3, after the backward pass changed (tools/flag_sweep.py): the tower
+# stream wins, 0.8058 vs 0.8223 ms
+LAYOUT_ON_MAIN = os.environ.get("MAPX_LAYOUT_ON_MAIN", "0") == "1"
 PLAN_AFTER_DNN = os.environ.get("MAPX_PLAN_AFTER_DNN", "1") == "1"
 X0_LINK = os.environ.get("MAPX_X0_LINK", "1") == "1"       # A/B switch of layers._X0Link
 

@@ -1031,7 +1031,11 @@ def cross_bwd_pre_colsum(g, x0, u, dx0=None, db=None, defer=False, plus_g=False)
     return t, dx0, db
 
 
-JOIN_FUSE = os.environ.get("MAPX_JOIN_FUSE", "1") == "1"      # fused backward epilogues + batched cross dW (A/B switch)
+JOIN_FUSE = os.environ.get("MAPX_JOIN_FUSE", "1") == "1"      # the heads' dX as one product per tower with fused epilogues
+# cross dX GEMMs do the next layer's elementwise backward: off by default — inside the tuned schedule (tools/flag_sweep.py,
+# round 3) the fused form is 1.1 % slower (0.8314 vs 0.8223 ms per step) although it saves three launches
+CROSS_FUSE = os.environ.get("MAPX_CROSS_FUSE", "0") == "1"
+DW_BATCH = os.environ.get("MAPX_DW_BATCH", "1") == "1"        # the cross layers' weight gradients from one launch
 
 
 def gemm_bwd_fused(dy, w, c0, add=None, mask=None, x0=None, u=None, dx0=None, plus_v=False, out=None):

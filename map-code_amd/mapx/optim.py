@@ -145,7 +145,11 @@ class MapxOptimizer:
         # a table may apply its update as soon as its gradient is final (ops.add_side_task) unless the
         # step needs all gradients first: a global clipping norm, or the gradient exchange of N ranks
         from . import parallel
-        early = (os.environ.get("MAPX_EARLY_TABLE_UPDATE", "1") == "1" and self.max_grad_norm <= 0
+        # Round 3 (tools/flag_sweep.py, one box each): in fp32, with the table gradients on the tower stream's late
+        # tasks, the early row updates LOSE (0.8058 vs 0.7975 ms per step: the updates run in step(), beside the
+        # optimizer's dense half); in the bf16 mode, whose GEMM chains are half as long, they WIN (0.5931 vs 0.6318).
+        early_default = "1" if self.bf16 else "0"
+        early = (os.environ.get("MAPX_EARLY_TABLE_UPDATE", early_default) == "1" and self.max_grad_norm <= 0
                  and not parallel.exchanging())
         for t in self.tables:
             t.early_ok, t.early_now = early, False

@@ -199,14 +199,17 @@ def sync_table_grad(table, maxc, merge_fn=hip_merge):
 # received — 1/world of the keys instead of all of them — with the deterministic reduce-by-key,
 # (4) all-gather of the owners' merged lists, padded with id -1 (the table optimizer skips
 # negative ids) to the largest owner load, which every rank can compute from the sizes of (1).
-# Against the all-gather of raw lists: a rank receives the union of touched rows once instead of
-# every rank's copy of it, and sorts world times fewer keys.
-# Which one is the default is a volume question: at Avazu-MFP a rank touches ~250 k of the 9.4 M NCE
-# rows per step and the ranks' sets overlap little, so the union all ranks must receive anyway is
-# most of the sum of the lists, and the padded owner gather moves about what the raw gather does;
-# the owner path then only saves the world-times-larger sort, against three more collectives and
-# ~0.25 ms of launches (one-rank RCCL rehearsal: 2.14 vs 1.89 ms per step).  "gather" stays the
-# default until an N-GPU measurement says otherwise (MAPX_DP_EXCHANGE=owner selects this path).
+# Against the all-gather of raw lists an owner merges world times fewer keys (measured on real per-rank
+# messages, DESIGN §5: NCE table at N = 8, 0.100 vs 0.147 ms).  What it does NOT save is volume on the way back:
+# step (4) must be sized by the host BEFORE the owners have merged, and the only bound the sizes of (1) give is
+# the number of rows an owner RECEIVES (`cap_o` below) — with the NCE table's heavily overlapping row sets
+# (8 ranks x 86 k rows merge to 101 k distinct rows) that is ~7x the merged list, so the padded owner gather
+# moves what the raw gather moves.  Sizing it by the merged counts needs a second host synchronisation in the
+# middle of the tail (merge -> publish -> MAX over ranks -> gather), i.e. a host round trip with nothing to
+# overlap it.  And contiguous id ranges are uneven in ROWS (56.7 k of a rank's 86 k NCE rows fall to owner 0:
+# every field's vocabulary starts with its frequent values).  "gather" therefore stays the default and the one
+# with a captured tail (trainer.GraphedExchangeTail); this path is kept, eager, for an N-GPU measurement
+# (MAPX_DP_EXCHANGE=owner).
 EXCHANGE = os.environ.get("MAPX_DP_EXCHANGE", "gather")     # "gather" | "owner"
 
 

@@ -790,7 +790,8 @@ def test_optimizer_state_with_another_flat_slot_size_is_repacked(tmp_path):
 @pytest.mark.parametrize("pt", ["MFP", "RFD"])
 def test_fused_backward_epilogues_equal_the_unfused_chain(tmp_path, pt):
     """The heads' dX GEMM doing both towers' first backward step, the cross layers' dX GEMMs doing the next
-    layer's elementwise backward, and the cross layers' weight gradients from one launch (ops.JOIN_FUSE) against
+    layer's elementwise backward, and the cross layers' weight gradients from one launch (ops.JOIN_FUSE / CROSS_FUSE /
+    DW_BATCH, whatever their defaults) against
     the chain of separate launches they replace: same parameters after 6 steps up to the order of the sums
     (bias gradients are added tile by tile instead of chunk by chunk, split-K slabs are cut differently)."""
     from mapx import ops
@@ -804,8 +805,9 @@ def test_fused_backward_epilogues_equal_the_unfused_chain(tmp_path, pt):
     cnt = np.bincount(ids.reshape(-1), minlength=cfg["V"]).astype(np.float32)
     out, calls = [], []
     real = ops.gemm_bwd_fused
+    defaults = (ops.JOIN_FUSE, ops.CROSS_FUSE, ops.DW_BATCH)
     for fuse in (True, False):
-        ops.JOIN_FUSE = fuse
+        ops.JOIN_FUSE = ops.CROSS_FUSE = ops.DW_BATCH = fuse
         try:
             if fuse:
                 ops.gemm_bwd_fused = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
@@ -827,7 +829,7 @@ def test_fused_backward_epilogues_equal_the_unfused_chain(tmp_path, pt):
             tr.optimizer.flush()
             out.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
         finally:
-            ops.JOIN_FUSE, ops.gemm_bwd_fused = True, real
+            (ops.JOIN_FUSE, ops.CROSS_FUSE, ops.DW_BATCH), ops.gemm_bwd_fused = defaults, real
     assert len(calls) == 6 * 3          # per step: the cross half of the head's dX + two of the three cross layers'
     for k in out[0]:
         if out[0][k].dtype.is_floating_point:

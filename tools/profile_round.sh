@@ -1,10 +1,10 @@
 #!/bin/bash
-# Regenerates profiles/rNN_* on a GPU box:  gpurun -- 'bash tools/profile_round.sh r02'
+# Regenerates profiles/rNN_* on a GPU box:  gpurun -- 'bash tools/profile_round.sh r03'
 # For each compute dtype (f32, then bf16 with the suffix _bf16): kernel stats of the graphed and of the
 # serial step and the two PMC passes behind roofline.traffic; for f32 also the kernel stats of the
 # one-rank RCCL rehearsal of the data-parallel step.  Copy gpurun_out/prof_rNN/out/* into profiles/.
 set -e
-R=${1:-r02}
+R=${1:-r03}
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
 O=gpurun_out/prof_$R
