@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 35
+#define MAPX_ABI_VERSION 36
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -199,11 +199,18 @@ int mapx_nce_fwd(const float* enc, int64_t B, int L, int F, int P, const int64_t
                  const int32_t* idx, int K, const float* emb, const float* bias,
                  const float* logq, int64_t V, float* h_out, float* dlogit, float* dh,
                  float* logits_opt, float* loss_out, int32_t* acc_out, void* ws, size_t ws_bytes,
-                 const int32_t* hpos_opt, float* dh_slots_opt, hipStream_t stream);
+                 const int32_t* hpos_opt, float* dh_slots_opt, int* partials_left_opt, hipStream_t stream);
+/* partials_left_opt != NULL: the loss / accuracy totals are NOT formed by this call (loss_out / acc_out stay
+ * unwritten); *partials_left_opt receives the number of per-block partials left in `ws`, which the caller keeps alive
+ * and hands to the mapx_nce_scatter_dh that follows (a training step: trainer.py:317-322 runs loss.backward() right
+ * behind the forward pass) — one launch less between the loss and the head's backward. */
 /* Backward of the field gather: denc[b, f*P+p] = g * sum_{l: mi[b,l]==f} dh[b,l,p]; denc
- * [B, F*P] fully written.  gscale_opt: device scalar (upstream dLoss) or NULL = 1. */
+ * [B, F*P] fully written.  gscale_opt: device scalar (upstream dLoss) or NULL = 1.
+ * partials_ws_opt (with n_partials, loss_out_opt [2], acc_out_opt [1]): the forward's workspace when its totals
+ * were left to this launch, which then writes them (same summation order as the forward's own finalize step). */
 int mapx_nce_scatter_dh(const float* dh, const int64_t* masked_index, const float* gscale_opt,
-                        int64_t B, int L, int F, int P, float* denc, hipStream_t stream);
+                        int64_t B, int L, int F, int P, float* denc, const void* partials_ws_opt, int n_partials,
+                        float* loss_out_opt, int32_t* acc_out_opt, hipStream_t stream);
 /* Output-table gradient rows for the plan over idx.flatten() (n = B*L*(K+1)):
  * out_emb[u,:] = sum dlogit*h, out_bias[u] = sum dlogit over run u. */
 size_t mapx_nce_table_grad_workspace_bytes(int64_t n, int P);

@@ -291,11 +291,34 @@ __global__ void nce_loss_finalize_kernel(const float* __restrict__ partial, cons
 // d enc[b, f*P + p] = g * sum_{l : masked_index[b,l] == f} dh[b,l,p]   (backward of the
 // field gather, models.py:75).  One thread per (b, p) walks l in order: duplicates in
 // masked_index accumulate deterministically, untouched fields are written as zero.
+// `partial` != null: this launch also sums the loss / accuracy partials that the forward kernel left (what
+// nce_loss_finalize_kernel does, same order: lane i takes partial[i], partial[i + 64], ..., then the butterfly) —
+// by the first wave of block 0, before its share of the scatter.  Inside a training step the head's backward follows
+// the forward at once, and the one-wave finalize launch sat between them on the step's critical chain.
 __global__ void __launch_bounds__(256) nce_scatter_dh_kernel(const float* __restrict__ dh,
                                                              const int64_t* __restrict__ masked_index,
                                                              const float* __restrict__ gscale,
                                                              int64_t B, int L, int F, int P,
-                                                             float* __restrict__ denc) {
+                                                             float* __restrict__ denc,
+                                                             const float* __restrict__ partial,
+                                                             const int32_t* __restrict__ acc_partial, int n_partial,
+                                                             float invT, float* __restrict__ loss,
+                                                             int32_t* __restrict__ acc) {
+  if (partial && blockIdx.x == 0 && threadIdx.x < kWave) {
+    float v = 0.f;
+    int a = 0;
+    for (int i = threadIdx.x; i < n_partial; i += kWave) {
+      v += partial[i];
+      a += acc_partial[i];
+    }
+    v = group_sum<kWave>(v);
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+    if (threadIdx.x == 0) {
+      loss[0] = v * invT;
+      loss[1] = (float)a * invT;
+      *acc = a;
+    }
+  }
   const float g = gscale ? *gscale : 1.f;
   const int64_t total = B * P;
   for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total;
@@ -361,7 +384,8 @@ extern "C" int mapx_nce_fwd(const float* enc, int64_t B, int L, int F, int P,
                             const float* emb, const float* bias, const float* logq, int64_t V,
                             float* h_out, float* dlogit, float* dh, float* logits_opt,
                             float* loss_out, int32_t* acc_out, void* ws, size_t ws_bytes,
-                            const int32_t* hpos_opt, float* dh_slots_opt, hipStream_t stream) {
+                            const int32_t* hpos_opt, float* dh_slots_opt, int* partials_left_opt,
+                            hipStream_t stream) {
   MAPX_REQUIRE(enc && masked_index && idx && emb && bias && logq && h_out && dlogit && dh &&
                    loss_out && acc_out && ws,
                "nce_fwd: null pointer");
@@ -378,6 +402,7 @@ extern "C" int mapx_nce_fwd(const float* enc, int64_t B, int L, int F, int P,
   if (T == 0) {
     MAPX_HIP(hipMemsetAsync(acc_out, 0, sizeof(int32_t), stream));
     MAPX_HIP(hipMemsetAsync(loss_out, 0, 2 * sizeof(float), stream));
+    if (partials_left_opt) *partials_left_opt = 0;
     return MAPX_OK;
   }
   const int LG = P / 4, GPB = 256 / LG;
@@ -406,18 +431,27 @@ extern "C" int mapx_nce_fwd(const float* enc, int64_t B, int L, int F, int P,
     default: MAPX_NCE(32); break;
   }
 #undef MAPX_NCE
-  hipLaunchKernelGGL(mapx::nce_loss_finalize_kernel, dim3(1), dim3(64), 0, stream, partial,
-                     acc_partial, grid, invT, loss_out, acc_out);
+  if (partials_left_opt)
+    *partials_left_opt = grid;         // the caller's mapx_nce_scatter_dh sums them (ws must live until then)
+  else
+    hipLaunchKernelGGL(mapx::nce_loss_finalize_kernel, dim3(1), dim3(64), 0, stream, partial,
+                       acc_partial, grid, invT, loss_out, acc_out);
   return mapx::check_launch("nce_fwd");
 }
 
 extern "C" int mapx_nce_scatter_dh(const float* dh, const int64_t* masked_index,
                                    const float* gscale_opt, int64_t B, int L, int F, int P,
-                                   float* denc, hipStream_t stream) {
+                                   float* denc, const void* partials_ws_opt, int n_partials, float* loss_out_opt,
+                                   int32_t* acc_out_opt, hipStream_t stream) {
   MAPX_REQUIRE(dh && masked_index && denc, "nce_scatter_dh: null pointer");
+  MAPX_REQUIRE(!partials_ws_opt || (n_partials >= 1 && n_partials <= mapx::kNceBlocks && loss_out_opt && acc_out_opt),
+               "nce_scatter_dh: loss totals need 1..%d partials and both outputs", mapx::kNceBlocks);
   if (B == 0) return MAPX_OK;
+  const float* partial = static_cast<const float*>(partials_ws_opt);
+  const int32_t* acc_partial = partial ? reinterpret_cast<const int32_t*>(partial + mapx::kNceBlocks) : nullptr;
   hipLaunchKernelGGL(mapx::nce_scatter_dh_kernel, dim3(mapx::grid_for(B * P, 256)), dim3(256), 0,
-                     stream, dh, masked_index, gscale_opt, B, L, F, P, denc);
+                     stream, dh, masked_index, gscale_opt, B, L, F, P, denc, partial, acc_partial, n_partials,
+                     1.0f / (float)(B * L), loss_out_opt, acc_out_opt);
   return mapx::check_launch("nce_scatter_dh");
 }
 

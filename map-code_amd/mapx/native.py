@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmapx_hip.so")
 
-MAPX_ABI_VERSION = 35
+MAPX_ABI_VERSION = 36
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_CROSS, EPI_ADD, EPI_RELU_MASK, EPI_RELU_MASK_COLSUM = range(7)
 
 _p, _i, _i64, _u64, _f, _d, _sz = (C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double,
@@ -51,8 +51,8 @@ SIGNATURES = {
     "mapx_nce_pack_idx": (_i, [_p, _p, _i64, _i, _i64, _p, _p, _p]),
     "mapx_nce_fwd_workspace_bytes": (_sz, []),
     "mapx_nce_fwd": (_i, [_p, _i64, _i, _i, _i, _p, _p, _i, _p, _p, _p, _i64, _p, _p, _p, _p, _p,
-                          _p, _p, _sz, _p, _p, _p]),
-    "mapx_nce_scatter_dh": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p, _p]),
+                          _p, _p, _sz, _p, _p, _p, _p]),
+    "mapx_nce_scatter_dh": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p, _p, _i, _p, _p, _p]),
     "mapx_nce_table_grad_workspace_bytes": (_sz, [_i64, _i]),
     "mapx_nce_table_grad": (_i, [_i64, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _sz, _p, _p]),
     "mapx_scale_inplace": (_i, [_p, _i64, _p, _p]),

@@ -66,8 +66,12 @@ def _head_side():
 class _NceLoss(Function):
     @staticmethod
     def forward(ctx, enc, emb_w, bias_w, logq, masked_index, idx, crit, F, P, want_logits):
+        # inside a training step (the Trainer's window) the head's backward follows at once: its first launch also
+        # forms the loss totals, one launch less between the loss and the backward pass
+        later = TOTALS_LATER and ops.step_window[0] and ctx.needs_input_grad[0]
         o = ops.nce_fwd(enc.contiguous(), masked_index, idx, emb_w, bias_w.view(-1), logq, F, P,
-                        want_logits=want_logits)
+                        want_logits=want_logits, totals_later=later)
+        ctx.totals = o["totals"]
         ctx.crit, ctx.F, ctx.P, ctx.K = crit, F, P, idx.shape[1] - 1
         ctx.plan = crit.table.plan
         ctx.save_for_backward(o["dlogit"], o["dh"], o["h"], masked_index)
@@ -81,7 +85,8 @@ class _NceLoss(Function):
     def backward(ctx, gl, _a, _l):
         dlogit, dh, h, mi = ctx.saved_tensors
         gl = gl.contiguous().float()
-        denc = ops.nce_scatter_dh(dh, mi, ctx.F, ctx.P, gscale=gl)
+        denc = ops.nce_scatter_dh(dh, mi, ctx.F, ctx.P, gscale=gl, totals=ctx.totals)
+        ctx.totals = None
         if ctx.plan is None:
             raise RuntimeError("NCE backward without a segment plan")
         plan = ctx.plan.get()
@@ -104,6 +109,7 @@ class _NceLoss(Function):
 
 
 HEAD_SIDE = os.environ.get("MAPX_HEAD_SIDE", "1") == "1"     # 0.871 vs 0.900 ms per step
+TOTALS_LATER = os.environ.get("MAPX_TOTALS_LATER", "1") == "1"     # loss totals formed by the head's first backward launch
 LATE_TABLE = os.environ.get("MAPX_LATE_TABLE", "1") == "1"
 
 
@@ -118,8 +124,10 @@ class _EncNceLoss(Function):
         final = final.contiguous()
         dh_slots = torch.empty(groups.cap, P, dtype=torch.float32, device=final.device)
         h_slots = ops.enc_grouped_fwd(final, w_enc, b_enc, groups, zero_slots=dh_slots)
+        later = TOTALS_LATER and ops.step_window[0] and ctx.needs_input_grad[0]      # (see _NceLoss.forward)
         o = ops.nce_fwd(h_slots, masked_index, idx, emb_w, bias_w.view(-1), logq, F, P,
-                        want_logits=want_logits, hpos=groups.hpos, dh_slots=dh_slots)
+                        want_logits=want_logits, hpos=groups.hpos, dh_slots=dh_slots, totals_later=later)
+        ctx.totals = o["totals"]
         ctx.crit, ctx.F, ctx.P, ctx.K, ctx.groups, ctx.join = crit, F, P, idx.shape[1] - 1, groups, join
         ctx.plan = crit.table.plan
         ctx.slots = (getattr(w_enc, "_mapx_grad", None), getattr(b_enc, "_mapx_grad", None))
@@ -135,7 +143,8 @@ class _EncNceLoss(Function):
         final, w_enc, dlogit, dh, h, mi, dh_slots = ctx.saved_tensors
         sw, sb = ctx.slots
         gl = gl.contiguous().float()
-        denc = ops.nce_scatter_dh(dh, mi, ctx.F, ctx.P, gscale=gl)          # dense [B, F*P]
+        denc = ops.nce_scatter_dh(dh, mi, ctx.F, ctx.P, gscale=gl, totals=ctx.totals)          # dense [B, F*P]
+        ctx.totals = None
         dfinal, joined = None, False
         if ctx.needs_input_grad[0]:
             join = ctx.join

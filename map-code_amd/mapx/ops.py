@@ -641,9 +641,12 @@ def nce_pack_idx(targets, noise, V, validate=False):
     return idx
 
 
-def nce_fwd(enc, masked_index, idx, emb, bias, logq, F, P, want_logits=False, hpos=None, dh_slots=None):
+def nce_fwd(enc, masked_index, idx, emb, bias, logq, F, P, want_logits=False, hpos=None, dh_slots=None,
+            totals_later=False):
     """-> dict(loss [2] = {mean loss, accuracy}, acc [1] i32, h [T,P], dlogit [T,K+1], dh [T,P], logits or None).
-    hpos (grouped encoder): `enc` is h_slots [slots,P]; dh_slots receives dh at the slots too."""
+    hpos (grouped encoder): `enc` is h_slots [slots,P]; dh_slots receives dh at the slots too.
+    totals_later: loss / acc are left UNWRITTEN and out["totals"] = (partials buffer, count, loss, acc) goes to the
+    nce_scatter_dh that must follow (the head's backward inside a training step)."""
     require_gpu(enc, masked_index, idx, emb, bias, logq)
     B, L = masked_index.shape
     T, K1 = idx.shape
@@ -654,13 +657,18 @@ def nce_fwd(enc, masked_index, idx, emb, bias, logq, F, P, want_logits=False, hp
                h=torch.empty(T, P, **f32), dlogit=torch.empty(T, K1, **f32),
                dh=torch.empty(T, P, **f32),
                logits=torch.empty(T, K1, **f32) if want_logits else None)
-    ws = scratch(lib.mapx_nce_fwd_workspace_bytes(), dev)
+    nws = lib.mapx_nce_fwd_workspace_bytes()
+    # (partials that outlive this call get a buffer of their own, not the stream's shared scratch)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev) if totals_later else scratch(nws, dev)
+    left = native_int() if totals_later else None
     # algorithmic bytes: per (target, sample) one table row + bias + log q + id
     with _timed("nce_fwd", T * K1 * (4.0 * P + 8 + 4)):
         check(lib.mapx_nce_fwd(ptr(enc), B, L, F, P, ptr(masked_index.contiguous()), ptr(idx), K1 - 1,
                                ptr(emb), ptr(bias), ptr(logq), emb.shape[0], ptr(out["h"]),
                                ptr(out["dlogit"]), ptr(out["dh"]), ptr(out["logits"]), ptr(out["loss"]),
-                               ptr(out["acc"]), ptr(ws), ws.numel(), ptr(hpos), ptr(dh_slots), stream()))
+                               ptr(out["acc"]), ptr(ws), ws.numel(), ptr(hpos), ptr(dh_slots),
+                               None if left is None else native_byref(left), stream()))
+    out["totals"] = (ws, left.value, out["loss"], out["acc"]) if (left is not None and left.value > 0) else None
     return out
 
 
@@ -718,12 +726,14 @@ def enc_grouped_dw(dh_slots, final, groups, out=None, gscale=None):
     return out
 
 
-def nce_scatter_dh(dh, masked_index, F, P, gscale=None):
+def nce_scatter_dh(dh, masked_index, F, P, gscale=None, totals=None):
+    """`totals`: nce_fwd(totals_later=True)'s out["totals"] — this launch then also writes the loss / accuracy."""
     require_gpu(dh, masked_index)
     B, L = masked_index.shape
     denc = torch.empty(B, F * P, dtype=torch.float32, device=dh.device)
+    ws, n, loss, acc = totals if totals is not None else (None, 0, None, None)
     check(lib.mapx_nce_scatter_dh(ptr(dh), ptr(masked_index.contiguous()), ptr(gscale), B, L, F, P,
-                                  ptr(denc), stream()))
+                                  ptr(denc), ptr(ws), n, ptr(loss), ptr(acc), stream()))
     return denc
 
 

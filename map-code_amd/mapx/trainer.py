@@ -480,33 +480,40 @@ class Trainer:
         self.optimizer.step()                                # + scheduler.step() + zero_grad()
         self.global_step += 1
 
-    def _backward(self, loss):
-        """loss.backward() of a step whose gradient exchange / optimizer.step() follows at once (see
-        MapxOptimizer.backward_window: tables may move their rows as soon as their gradient is final, side
-        streams are left for the optimizer to join)."""
+    @contextlib.contextmanager
+    def _step_window(self):
+        """Brackets forward + loss.backward() of a step whose gradient exchange / optimizer.step() follows at once
+        (MapxOptimizer.backward_window): tables may move their rows as soon as their gradient is final, side streams
+        are left for the optimizer to join, and the NCE head leaves its loss totals to its backward's first launch."""
         self.optimizer.backward_window(True)
         try:
-            loss.backward(self._one.view(loss.shape))
+            yield
         finally:
             self.optimizer.backward_window(False)
+
+    def _backward(self, loss):
+        loss.backward(self._one.view(loss.shape))
 
     # forward + backward of one step (what a data-parallel graph captures); *_step adds the
     # gradient exchange, the optimizer and the schedule
     def _mfp_fwd_bwd(self, X, Y):
         inputs = self.dynamic_mask({"input_ids": X, "labels": Y}, self.args.sampling_method)
-        loss, count, acc = self.model(**inputs)
-        self._backward(loss)
+        with self._step_window():
+            loss, count, acc = self.model(**inputs)
+            self._backward(loss)
         return loss.detach(), self.model.mfp_criterion.last_acc_ratio      # = acc / count, from the loss kernel
 
     def _rfd_fwd_bwd(self, X, Y):
         inputs = self.dynamic_mask({"input_ids": X, "labels": Y}, self.args.sampling_method)
-        loss, count, acc, pos_ratio = self.model(**inputs)
-        self._backward(loss)
+        with self._step_window():
+            loss, count, acc, pos_ratio = self.model(**inputs)
+            self._backward(loss)
         return loss.detach(), acc
 
     def _ctr_fwd_bwd(self, X, Y):
-        loss, logits = self.model(input_ids=X, labels=Y)
-        self._backward(loss)
+        with self._step_window():
+            loss, logits = self.model(input_ids=X, labels=Y)
+            self._backward(loss)
         return loss.detach(), logits.detach().view(-1)
 
     def _mfp_step(self, X, Y):

@@ -214,6 +214,12 @@ def test_nce_fwd_and_grads_vs_oracle(ops, B, F, P, K, V):
     np.testing.assert_allclose(float(o["loss"][1]), acc_ref / (B * L), rtol=1e-6)   # accuracy, same launch
     denc = ops.nce_scatter_dh(o["dh"], mi.to(DEV), F, P)
     np.testing.assert_allclose(_cpu(denc).numpy(), enc.grad.numpy(), rtol=1e-4, atol=1e-7)
+    # loss totals left to the scatter launch (a training step's form): same bits as the forward's own finalize step
+    o2 = ops.nce_fwd(enc.detach().to(DEV), mi.to(DEV), idx, emb.detach().to(DEV),
+                     bias.detach().view(-1).to(DEV), logq.to(DEV), F, P, totals_later=True)
+    assert o2["totals"] is not None
+    denc2 = ops.nce_scatter_dh(o2["dh"], mi.to(DEV), F, P, totals=o2["totals"])
+    assert torch.equal(o2["loss"], o["loss"]) and torch.equal(o2["acc"], o["acc"]) and torch.equal(denc2, denc)
     plan = ops.SegPlan(idx.view(-1), V)
     ge, gb = ops.nce_table_grad(plan, o["dlogit"], o["h"], K, P)
     U = plan.count()
