@@ -461,6 +461,13 @@ int mapx_layernorm_fwd(const float* x, int64_t R, int E, const float* w, const f
                        float* stats, hipStream_t stream);
 int mapx_layernorm_bwd(const float* dy, const float* x, const float* w, const float* stats, int64_t R, int E,
                        float* dx, float* dy_xhat, hipStream_t stream);
+/* `hidden_act` of MLPBlock other than relu (layers.py:55-80 get_act, :182): kind 1 tanh, 2 sigmoid, 3 none, 4 elu,
+ * 5 leu (layers.py:13-27, alpha = 1), 6 gelu (erf form, :36-37), 7 gelu_new (tanh form, :41-42), 8 swish (:46-47),
+ * 9 mish (:51-52).  y[m, 0:N] (row stride ldy) = f(z[m, :]) for contiguous z [M, N];  dz [M, N] = dy * f'(z) with
+ * the pre-activation z saved by the caller (dy row stride ld_dy).  relu stays fused in mapx_gemm_f32's epilogue. */
+int mapx_act_fwd(int kind, const float* z, int64_t M, int N, float* y, int64_t ldy, hipStream_t stream);
+int mapx_act_bwd(int kind, const float* dy, int64_t ld_dy, const float* z, int64_t M, int N, float* dz,
+                 hipStream_t stream);
 
 /* ------------------------------------------------------------------ vocabulary builders (f4)
  * One categorical field of data_preprocess/proc_avazu.py:237-262 / proc_criteo.py:147-163:

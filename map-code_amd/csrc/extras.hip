@@ -83,6 +83,70 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
   }
 }
 
+// The reference's other activations (code/layers.py:13-80 get_act: tanh, sigmoid, none, elu, leu, gelu (erf),
+// gelu_new (tanh form), swish, mish; `hidden_act` of MLPBlock, layers.py:173-188) as one elementwise pass
+// after the plain Linear (+ bias) GEMM, and dz = dy f'(z) recomputed from the saved pre-activation in backward.
+// Not the benchmarked path (every DCNv2 script uses relu, which is fused into the GEMM epilogue): HBM-bound.
+enum { kActTanh = 1, kActSigmoid, kActNone, kActElu, kActLeu, kActGelu, kActGeluNew, kActSwish, kActMish };
+
+__device__ inline float act_value(int kind, float z) {
+  switch (kind) {
+    case kActTanh: return tanhf(z);
+    case kActSigmoid: return 1.f / (1.f + expf(-z));
+    case kActElu: return z > 0.f ? z : expm1f(z);
+    case kActLeu: return z > 0.f ? logf(z + 1.f) : expf(z) - 1.f;                 // layers.py:22-27 (alpha = 1)
+    case kActGelu: return z * 0.5f * (1.f + erff(z * 0.70710678118654752f));       // layers.py:36-37
+    case kActGeluNew: {                                                            // layers.py:41-42
+      const float u = 0.79788456080286536f * (z + 0.044715f * z * z * z);
+      return 0.5f * z * (1.f + tanhf(u));
+    }
+    case kActSwish: return z / (1.f + expf(-z));                                   // layers.py:46-47
+    case kActMish: {                                                               // layers.py:51-52
+      const float sp = fmaxf(z, 0.f) + log1pf(expf(-fabsf(z)));
+      return z * tanhf(sp);
+    }
+    default: return z;
+  }
+}
+
+__device__ inline float act_slope(int kind, float z) {
+  switch (kind) {
+    case kActTanh: { const float t = tanhf(z); return 1.f - t * t; }
+    case kActSigmoid: { const float s = 1.f / (1.f + expf(-z)); return s * (1.f - s); }
+    case kActElu: return z > 0.f ? 1.f : expf(z);
+    case kActLeu: return z > 0.f ? 1.f / (z + 1.f) : expf(z);
+    case kActGelu:
+      return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * expf(-0.5f * z * z);
+    case kActGeluNew: {
+      const float u = 0.79788456080286536f * (z + 0.044715f * z * z * z), t = tanhf(u);
+      return 0.5f * (1.f + t) + 0.5f * z * (1.f - t * t) * 0.79788456080286536f * (1.f + 3.f * 0.044715f * z * z);
+    }
+    case kActSwish: { const float s = 1.f / (1.f + expf(-z)); return s + z * s * (1.f - s); }
+    case kActMish: {
+      const float sp = fmaxf(z, 0.f) + log1pf(expf(-fabsf(z))), t = tanhf(sp), s = 1.f / (1.f + expf(-z));
+      return t + z * (1.f - t * t) * s;
+    }
+    default: return 1.f;
+  }
+}
+
+// y[m, :] (row stride ldy) = f(z[m, :]);  dz = dy * f'(z)  (dy row stride ld_dy)
+__global__ void __launch_bounds__(256) act_fwd_kernel(int kind, const float* __restrict__ z, int64_t M, int N,
+                                                      float* __restrict__ y, int64_t ldy) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M * N; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / N;
+    y[m * ldy + (i - m * N)] = act_value(kind, z[i]);
+  }
+}
+__global__ void __launch_bounds__(256) act_bwd_kernel(int kind, const float* __restrict__ dy, int64_t ld_dy,
+                                                      const float* __restrict__ z, int64_t M, int N,
+                                                      float* __restrict__ dz) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M * N; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / N;
+    dz[i] = dy[m * ld_dy + (i - m * N)] * act_slope(kind, z[i]);
+  }
+}
+
 }  // namespace mapx
 
 extern "C" int mapx_dropout(const float* x, int64_t n, float p, uint64_t seed, uint64_t offset,
@@ -122,4 +186,25 @@ extern "C" int mapx_layernorm_bwd(const float* dy, const float* x, const float* 
   else if (lg == 8) hipLaunchKernelGGL(layernorm_bwd_kernel<8>, dim3(grid), dim3(256), 0, stream, dy, x, w, stats, R, E, dx, dy_xhat);
   else hipLaunchKernelGGL(layernorm_bwd_kernel<16>, dim3(grid), dim3(256), 0, stream, dy, x, w, stats, R, E, dx, dy_xhat);
   return check_launch("layernorm_bwd");
+}
+
+extern "C" int mapx_act_fwd(int kind, const float* z, int64_t M, int N, float* y, int64_t ldy, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(kind >= kActTanh && kind <= kActMish, "act_fwd: unknown activation %d", kind);
+  MAPX_REQUIRE(M >= 0 && N > 0 && ldy >= N, "act_fwd: bad sizes");
+  if (M == 0) return MAPX_OK;
+  MAPX_REQUIRE(z && y, "act_fwd: null pointer");
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(M * N, 256)), dim3(256), 0, stream, kind, z, M, N, y, ldy);
+  return check_launch("act_fwd");
+}
+
+extern "C" int mapx_act_bwd(int kind, const float* dy, int64_t ld_dy, const float* z, int64_t M, int N, float* dz,
+                            hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(kind >= kActTanh && kind <= kActMish, "act_bwd: unknown activation %d", kind);
+  MAPX_REQUIRE(M >= 0 && N > 0 && ld_dy >= N, "act_bwd: bad sizes");
+  if (M == 0) return MAPX_OK;
+  MAPX_REQUIRE(dy && z && dz, "act_bwd: null pointer");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(M * N, 256)), dim3(256), 0, stream, kind, dy, ld_dy, z, M, N, dz);
+  return check_launch("act_bwd");
 }

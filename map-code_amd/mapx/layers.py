@@ -570,19 +570,39 @@ class HipLinear(nn.Module):
         return _Linear.apply(x, self.weight, self.bias, self.relu, out, self.out_fp32, link_in, link_out)
 
 
+class _Act(Function):
+    """One of the reference's activations other than relu (layers.py:55-80) behind a plain Linear: y = f(z), the
+    pre-activation z saved for dz = dy f'(z)."""
+
+    @staticmethod
+    def forward(ctx, z, kind, out):
+        z = z.contiguous()
+        ctx.kind = kind
+        ctx.save_for_backward(z)
+        return ops.act_fwd(kind, z, out=out)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (z,) = ctx.saved_tensors
+        return ops.act_bwd(ctx.kind, dy, z), None, None
+
+
 class MLPBlock(nn.Module):
-    """[Linear, ReLU, Dropout(p)] x n; state_dict keys dnn.{0,3,6,...} like the reference's
-    nn.Sequential (layers.py:173-188).  Only relu / p = 0 (the DCNv2 scripts) are built."""
+    """[Linear, act, Dropout(p)] x n; state_dict keys dnn.{0,3,6,...} like the reference's nn.Sequential
+    (layers.py:173-188).  relu (every DCNv2 script) is fused into the GEMM epilogues; the other values of
+    `hidden_act` (layers.py:55-80: tanh, sigmoid, none, elu, leu, gelu, gelu_new, swish, mish) run as one
+    elementwise pass behind the Linear GEMM, fp32 only."""
 
     def __init__(self, input_dim, hidden_size=128, num_hidden_layers=3, hidden_act="relu",
                  hidden_dropout_rate=0.5, batch_norm=False):
         super().__init__()
-        if str(hidden_act).lower() != "relu":
-            raise NotImplementedError(f"hidden_act={hidden_act!r}: only relu is built (all four DCNv2 scripts use it)")
+        self.act = str(hidden_act).lower()
+        if self.act != "relu" and self.act not in ops.ACT_KINDS:
+            raise NotImplementedError(f"hidden_act={hidden_act!r}")                 # layers.py:79: get_act raises too
         self.dnn = nn.ModuleDict()
         self.p_drop = float(hidden_dropout_rate or 0.0)
         for i in range(num_hidden_layers):
-            self.dnn[str(3 * i)] = HipLinear(input_dim, hidden_size, relu=True)
+            self.dnn[str(3 * i)] = HipLinear(input_dim, hidden_size, relu=self.act == "relu")
             if self.p_drop > 0:                      # the reference's slot 3i+2 (no parameters, no state_dict key)
                 self.dnn[str(3 * i + 2)] = HipDropout(self.p_drop)
             input_dim = hidden_size
@@ -593,6 +613,16 @@ class MLPBlock(nn.Module):
         layers = [m for m in self.dnn.values() if isinstance(m, HipLinear)]
         drops = [m for m in self.dnn.values() if isinstance(m, HipDropout)]
         link = None
+        if self.act != "relu":
+            if x.dtype != torch.float32:
+                raise NotImplementedError(f"hidden_act={self.act!r} is built for compute_dtype=fp32")
+            for i, layer in enumerate(layers):
+                last = i == len(layers) - 1
+                to = out if (last and not drops) else None
+                x = _Act.apply(layer(x), self.act, to)
+                if drops:
+                    x = drops[i](x, out=out if last else None)
+            return x
         for i, layer in enumerate(layers):
             last = i == len(layers) - 1
             if drops:

@@ -211,6 +211,7 @@ class DCNV2(BaseModel):
             D, H = feat_embed.shape[1], self.config.hidden_size
             direct = self.config.num_cross_layers > 0
             if (direct and torch.is_grad_enabled() and feat_embed.dtype == torch.float32
+                    and self.parallel_dnn.act == "relu"
                     and not (self.parallel_dnn.p_drop > 0 and self.training)):
                 from .layers import _JoinLink
                 join = _JoinLink(D)            # towers -> the head's first layer (fused backward epilogue)

@@ -98,6 +98,8 @@ SIGNATURES = {
                                   _p, _p]),
     "mapx_adamw_dense": (_i, [_p, _p, _p, _p, _i64, _p, _i, _p, _d, _d, _d, _d, _p]),
     "mapx_step_advance": (_i, [_p, _p, _i64, _p]),
+    "mapx_act_fwd": (_i, [_i, _p, _i64, _i, _p, _i64, _p]),
+    "mapx_act_bwd": (_i, [_i, _p, _i64, _p, _i64, _i, _p, _p]),
     "mapx_vocab_table_init": (_i, [_p, _p, _p, _i64, _p]),
     "mapx_vocab_count": (_i, [_p, _i64, _p, _p, _p, _i64, _p, _p, _p]),
     "mapx_vocab_compact": (_i, [_p, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),

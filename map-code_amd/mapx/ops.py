@@ -1111,6 +1111,35 @@ def relu_mask(dy, y):
 
 
 # --------------------------------------------------------------------------- dropout / LayerNorm options
+ACT_KINDS = {"tanh": 1, "sigmoid": 2, "none": 3, "elu": 4, "leu": 5, "gelu": 6, "gelu_new": 7, "swish": 8, "mish": 9}
+
+
+def act_fwd(kind, z, out=None):
+    """y = f(z) for the reference's activations other than relu (layers.py:55-80); z [M,N] contiguous fp32,
+    `out`: optional destination with unit column stride (a column slice of a wider buffer)."""
+    require_gpu(z)
+    if z.dtype != torch.float32 or z.dim() != 2 or not z.is_contiguous():
+        raise TypeError("act_fwd: z must be a contiguous fp32 matrix")
+    M, Nn = z.shape
+    if out is None:
+        out = torch.empty_like(z)
+    if out.shape != z.shape or out.stride(1) != 1:
+        raise ValueError("act_fwd: `out` must have z's shape and unit column stride")
+    check(lib.mapx_act_fwd(ACT_KINDS[kind], ptr(z), M, Nn, out.data_ptr(), out.stride(0), stream()))
+    return out
+
+
+def act_bwd(kind, dy, z):
+    """dz = dy * f'(z); dy may be a row-strided slice."""
+    require_gpu(dy, z)
+    if dy.stride(1) != 1:
+        dy = dy.contiguous()
+    M, Nn = z.shape
+    dz = torch.empty_like(z)
+    check(lib.mapx_act_bwd(ACT_KINDS[kind], dy.data_ptr(), dy.stride(0), ptr(z), M, Nn, ptr(dz), stream()))
+    return dz
+
+
 def dropout(x, p, seed, offset, offset_dev=None, out=None):
     """out = keep ? x / (1 - p) : 0, keep mask = Philox(seed, offset + *offset_dev) (never stored: the
     backward pass calls this again on the gradient with the same seed / offset).  fp32."""

@@ -62,19 +62,46 @@ def _relu(z, key, relu_masks, preacts):
     return torch.relu(z)
 
 
-def dnn(params, x, num_hidden, tower="parallel_dnn", relu_masks=None, preacts=None):
+def act(kind, x):
+    """The reference's get_act (layers.py:55-80) other than relu, restated with the torch ops its classes use
+    (LEU :13-27 with alpha = 1, GELU :36-37, GELU_new :41-42, Swish :46-47, Mish :51-52)."""
+    kind = kind.lower()
+    if kind == "tanh":
+        return torch.tanh(x)
+    if kind == "sigmoid":
+        return torch.sigmoid(x)
+    if kind == "none":
+        return x
+    if kind == "elu":
+        return Fn.elu(x)
+    if kind == "leu":
+        return torch.where(x > 0, torch.log(x.clamp(min=0) + 1), torch.exp(x.clamp(max=0)) - 1)
+    if kind == "gelu":
+        return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+    if kind == "gelu_new":
+        return 0.5 * x * (1 + torch.tanh(math.sqrt(2 / math.pi) * (x + 0.044715 * torch.pow(x, 3))))
+    if kind == "swish":
+        return x * torch.sigmoid(x)
+    if kind == "mish":
+        return x * torch.tanh(Fn.softplus(x))
+    raise NotImplementedError(kind)
+
+
+def dnn(params, x, num_hidden, tower="parallel_dnn", relu_masks=None, preacts=None, hidden_act="relu"):
     for i in range(num_hidden):
         w = params[f"{tower}.dnn.{3 * i}.weight"]
         b = params[f"{tower}.dnn.{3 * i}.bias"]
-        x = _relu(x @ w.t() + b, f"{tower}.dnn.{3 * i}", relu_masks, preacts)
+        z = x @ w.t() + b
+        x = _relu(z, f"{tower}.dnn.{3 * i}", relu_masks, preacts) if hidden_act == "relu" else act(hidden_act, z)
     return x
 
 
-def trunk(params, ids, num_cross, num_hidden, relu_masks=None, preacts=None):
+def trunk(params, ids, num_cross, num_hidden, relu_masks=None, preacts=None, hidden_act="relu"):
     x0 = embed(params, ids)
     c = cross(params, x0, num_cross)
     if num_hidden > 0:
-        return torch.cat([c, dnn(params, x0, num_hidden, relu_masks=relu_masks, preacts=preacts)], dim=-1)
+        return torch.cat([c, dnn(params, x0, num_hidden, relu_masks=relu_masks, preacts=preacts,
+                                 hidden_act=hidden_act)], dim=-1)
     return c
 
 

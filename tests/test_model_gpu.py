@@ -428,3 +428,85 @@ def test_embed_norm_and_dropout_options_vs_torch():
     loss.backward()
     assert all(torch.isfinite(p.grad).all() for n, p in model.named_parameters() if p.grad is not None)
     assert model.embed.layer_norm.weight.grad is not None and float(model.embed.layer_norm.weight.grad.abs().sum()) > 0
+
+
+# --------------------------------------------------------------------------- hidden_act other than relu
+ACT_KINDS = ["tanh", "sigmoid", "none", "elu", "leu", "gelu", "gelu_new", "swish", "mish"]
+
+
+@pytest.mark.parametrize("kind", ACT_KINDS)
+def test_hidden_act_kernels_and_mlp_vs_reference(golden_dir, kind):
+    """`--hidden_act` other than relu (layers.py:55-80): the activation kernels and MLPBlock with them against outputs
+    and gradients of the reference's own classes (tests/golden/activations.npz), incl. +-0, +-1e-6, +-20 and +-88."""
+    import os
+    from mapx import ops
+    from mapx.layers import MLPBlock
+    z = np.load(os.path.join(golden_dir, "activations.npz"))
+    x = torch.from_numpy(z["x"]).to(DEV).view(4, -1).contiguous()
+    y = ops.act_fwd(kind, x)
+    dz = ops.act_bwd(kind, torch.ones_like(x), x)
+    # (absolute floor 3e-7 of values of order 1: where 1 + erf(z / sqrt 2) or 1 - tanh^2 cancel — z < -4 — the
+    # reference's own fp32 result has no more correct digits than that)
+    np.testing.assert_allclose(y.cpu().numpy().reshape(-1), z[f"{kind}/y"], rtol=2e-6, atol=3e-7)
+    np.testing.assert_allclose(dz.cpu().numpy().reshape(-1), z[f"{kind}/dy_dx"], rtol=1e-5, atol=1e-6)
+    # a destination that is a column slice of a wider buffer, an upstream gradient that is one too
+    wide = torch.full((4, x.shape[1] + 8), 7.0, device=DEV)
+    ops.act_fwd(kind, x, out=wide[:, 4:4 + x.shape[1]])
+    assert torch.equal(wide[:, 4:4 + x.shape[1]], y) and bool((wide[:, :4] == 7).all()) and bool((wide[:, -4:] == 7).all())
+    gw = torch.randn(4, x.shape[1] + 8, device=DEV)
+    assert torch.equal(ops.act_bwd(kind, gw[:, 2:2 + x.shape[1]], x), ops.act_bwd(kind, gw[:, 2:2 + x.shape[1]].contiguous(), x))
+    mlp = MLPBlock(24, hidden_size=20, num_hidden_layers=2, hidden_act=kind, hidden_dropout_rate=0.0).to(DEV)
+    with torch.no_grad():
+        for n, p in mlp.named_parameters():
+            p.copy_(torch.from_numpy(z[f"mlp/{kind}/p/{n}"]))
+    xin = torch.from_numpy(z["mlp/x"]).to(DEV).requires_grad_(True)
+    out = mlp(xin)
+    (out * torch.linspace(-1, 1, out.numel(), device=DEV).view_as(out)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), z[f"mlp/{kind}/y"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(xin.grad.cpu().numpy(), z[f"mlp/{kind}/dx"], rtol=1e-4, atol=1e-6)
+    for n, p in mlp.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), z[f"mlp/{kind}/g/{n}"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("kind", ["tanh", "gelu", "mish"])
+def test_dcnv2_step_with_another_hidden_act_vs_oracle(kind):
+    """DCNv2 + MFP with `hidden_act` != relu through the whole forward / backward (no fused ReLU links, the towers'
+    plain join): loss, logits and every gradient against the oracle on the same injected masks and negatives."""
+    import paramgen as pg
+    from oracle import ref_model as R
+    from util import load_case, make_config, t
+    from mapx import ops
+    from mapx.models import BaseModel
+    case = "B_f25_b64"
+    cfg, z, inp, params = load_case(case, "MFP")
+    config = make_config(cfg, "MFP", inp["feat_count"])
+    config.hidden_act = kind
+    model = BaseModel.from_config(config)
+    with torch.no_grad():
+        sd = model.state_dict()
+        for k, v in params.items():
+            sd[k].copy_(torch.from_numpy(v))
+    model = model.to(DEV)
+    model.mfp_criterion.return_logits = True
+    ids, mi = t(inp["input_ids"], DEV), t(inp["masked_index"], DEV)
+    masked, labels, _ = ops.dynamic_mask_mfp(ids, mi.shape[1], masked_index=mi)
+    model.train()
+    loss, count, acc = model(input_ids=masked, labels=labels, masked_index=mi, noise_samples=t(inp["noise"], DEV))
+    loss.backward()
+    P = {k: t(v).requires_grad_(True) for k, v in params.items()}
+    logq, _, _ = R.nce_buffers(inp["feat_count"])
+    m_ref, l_ref = R.dynamic_mask_mfp(t(inp["input_ids"]), t(inp["masked_index"]))
+    fin = R.trunk(P, m_ref, cfg["NC"], cfg["NL"], hidden_act=kind)
+    loss_ref, _, acc_ref = R.mfp_head(P, fin, l_ref, t(inp["masked_index"]), t(inp["noise"]), logq, cfg["F"], cfg["P"], cfg["K"])
+    loss_ref.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(loss_ref), rtol=1e-5)
+    assert int(acc) == acc_ref
+    for name, p in model.named_parameters():
+        if name in ("embed.embedding.weight", "mfp_criterion.emb.weight", "mfp_criterion.bias.weight"):
+            continue
+        g = p.grad if p.grad is not None else getattr(p, "_mapx_grad", None)
+        ref = P[name].grad
+        scale = float(ref.abs().max()) + 1e-12
+        np.testing.assert_allclose(g.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-5 * scale, err_msg=name)
+    g0, _ = model.embed.table.dense_grad()
+    np.testing.assert_allclose(g0.cpu().numpy(), P["embed.embedding.weight"].grad.numpy(), rtol=1e-4, atol=1e-7)

@@ -177,3 +177,29 @@ def test_vocab_oracle_matches_reference_preprocessing(golden_dir, name):
     assert list(feat_map.keys()) == [str(k) for k in z["feat_map_keys"]]
     assert list(feat_map.values()) == z["feat_map_ids"].tolist() == list(range(int(z["input_size"])))
     assert np.array_equal(np.array(rows, dtype=np.int64), z["feat_ids"])
+
+
+# --------------------------------------------------------------------------- hidden_act other than relu
+ACT_KINDS = ["tanh", "sigmoid", "none", "elu", "leu", "gelu", "gelu_new", "swish", "mish"]
+
+
+@pytest.mark.parametrize("kind", ACT_KINDS)
+def test_activation_restatement_matches_reference(golden_dir, kind):
+    """oracle act() / dnn(hidden_act=) against outputs and gradients of the reference's own get_act classes and
+    MLPBlock (tests/golden/activations.npz, from code/layers.py:13-80, 173-188)."""
+    import os
+    z = np.load(os.path.join(golden_dir, "activations.npz"))
+    x = torch.from_numpy(z["x"]).requires_grad_(True)
+    y = R.act(kind, x)
+    y.backward(torch.ones_like(y))
+    np.testing.assert_allclose(y.detach().numpy(), z[f"{kind}/y"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(x.grad.numpy(), z[f"{kind}/dy_dx"], rtol=1e-5, atol=1e-7)
+    params = {f"parallel_dnn.{k.split('/p/')[1]}": torch.from_numpy(z[k]).requires_grad_(True)
+              for k in z.files if k.startswith(f"mlp/{kind}/p/")}
+    xin = torch.from_numpy(z["mlp/x"]).requires_grad_(True)
+    out = R.dnn(params, xin, 2, hidden_act=kind)
+    (out * torch.linspace(-1, 1, out.numel()).view_as(out)).sum().backward()
+    np.testing.assert_allclose(out.detach().numpy(), z[f"mlp/{kind}/y"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(xin.grad.numpy(), z[f"mlp/{kind}/dx"], rtol=1e-4, atol=1e-6)
+    for k, p in params.items():
+        np.testing.assert_allclose(p.grad.numpy(), z[f"mlp/{kind}/g/{k.split('parallel_dnn.')[1]}"], rtol=1e-4, atol=1e-6)
