@@ -43,14 +43,11 @@ WORKLOADS = {
 
 # kernel class (ops.Timers name) -> substrings of the rocprof kernel names it launches
 PMC_MAP = {
-    "gemm_fwd_nt": [["gemm_f32_kernel<", ", true, true, true,"], ["gemm_f32x3_kernel<", ", true, true, true>"],
-                    ["gemm_bf16_kernel<", ", true, true, "]],
-    "gemm_dx_nn": [["gemm_f32_kernel<", ", true, false, true,"], ["gemm_f32x3_kernel<", ", true, false, true>"],
-                   ["gemm_bf16_kernel<", ", true, false, "]],
-    "gemm_dw_tn": [["gemm_f32_kernel<", ", false, false, true,"], ["gemm_tn_deep_kernel"],
-                   ["gemm_f32x3_kernel<", ", false, false, true>"], ["gemm_bf16_kernel<", ", false, false, "]],
-    "gemm_enc_grouped_fwd": [["gemm_grouped_kernel<false>"], ["gemm_grouped_x3_kernel<false>"]],
-    "gemm_enc_grouped_dw": [["gemm_grouped_kernel<true>"], ["gemm_grouped_x3_kernel<true>"]],
+    "gemm_fwd_nt": [["gemm_f32x3_kernel<", ", true, true, true>"], ["gemm_bf16_kernel<", ", true, true, "]],
+    "gemm_dx_nn": [["gemm_f32x3_kernel<", ", true, false, true>"], ["gemm_bf16_kernel<", ", true, false, "]],
+    "gemm_dw_tn": [["gemm_f32x3_kernel<", ", false, false, true>"], ["gemm_bf16_kernel<", ", false, false, "]],
+    "gemm_enc_grouped_fwd": [["gemm_grouped_x3_kernel<false>"]],
+    "gemm_enc_grouped_dw": [["gemm_grouped_x3_kernel<true>"]],
     "nce_fwd": ["nce_fwd_"],
     "nce_table_grad": ["seg_reduce_pass_a<8, true"],
     "seg_reduce_rows": ["seg_reduce_pass_a<4, false"],

@@ -3,8 +3,9 @@
 // plan serves the lazy-optimizer catch-up of the touched rows (optim.hip) and the
 // deterministic gradient reduce-by-key after the backward pass (segreduce.h).
 //
-// The sort is the hand-written 12-bit LSD radix sort of radixsort.h; the prefix scans are
-// rocPRIM device scans (header-only, compiled into this library).
+// The sort is the hand-written LSD radix sort of radixsort.h (8-bit digits: two launches per pass, two more for the
+// runs; 9- and 12-bit digits and a scan launch per pass were measured and lost).  rocPRIM (header-only, compiled
+// into this library) serves the comparison path MAPX_SORT=1 only.
 #include <cstdlib>
 #include <cstring>
 
