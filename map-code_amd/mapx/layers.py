@@ -923,6 +923,7 @@ class _JoinColumns(Function):
 
     @staticmethod
     def backward(ctx, g):
+        ops.run_main_tasks()          # joins that the head's backward left for this point of the main stream
         link = ctx.link
         if link is not None and link.g is not None:
             # the consumer formed the two towers' gradients separately (_JoinLink); `g` is a placeholder

@@ -275,6 +275,10 @@ class DCNV2(BaseModel):
                     nce_idx.record_stream(main)
             final_output = _JoinColumns.apply(cross_output, dnn_output, final_buf, join) if direct \
                 else torch.cat([cross_output, dnn_output], dim=-1)
+            if self._mfp_head(masked_index):
+                # the towers' join node and the cross tower's node run behind the head's backward: it may leave them
+                # a stream join and the table's gradient (nce._NceLoss.backward)
+                self.mfp_criterion.towers_follow = direct and torch.is_grad_enabled()
         else:
             self.embed.table.x0_link = None
             final_output = self.cross_net(feat_embed)

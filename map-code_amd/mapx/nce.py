@@ -89,8 +89,32 @@ class _NceLoss(Function):
         ctx.totals = None
         if ctx.plan is None:
             raise RuntimeError("NCE backward without a segment plan")
-        plan = ctx.plan.get()
         lazy = ctx.crit.table.lazy
+        early = lazy is not None and getattr(lazy, "early_now", False)
+        if (DEFER_PLAN_JOIN and getattr(ctx.crit, "towers_follow", False) and ops.step_window[0] and _head_side()
+                and dh.is_cuda and (early or ops.HEAD_SIDE_REDUCE_ONLY)):
+            # The dense-encoder head (bf16 mode).  Joined HERE the sort of the sampled ids held the main stream: with
+            # bf16 GEMMs the sort chain outlasts the forward pass (by 40 us at Avazu's sizes, 70 at Criteo's) and the
+            # whole backward pass waited for it.  The join moves behind the encoder's backward (the towers' join node
+            # runs it: ~130 us of main-stream work later, when the sort is long done), and the table's gradient + row
+            # update go to the END of the cross tower's chain, as in the grouped head (a tower <- plan edge of its own
+            # is what segfaults in hipStreamEndCapture; the tower stream syncs with the main one at the join node).
+            slot, crit, K, P = ctx.plan, ctx.crit, ctx.K, ctx.P
+            holder = {}
+            ops.add_main_task(lambda: holder.__setitem__("plan", slot.get()))
+
+            def table_work():
+                plan = holder.get("plan") or slot.get()
+                ge, gb = ops.nce_table_grad(plan, dlogit, h, K, P, gscale=gl)
+                crit.table.sparse_grad = (plan, ge, gb)
+                if early:            # (with a gradient exchange or a clipping norm ahead the row update has to wait)
+                    lazy.update()
+                cur = torch.cuda.current_stream()
+                for t in (dlogit, h, gl) + tuple(plan.tensors()):
+                    t.record_stream(cur)
+            ops.add_late_task(table_work)
+            return denc, None, None, None, None, None, None, None, None, None
+        plan = ctx.plan.get()
         if lazy is not None and getattr(lazy, "early_now", False) and _head_side() and dh.is_cuda:
             # as in _EncNceLoss.backward: the table's gradient and row update leave the main chain
             main, side = torch.cuda.current_stream(), ops.aux_stream("tower", dh.device)
@@ -109,6 +133,7 @@ class _NceLoss(Function):
 
 
 HEAD_SIDE = os.environ.get("MAPX_HEAD_SIDE", "1") == "1"     # 0.871 vs 0.900 ms per step
+DEFER_PLAN_JOIN = os.environ.get("MAPX_DEFER_PLAN_JOIN", "1") == "1"    # the dense-encoder head: see _NceLoss.backward
 TOTALS_LATER = os.environ.get("MAPX_TOTALS_LATER", "1") == "1"     # loss totals formed by the head's first backward launch
 LATE_TABLE = os.environ.get("MAPX_LATE_TABLE", "1") == "1"
 

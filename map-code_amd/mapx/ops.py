@@ -148,10 +148,26 @@ def run_late_tasks():
         _late_tasks.pop(0)()
 
 
+# Main tasks: stream joins a backward node wants on the MAIN stream but not yet (the wait for a segment plan that the
+# node's successors do not need); the towers' join node (layers._JoinColumns.backward) runs them, optimizer.step()
+# whatever is left — always before the late tasks, which may read what they joined.
+_main_tasks = []
+
+
+def add_main_task(fn):
+    _main_tasks.append(fn)
+
+
+def run_main_tasks():
+    while _main_tasks:
+        _main_tasks.pop(0)()
+
+
 def clear_side_tasks():
     """Drop tasks that an aborted backward pass left behind."""
     _side_tasks.clear()
     _late_tasks.clear()
+    _main_tasks.clear()
 
 
 def reset_aux_streams():
@@ -168,6 +184,7 @@ def reset_aux_streams():
     _deferred.clear()
     _side_tasks.clear()
     _late_tasks.clear()
+    _main_tasks.clear()
     dense_ready[0] = dense_ready[1] = None
 
 

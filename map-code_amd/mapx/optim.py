@@ -232,6 +232,7 @@ class MapxOptimizer:
         return moved
 
     def step(self):
+        ops.run_main_tasks()            # stream joins nobody picked up
         ops.join_pending()              # side work a backward node forked and left open
         ops.run_side_tasks()            # early table updates nobody picked up
         ops.run_late_tasks()            # optimizer-only gradients nobody picked up
