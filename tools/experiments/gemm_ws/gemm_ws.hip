@@ -136,7 +136,7 @@ __device__ inline int ws_slot(int r, int c) {
 template <bool A_KC, bool B_KC, int MODE, int PRIO>
 __global__ void __launch_bounds__(512) gemm_ws_kernel(GemmWsArgs g) {
   const GemmX3Args& a = g.e;
-  constexpr int BM = 128, BN = 128, NT = 512, S = MODE == 0 ? 3 : 2;
+  constexpr int BM = 128, BN = 128, NT = 512, S = MODE == 1 ? 2 : 3;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int nb = a.tiles_m * a.tiles_n;
@@ -278,6 +278,191 @@ __global__ void __launch_bounds__(512) gemm_ws_kernel(GemmWsArgs g) {
         MAPX_WS_PUT(1, c_wait);
         MAPX_WS_PUT(2, c_bar);
       }
+    } else if constexpr (MODE == 2) {
+      // HYBRID (round 3, after the two pure forms lost): operand A fp32 — loaded, cut and stored by the loader waves,
+      // two chunks of 8 floats per thread and tile — operand B as PLANES fetched by LDS-DMA (the weights of the
+      // forward and input-gradient products: only the optimizer would have to write planes).  Half the DMA volume
+      // of mode 0 (24 KB per K-step), half the cut work of mode 1.  Three stages; per K-step kt:
+      //   DMA B(kt+2) -> stage (kt+2) % 3 | wait for the registers loaded two K-steps ago, cut + store A(kt+2) |
+      //   load A(kt+4) into those registers | LDS stores done | barrier
+      const int tid = threadIdx.x - 256;
+      // ---- B: as mode 0
+      int64_t srcB[2];
+      int chB = 0;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = w + 4 * jj;
+        if (B_KC) {
+          const int rin = lane >> 2, c = (lane & 3) ^ ((rin >> 2) & 3);
+          int row = n0 + 16 * j + rin;
+          row = row < a.N ? row : a.N - 1;
+          srcB[jj] = (int64_t)row * g.ldbp + 8 * c;
+          chB = c;
+        } else {
+          const int kin = lane >> 4, c = (lane & 15) ^ (kin << 2);
+          int col = n0 + 8 * c;
+          col = col + 8 <= a.N ? col : 0;
+          srcB[jj] = (int64_t)(4 * j + kin) * g.ldbp + col;
+          chB = kin;
+        }
+      }
+      uint32_t offB[2][3];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) offB[jj][p] = (uint32_t)((srcB[jj] + p * g.pb) * 2);
+      auto dmaB_first = [&](int klen) __attribute__((always_inline)) {
+        const char* const bb = reinterpret_cast<const char*>(g.Bp) + (B_KC ? (int64_t)kbeg : (int64_t)kbeg * g.ldbp) * 2;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int j = w + 4 * jj;
+          const bool okB = B_KC ? 8 * chB + 8 <= klen : 4 * j + chB < klen;
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            ws_dma16(okB ? (const void*)(bb + offB[jj][p]) : (const void*)g.zeros, smem + kWsOp + p * kWsPlane + j * 1024);
+        }
+      };
+      auto dmaB = [&](int stage, int t) __attribute__((always_inline)) {
+        const int k0 = wk0 + kXBK * (t - 1);
+        const char* const bb = reinterpret_cast<const char*>(g.Bp) + (B_KC ? (int64_t)k0 : (int64_t)k0 * g.ldbp) * 2;
+        unsigned char* const sB = smem + stage * kWsStage + kWsOp;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int j = w + 4 * jj;
+#pragma unroll
+          for (int p = 0; p < 3; ++p) ws_dma16(bb + offB[jj][p], sB + p * kWsPlane + j * 1024);
+        }
+      };
+      // ---- A: named registers ra_<set>_<chunk>_<half> (see mode 1 on why not an array)
+      f32x4 ra_0_0_0 = {0.f, 0.f, 0.f, 0.f}, ra_0_0_1 = ra_0_0_0, ra_0_1_0 = ra_0_0_0, ra_0_1_1 = ra_0_0_0;
+      f32x4 ra_1_0_0 = ra_0_0_0, ra_1_0_1 = ra_0_0_0, ra_1_1_0 = ra_0_0_0, ra_1_1_1 = ra_0_0_0;
+      int64_t ga0, ga1;
+      int sa0, sa1, ka0, ka1;
+      auto setupA = [&](int f, int64_t& go, int& so, int& kq) __attribute__((always_inline)) {
+        if (A_KC) {
+          const int r = f >> 2, c = f & 3, row = m0 + r < a.M ? m0 + r : a.M - 1;
+          go = (int64_t)row * a.lda + 8 * c;
+          so = ws_slot<true>(r, c);
+          kq = 8 * c + 8;
+        } else {
+          const int r = f >> 4, c = f & 15, col = m0 + 8 * c + 8 <= a.M ? m0 + 8 * c : 0;
+          go = (int64_t)r * a.lda + col;
+          so = ws_slot<false>(r, c);
+          kq = r + 1;
+        }
+      };
+      setupA(tid, ga0, sa0, ka0);
+      setupA(tid + 256, ga1, sa1, ka1);
+      auto koffA = [&](int k0) { return A_KC ? (int64_t)k0 : (int64_t)k0 * a.lda; };
+      auto cut_store = [&](const f32x4& v0, const f32x4& v1, unsigned char* d, bool keep) __attribute__((always_inline)) {
+        const float x[8] = {keep ? v0[0] : 0.f, keep ? v0[1] : 0.f, keep ? v0[2] : 0.f, keep ? v0[3] : 0.f,
+                            keep ? v1[0] : 0.f, keep ? v1[1] : 0.f, keep ? v1[2] : 0.f, keep ? v1[3] : 0.f};
+        uint4 hi, mid, lo;
+        cut3_wide(x, hi, mid, lo);
+        // stores by inline assembly: a ds_write the compiler can see makes it wait for EVERY LDS-DMA in flight
+        // (it cannot tell the stages apart), which exposed the whole DMA latency in each K-step
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const uint32_t la = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)d;
+        const u32x4 h4 = {hi.x, hi.y, hi.z, hi.w}, m4 = {mid.x, mid.y, mid.z, mid.w}, l4 = {lo.x, lo.y, lo.z, lo.w};
+        asm volatile("ds_write_b128 %0, %1" ::"v"(la), "v"(h4) : "memory");
+        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(la), "v"(m4), "n"(kWsPlane) : "memory");
+        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(la), "v"(l4), "n"(2 * kWsPlane) : "memory");
+      };
+// The fp32 loads are inline assembly with hand-counted waits: with LDS-DMA in flight the compiler's own wait before
+// the first use of a loaded register is vmcnt(0), which exposed one whole load latency per K-step.  MAPX_WA ties the
+// wait to the registers so that nothing that reads them moves above it.
+#define MAPX_LA(S_, C_, PTR)                                                                              \
+  do {                                                                                                    \
+    const float* p_ = (PTR);                                                                              \
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"           \
+                 : "=&v"(ra_##S_##_##C_##_0), "=&v"(ra_##S_##_##C_##_1) : "v"(p_) : "memory");            \
+  } while (0)
+#define MAPX_WA(S_, CNT)                                                                                  \
+  asm volatile("s_waitcnt vmcnt(" #CNT ")"                                                                \
+               : "+v"(ra_##S_##_0_0), "+v"(ra_##S_##_0_1), "+v"(ra_##S_##_1_0), "+v"(ra_##S_##_1_1)::"memory")
+#define MAPX_SA(S_, C_, STAGE, KEEP) cut_store(ra_##S_##_##C_##_0, ra_##S_##_##C_##_1, smem + (STAGE) * kWsStage + sa##C_, KEEP)
+      // full tile t >= 1 starts at k = wk0 + 32 (t - 1); loads past the last tile re-read it (never stored)
+      auto ktile = [&](int t) { const int tc = t < nk - 1 ? t : nk - 1; return koffA(wk0 + kXBK * (tc - 1)); };
+      // prologue: tile 0 (the K remainder) and tile 1 into stages 0 / 1; A of tiles 2 / 3 into the register sets
+      {
+        const int rem = wk0 - kbeg;
+        const int64_t k0 = koffA(kbeg);
+        const int64_t back0 = ka0 <= rem ? 0 : (A_KC ? (int64_t)(ka0 - 8) : (int64_t)(ka0 - 1) * a.lda);
+        const int64_t back1 = ka1 <= rem ? 0 : (A_KC ? (int64_t)(ka1 - 8) : (int64_t)(ka1 - 1) * a.lda);
+        MAPX_LA(0, 0, a.A + ga0 + k0 - back0);
+        MAPX_LA(0, 1, a.A + ga1 + k0 - back1);
+        if (nk > 1) {
+          MAPX_LA(1, 0, a.A + ga0 + ktile(1));
+          MAPX_LA(1, 1, a.A + ga1 + ktile(1));
+        }
+        dmaB_first(rem);
+        if (nk > 1) dmaB(1, 1);
+        MAPX_WA(0, 0);
+        MAPX_WA(1, 0);
+        MAPX_SA(0, 0, 0, ka0 <= rem);
+        MAPX_SA(0, 1, 0, ka1 <= rem);
+        if (nk > 1) {
+          MAPX_SA(1, 0, 1, true);
+          MAPX_SA(1, 1, 1, true);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (nk > 2) {
+          MAPX_LA(0, 0, a.A + ga0 + ktile(2));
+          MAPX_LA(0, 1, a.A + ga1 + ktile(2));
+          MAPX_LA(1, 0, a.A + ga0 + ktile(3));
+          MAPX_LA(1, 1, a.A + ga1 + ktile(3));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      unsigned long long c_issue = 0, c_wait = 0, c_bar = 0;
+      (void)c_issue; (void)c_wait; (void)c_bar;
+      // iteration kt: tile kt + 2 (register set kt & 1) goes to stage (kt + 2) % 3, the set is refilled with tile
+      // kt + 4.  VMEM order per iteration: 6 DMA B(kt+2) | 4 loads A(kt+4); the wait before the cut leaves the 4 loads
+      // of A(kt+3) and the 6 DMA of B(kt+2) in flight (vmcnt 10): A(kt+2) is two K-steps old, B(kt+1) one.
+#define MAPX_HSTEP(S_, KT)                                                        \
+  do {                                                                            \
+    const int t2_ = (KT) + 2;                                                     \
+    if (t2_ < nk) {                                                               \
+      const int st_ = t2_ % S;                                                    \
+      MAPX_WS_T0();                                                               \
+      dmaB(st_, t2_);                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                          \
+      MAPX_WS_ACC(c_issue);                      /* stamp 0: DMA issue */         \
+      const unsigned long long t1_ = __builtin_amdgcn_s_memtime();               \
+      MAPX_WA(S_, 10);                                                            \
+      MAPX_SA(S_, 0, st_, true);                                                  \
+      MAPX_SA(S_, 1, st_, true);                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                          \
+      MAPX_LA(S_, 0, a.A + ga0 + ktile((KT) + 4));                                \
+      MAPX_LA(S_, 1, a.A + ga1 + ktile((KT) + 4));                                \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                          \
+      c_wait += __builtin_amdgcn_s_memtime() - t1_;   /* stamp 1: wait + cut + store + loads */ \
+    } else {                                                                      \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            \
+    }                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                            \
+    {                                                                             \
+      MAPX_WS_T0();                                                               \
+      __builtin_amdgcn_s_barrier();                                               \
+      MAPX_WS_ACC(c_bar);                                                         \
+    }                                                                             \
+  } while (0)
+      int kt = 0;
+      for (; kt + 1 < nk; kt += 2) {
+        MAPX_HSTEP(0, kt);
+        MAPX_HSTEP(1, kt + 1);
+      }
+      if (kt < nk) MAPX_HSTEP(0, kt);
+      if (w == 0) {
+        MAPX_WS_PUT(0, c_issue);
+        MAPX_WS_PUT(1, c_wait);
+        MAPX_WS_PUT(2, c_bar);
+      }
+#undef MAPX_HSTEP
+#undef MAPX_SA
+#undef MAPX_WA
+#undef MAPX_LA
     } else {
       // fp32 operands: this thread's two chunks of 8 floats per operand per tile, two register sets.
       // A K-step of a loader wave is chunk by chunk  cut (44 VALU) -> 3 LDS stores -> the 2 global loads that
@@ -482,7 +667,7 @@ __global__ void __launch_bounds__(512) gemm_ws_kernel(GemmWsArgs g) {
       }, std::make_integer_sequence<int, 24>{});
     };
     if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(2);
-    if constexpr (MODE == 0) __builtin_amdgcn_s_barrier(); else __syncthreads();
+    if constexpr (MODE != 1) __builtin_amdgcn_s_barrier(); else __syncthreads();
     MAPX_WS_STAMP_AT(1);
     unroll_seq([&](auto qc) __attribute__((always_inline)) {
       read_frag(std::integral_constant<int, 0>{}, qc, smem, smem + kWsOp, 0);
@@ -495,7 +680,7 @@ __global__ void __launch_bounds__(512) gemm_ws_kernel(GemmWsArgs g) {
       st = st + 1 == S ? 0 : st + 1;
       const unsigned char* const sN = smem + st * kWsStage;
       phase(std::integral_constant<int, 0>{}, sA, sA + kWsOp, 1);
-      if constexpr (MODE == 0) {
+      if constexpr (MODE != 1) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         MAPX_WS_T0();
         __builtin_amdgcn_s_barrier();
@@ -878,7 +1063,7 @@ static unsigned long long* g_ws_stamps = nullptr;
 
 template <bool A_KC, bool B_KC, int MODE, int PRIO>
 static hipError_t launch_ws(const GemmWsArgs& g, int nsplit, hipStream_t stream) {
-  constexpr size_t lds = (size_t)(MODE == 0 ? 3 : 2) * kWsStage;
+  constexpr size_t lds = (size_t)(MODE == 1 ? 2 : 3) * kWsStage;
   static_assert(lds >= (size_t)128 * 132 * 4 + 16 * 32 * 16, "epilogue tile + column-sum rows must fit");
   auto* fn = &gemm_ws_kernel<A_KC, B_KC, MODE, PRIO>;
   static hipError_t raised =
@@ -918,11 +1103,12 @@ extern "C" int mapx_gemm_ws(int mode, int a_kc, int b_kc, int M, int N, int K, c
   MAPX_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, "gemm_ws: bad arguments");
   const int prio = (mode & 4) ? 2 : (mode & 2) ? 1 : 0;    // experiment switches: 2 consumers / 4 loaders at raised priority
   const bool ws16 = (mode & 8) != 0;                        // 16 waves: 8 consumers of 64 x 32 + 8 loaders, fp32 operands
-  mode = ws16 ? 1 : (mode & 1);
+  const bool hybrid = (mode & 16) != 0;                     // A fp32 (loader waves cut), B planes (LDS-DMA)
+  mode = ws16 ? 1 : hybrid ? 2 : (mode & 1);
   MAPX_REQUIRE(!(a_kc == 0 && b_kc != 0), "gemm_ws: layout (A m-contiguous, B k-contiguous) unused");
   MAPX_REQUIRE(epi >= MAPX_EPI_NONE && epi <= MAPX_EPI_RELU_MASK_COLSUM, "gemm_ws: bad epilogue %d", epi);
   const int64_t align = mode == 0 ? 8 : 4;
-  MAPX_REQUIRE(lda % align == 0 && ldb % align == 0 && (uintptr_t)A % 16 == 0 && (uintptr_t)B % 16 == 0 &&
+  MAPX_REQUIRE(lda % align == 0 && ldb % (mode == 2 ? 8 : align) == 0 && (uintptr_t)A % 16 == 0 && (uintptr_t)B % 16 == 0 &&
                    pa % 8 == 0 && pb % 8 == 0,
                "gemm_ws: operands must be 16-byte aligned with 16-byte rows");
   MAPX_REQUIRE(K % 8 == 0 && (a_kc || M % 8 == 0) && (b_kc || N % 8 == 0),
@@ -940,6 +1126,12 @@ extern "C" int mapx_gemm_ws(int mode, int a_kc, int b_kc, int M, int N, int K, c
     static void* z = nullptr;                 // (resolved once: no runtime call inside a stream capture)
     if (!z) MAPX_HIP(hipGetSymbolAddress(&z, HIP_SYMBOL(g_ws_zero_page)));
     g.zeros = static_cast<const bf16_t*>(z);
+  } else if (mode == 2) {
+    e.A = static_cast<const float*>(A); e.lda = lda;
+    g.Bp = static_cast<const bf16_t*>(B); g.ldbp = ldb; g.pb = pb;
+    static void* z2 = nullptr;
+    if (!z2) MAPX_HIP(hipGetSymbolAddress(&z2, HIP_SYMBOL(g_ws_zero_page)));
+    g.zeros = static_cast<const bf16_t*>(z2);
   } else {
     e.A = static_cast<const float*>(A); e.lda = lda;
     e.B = static_cast<const float*>(B); e.ldb = ldb;
@@ -965,7 +1157,7 @@ extern "C" int mapx_gemm_ws(int mode, int a_kc, int b_kc, int M, int N, int K, c
 #define MAPX_WS_P(AK, BK_, MD)                                                                       \
   (prio == 2 ? launch_ws<AK, BK_, MD, 2>(g, nsplit, stream)                                          \
              : prio == 1 ? launch_ws<AK, BK_, MD, 1>(g, nsplit, stream) : launch_ws<AK, BK_, MD, 0>(g, nsplit, stream))
-#define MAPX_WS(AK, BK_) (mode == 0 ? MAPX_WS_P(AK, BK_, 0) : MAPX_WS_P(AK, BK_, 1))
+#define MAPX_WS(AK, BK_) (mode == 0 ? MAPX_WS_P(AK, BK_, 0) : mode == 2 ? MAPX_WS_P(AK, BK_, 2) : MAPX_WS_P(AK, BK_, 1))
   if (ws16) err = (a_kc && b_kc) ? launch_ws16<true, true>(g, nsplit, stream)
                   : a_kc ? launch_ws16<true, false>(g, nsplit, stream) : launch_ws16<false, false>(g, nsplit, stream);
   else if (a_kc && b_kc) err = MAPX_WS(true, true);

@@ -33,11 +33,11 @@ def planes_of(x):
 
 
 def gemm_ws(mode, A, B, a_kc, b_kc, M, N, K, out, epi=EPI_NONE, bias=None, nsplit=1, ws=None):
-    pl = (mode & 9) == 0
+    pl = (mode & 25) == 0
     lda = A.shape[-1]
     ldb = B.shape[-1]
     pa = A.shape[-2] * A.shape[-1] if pl else 0
-    pb = B.shape[-2] * B.shape[-1] if pl else 0
+    pb = B.shape[-2] * B.shape[-1] if pl or (mode & 16) else 0      # 16: hybrid, A fp32 / B planes
     check(lib.mapx_gemm_ws(mode, int(a_kc), int(b_kc), M, N, K, A.data_ptr(), lda, pa, B.data_ptr(), ldb, pb,
                            out.data_ptr(), out.stride(0), epi, bias.data_ptr() if bias is not None else None,
                            None, 0, None, 0, None, 0, nsplit, ws.data_ptr() if ws is not None else None,
@@ -84,9 +84,14 @@ def check_shapes():
         scale = float(R.abs().max())
         ws = torch.empty(ns * M * N, device="cuda") if ns > 1 else None
         row = []
-        for mode in (0, 1, 4, 5, 8):
+        for mode in (0, 1, 4, 5, 8, 16):
             out = torch.full((M, N), float("nan"), device="cuda")
             a_, b_ = (planes_of(A), planes_of(B)) if (mode & 9) == 0 else (A, B)
+            if mode & 16:
+                if B.shape[-1] % 8:
+                    row.append(float("nan"))
+                    continue
+                a_, b_ = A, planes_of(B)
             gemm_ws(mode, a_, b_, a_kc, b_kc, M, N, K, out, nsplit=ns, ws=ws)
             torch.cuda.synchronize()
             err = float((out.double() - R).abs().max()) / scale
@@ -126,8 +131,10 @@ def time_shapes():
         us = timeit(lambda: ops.gemm(A, B, a_kc, b_kc, M, N, K, out=out, nsplit=ns))
         line = f"  {name:24s} x3 {us:6.1f} us {fl / us / 1e6:6.1f} TF |"
         Ap, Bp = planes_of(A), planes_of(B)
-        for mode in (0, 4, 1, 5, 8):
+        for mode in (0, 4, 1, 5, 8, 16, 20):
             a_, b_ = (Ap, Bp) if (mode & 9) == 0 else (A, B)
+            if mode & 16:
+                a_, b_ = A, Bp
             us = timeit(lambda: gemm_ws(mode, a_, b_, a_kc, b_kc, M, N, K, out, nsplit=ns, ws=ws))
             line += f" m{mode} {us:6.1f} us {fl / us / 1e6:6.1f} TF |"
         print(line)
@@ -149,8 +156,8 @@ def stamp_shapes():
         Ap, Bp = planes_of(A), planes_of(B)
         nblk = ((M + 127) // 128) * ((N + 127) // 128) * ns
         nk = -(-(K // ns) // 32)
-        for mode in (0, 1, 8):
-            a_, b_ = (Ap, Bp) if mode == 0 else (A, B)
+        for mode in (0, 1, 8, 16):
+            a_, b_ = (Ap, Bp) if mode == 0 else (A, Bp) if mode == 16 else (A, B)
             st = torch.zeros(nblk * 16, dtype=torch.int64, device="cuda")
             check(lib.mapx_gemm_ws_set_stamps(st.data_ptr()))
             us = timeit(lambda: gemm_ws(mode, a_, b_, a_kc, b_kc, M, N, K, out, nsplit=ns, ws=ws), reps=40)
