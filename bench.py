@@ -145,10 +145,11 @@ def build(args, device, rank):
     F, V = wl["F"], wl["V"]
     ids, labels, _, _ = synth_table(args.rows, F, V, seed=42, uniform=args.uniform)
     feat_count = torch.from_numpy(np.bincount(ids.reshape(-1), minlength=V).astype(np.float32))
+    pt = getattr(args, "pt", "MFP")              # tools/step_bench.py times the RFD and finetune (CTR) steps too
     cfg = Config(model_name="DCNv2", data_dir=None, input_size=V, num_fields=F, embed_size=16,
                  embed_dropout_rate=0.0, embed_norm=False, hidden_size=1000, num_hidden_layers=3,
                  hidden_act="relu", hidden_dropout_rate=0.0, num_cross_layers=3, pt_neg_num=25,
-                 proj_size=32, pretrain=True, pt_type="MFP", RFD_replace="Unigram",
+                 proj_size=32, pretrain=pt != "CTR", pt_type="MFP" if pt == "CTR" else pt, RFD_replace="Unigram",
                  feat_count=feat_count, seed=42, rank=rank, compute_dtype="bf16" if args.dtype == "bf16" else "fp32")
     torch.manual_seed(42)
     model = BaseModel.from_config(cfg)
@@ -160,8 +161,8 @@ def build(args, device, rank):
     epochs = max(3, -(-need // steps_per_epoch))
     targs = TrainingArguments(output_dir="/tmp/mapx_bench", per_gpu_train_batch_size=args.batch,
                               per_gpu_eval_batch_size=args.batch, learning_rate=1e-3, lr_sched="cosine",
-                              weight_decay=5e-2, num_train_epochs=epochs, pretrain=True, pt_type="MFP",
-                              sampling_method="randint", mask_ratio=0.3, seed=42)
+                              weight_decay=5e-2, num_train_epochs=epochs, pretrain=pt != "CTR",
+                              pt_type="MFP" if pt == "CTR" else pt, sampling_method="randint", mask_ratio=0.3, seed=42)
     targs._device = device
     tr = Trainer(model, cfg, targs, OurDataset(ids, labels), OurDataset(ids[:args.batch], labels[:args.batch]))
     return tr, cfg, ids, labels, feat_count

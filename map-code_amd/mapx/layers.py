@@ -71,9 +71,10 @@ class RowTable:
             self.plan.start()
         return self.plan
 
-    def start_plan(self):
+    def start_plan(self, after=None):
+        """`after`: a stream whose work enqueued so far the sort must not delay (PlanSlot.start_many)."""
         if self.plan is not None:
-            self.plan.start()
+            self.plan.start(after=after)
 
     def join_plan(self, device):
         """Make the current stream wait for the plan being built on this table's side stream."""
@@ -99,6 +100,7 @@ class RowTable:
 
 
 IMPLIED = os.environ.get("MAPX_PLAN_IMPLIED", "1") == "1"
+HEAD_DW_LATE = os.environ.get("MAPX_HEAD_DW_LATE", "1") == "1"     # A/B switch (tools/ab_env.sh)
 
 # callables (table, plan) run on the plan stream right after a table's plan has been enqueued
 # (trainer.GraphedBackward publishes the plan's unique-row count to the host from there)
@@ -122,7 +124,7 @@ class PlanSlot:
         self.ready = ops.record_event()
         self.partners = []          # other tables' slots to build in the same chain of launches (start_many)
 
-    def start(self):
+    def start(self, after=None):
         if self.value is not None:
             return
         if self.partners:
@@ -131,6 +133,10 @@ class PlanSlot:
         keys, self.keys = self.keys, None
         side = _side_stream(keys.device, self.table.name)
         forked = ops.stream_wait_event(side, self.ready, self.origin)
+        if after is not None:            # (see start_many: left to itself the graph runtime runs the chain LAST)
+            with torch.cuda.stream(after):
+                ev = ops.record_event()
+            ops.stream_wait_event(side, ev, after)
         with torch.cuda.stream(side):
             self.value = ops.SegPlan(keys, self.table.num_rows)
             for observe in plan_observers:
@@ -530,7 +536,20 @@ class _Linear(Function):
             dw = None if sw is not None else dw
         elif ctx.relu and (ctx.half or gy.shape[1] % 4 == 0):      # ReLU mask and bias gradient in one pass over dY
             dz, db = ops.relu_mask_colsum(gy, y, db=sb, defer=True)      # gy may be a slice of d(concat)
-            dw = ops.linear_bwd_weight(dz, x, out=sw, defer=True) if ctx.needs_input_grad[1] else None
+            if (HEAD_DW_LATE and isinstance(ctx.link_in, _JoinLink) and ops.step_window[0] and sw is not None
+                    and ctx.needs_input_grad[1]):
+                # The heads' first layer (RFD's 1368 -> 736 predictor): both towers' backward passes wait for this
+                # node's dX, only the optimizer for its dW (83 us alone on the stream while the other queue idled) —
+                # it goes to the end of the cross tower's chain, like the MFP encoder's (ops.run_late_tasks).
+                def head_dw(dz=dz, x=x, sw=sw):
+                    cur = torch.cuda.current_stream()
+                    dz.record_stream(cur)
+                    x.record_stream(cur)
+                    ops.linear_bwd_weight(dz, x, out=sw, defer=True)
+                ops.add_late_task(head_dw)
+                dw = None
+            else:
+                dw = ops.linear_bwd_weight(dz, x, out=sw, defer=True) if ctx.needs_input_grad[1] else None
             dw, db = (None if sw is not None else dw), (None if sb is not None else db)
         else:
             dz = ops.relu_mask(gy.contiguous(), y.contiguous()) if ctx.relu else gy.contiguous()

@@ -33,6 +33,7 @@ JOINT_PLAN = os.environ.get("MAPX_JOINT_PLAN", "auto")
 # stream wins, 0.8058 vs 0.8223 ms
 LAYOUT_ON_MAIN = os.environ.get("MAPX_LAYOUT_ON_MAIN", "0") == "1"
 PLAN_AFTER_DNN = os.environ.get("MAPX_PLAN_AFTER_DNN", "1") == "1"
+PLAN_AFTER_TRUNK = os.environ.get("MAPX_PLAN_AFTER_TRUNK", "1") == "1"      # RFD / CTR steps: the one table's sort
 X0_LINK = os.environ.get("MAPX_X0_LINK", "1") == "1"       # A/B switch of layers._X0Link
 
 _OTHER_BACKBONES = ("trans", "fignn", "fgcnn")
@@ -261,7 +262,10 @@ class DCNV2(BaseModel):
                 # the head's backward node starts both (PlanSlot.start_many from IndexLinear's partner list)
                 self.mfp_criterion.table.plan.partners = [self.embed.table.plan]
             else:
-                self.embed.table.start_plan()
+                # (RFD / finetune steps: one table, one chain.  Forked from the ids alone the graph runtime ran it
+                # LAST, 127 us of sort + reduction + row update exposed behind the backward pass; behind the deep
+                # tower's forward GEMMs it runs beside the head)
+                self.embed.table.start_plan(after=main if PLAN_AFTER_TRUNK else None)
             ops.stream_wait(main, tower)
             if forked:
                 feat_embed.record_stream(tower)

@@ -539,6 +539,10 @@ class Trainer:
         (N > 1) or gradient clipping needs host-side decisions before the optimizer.  Ragged
         batches and host-side mask sampling ("normal") stay eager."""
         fn = {"mfp": self._mfp_step, "rfd": self._rfd_step, "ctr": self._ctr_step}[kind]
+        if isinstance(X, RowsRef) and (kind != "mfp" or self.args.pt_type != "MFP"):
+            # row references are the MFP mask kernel's input form: every other step takes the rows themselves
+            ref = X
+            X, Y = ref.X, (ref.Y if Y is ref else Y)
         graphable = (self.use_graph and X.shape[0] == self.args.per_gpu_train_batch_size
                      and (kind == "ctr" or self.args.sampling_method == "randint"))
         if not graphable:
