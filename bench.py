@@ -146,7 +146,7 @@ def build(args, device, rank):
     ids, labels, _, _ = synth_table(args.rows, F, V, seed=42, uniform=args.uniform)
     feat_count = torch.from_numpy(np.bincount(ids.reshape(-1), minlength=V).astype(np.float32))
     pt = getattr(args, "pt", "MFP")              # tools/step_bench.py times the RFD and finetune (CTR) steps too
-    cfg = Config(model_name="DCNv2", data_dir=None, input_size=V, num_fields=F, embed_size=16,
+    cfg = Config(model_name=getattr(args, "model", "DCNv2"), data_dir=None, input_size=V, num_fields=F, embed_size=16,
                  embed_dropout_rate=0.0, embed_norm=False, hidden_size=1000, num_hidden_layers=3,
                  hidden_act="relu", hidden_dropout_rate=0.0, num_cross_layers=3, pt_neg_num=25,
                  proj_size=32, pretrain=pt != "CTR", pt_type="MFP" if pt == "CTR" else pt, RFD_replace="Unigram",

@@ -236,6 +236,35 @@ extern "C" int mapx_dynamic_mask_mfp_rows(const int64_t* split_ids, int64_t N, c
   return check_launch("dynamic_mask_mfp_rows");
 }
 
+namespace mapx {
+// out[b, :] = src[sel[cursor + b], :] — the batch of an RFD / finetune step cut from the resident split inside the
+// step (the MFP mask kernel reads its rows through `sel` itself).  One thread per element.
+__global__ void __launch_bounds__(256) take_rows_i64_kernel(const int64_t* __restrict__ src, int64_t N, int F,
+                                                            const int64_t* __restrict__ sel,
+                                                            const int64_t* __restrict__ cursor, int64_t B,
+                                                            int64_t* __restrict__ out) {
+  const int64_t c0 = cursor ? *cursor : 0;
+  const int64_t total = B * F;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = e / F;
+    int64_t r = sel[c0 + b];
+    r = r < 0 ? 0 : (r >= N ? N - 1 : r);           // (caller-checked; a wrong cursor must not read out of bounds)
+    out[e] = src[r * F + (e - b * F)];
+  }
+}
+}  // namespace mapx
+
+extern "C" int mapx_take_rows_i64(const int64_t* src, int64_t N, int F, const int64_t* sel,
+                                  const int64_t* sel_cursor_dev_opt, int64_t B, int64_t* out, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(src && sel && out && N > 0 && F > 0 && B >= 0, "take_rows_i64: bad arguments");
+  if (B == 0) return MAPX_OK;
+  hipLaunchKernelGGL(take_rows_i64_kernel, dim3(grid_for(B * F, 256)), dim3(256), 0, stream, src, N, F, sel,
+                     sel_cursor_dev_opt, B, out);
+  return check_launch("take_rows_i64");
+}
+
 extern "C" int mapx_dynamic_mask_rfd(const int64_t* ids, int64_t B, int F, int L,
                                      const int64_t* masked_index_in, const int64_t* replace_in,
                                      const int64_t* x_train, int64_t N, int mode,

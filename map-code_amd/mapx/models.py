@@ -34,6 +34,7 @@ JOINT_PLAN = os.environ.get("MAPX_JOINT_PLAN", "auto")
 LAYOUT_ON_MAIN = os.environ.get("MAPX_LAYOUT_ON_MAIN", "0") == "1"
 PLAN_AFTER_DNN = os.environ.get("MAPX_PLAN_AFTER_DNN", "1") == "1"
 PLAN_AFTER_TRUNK = os.environ.get("MAPX_PLAN_AFTER_TRUNK", "1") == "1"      # RFD / CTR steps: the one table's sort
+
 X0_LINK = os.environ.get("MAPX_X0_LINK", "1") == "1"       # A/B switch of layers._X0Link
 
 _OTHER_BACKBONES = ("trans", "fignn", "fgcnn")
@@ -264,7 +265,8 @@ class DCNV2(BaseModel):
             else:
                 # (RFD / finetune steps: one table, one chain.  Forked from the ids alone the graph runtime ran it
                 # LAST, 127 us of sort + reduction + row update exposed behind the backward pass; behind the deep
-                # tower's forward GEMMs it runs beside the head)
+                # tower's forward GEMMs it runs beside the head: RFD 0.946 -> 0.845 ms, finetune 0.765 -> 0.664.  The
+                # single-stream backbones below measured neutral (RFD / CTR) or worse (DNN + MFP): left as they were)
                 self.embed.table.start_plan(after=main if PLAN_AFTER_TRUNK else None)
             ops.stream_wait(main, tower)
             if forked:

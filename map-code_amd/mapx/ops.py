@@ -1339,6 +1339,25 @@ def adamw_dense(p, g, m, v, sched, done, beta1, beta2, eps, wd, shadow=None):
                                               stream()))
 
 
+def take_rows(src, sel, cursor=None, batch=None):
+    """src[sel[c : c + batch]] for an int64 matrix / vector resident on the device (c = the device scalar `cursor`,
+    0 and batch = len(sel) without one): the batch of an RFD / finetune step, cut inside the step."""
+    require_gpu(src, sel)
+    if src.dtype != torch.int64 or sel.dtype != torch.int64 or not src.is_contiguous() or not sel.is_contiguous():
+        raise TypeError("take_rows: contiguous int64 source and row numbers")
+    if cursor is not None and (cursor.dtype != torch.int64 or cursor.numel() != 1 or batch is None):
+        raise TypeError("take_rows: the cursor is an int64 device scalar and comes with the batch size")
+    B = int(batch) if batch is not None else sel.numel()
+    if cursor is None and B > sel.numel():
+        raise IndexError(f"take_rows: {B} rows of a list of {sel.numel()}")
+    F = 1 if src.dim() == 1 else src.shape[1]
+    out = torch.empty((B,) if src.dim() == 1 else (B, F), dtype=torch.int64, device=src.device)
+    if B == 0:
+        return out
+    check(lib.mapx_take_rows_i64(ptr(src), src.shape[0], F, ptr(sel), ptr(cursor), B, ptr(out), stream()))
+    return out
+
+
 def step_advance(done, cursor=None, stride=0):
     """*done += 1; `cursor` (int64 device scalar): += stride in the same launch (the batch cursor of a step
     that walks the epoch's permutation, trainer.GraphedStep)."""

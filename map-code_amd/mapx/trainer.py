@@ -503,7 +503,21 @@ class Trainer:
             self._backward(loss)
         return loss.detach(), self.model.mfp_criterion.last_acc_ratio      # = acc / count, from the loss kernel
 
+    @staticmethod
+    def _rows_of(X, Y, labels=True):
+        """The tensors of a batch dealt as row references (DeviceSplit.batches(rows=True)): cut from the resident
+        split by one launch inside the step — a captured step walks the epoch's permutation by itself."""
+        if not isinstance(X, RowsRef):
+            return X, Y
+        ref = X
+        ids = ops.take_rows(ref.split.X, ref.sel, ref.cursor, ref.batch if ref.cursor is not None else None)
+        if Y is ref:
+            Y = ops.take_rows(ref.split.Y, ref.sel, ref.cursor,
+                              ref.batch if ref.cursor is not None else None) if labels else None
+        return ids, Y
+
     def _rfd_fwd_bwd(self, X, Y):
+        X, Y = self._rows_of(X, Y, labels=False)            # (RFD makes its own labels)
         inputs = self.dynamic_mask({"input_ids": X, "labels": Y}, self.args.sampling_method)
         with self._step_window():
             loss, count, acc, pos_ratio = self.model(**inputs)
@@ -511,6 +525,7 @@ class Trainer:
         return loss.detach(), acc
 
     def _ctr_fwd_bwd(self, X, Y):
+        X, Y = self._rows_of(X, Y)
         with self._step_window():
             loss, logits = self.model(input_ids=X, labels=Y)
             self._backward(loss)
@@ -539,9 +554,8 @@ class Trainer:
         (N > 1) or gradient clipping needs host-side decisions before the optimizer.  Ragged
         batches and host-side mask sampling ("normal") stay eager."""
         fn = {"mfp": self._mfp_step, "rfd": self._rfd_step, "ctr": self._ctr_step}[kind]
-        if isinstance(X, RowsRef) and (kind != "mfp" or self.args.pt_type != "MFP"):
-            # row references are the MFP mask kernel's input form: every other step takes the rows themselves
-            ref = X
+        if isinstance(X, RowsRef) and kind == "mfp" and self.args.pt_type != "MFP":
+            ref = X                                        # (the MFP mask kernel is what reads rows through `sel`)
             X, Y = ref.X, (ref.Y if Y is ref else Y)
         graphable = (self.use_graph and X.shape[0] == self.args.per_gpu_train_batch_size
                      and (kind == "ctr" or self.args.sampling_method == "randint"))
@@ -696,7 +710,7 @@ class Trainer:
         for epoch in range(self.args.num_train_epochs):
             logger.info(f"-------------------- epoch-{epoch} --------------------")
             self.model.train()
-            for X, Y in train.batches(B, True, self._generator(), (self.rank, self.world)):
+            for X, Y in train.batches(B, True, self._generator(), (self.rank, self.world), rows=True):
                 loss, acc = self.run_step("rfd", X, Y)
                 win += torch.stack([loss, acc])
                 if self.global_step % self.args.logging_steps == 0:
@@ -747,12 +761,14 @@ class Trainer:
         for epoch in range(self.args.num_train_epochs):
             logger.info(f"-------------------- epoch-{epoch} --------------------")
             self.model.train()
-            for X, Y in train.batches(B, True, self._generator(), (self.rank, self.world)):
+            for X, Y in train.batches(B, True, self._generator(), (self.rank, self.world), rows=True):
                 loss, logits = self.run_step("ctr", X, Y)
                 win_loss += loss
                 win_logits.append(logits.clone())
-                win_labels.append(Y)
+                win_labels.append(Y.sel if isinstance(Y, RowsRef) else Y)     # row numbers: the labels are cut below
                 if self.global_step % self.args.logging_steps == 0:
+                    if isinstance(Y, RowsRef):
+                        win_labels = [train.Y[torch.cat(win_labels)]]
                     try:
                         auc = ops.eval_metrics(torch.cat(win_logits), torch.cat(win_labels))["auc"]
                     except ValueError:                       # a window with one class only

@@ -1008,3 +1008,24 @@ def test_layernorm_vs_torch(ops, R, E):
     dx, dyx = ops.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), stats)
     np.testing.assert_allclose(_cpu(dx).numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(_cpu(dyx).double().sum(0).numpy(), wr.grad.numpy(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_take_rows_cuts_a_batch_behind_a_device_cursor(ops):
+    """mapx_take_rows_i64: rows sel[c : c + B] of a resident int64 matrix / vector (the RFD / finetune steps'
+    collate); row numbers out of range are clamped, not read."""
+    g = torch.Generator().manual_seed(3)
+    X = torch.randint(0, 1 << 40, (1000, 23), generator=g).to(DEV)
+    Y = torch.randint(0, 2, (1000,), generator=g).to(DEV)
+    sel = torch.randperm(1000, generator=g).to(DEV)
+    assert torch.equal(ops.take_rows(X, sel[:64].contiguous()), X[sel[:64]])
+    cur = torch.tensor([128], dtype=torch.int64, device=DEV)
+    assert torch.equal(ops.take_rows(X, sel, cur, 100), X[sel[128:228]])
+    assert torch.equal(ops.take_rows(Y, sel, cur, 100), Y[sel[128:228]])
+    assert ops.take_rows(X, sel[:0].contiguous()).shape == (0, 23)
+    bad = torch.tensor([-5, 2000, 7], dtype=torch.int64, device=DEV)
+    assert torch.equal(ops.take_rows(X, bad), X[torch.tensor([0, 999, 7], device=DEV)])
+    with pytest.raises(TypeError):
+        ops.take_rows(X.int(), sel)
+    with pytest.raises(IndexError):
+        ops.take_rows(X, sel[:10].contiguous(), batch=11)

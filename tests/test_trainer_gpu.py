@@ -327,6 +327,46 @@ def test_graph_replay_equals_eager_bitwise(max_grad_norm, backbone, full, epochs
         assert torch.equal(out[0][k], out[1][k]), k
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("pt", ["RFD", "CTR"])
+def test_rfd_and_finetune_steps_walk_row_references_like_the_eager_loop(pt):
+    """RFD pretraining and finetune epochs deal their batches as row references too (round 3): the captured step cuts
+    its rows from the resident split itself (mapx_take_rows_i64 behind the device cursor).  Same parameters as the
+    eager loop after two epochs with a ragged tail, bit for bit; the graph is the walking kind."""
+    from mapx.arguments import TrainingArguments
+    from mapx.dataset import OurDataset, synth_table
+    from mapx.models import BaseModel
+    from mapx.trainer import GraphedStep, Trainer
+    from util import make_config
+    cfg = dict(F=23, V=3000, E=16, H=64, NL=3, NC=3, P=32, K=25)
+    ids, labels, _, _ = synth_table(512 * 9 + 100, 23, cfg["V"], seed=3)
+    cnt = np.bincount(ids.reshape(-1), minlength=cfg["V"]).astype(np.float32)
+    out = []
+    for use_graph in (True, False):
+        torch.manual_seed(5)
+        config = make_config(cfg, pt, cnt)
+        model = BaseModel.from_config(config)
+        targs = TrainingArguments(output_dir="/tmp/mapx_rows_test", per_gpu_train_batch_size=512,
+                                  per_gpu_eval_batch_size=512, learning_rate=1e-3, lr_sched="cosine",
+                                  weight_decay=5e-2, num_train_epochs=2, pretrain=pt != "CTR",
+                                  pt_type="MFP" if pt == "CTR" else pt, RFD_replace="Unigram",
+                                  sampling_method="randint", mask_ratio=0.3, logging_steps=7, seed=11,
+                                  patience=100)
+        targs._device = torch.device(DEV)
+        os.makedirs(targs.output_dir, exist_ok=True)
+        tr = Trainer(model, config, targs, OurDataset(ids, labels), OurDataset(ids[:600], labels[:600]))
+        tr.use_graph = use_graph
+        tr.RFD_pretrain() if pt == "RFD" else tr.train()
+        assert tr.global_step == 2 * 10
+        graphs = [g for g in tr._graphs.values() if not isinstance(g, int)]
+        assert bool(graphs) == use_graph
+        if use_graph:
+            assert isinstance(graphs[0], GraphedStep) and graphs[0].walk
+        out.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    for k in out[0]:
+        assert torch.equal(out[0][k], out[1][k]), k
+
+
 def test_resume_state_continues_bit_exactly(tmp_path):
     """save_training_state / load_training_state: 6 steps == 3 steps + save + fresh trainer + load + 3 steps."""
     from mapx.arguments import TrainingArguments

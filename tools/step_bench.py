@@ -18,6 +18,7 @@ import bench  # noqa: E402  (puts map-code_amd on the path)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pt", default="RFD", choices=["MFP", "RFD", "CTR"])
+    ap.add_argument("--model", default="DCNv2", choices=["DCNv2", "DNN", "DeepFM", "xDeepFM", "AutoInt"])
     ap.add_argument("--workload", default="avazu", choices=sorted(bench.WORKLOADS))
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--batch", type=int, default=4096)
@@ -25,6 +26,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--preroll", type=int, default=200)
+    ap.add_argument("--tensors", action="store_true", help="deal the batches as tensors (A/B of the row references)")
     a = ap.parse_args()
     a.uniform = False
     device = torch.device("cuda", 0)
@@ -33,7 +35,7 @@ def main():
     train = tr._begin("bench")
     gen = tr._generator()
     kind = a.pt.lower()
-    rows = kind == "mfp"                       # as the Trainer's loops deal them: row references for MFP only
+    rows = not a.tensors                       # as the Trainer's loops deal them: row references into the split
     state = {"it": train.batches(a.batch, True, gen, (0, 1), rows=rows)}
 
     def next_batch():
@@ -53,7 +55,7 @@ def main():
         out = tr.run_step(kind, *next_batch())
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(json.dumps({"step": f"DCNv2 {a.pt}", "workload": a.workload, "dtype": a.dtype, "batch": a.batch,
+    print(json.dumps({"step": f"{a.model} {a.pt}", "workload": a.workload, "dtype": a.dtype, "batch": a.batch,
                       "ms_per_step": 1e3 * dt / a.steps, "samples_per_s": a.batch * a.steps / dt,
                       "graphed": bool(tr.use_graph and live), "loss": float(out[0].detach())}))
 
