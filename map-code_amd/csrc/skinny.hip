@@ -1,0 +1,207 @@
+// Linear layers with at most 32 outputs — the heads' last layers: RFD's Linear(736 -> F) (reference models.py:119-124),
+// the finetune head Linear(D + H -> 1) (models.py:304, 319).  On the MFMA GEMM these cost a 64 x 64 or 128 x 128 tile
+// per 23 (or 1) useful columns and the scalar (non-vectorised) operand path: 16-37 us per product for 0.01-0.14 GF.
+// They are streaming problems — one pass over the [M, K] activations — so they run as fp32 FMA kernels here:
+//   fwd  y[m, n]  = sum_k x[m, k] w[n, k] + b[n]          a wave per 4 rows, lanes over k, butterfly reduction
+//   dW   dw[n, k] = sum_m dy[m, n] x[m, k]                threads over k, row chunks -> partial rows (summed by
+//                                                         mapx_sum_tasks with the step's other partial sums)
+//   dX   dx[m, k] = sum_n dy[m, n] w[n, k]                a thread per 4 rows x 4 columns
+// K % 4 == 0, rows 16-byte aligned (host-checked).  Results are plain fp32 sums (not the six-product arithmetic of
+// gemm_x3.hip): closer to the fp64 value, not bit-identical to the GEMM path.
+#include "common.h"
+
+namespace mapx {
+
+constexpr int kSkinnyChunks = 128;       // row chunks of the weight gradient (= partial rows per output)
+
+template <int NT>
+__global__ void __launch_bounds__(256) skinny_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                         const float* __restrict__ w, int64_t ldw,
+                                                         const float* __restrict__ bias, int M, int N, int K, int relu,
+                                                         float* __restrict__ y, int64_t ldy) {
+  constexpr int R = 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * R;
+  if (r0 >= M) return;
+  float acc[R][NT];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[r][n] = 0.f;
+  const float* xr[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) xr[r] = x + (r0 + r < M ? r0 + r : (int64_t)M - 1) * ldx;
+  for (int k = 4 * lane; k < K; k += 256) {
+    float4 xv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) xv[r] = *reinterpret_cast<const float4*>(xr[r] + k);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      if (n < N) {
+        const float4 wv = *reinterpret_cast<const float4*>(w + (int64_t)n * ldw + k);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          acc[r][n] += xv[r].x * wv.x + xv[r].y * wv.y + xv[r].z * wv.z + xv[r].w * wv.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      float v = acc[r][n];
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);       // fixed order: bit-reproducible
+      acc[r][n] = v;
+    }
+  if (lane == 0) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (r0 + r >= M) break;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        if (n < N) {
+          float v = acc[r][n] + (bias ? bias[n] : 0.f);
+          if (relu) v = v > 0.f ? v : 0.f;
+          y[(r0 + r) * ldy + n] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256) skinny_dw_kernel(const float* __restrict__ dy, int64_t ldy,
+                                                        const float* __restrict__ x, int64_t ldx, int M, int N, int K,
+                                                        float* __restrict__ part) {
+  const int k = 4 * (blockIdx.x * 256 + threadIdx.x);
+  const int rows_per = (M + kSkinnyChunks - 1) / kSkinnyChunks;
+  const int m0 = blockIdx.y * rows_per, m1 = (m0 + rows_per < M) ? m0 + rows_per : M;
+  if (k >= K) return;
+  float4 acc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int m = m0; m < m1; ++m) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)m * ldx + k);
+    const float* __restrict__ d = dy + (int64_t)m * ldy;       // the same N values for every thread: one line
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      if (n < N) {
+        const float g = d[n];
+        acc[n].x += g * xv.x; acc[n].y += g * xv.y; acc[n].z += g * xv.z; acc[n].w += g * xv.w;
+      }
+    }
+  }
+  float* __restrict__ p = part + (int64_t)blockIdx.y * N * K + k;
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+    if (n < N) *reinterpret_cast<float4*>(p + (int64_t)n * K) = acc[n];
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256) skinny_dx_kernel(const float* __restrict__ dy, int64_t ldy,
+                                                        const float* __restrict__ w, int64_t ldw, int M, int N, int K,
+                                                        float* __restrict__ dx, int64_t lddx) {
+  constexpr int R = 4;
+  const int kq = K / 4;                                        // float4 columns
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t rg = t / kq;
+  const int k = 4 * (int)(t - rg * kq);
+  const int64_t r0 = rg * R;
+  if (r0 >= M) return;
+  float4 acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* dr[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) dr[r] = dy + (r0 + r < M ? r0 + r : (int64_t)M - 1) * ldy;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    if (n < N) {
+      const float4 wv = *reinterpret_cast<const float4*>(w + (int64_t)n * ldw + k);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float g = dr[r][n];
+        acc[r].x += g * wv.x; acc[r].y += g * wv.y; acc[r].z += g * wv.z; acc[r].w += g * wv.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (r0 + r < M) *reinterpret_cast<float4*>(dx + (r0 + r) * lddx + k) = acc[r];
+}
+
+template <template <int> class Launch, class... A>
+static bool skinny_dispatch(int N, A... a) {
+  if (N <= 1) Launch<1>::go(a...);
+  else if (N <= 4) Launch<4>::go(a...);
+  else if (N <= 8) Launch<8>::go(a...);
+  else if (N <= 16) Launch<16>::go(a...);
+  else if (N <= 24) Launch<24>::go(a...);
+  else if (N <= 32) Launch<32>::go(a...);
+  else return false;
+  return true;
+}
+
+template <int NT>
+struct FwdLaunch {
+  static void go(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int M, int N, int K,
+                 int relu, float* y, int64_t ldy, hipStream_t stream) {
+    hipLaunchKernelGGL(skinny_fwd_kernel<NT>, dim3(grid_for(M, 16)), dim3(256), 0, stream, x, ldx, w, ldw, bias, M, N,
+                       K, relu, y, ldy);
+  }
+};
+template <int NT>
+struct DwLaunch {
+  static void go(const float* dy, int64_t ldy, const float* x, int64_t ldx, int M, int N, int K, float* part,
+                 hipStream_t stream) {
+    hipLaunchKernelGGL(skinny_dw_kernel<NT>, dim3(grid_for(K / 4, 256), kSkinnyChunks), dim3(256), 0, stream, dy, ldy,
+                       x, ldx, M, N, K, part);
+  }
+};
+template <int NT>
+struct DxLaunch {
+  static void go(const float* dy, int64_t ldy, const float* w, int64_t ldw, int M, int N, int K, float* dx,
+                 int64_t lddx, hipStream_t stream) {
+    const int64_t threads = (int64_t)((M + 3) / 4) * (K / 4);
+    hipLaunchKernelGGL(skinny_dx_kernel<NT>, dim3(grid_for(threads, 256)), dim3(256), 0, stream, dy, ldy, w, ldw, M, N,
+                       K, dx, lddx);
+  }
+};
+
+static bool al16(const void* p, int64_t ld) { return ((uintptr_t)p % 16 == 0) && ld % 4 == 0; }
+
+}  // namespace mapx
+
+extern "C" int mapx_skinny_chunks(void) { return mapx::kSkinnyChunks; }
+
+extern "C" int mapx_skinny_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias_opt,
+                                      int M, int N, int K, int relu, float* y, int64_t ldy, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(x && w && y && M >= 0 && N >= 1 && N <= 32 && K >= 4 && K % 4 == 0, "skinny_linear_fwd: bad sizes");
+  MAPX_REQUIRE(al16(x, ldx) && al16(w, ldw) && ldy >= N, "skinny_linear_fwd: rows of x and w must be 16-byte aligned");
+  if (M == 0) return MAPX_OK;
+  skinny_dispatch<FwdLaunch>(N, x, ldx, w, ldw, bias_opt, M, N, K, relu, y, ldy, stream);
+  return check_launch("skinny_linear_fwd");
+}
+
+extern "C" int mapx_skinny_linear_dw(const float* dy, int64_t ldy, const float* x, int64_t ldx, int M, int N, int K,
+                                     float* part, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(dy && x && part && M >= 1 && N >= 1 && N <= 32 && K >= 4 && K % 4 == 0 && ldy >= N,
+               "skinny_linear_dw: bad sizes");
+  MAPX_REQUIRE(al16(x, ldx) && (uintptr_t)part % 16 == 0, "skinny_linear_dw: rows of x must be 16-byte aligned");
+  skinny_dispatch<DwLaunch>(N, dy, ldy, x, ldx, M, N, K, part, stream);
+  return check_launch("skinny_linear_dw");
+}
+
+extern "C" int mapx_skinny_linear_dx(const float* dy, int64_t ldy, const float* w, int64_t ldw, int M, int N, int K,
+                                     float* dx, int64_t lddx, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(dy && w && dx && M >= 0 && N >= 1 && N <= 32 && K >= 4 && K % 4 == 0 && ldy >= N,
+               "skinny_linear_dx: bad sizes");
+  MAPX_REQUIRE(al16(w, ldw) && al16(dx, lddx), "skinny_linear_dx: rows of w and dx must be 16-byte aligned");
+  if (M == 0) return MAPX_OK;
+  skinny_dispatch<DxLaunch>(N, dy, ldy, w, ldw, M, N, K, dx, lddx, stream);
+  return check_launch("skinny_linear_dx");
+}

@@ -963,6 +963,9 @@ class _Bce(Function):
     @staticmethod
     def backward(ctx, g, _):
         (dl,) = ctx.saved_tensors
+        unit = ops.unit_gradient[0]
+        if unit is not None and g.numel() == 1 and g.data_ptr() == unit.data_ptr():
+            return dl, None            # the Trainer's loss.backward(ones): no elementwise launch on the head's chain
         return dl * g, None
 
 

@@ -33,7 +33,8 @@ JOINT_PLAN = os.environ.get("MAPX_JOINT_PLAN", "auto")
 # stream wins, 0.8058 vs 0.8223 ms
 LAYOUT_ON_MAIN = os.environ.get("MAPX_LAYOUT_ON_MAIN", "0") == "1"
 PLAN_AFTER_DNN = os.environ.get("MAPX_PLAN_AFTER_DNN", "1") == "1"
-PLAN_AFTER_TRUNK = os.environ.get("MAPX_PLAN_AFTER_TRUNK", "1") == "1"      # RFD / CTR steps: the one table's sort
+# RFD / finetune steps: what the one table's sort goes behind: auto | main | tower | 0 (A/B switch)
+PLAN_AFTER_TRUNK = os.environ.get("MAPX_PLAN_AFTER_TRUNK", "auto")
 
 X0_LINK = os.environ.get("MAPX_X0_LINK", "1") == "1"       # A/B switch of layers._X0Link
 
@@ -265,9 +266,12 @@ class DCNV2(BaseModel):
             else:
                 # (RFD / finetune steps: one table, one chain.  Forked from the ids alone the graph runtime ran it
                 # LAST, 127 us of sort + reduction + row update exposed behind the backward pass; behind the deep
-                # tower's forward GEMMs it runs beside the head: RFD 0.946 -> 0.845 ms, finetune 0.765 -> 0.664.  The
+                # tower's forward GEMMs ("main") it runs beside the head: RFD 0.946 -> 0.845 ms, finetune 0.765 -> 0.664.  The
                 # single-stream backbones below measured neutral (RFD / CTR) or worse (DNN + MFP): left as they were)
-                self.embed.table.start_plan(after=main if PLAN_AFTER_TRUNK else None)
+                # Behind the CROSS tower's (the head is short then and the deep tower's backward would wait for the
+                # sort on its queue): finetune 0.636 -> 0.619 ms, RFD 0.768 -> 0.786 — so by the head.
+                where = PLAN_AFTER_TRUNK if PLAN_AFTER_TRUNK != "auto" else ("main" if self.config.pretrain else "tower")
+                self.embed.table.start_plan(after={"main": main, "tower": tower}.get(where))
             ops.stream_wait(main, tower)
             if forked:
                 feat_embed.record_stream(tower)

@@ -118,6 +118,9 @@ def join_pending():
 # "every dense gradient of this backward pass is final": an event recorded by the model's LAST backward node
 # (the embedding gather of a tower model) before its own kernels; the optimizer's dense half may start there
 dense_ready = [None, None]        # [event, stream it was recorded on]
+# the Trainer's device scalar 1.0 that seeds loss.backward() (held here, so its address cannot be recycled):
+# a head whose incoming gradient IS that tensor skips the multiply by it
+unit_gradient = [None]
 # True between MapxOptimizer.backward_window(True) and (False): optimizer.step() follows this backward pass at
 # once and joins what it left open; outside the window backward() joins its side streams itself
 step_window = [False]
@@ -857,12 +860,42 @@ def gemm(a, b, a_kc, b_kc, M, N, K, out=None, ldc=None, epi=N.EPI_NONE, bias=Non
     return out
 
 
+# Layers with at most 32 outputs (RFD's last predictor layer, the finetune head) as fp32 streaming kernels instead of
+# MFMA GEMM tiles that are mostly padding (csrc/skinny.hip).  A/B switch: MAPX_SKINNY=0.
+SKINNY = os.environ.get("MAPX_SKINNY", "1") == "1"
+
+
+def _rows16(t):
+    return t.dim() == 2 and t.dtype == torch.float32 and t.stride(1) == 1 and t.stride(0) % 4 == 0 \
+        and t.data_ptr() % 16 == 0
+
+
+SKINNY_MAX = int(os.environ.get("MAPX_SKINNY_MAX", "8"))
+
+
+def _skinny(Nn, K, *mats):
+    return SKINNY and 1 <= Nn <= SKINNY_MAX and K >= 4 and K % 4 == 0 and all(_rows16(m) for m in mats)
+
+
+def _sum_now(dst, src, stride, nsplit, n):
+    arr = (N.SumTask * 1)()
+    arr[0].dst, arr[0].src, arr[0].stride, arr[0].n, arr[0].nsplit = dst.data_ptr(), src.data_ptr(), stride, n, nsplit
+    check(lib.mapx_sum_tasks(arr, 1, stream()))
+
+
 def linear_fwd(x, w, b, relu=False, out=None, out_dtype=None):
     """nn.Linear (+ReLU): x [M,K], w [N,K], b [N] -> [M,N]; `out` may be a column slice.  bf16 x:
     `w` is the weight's bf16 operand (ops.bf16_weight), b stays fp32, the result is bf16 or
     (`out_dtype=torch.float32`: the heads' logits) fp32."""
     M, K = x.shape
     Nn = w.shape[0]
+    if out_dtype in (None, torch.float32) and _skinny(Nn, K, x, w) and (out is None or out.dtype == torch.float32):
+        require_gpu(x, w)
+        y = out if out is not None else torch.empty(M, Nn, dtype=torch.float32, device=x.device)
+        with _timed("skinny_linear", 4.0 * (M * K + Nn * K + M * Nn)):
+            check(lib.mapx_skinny_linear_fwd(ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(b), M, Nn, K, int(relu),
+                                             y.data_ptr(), y.stride(0), stream()))
+        return y
     return gemm(x, w, True, True, M, Nn, K, out=out, epi=N.EPI_BIAS_RELU if relu else N.EPI_BIAS,
                 bias=b, out_dtype=out_dtype)
 
@@ -889,6 +922,14 @@ def linear_bwd_input(dy, w, out=None, add=None, relu_of=None, colsum_to=None):
     128-row tile, summed into `colsum_to` by flush_deferred()."""
     M, Nn = dy.shape
     K = w.shape[1]
+    if add is None and relu_of is None and _skinny(Nn, K, w) and dy.dtype == torch.float32 and dy.dim() == 2 \
+            and dy.stride(1) == 1 and (out is None or _rows16(out)):
+        require_gpu(dy, w)
+        dx = out if out is not None else torch.empty(M, K, dtype=torch.float32, device=dy.device)
+        with _timed("skinny_linear", 4.0 * (M * K + Nn * K + M * Nn)):
+            check(lib.mapx_skinny_linear_dx(ptr(dy), dy.stride(0), ptr(w), w.stride(0), M, Nn, K, dx.data_ptr(),
+                                            dx.stride(0), stream()))
+        return dx
     epi, aux, out2 = N.EPI_NONE, None, None
     if add is not None:
         epi, aux = N.EPI_ADD, add
@@ -917,6 +958,19 @@ def linear_bwd_weight(dy, x, out=None, defer=False):
     """dW = dY^T X.  dy [B,N], x [B,K] -> [N,K].  defer: leave split-K slabs for flush_deferred()."""
     Bn, Nn = dy.shape
     K = x.shape[1]
+    if Bn >= 1 and _skinny(Nn, K, x) and dy.dtype == torch.float32 and dy.dim() == 2 and dy.stride(1) == 1 \
+            and (out is None or (out.dtype == torch.float32 and out.is_contiguous())):
+        require_gpu(dy, x)
+        chunks = lib.mapx_skinny_chunks()
+        dw = out if out is not None else torch.empty(Nn, K, dtype=torch.float32, device=dy.device)
+        part = torch.empty(chunks, Nn * K, dtype=torch.float32, device=dy.device)
+        with _timed("skinny_linear", 4.0 * (Bn * K + Bn * Nn + chunks * Nn * K)):
+            check(lib.mapx_skinny_linear_dw(ptr(dy), dy.stride(0), ptr(x), x.stride(0), Bn, Nn, K, ptr(part), stream()))
+        if DEFER_COLSUM and defer and out is not None:
+            defer_sum(dw, part, Nn * K, chunks, Nn * K)          # with the step's other partial sums
+        else:
+            _sum_now(dw, part, Nn * K, chunks, Nn * K)
+        return dw
     # the bf16-MFMA kernels want 128 x 128 tiles (half the L2 -> LDS bytes per flop of 64 x 64 ones)
     ns = _splits_wide_tiles(Nn, K, Bn)
     if out is not None and out.stride(0) != K:

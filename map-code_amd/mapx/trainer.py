@@ -453,6 +453,7 @@ class Trainer:
         t_warmup = int(t_total * self.args.warmup_ratio)
         self.model.to(self.device)
         self._one = torch.ones((), device=self.device)       # dLoss/dLoss, allocated once (no fill launch per step)
+        ops.unit_gradient[0] = self._one
         self.optimizer = self.get_optimizer(t_total, t_warmup)
         self.scheduler = self.optimizer                      # get_last_lr() lives there
         if hasattr(self.model, "mfp_criterion"):

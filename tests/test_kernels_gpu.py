@@ -1029,3 +1029,36 @@ def test_take_rows_cuts_a_batch_behind_a_device_cursor(ops):
         ops.take_rows(X.int(), sel)
     with pytest.raises(IndexError):
         ops.take_rows(X, sel[:10].contiguous(), batch=11)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(4096, 1, 1368), (4096, 23, 736), (777, 32, 64), (5, 7, 4), (64, 24, 2004)])
+def test_skinny_linear_kernels_vs_fp64(ops, monkeypatch, M, N, K):
+    """Narrow layers (the finetune head's single output; the kernels take up to 32) run as fp32 streaming
+    kernels (csrc/skinny.hip): forward (+ bias, ReLU, strided destination), weight gradient (row-chunk partials
+    + mapx_sum_tasks, immediate and deferred), input gradient — against fp64.  (The dispatch keeps layers wider
+    than ops.SKINNY_MAX = 8 on the GEMM, where they measured faster; lifted here to test every width.)"""
+    monkeypatch.setattr(ops, "SKINNY_MAX", 32)
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    dy = torch.randn(M, N, generator=g).to(DEV)
+    assert ops._skinny(N, K, x, w)
+    ref = x.double() @ w.double().T + b.double()
+    y = ops.linear_fwd(x, w, b)
+    assert float((y.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    wide = torch.full((M, N + 9), -7.0, device=DEV)
+    yr = ops.linear_fwd(x, w, b, relu=True, out=wide[:, 4:4 + N])
+    assert yr.data_ptr() == wide[:, 4:].data_ptr() and torch.equal(yr, torch.relu(y))
+    assert float(wide[:, :4].max()) == -7.0 and float(wide[:, 4 + N:].max()) == -7.0
+    dw_ref = dy.double().T @ x.double()
+    dw = ops.linear_bwd_weight(dy, x)
+    assert float((dw.double() - dw_ref).abs().max()) <= 3e-6 * float(dw_ref.abs().max())
+    slot = torch.zeros(N, K, device=DEV)
+    ops.linear_bwd_weight(dy, x, out=slot, defer=True)
+    ops.flush_deferred()
+    assert torch.equal(slot, dw)                          # same partials, same sum
+    dx_ref = dy.double() @ w.double()
+    dx = ops.linear_bwd_input(dy, w)
+    assert float((dx.double() - dx_ref).abs().max()) <= 2e-6 * float(dx_ref.abs().max())
