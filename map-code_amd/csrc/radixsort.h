@@ -19,7 +19,9 @@ namespace mapx {
 
 constexpr int kSortTile = 4096;   // keys per block
 constexpr int kSortItems = 16;    // per thread
-constexpr int kSortBits = 8;      // digit width (12-bit digits: 4096x156 scattered histogram cells cost more than the extra pass)
+constexpr int kSortBits = 8;      // digit width (12-bit digits: 4096x156 scattered histogram cells cost more than the extra pass;
+                                  // 9-bit digits for Criteo's 26-bit keys, 3 passes instead of 4, two digits per thread in
+                                  // the scans: the step 0.846 vs 0.821 ms bf16, 1.223 vs 1.197 fp32 — round 3, not kept)
 
 // leading dimension of the digit-major histogram matrix: a multiple of 4 so that a row can be
 // read with 16-byte loads
