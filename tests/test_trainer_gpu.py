@@ -328,11 +328,12 @@ def test_graph_replay_equals_eager_bitwise(max_grad_norm, backbone, full, epochs
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pt", ["RFD", "CTR"])
-def test_rfd_and_finetune_steps_walk_row_references_like_the_eager_loop(pt):
+@pytest.mark.parametrize("pt,max_grad_norm", [("RFD", 0.0), ("CTR", 0.0), ("RFD", 0.5), ("CTR", 0.5)])
+def test_rfd_and_finetune_steps_walk_row_references_like_the_eager_loop(pt, max_grad_norm):
     """RFD pretraining and finetune epochs deal their batches as row references too (round 3): the captured step cuts
     its rows from the resident split itself (mapx_take_rows_i64 behind the device cursor).  Same parameters as the
-    eager loop after two epochs with a ragged tail, bit for bit; the graph is the walking kind."""
+    eager loop after two epochs with a ragged tail, bit for bit; the graph is the walking kind.  With gradient
+    clipping (as with N > 1) forward + backward replay from a graph that takes the batch's row numbers."""
     from mapx.arguments import TrainingArguments
     from mapx.dataset import OurDataset, synth_table
     from mapx.models import BaseModel
@@ -351,7 +352,7 @@ def test_rfd_and_finetune_steps_walk_row_references_like_the_eager_loop(pt):
                                   weight_decay=5e-2, num_train_epochs=2, pretrain=pt != "CTR",
                                   pt_type="MFP" if pt == "CTR" else pt, RFD_replace="Unigram",
                                   sampling_method="randint", mask_ratio=0.3, logging_steps=7, seed=11,
-                                  patience=100)
+                                  patience=100, max_grad_norm=max_grad_norm)
         targs._device = torch.device(DEV)
         os.makedirs(targs.output_dir, exist_ok=True)
         tr = Trainer(model, config, targs, OurDataset(ids, labels), OurDataset(ids[:600], labels[:600]))
@@ -360,7 +361,9 @@ def test_rfd_and_finetune_steps_walk_row_references_like_the_eager_loop(pt):
         assert tr.global_step == 2 * 10
         graphs = [g for g in tr._graphs.values() if not isinstance(g, int)]
         assert bool(graphs) == use_graph
-        if use_graph:
+        if use_graph and max_grad_norm > 0:
+            assert type(graphs[0]).__name__ == "GraphedBackward"
+        elif use_graph:
             assert isinstance(graphs[0], GraphedStep) and graphs[0].walk
         out.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
     for k in out[0]:
