@@ -2,7 +2,8 @@
 # Regenerates profiles/rNN_* on a GPU box:  gpurun -- 'bash tools/profile_round.sh r03'
 # For each compute dtype (f32, then bf16 with the suffix _bf16): kernel stats of the graphed and of the
 # serial step and the two PMC passes behind roofline.traffic; for f32 also the kernel stats of the
-# one-rank RCCL rehearsal of the data-parallel step.  Copy gpurun_out/prof_rNN/out/* into profiles/.
+# one-rank RCCL rehearsal of the data-parallel step and of the RFD / finetune steps (tools/step_bench.py).
+# Copy gpurun_out/prof_rNN/out/* into profiles/.
 set -e
 R=${1:-r03}
 cd ${GRAFT_REPO_ROOT:-.}
@@ -26,6 +27,12 @@ done
 B="python3 bench.py --steps 30 --warmup 5 --preroll 100 --no-cpu-baseline"
 MAPX_FORCE_DP=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dp -o d -- $B > $O/dp.log 2>&1
 cp $(find $O/dp -name '*kernel_stats.csv' | head -1) $O/out/${R}_dp_rehearsal_kernel_stats.csv
+# the other BASELINE configurations' captured steps (configs[3] RFD, configs[4] finetune): kernel stats inside the graph
+for PT in RFD CTR; do
+  L=$(echo $PT | tr A-Z a-z)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/$L -o p -- python3 tools/step_bench.py --pt $PT --steps 30 --warmup 5 --preroll 100 > $O/$L.log 2>&1
+  cp $(find $O/$L -name '*kernel_stats.csv' | head -1) $O/out/${R}_${L}_step_kernel_stats.csv
+done
 # keep the merge-back small: only the summaries travel
 find $O -mindepth 1 -maxdepth 1 ! -name out ! -name '*.log' -exec rm -rf {} +
 ls -la $O/out
