@@ -870,11 +870,13 @@ def _rows16(t):
         and t.data_ptr() % 16 == 0
 
 
-SKINNY_MAX = int(os.environ.get("MAPX_SKINNY_MAX", "8"))
+SKINNY_MAX = int(os.environ.get("MAPX_SKINNY_MAX", "8"))            # forward: wider layers measured faster on the GEMM
+SKINNY_MAX_BWD = int(os.environ.get("MAPX_SKINNY_MAX_BWD", "32"))   # dW / dX (RFD's 23-wide layer: 14.6 / 8.6 vs 28 / 12 us)
 
 
-def _skinny(Nn, K, *mats):
-    return SKINNY and 1 <= Nn <= SKINNY_MAX and K >= 4 and K % 4 == 0 and all(_rows16(m) for m in mats)
+def _skinny(Nn, K, *mats, bwd=False):
+    return SKINNY and 1 <= Nn <= (SKINNY_MAX_BWD if bwd else SKINNY_MAX) and K >= 4 and K % 4 == 0 \
+        and all(_rows16(m) for m in mats)
 
 
 def _sum_now(dst, src, stride, nsplit, n):
@@ -922,7 +924,7 @@ def linear_bwd_input(dy, w, out=None, add=None, relu_of=None, colsum_to=None):
     128-row tile, summed into `colsum_to` by flush_deferred()."""
     M, Nn = dy.shape
     K = w.shape[1]
-    if add is None and relu_of is None and _skinny(Nn, K, w) and dy.dtype == torch.float32 and dy.dim() == 2 \
+    if add is None and relu_of is None and _skinny(Nn, K, w, bwd=True) and dy.dtype == torch.float32 and dy.dim() == 2 \
             and dy.stride(1) == 1 and (out is None or _rows16(out)):
         require_gpu(dy, w)
         dx = out if out is not None else torch.empty(M, K, dtype=torch.float32, device=dy.device)
@@ -958,7 +960,7 @@ def linear_bwd_weight(dy, x, out=None, defer=False):
     """dW = dY^T X.  dy [B,N], x [B,K] -> [N,K].  defer: leave split-K slabs for flush_deferred()."""
     Bn, Nn = dy.shape
     K = x.shape[1]
-    if Bn >= 1 and _skinny(Nn, K, x) and dy.dtype == torch.float32 and dy.dim() == 2 and dy.stride(1) == 1 \
+    if Bn >= 1 and _skinny(Nn, K, x, bwd=True) and dy.dtype == torch.float32 and dy.dim() == 2 and dy.stride(1) == 1 \
             and (out is None or (out.dtype == torch.float32 and out.is_contiguous())):
         require_gpu(dy, x)
         chunks = lib.mapx_skinny_chunks()

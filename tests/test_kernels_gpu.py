@@ -1032,13 +1032,16 @@ def test_take_rows_cuts_a_batch_behind_a_device_cursor(ops):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,N,K", [(4096, 1, 1368), (4096, 23, 736), (777, 32, 64), (5, 7, 4), (64, 24, 2004)])
+@pytest.mark.parametrize("M,N,K", [(4096, 1, 1368), (4096, 23, 736), (777, 32, 64), (5, 7, 4), (64, 24, 2004),
+                                   (8500, 23, 40)])
 def test_skinny_linear_kernels_vs_fp64(ops, monkeypatch, M, N, K):
     """Narrow layers (the finetune head's single output; the kernels take up to 32) run as fp32 streaming
     kernels (csrc/skinny.hip): forward (+ bias, ReLU, strided destination), weight gradient (row-chunk partials
     + mapx_sum_tasks, immediate and deferred), input gradient — against fp64.  (The dispatch keeps layers wider
-    than ops.SKINNY_MAX = 8 on the GEMM, where they measured faster; lifted here to test every width.)"""
+    than ops.SKINNY_MAX = 8 on the GEMM in forward, where they measured faster; lifted here to test every width.
+    M = 8192 rows per chunk > 64: the untiled weight-gradient kernel.)"""
     monkeypatch.setattr(ops, "SKINNY_MAX", 32)
+    monkeypatch.setattr(ops, "SKINNY_MAX_BWD", 32)
     g = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g).to(DEV)
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
