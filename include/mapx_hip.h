@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 38
+#define MAPX_ABI_VERSION 39
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -302,6 +302,16 @@ int mapx_skinny_linear_dw(const float* dy, int64_t ldy, const float* x, int64_t 
                           hipStream_t stream);
 int mapx_skinny_linear_dx(const float* dy, int64_t ldy, const float* w, int64_t ldw, int M, int N, int K, float* dx,
                           int64_t lddx, hipStream_t stream);
+/* dL/d(final) of a head of N <= 8 outputs over DCNv2's two towers (the finetune head; reference models.py:304, 319
+ * behind models.py:306-318's concat), with both towers' first backward step in the same pass (what
+ * mapx_gemm_f32_bwd_fused and mapx_gemm_f32's EPI_RELU_MASK_COLSUM do for wide heads):  v = dz w [M, D+H];
+ * columns < D: g = v, t = v x0, dx0 = v u (+ v when plus_v), part_cross [ceil(M/128)][D] = column sums of t per
+ * 128-row tile; columns >= D: dzr = final > 0 ? v : 0, part_deep [ceil(M/128)][H] likewise (mapx_sum_tasks adds the
+ * tiles into the bias gradients).  D % 4 == H % 4 == 0, rows 16-byte aligned. */
+int mapx_skinny_join_bwd(const float* dz, int64_t lddz, const float* w, int64_t ldw, int M, int N, int D, int H,
+                         const float* final_act, int64_t ldf, const float* x0, int64_t ldx0, const float* u, int64_t ldu,
+                         int plus_v, float* g, int64_t ldg, float* t, int64_t ldt, float* dx0, int64_t lddx0, float* dzr,
+                         int64_t lddzr, float* part_cross, float* part_deep, hipStream_t stream);
 /* row chunks of the column-sum kernels: with out/db == NULL they leave `chunks` partial rows
  * [chunks][N] in `ws` for a later mapx_sum_tasks (stride N, nsplit = chunks). */
 int mapx_colsum_chunks(void);

@@ -169,6 +169,73 @@ __global__ void __launch_bounds__(256) skinny_dw_tiled_kernel(const float* __res
     if (q + 8 * j < N) *reinterpret_cast<float4*>(p + (int64_t)(q + 8 * j) * K) = acc[j];
 }
 
+// The input gradient of a narrow head over DCNv2's two towers (finetune: Linear(D + H -> 1)), with both towers' first
+// backward step in the same pass — what layers.join_bwd_input does with two MFMA products and their epilogues
+// (gemm_x3.hip EPI_BWD_FUSED / EPI_RELU_MASK_COLSUM), here one streaming launch:  v = dz w  (N <= 8 terms), then
+//   columns c <  D (cross tower):  g = v,  t = v x0,  dx0 = v u (+ v),          partial column sums of t
+//   columns c >= D (deep tower):   dzr = final > 0 ? v : 0,                     partial column sums of dzr
+// one partial row per 128-row tile (the layout the GEMM epilogues leave for mapx_sum_tasks).
+// Block = 64 float4 columns x 4 row lanes over a 128-row tile; the row lanes' sums meet in LDS in a fixed order.
+template <int NT>
+__global__ void __launch_bounds__(256) skinny_join_bwd_kernel(
+    const float* __restrict__ dz, int64_t lddz, const float* __restrict__ w, int64_t ldw, int M, int N, int D, int H,
+    const float* __restrict__ fin, int64_t ldf, const float* __restrict__ x0, int64_t ldx0, const float* __restrict__ u,
+    int64_t ldu, int plus_v, float* __restrict__ g, int64_t ldg, float* __restrict__ t, int64_t ldt,
+    float* __restrict__ dx0, int64_t lddx0, float* __restrict__ dzr, int64_t lddzr, float* __restrict__ part_cross,
+    float* __restrict__ part_deep) {
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = 4 * (blockIdx.x * 64 + cl);
+  const int m0 = blockIdx.y * 128, m1 = (m0 + 128 < M) ? m0 + 128 : M;
+  const bool live = c < D + H, cross = c < D;
+  float4 wv[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+    wv[n] = (live && n < N) ? *reinterpret_cast<const float4*>(w + (int64_t)n * ldw + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) {
+    for (int m = m0 + rl; m < m1; m += 4) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        if (n < N) {
+          const float d = dz[(int64_t)m * lddz + n];
+          v.x += d * wv[n].x; v.y += d * wv[n].y; v.z += d * wv[n].z; v.w += d * wv[n].w;
+        }
+      }
+      if (cross) {
+        const float4 a = *reinterpret_cast<const float4*>(x0 + (int64_t)m * ldx0 + c);
+        const float4 b = *reinterpret_cast<const float4*>(u + (int64_t)m * ldu + c);
+        const float4 tt = make_float4(v.x * a.x, v.y * a.y, v.z * a.z, v.w * a.w);
+        float4 dd = make_float4(v.x * b.x, v.y * b.y, v.z * b.z, v.w * b.w);
+        if (plus_v) { dd.x += v.x; dd.y += v.y; dd.z += v.z; dd.w += v.w; }
+        *reinterpret_cast<float4*>(g + (int64_t)m * ldg + c) = v;
+        *reinterpret_cast<float4*>(t + (int64_t)m * ldt + c) = tt;
+        *reinterpret_cast<float4*>(dx0 + (int64_t)m * lddx0 + c) = dd;
+        sum.x += tt.x; sum.y += tt.y; sum.z += tt.z; sum.w += tt.w;
+      } else {
+        const float4 f = *reinterpret_cast<const float4*>(fin + (int64_t)m * ldf + c);
+        const float4 z = make_float4(f.x > 0.f ? v.x : 0.f, f.y > 0.f ? v.y : 0.f, f.z > 0.f ? v.z : 0.f,
+                                     f.w > 0.f ? v.w : 0.f);
+        *reinterpret_cast<float4*>(dzr + (int64_t)m * lddzr + (c - D)) = z;
+        sum.x += z.x; sum.y += z.y; sum.z += z.z; sum.w += z.w;
+      }
+    }
+  }
+  __shared__ float4 red[4][64];
+  red[rl][cl] = sum;
+  __syncthreads();
+  if (rl == 0 && live) {
+    float4 s4 = red[0][cl];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      const float4 q = red[k][cl];
+      s4.x += q.x; s4.y += q.y; s4.z += q.z; s4.w += q.w;
+    }
+    if (cross) *reinterpret_cast<float4*>(part_cross + (int64_t)blockIdx.y * D + c) = s4;
+    else *reinterpret_cast<float4*>(part_deep + (int64_t)blockIdx.y * H + (c - D)) = s4;
+  }
+}
+
 template <template <int> class Launch, class... A>
 static bool skinny_dispatch(int N, A... a) {
   if (N <= 1) Launch<1>::go(a...);
@@ -246,4 +313,28 @@ extern "C" int mapx_skinny_linear_dx(const float* dy, int64_t ldy, const float* 
   if (M == 0) return MAPX_OK;
   skinny_dispatch<DxLaunch>(N, dy, ldy, w, ldw, M, N, K, dx, lddx, stream);
   return check_launch("skinny_linear_dx");
+}
+
+extern "C" int mapx_skinny_join_bwd(const float* dz, int64_t lddz, const float* w, int64_t ldw, int M, int N, int D,
+                                    int H, const float* final_act, int64_t ldf, const float* x0, int64_t ldx0,
+                                    const float* u, int64_t ldu, int plus_v, float* g, int64_t ldg, float* t,
+                                    int64_t ldt, float* dx0, int64_t lddx0, float* dzr, int64_t lddzr,
+                                    float* part_cross, float* part_deep, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(dz && w && final_act && x0 && u && g && t && dx0 && dzr && part_cross && part_deep,
+               "skinny_join_bwd: null pointer");
+  MAPX_REQUIRE(M >= 1 && N >= 1 && N <= 8 && D >= 4 && H >= 4 && D % 4 == 0 && H % 4 == 0 && lddz >= N,
+               "skinny_join_bwd: bad sizes");
+  MAPX_REQUIRE(al16(w, ldw) && al16(final_act, ldf) && al16(x0, ldx0) && al16(u, ldu) && al16(g, ldg) && al16(t, ldt) &&
+                   al16(dx0, lddx0) && al16(dzr, lddzr) && (uintptr_t)part_cross % 16 == 0 && (uintptr_t)part_deep % 16 == 0,
+               "skinny_join_bwd: rows must be 16-byte aligned");
+  const dim3 grid(grid_for((D + H) / 4, 64), (M + 127) / 128);
+#define MAPX_SJ(NT)                                                                                                   \
+  hipLaunchKernelGGL(skinny_join_bwd_kernel<NT>, grid, dim3(256), 0, stream, dz, lddz, w, ldw, M, N, D, H, final_act, \
+                     ldf, x0, ldx0, u, ldu, plus_v, g, ldg, t, ldt, dx0, lddx0, dzr, lddzr, part_cross, part_deep)
+  if (N == 1) MAPX_SJ(1);
+  else if (N <= 4) MAPX_SJ(4);
+  else MAPX_SJ(8);
+#undef MAPX_SJ
+  return check_launch("skinny_join_bwd");
 }

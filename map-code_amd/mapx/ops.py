@@ -1145,6 +1145,25 @@ def gemm_bwd_fused(dy, w, c0, add=None, mask=None, x0=None, u=None, dx0=None, pl
     return C, t, dx0, part
 
 
+def skinny_join_bwd(dz, w, final, D, x0, u, plus_v):
+    """The input gradient of a head of at most 8 outputs over DCNv2's towers, both towers' first backward step included
+    (csrc/skinny.hip; the wide heads' form: gemm_bwd_fused + linear_bwd_input(relu_of=, colsum_to=)).
+    -> (g, t, dx0 [M, D], dzr [M, H], part_cross [tiles, D], part_deep [tiles, H])."""
+    require_gpu(dz, w, final, x0, u)
+    M, Nn = dz.shape
+    H = final.shape[1] - D
+    f32 = dict(dtype=torch.float32, device=dz.device)
+    g, t, dx0 = torch.empty(M, D, **f32), torch.empty(M, D, **f32), torch.empty(M, D, **f32)
+    dzr = torch.empty(M, H, **f32)
+    tiles = (M + 127) // 128
+    pc, pd = torch.empty(tiles, D, **f32), torch.empty(tiles, H, **f32)
+    with _timed("skinny_linear", 4.0 * (3.0 * M * (D + H) + 3.0 * M * D)):
+        check(lib.mapx_skinny_join_bwd(ptr(dz), dz.stride(0), ptr(w), w.stride(0), M, Nn, D, H, final.data_ptr(),
+                                       final.stride(0), ptr(x0), x0.stride(0), ptr(u), u.stride(0), int(plus_v), ptr(g),
+                                       D, ptr(t), D, ptr(dx0), D, ptr(dzr), H, ptr(pc), ptr(pd), stream()))
+    return g, t, dx0, dzr, pc, pd
+
+
 def defer_part_rows(dst, part, col0, ncols):
     """Queue dst[0:ncols] = column sums of part[:, col0 : col0 + ncols] (partial rows of a fused epilogue)."""
     defer_sum(dst, part.view(-1)[col0:], part.stride(0), part.shape[0], ncols)

@@ -1065,3 +1065,26 @@ def test_skinny_linear_kernels_vs_fp64(ops, monkeypatch, M, N, K):
     dx_ref = dy.double() @ w.double()
     dx = ops.linear_bwd_input(dy, w)
     assert float((dx.double() - dx_ref).abs().max()) <= 2e-6 * float(dx_ref.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,D,H,plus_v", [(4096, 1, 368, 1000, False), (300, 3, 8, 12, True), (129, 8, 64, 4, False)])
+def test_skinny_join_bwd_vs_fp64(ops, M, N, D, H, plus_v):
+    """The narrow heads' input gradient over DCNv2's towers with both towers' first backward step in one streaming
+    pass (mapx_skinny_join_bwd): every output and the per-tile partial sums against fp64."""
+    g_ = torch.Generator().manual_seed(M + N + D)
+    dz = torch.randn(M, N, generator=g_).to(DEV)
+    w = torch.randn(N, D + H, generator=g_).to(DEV)
+    final = torch.randn(M, D + H, generator=g_).to(DEV)
+    x0 = torch.randn(M, D, generator=g_).to(DEV)
+    u = torch.randn(M, D, generator=g_).to(DEV)
+    g, t, dx0, dzr, pc, pd = ops.skinny_join_bwd(dz, w, final, D, x0, u, plus_v)
+    v = dz.double() @ w.double()
+    vc, vd = v[:, :D], v[:, D:]
+    ref = dict(g=vc, t=vc * x0.double(), dx0=vc * u.double() + (vc if plus_v else 0.0),
+               dzr=torch.where(final[:, D:] > 0, vd, torch.zeros_like(vd)))
+    for name, got in (("g", g), ("t", t), ("dx0", dx0), ("dzr", dzr)):
+        assert float((got.double() - ref[name]).abs().max()) <= 2e-6 * max(1.0, float(ref[name].abs().max())), name
+    assert pc.shape == ((M + 127) // 128, D) and pd.shape == ((M + 127) // 128, H)
+    assert float((pc.double().sum(0) - ref["t"].sum(0)).abs().max()) <= 1e-4 * max(1.0, float(ref["t"].sum(0).abs().max()))
+    assert float((pd.double().sum(0) - ref["dzr"].sum(0)).abs().max()) <= 1e-4 * max(1.0, float(ref["dzr"].sum(0).abs().max()))
