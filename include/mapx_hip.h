@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 39
+#define MAPX_ABI_VERSION 40
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -393,9 +393,11 @@ int mapx_dynamic_mask_mfp_rows(const int64_t* split_ids, int64_t N, const int64_
 /* out [B,F] = rows sel[c .. c + B) of src [N,F] (c = *sel_cursor_dev_opt, 0 when NULL): the batch of an RFD or
  * finetune step cut from the HBM-resident split inside the step — the DataLoader's collate of trainer.py:51-58,
  * 122-129, 431-438 — so that a captured step walks an epoch's permutation by itself (mapx_step_advance moves the
- * cursor).  Labels: F = 1.  Row numbers outside [0, N) are clamped. */
+ * cursor).  Labels: F = 1; out_f32_opt (then `out` may be NULL): the values as fp32 — the finetune step's
+ * labels.float() (models.py:91) without a launch of its own.  Row numbers outside [0, N) are clamped. */
 int mapx_take_rows_i64(const int64_t* src, int64_t N, int F, const int64_t* sel,
-                       const int64_t* sel_cursor_dev_opt, int64_t B, int64_t* out, hipStream_t stream);
+                       const int64_t* sel_cursor_dev_opt, int64_t B, int64_t* out, float* out_f32_opt,
+                       hipStream_t stream);
 /* trainer.py:233-262 (RFD).  mode = RFD_replace: 0 Unigram, 1 Uniform (idx_low/idx_high [F]),
  * 2 Whole-Uniform (ids 10..V-1), 3 Whole-Unigram; x_train [N,F] device-resident; labels f32 [B,F]. */
 int mapx_dynamic_mask_rfd(const int64_t* ids, int64_t B, int F, int L,

@@ -242,7 +242,7 @@ namespace mapx {
 __global__ void __launch_bounds__(256) take_rows_i64_kernel(const int64_t* __restrict__ src, int64_t N, int F,
                                                             const int64_t* __restrict__ sel,
                                                             const int64_t* __restrict__ cursor, int64_t B,
-                                                            int64_t* __restrict__ out) {
+                                                            int64_t* __restrict__ out, float* __restrict__ out_f32) {
   const int64_t c0 = cursor ? *cursor : 0;
   const int64_t total = B * F;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -250,18 +250,21 @@ __global__ void __launch_bounds__(256) take_rows_i64_kernel(const int64_t* __res
     const int64_t b = e / F;
     int64_t r = sel[c0 + b];
     r = r < 0 ? 0 : (r >= N ? N - 1 : r);           // (caller-checked; a wrong cursor must not read out of bounds)
-    out[e] = src[r * F + (e - b * F)];
+    const int64_t v = src[r * F + (e - b * F)];
+    if (out_f32) out_f32[e] = (float)v;
+    else out[e] = v;
   }
 }
 }  // namespace mapx
 
 extern "C" int mapx_take_rows_i64(const int64_t* src, int64_t N, int F, const int64_t* sel,
-                                  const int64_t* sel_cursor_dev_opt, int64_t B, int64_t* out, hipStream_t stream) {
+                                  const int64_t* sel_cursor_dev_opt, int64_t B, int64_t* out, float* out_f32_opt,
+                                  hipStream_t stream) {
   using namespace mapx;
-  MAPX_REQUIRE(src && sel && out && N > 0 && F > 0 && B >= 0, "take_rows_i64: bad arguments");
+  MAPX_REQUIRE(src && sel && (out || out_f32_opt) && N > 0 && F > 0 && B >= 0, "take_rows_i64: bad arguments");
   if (B == 0) return MAPX_OK;
   hipLaunchKernelGGL(take_rows_i64_kernel, dim3(grid_for(B * F, 256)), dim3(256), 0, stream, src, N, F, sel,
-                     sel_cursor_dev_opt, B, out);
+                     sel_cursor_dev_opt, B, out, out_f32_opt);
   return check_launch("take_rows_i64");
 }
 

@@ -968,7 +968,7 @@ class _Bce(Function):
         ctx.save_for_backward(dl)
         ctx.mark_non_differentiable(out3)
         ctx.set_materialize_grads(False)
-        return out3[0].clone(), out3
+        return out3[0], out3                   # (a view of the non-differentiable statistics: no copy launch)
 
     @staticmethod
     def backward(ctx, g, _):

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmapx_hip.so")
 
-MAPX_ABI_VERSION = 39
+MAPX_ABI_VERSION = 40
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_CROSS, EPI_ADD, EPI_RELU_MASK, EPI_RELU_MASK_COLSUM = range(7)
 
 _p, _i, _i64, _u64, _f, _d, _sz = (C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double,
@@ -104,7 +104,7 @@ SIGNATURES = {
                                   _p, _p]),
     "mapx_adamw_dense": (_i, [_p, _p, _p, _p, _i64, _p, _i, _p, _d, _d, _d, _d, _p]),
     "mapx_step_advance": (_i, [_p, _p, _i64, _p]),
-    "mapx_take_rows_i64": (_i, [_p, _i64, _i, _p, _p, _i64, _p, _p]),
+    "mapx_take_rows_i64": (_i, [_p, _i64, _i, _p, _p, _i64, _p, _p, _p]),
     "mapx_act_fwd": (_i, [_i, _p, _i64, _i, _p, _i64, _p]),
     "mapx_act_bwd": (_i, [_i, _p, _i64, _p, _i64, _i, _p, _p]),
     "mapx_vocab_table_init": (_i, [_p, _p, _p, _i64, _p]),

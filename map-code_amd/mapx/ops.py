@@ -1414,9 +1414,10 @@ def adamw_dense(p, g, m, v, sched, done, beta1, beta2, eps, wd, shadow=None):
                                               stream()))
 
 
-def take_rows(src, sel, cursor=None, batch=None):
+def take_rows(src, sel, cursor=None, batch=None, as_f32=False):
     """src[sel[c : c + batch]] for an int64 matrix / vector resident on the device (c = the device scalar `cursor`,
-    0 and batch = len(sel) without one): the batch of an RFD / finetune step, cut inside the step."""
+    0 and batch = len(sel) without one): the batch of an RFD / finetune step, cut inside the step.
+    as_f32: the values as float32 (the finetune labels: no labels.float() launch behind it)."""
     require_gpu(src, sel)
     if src.dtype != torch.int64 or sel.dtype != torch.int64 or not src.is_contiguous() or not sel.is_contiguous():
         raise TypeError("take_rows: contiguous int64 source and row numbers")
@@ -1426,10 +1427,12 @@ def take_rows(src, sel, cursor=None, batch=None):
     if cursor is None and B > sel.numel():
         raise IndexError(f"take_rows: {B} rows of a list of {sel.numel()}")
     F = 1 if src.dim() == 1 else src.shape[1]
-    out = torch.empty((B,) if src.dim() == 1 else (B, F), dtype=torch.int64, device=src.device)
+    out = torch.empty((B,) if src.dim() == 1 else (B, F), dtype=torch.float32 if as_f32 else torch.int64,
+                      device=src.device)
     if B == 0:
         return out
-    check(lib.mapx_take_rows_i64(ptr(src), src.shape[0], F, ptr(sel), ptr(cursor), B, ptr(out), stream()))
+    check(lib.mapx_take_rows_i64(ptr(src), src.shape[0], F, ptr(sel), ptr(cursor), B, None if as_f32 else ptr(out),
+                                 ptr(out) if as_f32 else None, stream()))
     return out
 
 

@@ -513,7 +513,8 @@ class Trainer:
         ref = X
         ids = ops.take_rows(ref.split.X, ref.sel, ref.cursor, ref.batch if ref.cursor is not None else None)
         if isinstance(Y, RowsRef):        # (the same object, or its twin in a captured step's static inputs)
-            Y = ops.take_rows(Y.split.Y, Y.sel, Y.cursor, Y.batch if Y.cursor is not None else None) if labels else None
+            Y = ops.take_rows(Y.split.Y, Y.sel, Y.cursor, Y.batch if Y.cursor is not None else None,
+                              as_f32=True) if labels else None          # (the BCE head takes labels.float())
         return ids, Y
 
     def _rfd_fwd_bwd(self, X, Y):

@@ -1022,6 +1022,8 @@ def test_take_rows_cuts_a_batch_behind_a_device_cursor(ops):
     cur = torch.tensor([128], dtype=torch.int64, device=DEV)
     assert torch.equal(ops.take_rows(X, sel, cur, 100), X[sel[128:228]])
     assert torch.equal(ops.take_rows(Y, sel, cur, 100), Y[sel[128:228]])
+    yf = ops.take_rows(Y, sel, cur, 100, as_f32=True)
+    assert yf.dtype == torch.float32 and torch.equal(yf, Y[sel[128:228]].float())
     assert ops.take_rows(X, sel[:0].contiguous()).shape == (0, 23)
     bad = torch.tensor([-5, 2000, 7], dtype=torch.int64, device=DEV)
     assert torch.equal(ops.take_rows(X, bad), X[torch.tensor([0, 999, 7], device=DEV)])
