@@ -224,7 +224,8 @@ class GraphedBackward:
     def __init__(self, trainer, fwd_bwd_fn, X, Y):
         from . import layers
         self.trainer = _weak(trainer)       # no trainer <-> graph cycle: both die by reference count
-        self.X, self.Y = X.clone(), Y.clone()
+        self.X = X.clone()
+        self.Y = self.X if Y is X else Y.clone()        # (row references: one list of row numbers, one copy per step)
         # (gloo stages every message through host memory and synchronises the device doing so: its exchange stays
         # eager unless MAPX_DP_GLOO_GRAPH=1 asks for the captured tail — the 2-rank test on one GPU does)
         self.early = (parallel.exchanging() and parallel.EXCHANGE == "gather" and X.is_cuda
@@ -323,7 +324,8 @@ class GraphedBackward:
     def __call__(self, X, Y):
         t = [time.perf_counter()]
         self.X.copy_(X)
-        self.Y.copy_(Y)
+        if self.Y is not self.X:
+            self.Y.copy_(Y)
         self._t_launch = time.perf_counter()
         self.graph.replay()
         self.replays += 1
