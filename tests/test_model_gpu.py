@@ -510,3 +510,37 @@ def test_dcnv2_step_with_another_hidden_act_vs_oracle(kind):
         np.testing.assert_allclose(g.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-5 * scale, err_msg=name)
     g0, _ = model.embed.table.dense_grad()
     np.testing.assert_allclose(g0.cpu().numpy(), P["embed.embedding.weight"].grad.numpy(), rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,relu", [(1001, False), (1001, True), (37, True)])
+def test_linear_with_an_input_width_that_is_not_a_multiple_of_8(K, relu):
+    """DeepFM's heads read cat([dnn, lr + fm]) — 1001 columns: layers._Linear pads both GEMM operands with zero
+    columns to the next multiple of 8 (the vectorised operand path) and cuts the gradients back.  Forward, dX, dW
+    and db against fp64, with and without the optimizer's gradient slot."""
+    from mapx import layers
+    torch.manual_seed(K)
+    lin = layers.HipLinear(K, 64, relu=relu).to(DEV)
+    x = torch.randn(512, K, device=DEV, requires_grad=True)
+    r = torch.randn(512, 64, device=DEV)
+    y = lin(x)
+    (y * r).sum().backward()
+    xd = x.detach().double().requires_grad_(True)
+    wd, bd = lin.weight.detach().double().requires_grad_(True), lin.bias.detach().double().requires_grad_(True)
+    yd = xd @ wd.T + bd
+    yd = torch.relu(yd) if relu else yd
+    (yd * r.double()).sum().backward()
+    tol = lambda ref: 3e-6 * max(1.0, float(ref.detach().abs().max()))
+    assert float((y.detach().double() - yd.detach()).abs().max()) <= tol(yd)
+    assert x.grad.shape == (512, K) and float((x.grad.double() - xd.grad).abs().max()) <= tol(xd.grad)
+    assert float((lin.weight.grad.double() - wd.grad).abs().max()) <= tol(wd.grad)
+    assert float((lin.bias.grad.double() - bd.grad).abs().max()) <= tol(bd.grad)
+    # the optimizer-owned slot: the padded dW is copied into it, autograd gets None
+    slot = torch.zeros_like(lin.weight)
+    lin.weight._mapx_grad = slot
+    lin.weight.grad = None
+    (lin(x.detach()) * r).sum().backward()
+    assert lin.weight.grad is None
+    from mapx import ops
+    ops.flush_deferred()
+    assert float((slot.double() - wd.grad).abs().max()) <= tol(wd.grad)
