@@ -150,7 +150,11 @@ def build(args, device, rank):
                  embed_dropout_rate=0.0, embed_norm=False, hidden_size=1000, num_hidden_layers=3,
                  hidden_act="relu", hidden_dropout_rate=0.0, num_cross_layers=3, pt_neg_num=25,
                  proj_size=32, pretrain=pt != "CTR", pt_type="MFP" if pt == "CTR" else pt, RFD_replace="Unigram",
-                 feat_count=feat_count, seed=42, rank=rank, compute_dtype="bf16" if args.dtype == "bf16" else "fp32")
+                 feat_count=feat_count, seed=42, rank=rank, compute_dtype="bf16" if args.dtype == "bf16" else "fp32",
+                 # (the secondary backbones of tools/step_bench.py --model: the reference scripts' values)
+                 cin_layer_units="50,50", use_lr=False, num_attn_layers=2, attn_size=40, num_attn_heads=1,
+                 attn_probs_dropout_rate=0.0, res_conn=False, attn_scale=False, dnn_size=1000, num_dnn_layers=0,
+                 dnn_act="relu", dnn_drop=0.0)
     torch.manual_seed(42)
     model = BaseModel.from_config(cfg)
     # the cosine schedule must outlast the run at every world size (the sharded epoch shrinks with N),

@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 40
+#define MAPX_ABI_VERSION 41
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -137,9 +137,11 @@ int mapx_host_free(void* p);
  * (dxi[r,m] = sum_h dhad[r,h,m] x0t[r,h]; dx0t[r,h] (+)= sum_m dhad[r,h,m] xi[r,m]); pooling
  * out[b*ld_out+o] = sum_d xt[b,d,o] and its backward dxt[b,d,o] (+)= g[b*ld_g+o]. */
 int mapx_transpose_batched(const float* x, int64_t B, int R, int C, float* out, hipStream_t stream);
-int mapx_cin_outer_fwd(const float* x0t, int F, const float* xi, int H, int64_t R, float* had,
+/* (ld_had / ld_dhad >= F*H: row stride of the Hadamard matrix; the forward zeroes columns F*H .. ld - 1, so that a stride
+ * that is a multiple of 8 floats gives the 1x1 convolution's GEMM aligned rows and a vectorisable K) */
+int mapx_cin_outer_fwd(const float* x0t, int F, const float* xi, int H, int64_t R, float* had, int64_t ld_had,
                        hipStream_t stream);
-int mapx_cin_outer_bwd(const float* dhad, const float* x0t, int F, const float* xi, int H, int64_t R,
+int mapx_cin_outer_bwd(const float* dhad, int64_t ld_dhad, const float* x0t, int F, const float* xi, int H, int64_t R,
                        float* dx0t, int accumulate_x0, float* dxi, hipStream_t stream);
 int mapx_cin_pool_fwd(const float* xt, int64_t B, int E, int H, float* out, int64_t ld_out,
                       hipStream_t stream);

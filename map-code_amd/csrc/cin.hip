@@ -25,17 +25,18 @@ __global__ void __launch_bounds__(256) transpose_batched_kernel(const float* __r
   }
 }
 
-// had[r, h*H + m] = x0t[r, h] * xi[r, m]
+// had[r * ld + h*H + m] = x0t[r, h] * xi[r, m]; columns F*H .. ld - 1 (the padding that gives the 1x1 convolution's GEMM
+// 16-byte rows and a K that is a multiple of 8: F*H = 529 or 1150 left it the scalar operand path) are zeroed
 __global__ void __launch_bounds__(256) cin_outer_fwd_kernel(const float* __restrict__ x0t, int F,
                                                             const float* __restrict__ xi, int H, int64_t R,
-                                                            float* __restrict__ had) {
-  const int64_t K = (int64_t)F * H, n = R * K;
+                                                            float* __restrict__ had, int64_t ld) {
+  const int64_t K = (int64_t)F * H, n = R * ld;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
        t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = t / K;
-    const int k = (int)(t - r * K);
+    const int64_t r = t / ld;
+    const int k = (int)(t - r * ld);
     const int h = k / H, m = k - h * H;
-    had[t] = x0t[r * F + h] * xi[r * H + m];
+    had[t] = k < K ? x0t[r * F + h] * xi[r * H + m] : 0.f;
   }
 }
 
@@ -44,11 +45,11 @@ __global__ void __launch_bounds__(256) cin_outer_bwd_kernel(const float* __restr
                                                             const float* __restrict__ x0t, int F,
                                                             const float* __restrict__ xi, int H, int64_t R,
                                                             float* __restrict__ dx0t, int accumulate_x0,
-                                                            float* __restrict__ dxi) {
+                                                            float* __restrict__ dxi, int64_t ld) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= R) return;
-  const float* __restrict__ g = dhad + r * (int64_t)F * H;
+  const float* __restrict__ g = dhad + r * ld;
   const float* __restrict__ a = x0t + r * F;
   const float* __restrict__ c = xi + r * H;
   for (int m0 = 0; m0 < H; m0 += 64) {                  // dxi: lanes over m, loop over h
@@ -107,23 +108,24 @@ extern "C" int mapx_transpose_batched(const float* x, int64_t B, int R, int C, f
 }
 
 extern "C" int mapx_cin_outer_fwd(const float* x0t, int F, const float* xi, int H, int64_t R, float* had,
-                                  hipStream_t stream) {
+                                  int64_t ld_had, hipStream_t stream) {
   using namespace mapx;
-  MAPX_REQUIRE(R >= 0 && F > 0 && H > 0, "cin_outer_fwd: bad sizes");
+  MAPX_REQUIRE(R >= 0 && F > 0 && H > 0 && ld_had >= (int64_t)F * H, "cin_outer_fwd: bad sizes");
   if (R == 0) return MAPX_OK;
   MAPX_REQUIRE(x0t && xi && had, "cin_outer_fwd: null pointer");
-  hipLaunchKernelGGL(cin_outer_fwd_kernel, dim3(grid_for(R * F * H, 256)), dim3(256), 0, stream, x0t, F, xi, H, R, had);
+  hipLaunchKernelGGL(cin_outer_fwd_kernel, dim3(grid_for(R * ld_had, 256)), dim3(256), 0, stream, x0t, F, xi, H, R, had,
+                     ld_had);
   return check_launch("cin_outer_fwd");
 }
 
-extern "C" int mapx_cin_outer_bwd(const float* dhad, const float* x0t, int F, const float* xi, int H, int64_t R,
-                                  float* dx0t, int accumulate_x0, float* dxi, hipStream_t stream) {
+extern "C" int mapx_cin_outer_bwd(const float* dhad, int64_t ld_dhad, const float* x0t, int F, const float* xi, int H,
+                                  int64_t R, float* dx0t, int accumulate_x0, float* dxi, hipStream_t stream) {
   using namespace mapx;
-  MAPX_REQUIRE(R >= 0 && F > 0 && H > 0 && R < (1LL << 33), "cin_outer_bwd: bad sizes");
+  MAPX_REQUIRE(R >= 0 && F > 0 && H > 0 && R < (1LL << 33) && ld_dhad >= (int64_t)F * H, "cin_outer_bwd: bad sizes");
   if (R == 0) return MAPX_OK;
   MAPX_REQUIRE(dhad && x0t && xi && dx0t && dxi, "cin_outer_bwd: null pointer");
   hipLaunchKernelGGL(cin_outer_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, stream, dhad, x0t, F, xi, H,
-                     R, dx0t, accumulate_x0, dxi);
+                     R, dx0t, accumulate_x0, dxi, ld_dhad);
   return check_launch("cin_outer_bwd");
 }
 

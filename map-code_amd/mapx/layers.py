@@ -900,12 +900,22 @@ class _CinStack(Function):
         units = [w.shape[0] for w in ws]
         out = torch.empty(B, sum(units), dtype=torch.float32, device=x3.device)
         xi, saved, col = x0t, [], 0
+        pad = PAD_K and B * E >= 256
+        wps = []
         for w, b in zip(ws, bs):
-            had = ops.cin_outer_fwd(x0t, xi)
-            nxt = ops.linear_fwd(had, w.view(w.shape[0], -1), b)
+            # The Hadamard matrix has F * H_i columns (529, 1150 at Avazu's sizes) and the layer `units` = 50 outputs:
+            # neither a multiple of 8 floats, which left all three GEMMs of a layer the scalar operand path (380 + 167 us
+            # forward, 266 + 133 dX, 238 + 188 dW in a 2.9-ms step).  Its rows are padded with zero columns by the kernel
+            # that writes them, the weight (50 x K floats) by a copy.
+            had = ops.cin_outer_fwd(x0t, xi, pad_to=8 if pad else 1)
+            w2 = w.detach().view(w.shape[0], -1)
+            wp = torch.nn.functional.pad(w2, (0, had.shape[1] - w2.shape[1])) if had.shape[1] != w2.shape[1] else w2
+            nxt = ops.linear_fwd(had, wp, b)
             ops.cin_pool_fwd(nxt, B, E, out[:, col:col + w.shape[0]])
             saved.append((xi, had))
+            wps.append(wp)
             xi, col = nxt, col + w.shape[0]
+        ctx.wps = wps
         ctx.saved, ctx.x0t, ctx.shape = saved, x0t, (B, F, E)
         ctx.ws = ws
         ctx.slots = [(_grad_slot(w), _grad_slot(b)) for w, b in zip(ws, bs)]
@@ -927,12 +937,25 @@ class _CinStack(Function):
             dy = dnext if dnext is not None else torch.empty(B * E, u, dtype=torch.float32, device=g.device)
             ops.cin_pool_bwd(g[:, col:col + u], B, E, dy, accumulate=dnext is not None)
             sw, sb = ctx.slots[i]
-            w2 = w.view(u, -1)
-            dw = ops.linear_bwd_weight(dy, had, out=None if sw is None else sw.view(u, -1))
+            wp = ctx.wps[i]
+            Kc, Kp = w[0].numel(), wp.shape[1]
             db = ops.colsum(dy, out=sb)
-            grads[2 * i] = None if sw is not None else dw.view_as(w)
             grads[2 * i + 1] = None if sb is not None else db
-            dhad = ops.linear_bwd_input(dy, w2)
+            if Kp != Kc or (PAD_K and u % 8 != 0 and dy.shape[0] >= 256):
+                # dy's `units` columns padded to a multiple of 8 as well (a 15-MB copy): dW and dX both read it
+                up = (u + 7) // 8 * 8
+                dyp = torch.nn.functional.pad(dy, (0, up - u))
+                wpp = torch.nn.functional.pad(wp, (0, 0, 0, up - u))
+                dwp = ops.linear_bwd_weight(dyp, had)                       # [up, Kp]
+                if sw is not None:
+                    sw.view(u, -1).copy_(dwp[:u, :Kc])
+                else:
+                    grads[2 * i] = dwp[:u, :Kc].contiguous().view_as(w)
+                dhad = ops.linear_bwd_input(dyp, wpp)                       # [R, Kp]
+            else:
+                dw = ops.linear_bwd_weight(dy, had, out=None if sw is None else sw.view(u, -1))
+                grads[2 * i] = None if sw is not None else dw.view_as(w)
+                dhad = ops.linear_bwd_input(dy, wp)
             dxi = ops.cin_outer_bwd(dhad, x0t, xi, dx0t, accumulate_x0=i != len(ws) - 1)
             if i == 0:                         # layer 1's X_i IS X_0
                 dx0t += dxi

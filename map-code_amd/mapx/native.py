@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmapx_hip.so")
 
-MAPX_ABI_VERSION = 40
+MAPX_ABI_VERSION = 41
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_CROSS, EPI_ADD, EPI_RELU_MASK, EPI_RELU_MASK_COLSUM = range(7)
 
 _p, _i, _i64, _u64, _f, _d, _sz = (C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double,
@@ -34,8 +34,8 @@ SIGNATURES = {
     "mapx_pack_sparse": (_i, [_p, _p, _i, _p, _p, _i64, _i64, _f, C.c_int32, _p, _p, _p]),
     "mapx_publish_i32": (_i, [_p, _i, _p, _p, _p]),
     "mapx_transpose_batched": (_i, [_p, _i64, _i, _i, _p, _p]),
-    "mapx_cin_outer_fwd": (_i, [_p, _i, _p, _i, _i64, _p, _p]),
-    "mapx_cin_outer_bwd": (_i, [_p, _p, _i, _p, _i, _i64, _p, _i, _p, _p]),
+    "mapx_cin_outer_fwd": (_i, [_p, _i, _p, _i, _i64, _p, _i64, _p]),
+    "mapx_cin_outer_bwd": (_i, [_p, _i64, _p, _i, _p, _i, _i64, _p, _i, _p, _p]),
     "mapx_cin_pool_fwd": (_i, [_p, _i64, _i, _i, _p, _i64, _p]),
     "mapx_cin_pool_bwd": (_i, [_p, _i64, _i64, _i, _i, _p, _i, _p]),
     "mapx_host_alloc_coherent": (_i, [C.c_size_t, C.POINTER(C.c_void_p)]),

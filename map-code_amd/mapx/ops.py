@@ -533,13 +533,15 @@ def transpose_batched(x):
     return out
 
 
-def cin_outer_fwd(x0t, xi):
-    """had[r, h*H+m] = x0t[r,h] * xi[r,m]: x0t [R,F], xi [R,H] -> [R, F*H]  (layers.py:714-715)."""
+def cin_outer_fwd(x0t, xi, pad_to=1):
+    """had[r, h*H+m] = x0t[r,h] * xi[r,m]: x0t [R,F], xi [R,H] -> [R, F*H]  (layers.py:714-715); pad_to = 8: the row
+    is padded with zero columns to a multiple of 8 floats (-> [R, ceil8(F*H)], the GEMM's vectorised operand path)."""
     require_gpu(x0t, xi)
     R, F = x0t.shape
     H = xi.shape[1]
-    had = torch.empty(R, F * H, dtype=torch.float32, device=x0t.device)
-    check(lib.mapx_cin_outer_fwd(ptr(x0t), F, ptr(xi), H, R, ptr(had), stream()))
+    ld = (F * H + pad_to - 1) // pad_to * pad_to
+    had = torch.empty(R, ld, dtype=torch.float32, device=x0t.device)
+    check(lib.mapx_cin_outer_fwd(ptr(x0t), F, ptr(xi), H, R, ptr(had), ld, stream()))
     return had
 
 
@@ -549,8 +551,10 @@ def cin_outer_bwd(dhad, x0t, xi, dx0t, accumulate_x0):
     R, F = x0t.shape
     H = xi.shape[1]
     dxi = torch.empty(R, H, dtype=torch.float32, device=x0t.device)
-    check(lib.mapx_cin_outer_bwd(ptr(dhad), ptr(x0t), F, ptr(xi), H, R, ptr(dx0t), int(accumulate_x0), ptr(dxi),
-                                 stream()))
+    if dhad.stride(1) != 1 or dhad.shape[1] < F * H:
+        raise ValueError("cin_outer_bwd: dhad [R, >= F*H] with unit column stride")
+    check(lib.mapx_cin_outer_bwd(ptr(dhad), dhad.stride(0), ptr(x0t), F, ptr(xi), H, R, ptr(dx0t), int(accumulate_x0),
+                                 ptr(dxi), stream()))
     return dxi
 
 
