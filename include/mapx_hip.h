@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 41
+#define MAPX_ABI_VERSION 42
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -294,14 +294,16 @@ int mapx_sum_tasks(const mapx_sum_task* tasks_host, int ntasks, hipStream_t stre
  * RFD's Linear(F*P -> F) (reference models.py:119-124: pred_rfd[2]) and the finetune head Linear(D+H -> 1)
  * (models.py:304, 319: fc_out).  x [M,K], w [N,K], dy / y [M,N]; K % 4 == 0, rows of x / w / dx 16-byte aligned.
  *   fwd: y = x w^T + bias_opt (relu != 0: max(., 0));   dx = dy w;
- *   dw:  part [mapx_skinny_chunks()][N*K] <- per-row-chunk partial sums of dy^T x; the caller adds the chunks with
- *        mapx_sum_tasks (stride N*K, nsplit = chunks), alone or with the step's other deferred sums.
+ *   dw:  part [chunks][N*K] <- per-row-chunk partial sums of dy^T x (chunks: mapx_skinny_chunks() = 128 for a batch
+ *        of a few thousand rows; more for taller problems: a chunk is one workgroup); the caller adds the chunks with
+ *        mapx_sum_tasks (stride N*K, nsplit = chunks), alone or with the step's other deferred sums.  Also N <= 64 when
+ *        K <= 64 (AutoInt's attention projections, layers.py:724-744: dW [40, 16 | 40] over B*F rows).
  * Plain fp32 sums in a fixed order (bit-reproducible), not the six-product arithmetic of mapx_gemm_f32. */
 int mapx_skinny_chunks(void);
 int mapx_skinny_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias_opt, int M,
                            int N, int K, int relu, float* y, int64_t ldy, hipStream_t stream);
 int mapx_skinny_linear_dw(const float* dy, int64_t ldy, const float* x, int64_t ldx, int M, int N, int K, float* part,
-                          hipStream_t stream);
+                          int chunks, hipStream_t stream);
 int mapx_skinny_linear_dx(const float* dy, int64_t ldy, const float* w, int64_t ldw, int M, int N, int K, float* dx,
                           int64_t lddx, hipStream_t stream);
 /* dL/d(final) of a head of N <= 8 outputs over DCNv2's two towers (the finetune head; reference models.py:304, 319

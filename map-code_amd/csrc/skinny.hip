@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256) skinny_dw_kernel(const float* __restrict_
                                                         const float* __restrict__ x, int64_t ldx, int M, int N, int K,
                                                         float* __restrict__ part) {
   const int k = 4 * (blockIdx.x * 256 + threadIdx.x);
-  const int rows_per = (M + kSkinnyChunks - 1) / kSkinnyChunks;
+  const int rows_per = (M + (int)gridDim.y - 1) / (int)gridDim.y;
   const int m0 = blockIdx.y * rows_per, m1 = (m0 + rows_per < M) ? m0 + rows_per : M;
   if (k >= K) return;
   float4 acc[NT];
@@ -141,7 +141,7 @@ constexpr int kTK = 128;                                   // columns per block
 __global__ void __launch_bounds__(256) skinny_dw_tiled_kernel(const float* __restrict__ dy, int64_t ldy,
                                                               const float* __restrict__ x, int64_t ldx, int M, int N,
                                                               int K, float* __restrict__ part) {
-  const int rows_per = (M + kSkinnyChunks - 1) / kSkinnyChunks;          // <= 64 (host-checked)
+  const int rows_per = (M + (int)gridDim.y - 1) / (int)gridDim.y;        // <= 64 (host-checked)
   __shared__ float ds[64 * 33];
   const int t = threadIdx.x, k4 = t & 31, q = t >> 5;
   const int m0 = blockIdx.y * rows_per, m1 = (m0 + rows_per < M) ? m0 + rows_per : M;
@@ -167,6 +167,69 @@ __global__ void __launch_bounds__(256) skinny_dw_tiled_kernel(const float* __res
 #pragma unroll
   for (int j = 0; j < 4; ++j)
     if (q + 8 * j < N) *reinterpret_cast<float4*>(p + (int64_t)(q + 8 * j) * K) = acc[j];
+}
+
+// Tall weight gradients with BOTH dimensions small (AutoInt's attention projections: dW [40, 16] or [40, 40] over
+// B*F = 94 208 rows — 97 us each as a one-tile split-K GEMM).  N <= 64, K <= 64.  Thread (k4 = t % 16, ng = (t / 16) % 4,
+// rl = t / 64): float4 column k4, outputs 16 ng .. 16 ng + 15, every fourth 64-row stage row; dy stages go through
+// LDS, the four row lanes' sums meet in LDS in a fixed order.
+__global__ void __launch_bounds__(256) skinny_dw_tall_kernel(const float* __restrict__ dy, int64_t ldy,
+                                                             const float* __restrict__ x, int64_t ldx, int M, int N,
+                                                             int K, float* __restrict__ part) {
+  const int rows_per = (M + (int)gridDim.y - 1) / (int)gridDim.y;
+  __shared__ __attribute__((aligned(16))) float ds[64 * 68];             // 64 rows x 64 outputs (+ 4: rows 4 banks apart)
+  __shared__ __attribute__((aligned(16))) float xs[64 * 68];             // 64 rows x K <= 64 inputs
+  __shared__ float4 red[3][64];
+  const int t = threadIdx.x, k4 = t & 15, ng = (t >> 4) & 3, rl = t >> 6;
+  const int m0 = blockIdx.y * rows_per, m1 = (m0 + rows_per < M) ? m0 + rows_per : M;
+  const int k = 4 * k4;
+  const bool live = k < K;
+  float4 acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s0 = m0; s0 < m1; s0 += 64) {
+    const int rows = (m1 - s0 < 64) ? m1 - s0 : 64;
+    __syncthreads();
+    for (int e = t; e < rows * 64; e += 256) {              // both operands of the stage: coalesced, all in flight at once
+      const int row = e >> 6, n = e & 63;
+      ds[row * 68 + n] = n < N ? dy[(int64_t)(s0 + row) * ldy + n] : 0.f;
+      xs[row * 68 + n] = n < K ? x[(int64_t)(s0 + row) * ldx + n] : 0.f;
+    }
+    __syncthreads();
+    if (live) {
+      for (int r = rl; r < rows; r += 4) {
+        const float4 xv = *reinterpret_cast<const float4*>(xs + r * 68 + k);
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+          const float4 g = *reinterpret_cast<const float4*>(ds + r * 68 + 16 * ng + 4 * j4);
+          const float gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float4& a = acc[4 * j4 + e];
+            a.x += gg[e] * xv.x; a.y += gg[e] * xv.y; a.z += gg[e] * xv.z; a.w += gg[e] * xv.w;
+          }
+        }
+      }
+    }
+  }
+  // the four row lanes -> one sum, lane 0 last (fixed order), 16 outputs at a time through 3 KB of LDS
+  float* __restrict__ p = part + (int64_t)blockIdx.y * N * K + k;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    __syncthreads();
+    if (rl > 0) red[rl - 1][t & 63] = acc[j];
+    __syncthreads();
+    if (rl == 0) {
+      float4 v = acc[j];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const float4 o = red[q][t & 63];
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+      }
+      const int n = 16 * ng + j;
+      if (live && n < N) *reinterpret_cast<float4*>(p + (int64_t)n * K) = v;
+    }
+  }
 }
 
 // The input gradient of a narrow head over DCNv2's two towers (finetune: Linear(D + H -> 1)), with both towers' first
@@ -262,8 +325,8 @@ struct FwdLaunch {
 template <int NT>
 struct DwLaunch {
   static void go(const float* dy, int64_t ldy, const float* x, int64_t ldx, int M, int N, int K, float* part,
-                 hipStream_t stream) {
-    hipLaunchKernelGGL(skinny_dw_kernel<NT>, dim3(grid_for(K / 4, 256), kSkinnyChunks), dim3(256), 0, stream, dy, ldy,
+                 int chunks, hipStream_t stream) {
+    hipLaunchKernelGGL(skinny_dw_kernel<NT>, dim3(grid_for(K / 4, 256), chunks), dim3(256), 0, stream, dy, ldy,
                        x, ldx, M, N, K, part);
   }
 };
@@ -294,16 +357,20 @@ extern "C" int mapx_skinny_linear_fwd(const float* x, int64_t ldx, const float* 
 }
 
 extern "C" int mapx_skinny_linear_dw(const float* dy, int64_t ldy, const float* x, int64_t ldx, int M, int N, int K,
-                                     float* part, hipStream_t stream) {
+                                     float* part, int chunks, hipStream_t stream) {
   using namespace mapx;
-  MAPX_REQUIRE(dy && x && part && M >= 1 && N >= 1 && N <= 32 && K >= 4 && K % 4 == 0 && ldy >= N,
-               "skinny_linear_dw: bad sizes");
+  MAPX_REQUIRE(dy && x && part && M >= 1 && N >= 1 && (N <= 32 || (N <= 64 && K <= 64)) && K >= 4 && K % 4 == 0 &&
+                   ldy >= N && chunks >= 1 && chunks <= 65535,
+               "skinny_linear_dw: bad sizes (N <= 32, or N <= 64 with K <= 64)");
   MAPX_REQUIRE(al16(x, ldx) && (uintptr_t)part % 16 == 0, "skinny_linear_dw: rows of x must be 16-byte aligned");
-  if (N > 8 && (M + kSkinnyChunks - 1) / kSkinnyChunks <= 64)
-    hipLaunchKernelGGL(skinny_dw_tiled_kernel, dim3(grid_for(K, kTK), kSkinnyChunks), dim3(256), 0, stream, dy, ldy, x,
-                       ldx, M, N, K, part);
+  const int rows_per = (M + chunks - 1) / chunks;
+  if (K <= 64 && (N > 32 || (N > 8 && rows_per > 64)))
+    hipLaunchKernelGGL(skinny_dw_tall_kernel, dim3(1, chunks), dim3(256), 0, stream, dy, ldy, x, ldx, M, N, K, part);
+  else if (N > 8 && rows_per <= 64)
+    hipLaunchKernelGGL(skinny_dw_tiled_kernel, dim3(grid_for(K, kTK), chunks), dim3(256), 0, stream, dy, ldy, x, ldx, M,
+                       N, K, part);
   else
-    skinny_dispatch<DwLaunch>(N, dy, ldy, x, ldx, M, N, K, part, stream);
+    skinny_dispatch<DwLaunch>(N, dy, ldy, x, ldx, M, N, K, part, chunks, stream);
   return check_launch("skinny_linear_dw");
 }
 

@@ -874,6 +874,7 @@ def _rows16(t):
         and t.data_ptr() % 16 == 0
 
 
+_TALL_ROWS = int(os.environ.get("MAPX_TALL_ROWS", "128"))
 SKINNY_MAX = int(os.environ.get("MAPX_SKINNY_MAX", "8"))            # forward: wider layers measured faster on the GEMM
 SKINNY_MAX_BWD = int(os.environ.get("MAPX_SKINNY_MAX_BWD", "32"))   # dW / dX (RFD's 23-wide layer: 14.6 / 8.6 vs 28 / 12 us)
 
@@ -964,14 +965,20 @@ def linear_bwd_weight(dy, x, out=None, defer=False):
     """dW = dY^T X.  dy [B,N], x [B,K] -> [N,K].  defer: leave split-K slabs for flush_deferred()."""
     Bn, Nn = dy.shape
     K = x.shape[1]
-    if Bn >= 1 and _skinny(Nn, K, x, bwd=True) and dy.dtype == torch.float32 and dy.dim() == 2 and dy.stride(1) == 1 \
+    # (also: both dimensions small over many rows — AutoInt's attention projections, dW [40, 16 | 40] over B*F rows)
+    tall = SKINNY and 32 < Nn <= 64 and 4 <= K <= 64 and K % 4 == 0 and Bn >= 8192 and _rows16(x)
+    if Bn >= 1 and (_skinny(Nn, K, x, bwd=True) or tall) and dy.dtype == torch.float32 and dy.dim() == 2 \
+            and dy.stride(1) == 1 \
             and (out is None or (out.dtype == torch.float32 and out.is_contiguous())):
         require_gpu(dy, x)
         chunks = lib.mapx_skinny_chunks()
+        while Bn // chunks > _TALL_ROWS and chunks < 2048:  # tall problems: a chunk is a workgroup
+            chunks *= 2
         dw = out if out is not None else torch.empty(Nn, K, dtype=torch.float32, device=dy.device)
         part = torch.empty(chunks, Nn * K, dtype=torch.float32, device=dy.device)
         with _timed("skinny_linear", 4.0 * (Bn * K + Bn * Nn + chunks * Nn * K)):
-            check(lib.mapx_skinny_linear_dw(ptr(dy), dy.stride(0), ptr(x), x.stride(0), Bn, Nn, K, ptr(part), stream()))
+            check(lib.mapx_skinny_linear_dw(ptr(dy), dy.stride(0), ptr(x), x.stride(0), Bn, Nn, K, ptr(part), chunks,
+                                            stream()))
         if DEFER_COLSUM and defer and out is not None:
             defer_sum(dw, part, Nn * K, chunks, Nn * K)          # with the step's other partial sums
         else:
