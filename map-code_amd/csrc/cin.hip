@@ -26,21 +26,37 @@ __global__ void __launch_bounds__(256) transpose_batched_kernel(const float* __r
 }
 
 // had[r * ld + h*H + m] = x0t[r, h] * xi[r, m]; columns F*H .. ld - 1 (the padding that gives the 1x1 convolution's GEMM
-// 16-byte rows and a K that is a multiple of 8: F*H = 529 or 1150 left it the scalar operand path) are zeroed
+// 16-byte rows and a K that is a multiple of 8: F*H = 529 or 1150 left it the scalar operand path) are zeroed.
+// A thread owns up to four COLUMNS (k = t, t + 256, ...): their (h, m) are worked out once, the rows are walked
+// without a division (the element-per-thread form spent its time on 64-bit t / ld, k / H: 159 us for 302 MB).
 __global__ void __launch_bounds__(256) cin_outer_fwd_kernel(const float* __restrict__ x0t, int F,
                                                             const float* __restrict__ xi, int H, int64_t R,
                                                             float* __restrict__ had, int64_t ld) {
-  const int64_t K = (int64_t)F * H, n = R * ld;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
-       t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = t / ld;
-    const int k = (int)(t - r * ld);
-    const int h = k / H, m = k - h * H;
-    had[t] = k < K ? x0t[r * F + h] * xi[r * H + m] : 0.f;
+  constexpr int CPT = 8;                                  // columns per thread; blockIdx.y: groups of 2048 columns
+  const int K = F * H, kb = blockIdx.y * (256 * CPT);
+  int hh[CPT], mm[CPT];
+  bool in[CPT], live[CPT];
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) {
+    const int k = kb + threadIdx.x + 256 * j;
+    live[j] = k < ld;
+    in[j] = k < K;
+    hh[j] = in[j] ? k / H : 0;
+    mm[j] = in[j] ? k - hh[j] * H : 0;
+  }
+  for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+    const float* __restrict__ a = x0t + r * F;
+    const float* __restrict__ c = xi + r * H;
+    float* __restrict__ o = had + r * ld;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j)
+      if (live[j]) o[kb + threadIdx.x + 256 * j] = in[j] ? a[hh[j]] * c[mm[j]] : 0.f;
   }
 }
 
-// one wave per row r:  dxi[r, m] = sum_h dhad[r,h,m] x0t[r,h];  dx0t[r, h] (+)= sum_m dhad[r,h,m] xi[r,m]
+// one wave per row r, ONE pass over the row of dhad:  lane m (and m + 64 ...) holds its column of all F rows h,
+//   dxi[r, m] = sum_h dhad[r,h,m] x0t[r,h]  per lane;   dx0t[r, h] (+)= sum_m dhad[r,h,m] xi[r,m]  by a wave reduction
+// per h, fixed order.  (The two-pass form read the 302-MB matrix twice: 232 us.)  H <= 256 (four columns per lane).
 __global__ void __launch_bounds__(256) cin_outer_bwd_kernel(const float* __restrict__ dhad,
                                                             const float* __restrict__ x0t, int F,
                                                             const float* __restrict__ xi, int H, int64_t R,
@@ -52,19 +68,33 @@ __global__ void __launch_bounds__(256) cin_outer_bwd_kernel(const float* __restr
   const float* __restrict__ g = dhad + r * ld;
   const float* __restrict__ a = x0t + r * F;
   const float* __restrict__ c = xi + r * H;
-  for (int m0 = 0; m0 < H; m0 += 64) {                  // dxi: lanes over m, loop over h
-    const int m = m0 + lane;
-    if (m < H) {
-      float s = 0.f;
-      for (int h = 0; h < F; ++h) s += g[h * H + m] * a[h];
-      dxi[r * H + m] = s;
-    }
+  constexpr int CM = 4;                                    // columns per lane: H <= 256
+  float cv[CM], sv[CM];
+#pragma unroll
+  for (int q = 0; q < CM; ++q) {
+    const int m = lane + 64 * q;
+    cv[q] = m < H ? c[m] : 0.f;
+    sv[q] = 0.f;
   }
-  for (int h = 0; h < F; ++h) {                         // dx0t: wave reduction over m, fixed order
-    float s = 0.f;
-    for (int m = lane; m < H; m += 64) s += g[h * H + m] * c[m];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, kWave);
-    if (lane == 0) dx0t[r * F + h] = accumulate_x0 ? dx0t[r * F + h] + s : s;
+  for (int h = 0; h < F; ++h) {
+    const float ah = a[h];
+    float p = 0.f;
+#pragma unroll
+    for (int q = 0; q < CM; ++q) {
+      const int m = lane + 64 * q;
+      if (64 * q < H) {                                    // (wave-uniform)
+        const float gv = m < H ? g[h * H + m] : 0.f;
+        sv[q] += gv * ah;
+        p += gv * cv[q];
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) p += __shfl_down(p, o, kWave);
+    if (lane == 0) dx0t[r * F + h] = accumulate_x0 ? dx0t[r * F + h] + p : p;
+  }
+#pragma unroll
+  for (int q = 0; q < CM; ++q) {
+    const int m = lane + 64 * q;
+    if (m < H) dxi[r * H + m] = sv[q];
   }
 }
 
@@ -113,15 +143,16 @@ extern "C" int mapx_cin_outer_fwd(const float* x0t, int F, const float* xi, int 
   MAPX_REQUIRE(R >= 0 && F > 0 && H > 0 && ld_had >= (int64_t)F * H, "cin_outer_fwd: bad sizes");
   if (R == 0) return MAPX_OK;
   MAPX_REQUIRE(x0t && xi && had, "cin_outer_fwd: null pointer");
-  hipLaunchKernelGGL(cin_outer_fwd_kernel, dim3(grid_for(R * ld_had, 256)), dim3(256), 0, stream, x0t, F, xi, H, R, had,
-                     ld_had);
+  hipLaunchKernelGGL(cin_outer_fwd_kernel, dim3((unsigned)(R < 8192 ? R : 8192), (unsigned)((ld_had + 2047) / 2048)),
+                     dim3(256), 0, stream, x0t, F, xi, H, R, had, ld_had);
   return check_launch("cin_outer_fwd");
 }
 
 extern "C" int mapx_cin_outer_bwd(const float* dhad, int64_t ld_dhad, const float* x0t, int F, const float* xi, int H,
                                   int64_t R, float* dx0t, int accumulate_x0, float* dxi, hipStream_t stream) {
   using namespace mapx;
-  MAPX_REQUIRE(R >= 0 && F > 0 && H > 0 && R < (1LL << 33) && ld_dhad >= (int64_t)F * H, "cin_outer_bwd: bad sizes");
+  MAPX_REQUIRE(R >= 0 && F > 0 && H > 0 && H <= 256 && R < (1LL << 33) && ld_dhad >= (int64_t)F * H,
+               "cin_outer_bwd: bad sizes (H <= 256)");
   if (R == 0) return MAPX_OK;
   MAPX_REQUIRE(dhad && x0t && xi && dx0t && dxi, "cin_outer_bwd: null pointer");
   hipLaunchKernelGGL(cin_outer_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, stream, dhad, x0t, F, xi, H,
