@@ -469,7 +469,8 @@ int mapx_seg_reduce_rows_bf16(int64_t n, const int32_t* perm, const int32_t* ran
                               size_t ws_bytes, int32_t* zeroed_counter_opt, hipStream_t stream);
 /* bf16 counterparts of mapx_colsum / mapx_relu_mask_colsum / mapx_cross_bwd_pre_colsum /
  * mapx_relu_mask: activations and their gradients bf16, column sums (bias gradients) and the running
- * dL/dX0 of the cross tower fp32.  Any N and leading dimensions. */
+ * dL/dX0 of the cross tower fp32.  Any N and leading dimensions.  out / db == NULL: the chunk rows stay in `ws`
+ * ([mapx_colsum_bf16_workspace_bytes(N) / (4 N)][N] fp32) for a later mapx_sum_tasks, as with mapx_colsum. */
 size_t mapx_colsum_bf16_workspace_bytes(int N);
 int mapx_colsum_bf16(const mapx_bf16* x, int64_t ld, int M, int N, float* out, void* ws, size_t ws_bytes,
                      hipStream_t stream);

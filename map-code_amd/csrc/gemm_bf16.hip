@@ -986,12 +986,13 @@ static int colsum_ws_ok(const char* what, void* ws, size_t ws_bytes, int N) {
 extern "C" int mapx_colsum_bf16(const mapx_bf16* x, int64_t ld, int M, int N, float* out, void* ws, size_t ws_bytes,
                                 hipStream_t stream) {
   using namespace mapx;
-  MAPX_REQUIRE(x && out && M >= 0 && N > 0 && ld >= N, "colsum_bf16: bad arguments");
+  MAPX_REQUIRE(x && M >= 0 && N > 0 && ld >= N, "colsum_bf16: bad arguments");
   if (!colsum_ws_ok("colsum_bf16", ws, ws_bytes, N)) return MAPX_EWORKSPACE;
   float* part = static_cast<float*>(ws);
   const bf16_t* xb = reinterpret_cast<const bf16_t*>(x);
   launch_ew_colsum_h<2>(xb, ld, xb, ld, xb, ld, M, N, nullptr, nullptr, 0, part, stream);
-  hipLaunchKernelGGL(colsum_stage2_h_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, out);
+  if (out)     // out == NULL: the caller adds the chunk rows later (mapx_sum_tasks), as with mapx_colsum
+    hipLaunchKernelGGL(colsum_stage2_h_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, out);
   return check_launch("colsum_bf16");
 }
 
@@ -999,13 +1000,13 @@ extern "C" int mapx_relu_mask_colsum_bf16(const mapx_bf16* dy, int64_t ld_dy, co
                                           int N, mapx_bf16* dz, float* db, void* ws, size_t ws_bytes,
                                           hipStream_t stream) {
   using namespace mapx;
-  MAPX_REQUIRE(dy && y && dz && db && M >= 0 && N > 0 && ld_dy >= N && ld_y >= N, "relu_mask_colsum_bf16: bad arguments");
+  MAPX_REQUIRE(dy && y && dz && M >= 0 && N > 0 && ld_dy >= N && ld_y >= N, "relu_mask_colsum_bf16: bad arguments");
   if (!colsum_ws_ok("relu_mask_colsum_bf16", ws, ws_bytes, N)) return MAPX_EWORKSPACE;
   float* part = static_cast<float*>(ws);
   launch_ew_colsum_h<0>(reinterpret_cast<const bf16_t*>(dy), ld_dy, reinterpret_cast<const bf16_t*>(y), ld_y,
                         reinterpret_cast<const bf16_t*>(y), ld_y, M, N, reinterpret_cast<bf16_t*>(dz), nullptr, 0, part,
                         stream);
-  hipLaunchKernelGGL(colsum_stage2_h_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, db);
+  if (db) hipLaunchKernelGGL(colsum_stage2_h_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, db);
   return check_launch("relu_mask_colsum_bf16");
 }
 
@@ -1013,13 +1014,13 @@ extern "C" int mapx_cross_bwd_pre_colsum_bf16(const mapx_bf16* g, int64_t ld_g, 
                                               int M, int N, mapx_bf16* t, float* dx0, int accumulate, float* db,
                                               void* ws, size_t ws_bytes, hipStream_t stream) {
   using namespace mapx;
-  MAPX_REQUIRE(g && x0 && u && t && dx0 && db && M >= 0 && N > 0 && ld_g >= N, "cross_bwd_pre_colsum_bf16: bad arguments");
+  MAPX_REQUIRE(g && x0 && u && t && dx0 && M >= 0 && N > 0 && ld_g >= N, "cross_bwd_pre_colsum_bf16: bad arguments");
   if (!colsum_ws_ok("cross_bwd_pre_colsum_bf16", ws, ws_bytes, N)) return MAPX_EWORKSPACE;
   float* part = static_cast<float*>(ws);
   launch_ew_colsum_h<1>(reinterpret_cast<const bf16_t*>(g), ld_g, reinterpret_cast<const bf16_t*>(x0), (int64_t)N,
                         reinterpret_cast<const bf16_t*>(u), (int64_t)N, M, N, reinterpret_cast<bf16_t*>(t), dx0,
                         accumulate, part, stream);
-  hipLaunchKernelGGL(colsum_stage2_h_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, db);
+  if (db) hipLaunchKernelGGL(colsum_stage2_h_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, db);
   return check_launch("cross_bwd_pre_colsum_bf16");
 }
 

@@ -264,6 +264,9 @@ DEFER = os.environ.get("MAPX_DEFER", "0") == "1"
 # 128 x N floats each: nothing to go cold)
 # measured: 0.943 / 0.950 vs 0.952 / 0.954 ms per step, same box: on by default
 DEFER_COLSUM = DEFER or os.environ.get("MAPX_DEFER_COLSUM", "1") == "1"
+# the same for the bf16 mode's column-sum kernels (round 3: each bias gradient had a second-stage launch of its own,
+# 7-10 us apiece on the backward chains of a 0.5-ms step)
+DEFER_COLSUM_H = os.environ.get("MAPX_DEFER_COLSUM_H", "1") == "1"
 
 
 def defer_sum(dst, src, stride, nsplit, n):
@@ -993,6 +996,14 @@ def linear_bwd_weight(dy, x, out=None, defer=False):
     return gemm(dy, x, False, False, Nn, K, Bn, out=out, nsplit=ns, defer=DEFER and defer and out is not None)
 
 
+def _partials_h(Nn, device, defer):
+    """Workspace of the bf16 column-sum kernels -> (buffer, chunk rows); defer: a buffer of its own (it lives until
+    flush_deferred sums it) instead of the stream's scratch."""
+    nb = lib.mapx_colsum_bf16_workspace_bytes(Nn)
+    buf = torch.empty(nb, dtype=torch.uint8, device=device) if defer else scratch(nb, device)
+    return buf, nb // (4 * Nn)
+
+
 def _partials(Nn, device, defer):
     nb = lib.mapx_colsum_workspace_bytes(Nn)
     return torch.empty(nb, dtype=torch.uint8, device=device) if defer else scratch(nb, device)
@@ -1003,12 +1014,16 @@ def colsum(x, out=None, defer=False):
     require_gpu(x)
     M, Nn = x.shape
     if is_bf16(x):
+        later = DEFER_COLSUM and DEFER_COLSUM_H and defer and out is not None
         if out is None:
             out = torch.empty(Nn, dtype=torch.float32, device=x.device)
         if x.stride(1) != 1:
             x = x.contiguous()
-        ws = scratch(lib.mapx_colsum_bf16_workspace_bytes(Nn), x.device)
-        check(lib.mapx_colsum_bf16(x.data_ptr(), x.stride(0), M, Nn, ptr(out), ptr(ws), ws.numel(), stream()))
+        ws, chunks = _partials_h(Nn, x.device, later)
+        check(lib.mapx_colsum_bf16(x.data_ptr(), x.stride(0), M, Nn, None if later else ptr(out), ptr(ws), ws.numel(),
+                                   stream()))
+        if later:
+            defer_sum(out, ws.view(torch.float32), Nn, chunks, Nn)
         return out
     defer = DEFER_COLSUM and defer and out is not None
     if out is None:
@@ -1065,11 +1080,14 @@ def relu_mask_colsum(dy, y, db=None, defer=False):
             y = y.contiguous()
         M, Nn = dy.shape
         dz = torch.empty(M, Nn, dtype=BF16, device=dy.device)
+        later = DEFER_COLSUM and DEFER_COLSUM_H and defer and db is not None
         if db is None:
             db = torch.empty(Nn, dtype=torch.float32, device=dy.device)
-        ws = scratch(lib.mapx_colsum_bf16_workspace_bytes(Nn), dy.device)
+        ws, chunks = _partials_h(Nn, dy.device, later)
         check(lib.mapx_relu_mask_colsum_bf16(dy.data_ptr(), dy.stride(0), y.data_ptr(), y.stride(0), M, Nn, ptr(dz),
-                                             ptr(db), ptr(ws), ws.numel(), stream()))
+                                             None if later else ptr(db), ptr(ws), ws.numel(), stream()))
+        if later:
+            defer_sum(db, ws.view(torch.float32), Nn, chunks, Nn)
         return dz, db
     if not row_sliceable(dy):
         dy = dy.contiguous()
@@ -1099,12 +1117,15 @@ def cross_bwd_pre_colsum(g, x0, u, dx0=None, db=None, defer=False, plus_g=False)
         acc = dx0 is not None
         if dx0 is None:
             dx0 = torch.empty(M, Nn, dtype=torch.float32, device=g.device)
+        later = DEFER_COLSUM and DEFER_COLSUM_H and defer and db is not None
         if db is None:
             db = torch.empty(Nn, dtype=torch.float32, device=g.device)
-        ws = scratch(lib.mapx_colsum_bf16_workspace_bytes(Nn), g.device)
+        ws, chunks = _partials_h(Nn, g.device, later)
         check(lib.mapx_cross_bwd_pre_colsum_bf16(g.data_ptr(), g.stride(0), ptr(x0), ptr(u), M, Nn, ptr(t), ptr(dx0),
-                                                 int(acc) | (2 if plus_g else 0), ptr(db), ptr(ws), ws.numel(),
-                                                 stream()))
+                                                 int(acc) | (2 if plus_g else 0), None if later else ptr(db), ptr(ws),
+                                                 ws.numel(), stream()))
+        if later:
+            defer_sum(db, ws.view(torch.float32), Nn, chunks, Nn)
         return t, dx0, db
     if not row_sliceable(g):
         g = g.contiguous()
