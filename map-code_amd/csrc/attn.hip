@@ -12,26 +12,32 @@ namespace mapx {
 
 constexpr int kAttnMaxF = 64, kAttnMaxA = 64;   // one lane per field; LDS budget
 
+// GPW groups per wave: with F <= 32 fields a wave takes TWO groups, one per half (lane & 31 = the query row): the
+// one-group form left 41 of 64 lanes idle at Avazu's 23 fields.
+template <int GPW>
 __global__ void __launch_bounds__(64) attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                      const float* __restrict__ v, int F, int A, float inv_scale,
-                                                      float* __restrict__ o, float* __restrict__ p) {
-  extern __shared__ float sm[];                 // Q, K, V [F][A+1]; P [F][F+1]
+                                                      const float* __restrict__ v, int64_t G, int F, int A,
+                                                      float inv_scale, float* __restrict__ o, float* __restrict__ p) {
+  extern __shared__ float sm[];                 // per group: Q, K, V [F][A+1]; P [F][F+1]
+  constexpr int LW = 64 / GPW;                  // lanes per group
   const int LD = A + 1, LF = F + 1;
-  float* Qs = sm;
+  const int half = threadIdx.x / LW, li = threadIdx.x % LW;
+  float* Qs = sm + half * (3 * F * LD + F * LF);
   float* Ks = Qs + F * LD;
   float* Vs = Ks + F * LD;
   float* Ps = Vs + F * LD;
-  const int64_t g = blockIdx.x;
+  const int64_t g = (int64_t)blockIdx.x * GPW + half;
+  const bool have = g < G;
   const int64_t base = g * F * A;
-  for (int t = threadIdx.x; t < F * A; t += 64) {
+  for (int t = li; have && t < F * A; t += LW) {
     const int r = t / A, c = t - r * A;
     Qs[r * LD + c] = q[base + t];
     Ks[r * LD + c] = k[base + t];
     Vs[r * LD + c] = v[base + t];
   }
   __syncthreads();
-  const int i = threadIdx.x;
-  if (i < F) {
+  const int i = li;
+  if (have && i < F) {
     float mx = -3.4e38f;
     for (int j = 0; j < F; ++j) {
       float s = 0.f;
@@ -55,42 +61,46 @@ __global__ void __launch_bounds__(64) attn_fwd_kernel(const float* __restrict__ 
     }
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < F * F; t += 64) {      // coalesced copy of the probabilities for backward
+  for (int t = li; have && t < F * F; t += LW) {       // coalesced copy of the probabilities for backward
     const int r = t / F, c = t - r * F;
     p[g * F * F + t] = Ps[r * LF + c];
   }
 }
 
 // dV = P^T dO;  dP = dO V^T;  dS = P (dP - rowsum(P dP)) * inv_scale;  dQ = dS K;  dK = dS^T Q
+template <int GPW>
 __global__ void __launch_bounds__(64) attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                       const float* __restrict__ v, const float* __restrict__ p,
-                                                      const float* __restrict__ d_o, int F, int A,
+                                                      const float* __restrict__ d_o, int64_t G, int F, int A,
                                                       float inv_scale, float* __restrict__ dq,
                                                       float* __restrict__ dk, float* __restrict__ dv) {
-  extern __shared__ float sm[];                 // K, V, Q, dO [F][A+1] each; dS [F][F+1]; P [F][F+1]
+  extern __shared__ float sm[];                 // per group: K, V, Q, dO [F][A+1] each; dS [F][F+1]; P [F][F+1]
+  constexpr int LW = 64 / GPW;
   const int LD = A + 1, LF = F + 1;
-  float* Ks = sm;
+  const int half = threadIdx.x / LW, li = threadIdx.x % LW;
+  float* Ks = sm + half * (4 * F * LD + 2 * F * LF);
   float* Vs = Ks + F * LD;
   float* Qs = Vs + F * LD;
   float* Ds = Qs + F * LD;
   float* dS = Ds + F * LD;
   float* Ps = dS + F * LF;
-  const int64_t g = blockIdx.x;
+  const int64_t g = (int64_t)blockIdx.x * GPW + half;
+  const bool have = g < G;
   const int64_t base = g * F * A;
-  for (int t = threadIdx.x; t < F * A; t += 64) {
+  for (int t = li; have && t < F * A; t += LW) {
     const int r = t / A, c = t - r * A;
     Ks[r * LD + c] = k[base + t];
     Vs[r * LD + c] = v[base + t];
     Qs[r * LD + c] = q[base + t];
     Ds[r * LD + c] = d_o[base + t];
   }
-  for (int t = threadIdx.x; t < F * F; t += 64) {
+  for (int t = li; have && t < F * F; t += LW) {
     const int r = t / F, c = t - r * F;
     Ps[r * LF + c] = p[g * F * F + t];
   }
   __syncthreads();
-  const int i = threadIdx.x;
-  if (i < F) {
+  const int i = li;
+  if (have && i < F) {
     float dot = 0.f;
     for (int j = 0; j < F; ++j) {
       float dp = 0.f;
@@ -106,7 +116,7 @@ __global__ void __launch_bounds__(64) attn_bwd_kernel(const float* __restrict__ 
     }
   }
   __syncthreads();
-  if (i < F) {                                   // lane i now owns key / value row i: column sums over queries
+  if (have && i < F) {                           // lane i now owns key / value row i: column sums over queries
     for (int a = 0; a < A; ++a) {
       float sk = 0.f, sv = 0.f;
       for (int r = 0; r < F; ++r) {
@@ -122,11 +132,12 @@ __global__ void __launch_bounds__(64) attn_bwd_kernel(const float* __restrict__ 
 // F = A = 64 needs 100 KB of dynamic LDS in backward: above the 64 KB default, inside the CU's 160 KB
 static hipError_t raise_lds_limit() {
   static hipError_t done = [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    for (const void* fn : {reinterpret_cast<const void*>(&attn_fwd_kernel<1>), reinterpret_cast<const void*>(&attn_fwd_kernel<2>),
+                           reinterpret_cast<const void*>(&attn_bwd_kernel<1>), reinterpret_cast<const void*>(&attn_bwd_kernel<2>)}) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
   }();
   return done;
 }
@@ -143,7 +154,11 @@ extern "C" int mapx_attn_fwd(const float* q, const float* k, const float* v, int
   const float inv_scale = scaled ? 1.0f / sqrtf((float)A) : 1.0f;
   const size_t lds = ((size_t)3 * F * (A + 1) + (size_t)F * (F + 1)) * sizeof(float);
   MAPX_HIP(raise_lds_limit());
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)G), dim3(64), lds, stream, q, k, v, F, A, inv_scale, o, p);
+  if (F <= 32)
+    hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3((unsigned)((G + 1) / 2)), dim3(64), 2 * lds, stream, q, k, v, G, F, A,
+                       inv_scale, o, p);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3((unsigned)G), dim3(64), lds, stream, q, k, v, G, F, A, inv_scale, o, p);
   return check_launch("attn_fwd");
 }
 
@@ -158,7 +173,11 @@ extern "C" int mapx_attn_bwd(const float* q, const float* k, const float* v, con
   const float inv_scale = scaled ? 1.0f / sqrtf((float)A) : 1.0f;
   const size_t lds = ((size_t)4 * F * (A + 1) + (size_t)2 * F * (F + 1)) * sizeof(float);
   MAPX_HIP(raise_lds_limit());
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)G), dim3(64), lds, stream, q, k, v, p, d_o, F, A, inv_scale,
-                     dq, dk, dv);
+  if (F <= 32)
+    hipLaunchKernelGGL(attn_bwd_kernel<2>, dim3((unsigned)((G + 1) / 2)), dim3(64), 2 * lds, stream, q, k, v, p, d_o, G,
+                       F, A, inv_scale, dq, dk, dv);
+  else
+    hipLaunchKernelGGL(attn_bwd_kernel<1>, dim3((unsigned)G), dim3(64), lds, stream, q, k, v, p, d_o, G, F, A,
+                       inv_scale, dq, dk, dv);
   return check_launch("attn_bwd");
 }
