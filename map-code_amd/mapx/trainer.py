@@ -360,6 +360,9 @@ class GraphedBackward:
         return self.out
 
 
+PACK_FIRST = os.environ.get("MAPX_DP_PACK_FIRST", "1") == "1"      # A/B switch (GraphedExchangeTail)
+
+
 class GraphedExchangeTail:
     """Everything between the last backward kernel and the next step, for ONE tuple of exchange
     message sizes: graph 1 packs every table's (id, row) message; the all-gathers run eagerly as
@@ -402,10 +405,15 @@ class GraphedExchangeTail:
 
     def __call__(self, host_s):
         opt = self.trainer.optimizer
+        if PACK_FIRST:
+            # the messages are packed BEFORE the dense all-reduce is issued: the two collectives then follow each other
+            # on the communicator's stream without a hop to the main stream and back between them
+            self.pack.replay()
         t0 = time.perf_counter()
         parallel.sync_dense(opt)
         host_s[3] += time.perf_counter() - t0
-        self.pack.replay()
+        if not PACK_FIRST:
+            self.pack.replay()
         parallel.all_gather_tables(self.msgs, self.gathered)
         self.merge.replay()
         opt.steps_done += 1
