@@ -361,6 +361,7 @@ class GraphedBackward:
 
 
 PACK_FIRST = os.environ.get("MAPX_DP_PACK_FIRST", "1") == "1"      # A/B switch (GraphedExchangeTail)
+MERGE_SIDE = os.environ.get("MAPX_DP_MERGE_SIDE", "1") == "1"      # A/B switch: one branch per table's merge
 
 
 class GraphedExchangeTail:
@@ -389,11 +390,11 @@ class GraphedExchangeTail:
                 # dense AdamW as a third branch was measured slower)
                 main = torch.cuda.current_stream()
                 order = sorted(range(len(tables)), key=lambda i: -sizes[i])
-                side = [ops.aux_stream(f"merge{j}", main.device) for j in range(len(order) - 1)]
+                side = [ops.aux_stream(f"merge{j}", main.device) for j in range(len(order) - 1)] if MERGE_SIDE else []
                 for st in side:
                     ops.stream_wait(st, main)
                 for j, i in enumerate(order):
-                    with torch.cuda.stream(main if j == 0 else side[j - 1]):
+                    with torch.cuda.stream(main if (j == 0 or not side) else side[j - 1]):
                         parallel.merge_table(tables[i], *self.gathered[i])
                 for st in side:
                     ops.stream_wait(main, st)
