@@ -37,6 +37,7 @@ PLAN_AFTER_DNN = os.environ.get("MAPX_PLAN_AFTER_DNN", "1") == "1"
 PLAN_AFTER_TRUNK = os.environ.get("MAPX_PLAN_AFTER_TRUNK", "auto")
 
 X0_LINK = os.environ.get("MAPX_X0_LINK", "1") == "1"       # A/B switch of layers._X0Link
+EARLY_NCE_ALL = os.environ.get("MAPX_EARLY_NCE_ALL", "1") == "1"   # A/B switch: BaseModel._sample_early
 
 _OTHER_BACKBONES = ("trans", "fignn", "fgcnn")
 
@@ -88,6 +89,37 @@ class BaseModel(nn.Module):
             logger.info(f"  {key} = {getattr(self.config, key)}")
 
     # ------------------------------------------------------------------ heads
+    def _sample_early(self, labels, masked_index, noise_samples):
+        """MFP over a single-stream trunk (DNN, DeepFM, xDeepFM, AutoInt): the NCE head's sampling and the lazy
+        catch-up of the sampled rows need only the targets — they run on the tower stream beside the trunk instead of
+        between the trunk and the loss (as DCNV2.forward does by hand).  -> (ids | None, join state)."""
+        if not (EARLY_NCE_ALL and self.config.pretrain and self.config.pt_type == "MFP" and masked_index is not None
+                and labels is not None and labels.is_cuda):
+            return None, None
+        main = torch.cuda.current_stream()
+        tower = ops.aux_stream("tower", labels.device)
+        forked = ops.stream_wait(tower, main)
+        with torch.cuda.stream(tower):
+            idx = self.mfp_criterion.sample_ids(labels, noise_samples)
+        return idx, (main, tower, forked, labels)
+
+    def _plans_and_join(self, idx, state):
+        """Behind the trunk: both tables' segment plans from ONE chain of launches (behind what the main stream holds),
+        then the main stream takes the sampled ids over."""
+        if state is None:
+            self.embed.table.start_plan()
+            return
+        main, tower, forked, labels = state
+        from .layers import PlanSlot
+        if self.mfp_criterion.table.plan is not None and self.embed.table.plan is not None:
+            PlanSlot.start_many([self.embed.table.plan, self.mfp_criterion.table.plan], after=main)
+        else:
+            self.embed.table.start_plan()
+        ops.stream_wait(main, tower)
+        if forked:
+            labels.record_stream(tower)
+            idx.record_stream(main)
+
     def get_outputs(self, inputs, labels=None, masked_index=None, is_pretrain=None, noise_samples=None,
                     groups=None, nce_idx=None, join=None):
         """MFP -> (loss, #signals, #targets ranked first)            (models.py:71-78)
@@ -318,10 +350,11 @@ class DNN(BaseModel):
 
     def forward(self, input_ids, labels=None, masked_index=None, noise_samples=None):
         feat_embed = self.embed(input_ids).flatten(start_dim=1)
+        nce_idx, early = self._sample_early(labels, masked_index, noise_samples)
         nn_output = self.dnn(feat_embed)
-        self.embed.table.start_plan()        # the sort forks from the ids, enqueued behind the trunk
+        self._plans_and_join(nce_idx, early)     # the sort(s) fork from the ids, enqueued behind the trunk
         if self.config.pretrain:
-            return self.get_outputs(nn_output, labels, masked_index, noise_samples=noise_samples)
+            return self.get_outputs(nn_output, labels, masked_index, noise_samples=noise_samples, nce_idx=nce_idx)
         return self.get_outputs(self.fc_out(nn_output), labels)
 
 
@@ -374,12 +407,13 @@ class DeepFM(BaseModel):
 
     def forward(self, input_ids, labels=None, masked_index=None, noise_samples=None):
         x3, lr = self.embed.forward_with_linear(input_ids, self.lr_layer.embed_w.weight)
+        nce_idx, early = self._sample_early(labels, masked_index, noise_samples)
         dnn_vec = self.dnn(x3.flatten(start_dim=1))
-        self.embed.table.start_plan()
+        self._plans_and_join(nce_idx, early)
         lr_fm = lr.view(-1, 1) + self.lr_layer.bias + fm_product_sum(x3)
         if self.config.pretrain:
             final_vec = torch.cat([dnn_vec, lr_fm], dim=1)
-            return self.get_outputs(final_vec, labels, masked_index, noise_samples=noise_samples)
+            return self.get_outputs(final_vec, labels, masked_index, noise_samples=noise_samples, nce_idx=nce_idx)
         return self.get_outputs(self.dnn_fc_out(dnn_vec) + lr_fm, labels)
 
 
@@ -410,10 +444,11 @@ class AutoInt(BaseModel):
 
     def forward(self, input_ids, labels=None, masked_index=None, noise_samples=None):
         x = self.embed(input_ids)
+        nce_idx, early = self._sample_early(labels, masked_index, noise_samples)
         attention_out = self.self_attention(x).flatten(start_dim=1)
-        self.embed.table.start_plan()
+        self._plans_and_join(nce_idx, early)
         if self.config.pretrain:
-            return self.get_outputs(attention_out, labels, masked_index, noise_samples=noise_samples)
+            return self.get_outputs(attention_out, labels, masked_index, noise_samples=noise_samples, nce_idx=nce_idx)
         return self.get_outputs(self.attn_out(attention_out), labels)
 
 
@@ -451,10 +486,11 @@ class xDeepFM(BaseModel):
             x3, lr = self.embed.forward_with_linear(input_ids, self.lr_layer.embed_w.weight)
         else:
             x3 = self.embed(input_ids)
+        nce_idx, early = self._sample_early(labels, masked_index, noise_samples)
         final_vec = torch.cat([self.cin(x3), self.dnn(x3.flatten(start_dim=1))], dim=1)
-        self.embed.table.start_plan()
+        self._plans_and_join(nce_idx, early)
         if self.config.pretrain:
-            return self.get_outputs(final_vec, labels, masked_index, noise_samples=noise_samples)
+            return self.get_outputs(final_vec, labels, masked_index, noise_samples=noise_samples, nce_idx=nce_idx)
         logits = self.fc(final_vec)
         if lr is not None:
             logits = logits + lr.view(-1, 1) + self.lr_layer.bias
