@@ -21,7 +21,13 @@
 
 namespace mapx {
 
-constexpr int kSegChunk = 32;  // sorted positions per lane group in pass A
+constexpr int kSegChunk = 32;  // sorted positions per lane group in pass A ...
+// ... and 16 for small problems (round 3): the embedding gradient's 94 k positions are 46 workgroups at 32 — a chain of
+// dependent misses per group with most of the chip idle (19 us); at 16 they are 92 and the walk is half as long
+// (13.5 us).  The NCE table's 639 k positions lose at 16 (37 -> 48 us: twice the partial rows and owners).
+constexpr int kSegChunkSmall = 16;
+constexpr int64_t kSegSmallN = 1 << 18;
+inline __host__ __device__ int seg_chunk_for(int64_t n) { return n <= kSegSmallN ? kSegChunkSmall : kSegChunk; }
 
 struct SegPlanView {
   int64_t n;
@@ -137,7 +143,7 @@ __device__ inline void add4(float4& a, const float4& b) {
 // contributions are fetched 8 entries ahead of the accumulate/flush walk (which is serial by
 // nature), so the random reads behind `perm` overlap instead of paying their latency 32 times.
 // A chunk whose tail run continues into the next chunk appends itself to `owners`.
-template <int LG, bool EXTRA, class Contrib, int BATCH = 8>
+template <int LG, bool EXTRA, class Contrib, int BATCH = 8, int CH = kSegChunk>
 __global__ void __launch_bounds__(256) seg_reduce_pass_a(SegPlanView pl, Contrib contrib, int W,
                                                          float* __restrict__ out,
                                                          float* __restrict__ out_extra,
@@ -145,16 +151,16 @@ __global__ void __launch_bounds__(256) seg_reduce_pass_a(SegPlanView pl, Contrib
                                                          float* __restrict__ part_tail,
                                                          int32_t* __restrict__ owners,
                                                          int32_t* __restrict__ n_owners) {
-  constexpr int NPL = kSegChunk / LG;          // entries each lane preloads; BATCH = contributions in flight per walk step
+  constexpr int NPL = CH / LG;          // entries each lane preloads; BATCH = contributions in flight per walk step
   contrib.prepare();
   const int WS = EXTRA ? W + 4 : W;
   const int lane = threadIdx.x % kWave;
   const int lig = lane % LG, gbase = lane - lig;
   const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LG;
-  const int64_t ngroups = ceil_div(pl.n, kSegChunk);
+  const int64_t ngroups = ceil_div(pl.n, CH);
   const bool active = group < ngroups;         // whole groups are active or not; shuffles need all lanes
-  const int64_t j0 = active ? group * kSegChunk : 0;
-  const int64_t j1 = active ? ((j0 + kSegChunk < pl.n) ? j0 + kSegChunk : pl.n) : 0;
+  const int64_t j0 = active ? group * CH : 0;
+  const int64_t j1 = active ? ((j0 + CH < pl.n) ? j0 + CH : pl.n) : 0;
   int myrank[NPL], myperm[NPL];
 #pragma unroll
   for (int i = 0; i < NPL; ++i) {
@@ -172,7 +178,7 @@ __global__ void __launch_bounds__(256) seg_reduce_pass_a(SegPlanView pl, Contrib
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float accx = 0.f;
 #pragma unroll
-    for (int e0 = 0; e0 < kSegChunk; e0 += BATCH) {
+    for (int e0 = 0; e0 < CH; e0 += BATCH) {
       float4 v[BATCH];
       float ex[BATCH];
       int rk[BATCH];
@@ -236,7 +242,7 @@ __global__ void __launch_bounds__(256) seg_reduce_pass_a(SegPlanView pl, Contrib
 }
 
 // One wave per OWNER chunk (listed by pass A): sum = tail[c] + head[c+1] + ... + head[c_last].
-template <int LG, bool EXTRA>
+template <int LG, bool EXTRA, int CH = kSegChunk>
 __global__ void __launch_bounds__(256) seg_reduce_pass_b(SegPlanView pl, int W,
                                                          float* __restrict__ out,
                                                          float* __restrict__ out_extra,
@@ -250,9 +256,9 @@ __global__ void __launch_bounds__(256) seg_reduce_pass_b(SegPlanView pl, int W,
   for (int64_t oi = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave; oi < nown;
        oi += ((int64_t)gridDim.x * blockDim.x) / kWave) {
   const int64_t c = owners[oi];
-  const int64_t j1 = c * kSegChunk + kSegChunk;
+  const int64_t j1 = c * CH + CH;
   const int cur = pl.rank[j1 - 1];
-  const int64_t c_last = (pl.seg_start[cur] - 1) / kSegChunk;
+  const int64_t c_last = (pl.seg_start[cur] - 1) / CH;
   constexpr int G = kWave / LG;                 // lane groups per wave
   const int g = lane / LG, lig = lane % LG;
   for (int sub0 = 0; sub0 * 4 < W; sub0 += LG) {   // wave-uniform trip count (shuffles inside)
@@ -325,7 +331,7 @@ __global__ void __launch_bounds__(256) seg_reduce_pass_b(SegPlanView pl, int W,
 // Bytes of partial storage seg_reduce needs for n keys of row width W (+extra).
 inline size_t seg_reduce_partial_bytes(int64_t n, int W, bool extra) {
   const int WS = extra ? W + 4 : W;
-  const size_t chunks = (size_t)ceil_div(n > 0 ? n : 1, kSegChunk);
+  const size_t chunks = (size_t)ceil_div(n > 0 ? n : 1, seg_chunk_for(n));
   return chunks * WS * sizeof(float) * 2 + (chunks + 64) * sizeof(int32_t);   // + owner list, counter
 }
 
@@ -341,7 +347,8 @@ int seg_reduce_launch(const SegPlanView& pl, const Contrib& contrib, int W, floa
     return MAPX_EWORKSPACE;
   }
   const int WS = EXTRA ? W + 4 : W;
-  const int64_t nchunks = ceil_div(pl.n, kSegChunk);
+  const int ch = seg_chunk_for(pl.n);
+  const int64_t nchunks = ceil_div(pl.n, ch);
   float* part_head = static_cast<float*>(ws);
   float* part_tail = part_head + nchunks * WS;
   int32_t* n_owners = reinterpret_cast<int32_t*>(part_tail + nchunks * WS);
@@ -360,16 +367,22 @@ int seg_reduce_launch(const SegPlanView& pl, const Contrib& contrib, int W, floa
   const int grid_b = (int)(gb > 1024 ? 1024 : gb);
   // (8 contributions in flight per walk step; 16 and 32 were measured and change nothing: 38.3 / 38.8 / 42.7 us for
   // the NCE table's reduction, 20.4 / 22.5 / 17.9 us for the embedding's — the walk is not bound by its loads in flight)
-#define MAPX_SEG_LAUNCH(LG_)                                                                    \
-  hipLaunchKernelGGL((seg_reduce_pass_a<LG_, EXTRA, Contrib, 8>), dim3(grid_a), dim3(256), 0,   \
-                     stream, pl, contrib, W, out, out_extra, part_head, part_tail, owners,     \
-                     n_owners);                                                                 \
-  hipLaunchKernelGGL((seg_reduce_pass_b<LG_, EXTRA>), dim3(grid_b), dim3(256), 0, stream, pl,   \
+#define MAPX_SEG_LAUNCH2(LG_, CH_)                                                                      \
+  hipLaunchKernelGGL((seg_reduce_pass_a<LG_, EXTRA, Contrib, 8, CH_>), dim3(grid_a), dim3(256), 0,         \
+                     stream, pl, contrib, W, out, out_extra, part_head, part_tail, owners,               \
+                     n_owners);                                                                           \
+  hipLaunchKernelGGL((seg_reduce_pass_b<LG_, EXTRA, CH_>), dim3(grid_b), dim3(256), 0, stream, pl,        \
                      W, out, out_extra, part_head, part_tail, owners, n_owners)
+#define MAPX_SEG_LAUNCH(LG_)                                                                              \
+  do {                                                                                                    \
+    if (ch == kSegChunkSmall) { MAPX_SEG_LAUNCH2(LG_, kSegChunkSmall); }                                  \
+    else { MAPX_SEG_LAUNCH2(LG_, kSegChunk); }                                                            \
+  } while (0)
   if (lg == 4) { MAPX_SEG_LAUNCH(4); }
   else if (lg == 8) { MAPX_SEG_LAUNCH(8); }
   else { MAPX_SEG_LAUNCH(16); }
 #undef MAPX_SEG_LAUNCH
+#undef MAPX_SEG_LAUNCH2
   return check_launch(what);
 }
 
