@@ -32,7 +32,7 @@ JOINT_PLAN = os.environ.get("MAPX_JOINT_PLAN", "auto")
 # won (0.869 / 0.873 vs 0.876 / 0.882 ms); round 3, after the backward pass changed (tools/flag_sweep.py): the tower
 # stream wins, 0.8058 vs 0.8223 ms
 LAYOUT_ON_MAIN = os.environ.get("MAPX_LAYOUT_ON_MAIN", "0") == "1"
-PLAN_AFTER_DNN = os.environ.get("MAPX_PLAN_AFTER_DNN", "1") == "1"
+PLAN_AFTER_DNN = os.environ.get("MAPX_PLAN_AFTER_DNN", "1")       # 1 | tower | 0: what the joint plan goes behind
 # RFD / finetune steps: what the one table's sort goes behind: auto | main | tower | 0 (A/B switch)
 PLAN_AFTER_TRUNK = os.environ.get("MAPX_PLAN_AFTER_TRUNK", "auto")
 
@@ -291,7 +291,7 @@ class DCNV2(BaseModel):
                 # implies that the embedding's keys are final)
                 PlanSlot.start_many([self.embed.table.plan, self.mfp_criterion.table.plan],
                                     implied=[self.embed.table.plan] if IMPLIED else (),
-                                    after=main if PLAN_AFTER_DNN else None)
+                                    after={"1": main, "tower": tower}.get(PLAN_AFTER_DNN))
             elif nce_idx is not None and mode == "bwd" and self.mfp_criterion.table.plan is not None:
                 # the head's backward node starts both (PlanSlot.start_many from IndexLinear's partner list)
                 self.mfp_criterion.table.plan.partners = [self.embed.table.plan]
