@@ -292,12 +292,13 @@ int mapx_sum_tasks(const mapx_sum_task* tasks_host, int ntasks, hipStream_t stre
 
 /* Linear layers with N <= 32 outputs as fp32 FMA streaming kernels (csrc/skinny.hip) — the heads' last layers:
  * RFD's Linear(F*P -> F) (reference models.py:119-124: pred_rfd[2]) and the finetune head Linear(D+H -> 1)
- * (models.py:304, 319: fc_out).  x [M,K], w [N,K], dy / y [M,N]; K % 4 == 0, rows of x / w / dx 16-byte aligned.
+ * (models.py:304, 319: fc_out).  x [M,K], w [N,K], dy / y [M,N]; K % 4 == 0, rows of x / w / dx 16-byte aligned (fwd: N <= 32; dw, dx: N <= 64).
  *   fwd: y = x w^T + bias_opt (relu != 0: max(., 0));   dx = dy w;
  *   dw:  part [chunks][N*K] <- per-row-chunk partial sums of dy^T x (chunks: mapx_skinny_chunks() = 128 for a batch
  *        of a few thousand rows; more for taller problems: a chunk is one workgroup); the caller adds the chunks with
- *        mapx_sum_tasks (stride N*K, nsplit = chunks), alone or with the step's other deferred sums.  Also N <= 64 when
- *        K <= 64 (AutoInt's attention projections, layers.py:724-744: dW [40, 16 | 40] over B*F rows).
+ *        mapx_sum_tasks (stride N*K, nsplit = chunks), alone or with the step's other deferred sums.  (33..64 outputs
+ *        over more than 64 columns: at most 64 rows per chunk.  AutoInt's attention projections, layers.py:724-744, are
+ *        the tall case: dW [40, 16 | 40] over B*F rows.)
  * Plain fp32 sums in a fixed order (bit-reproducible), not the six-product arithmetic of mapx_gemm_f32. */
 int mapx_skinny_chunks(void);
 int mapx_skinny_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias_opt, int M,

@@ -138,34 +138,36 @@ __global__ void __launch_bounds__(256) skinny_dx_kernel(const float* __restrict_
 // 32-row LDS-tiled streaming forward measured 25.8, the butterfly one 27.9 — the host dispatch sends only N <= 8 here.)
 constexpr int kTK = 128;                                   // columns per block
 
+template <int NJ>                                          // outputs per thread: N <= 8 NJ
 __global__ void __launch_bounds__(256) skinny_dw_tiled_kernel(const float* __restrict__ dy, int64_t ldy,
                                                               const float* __restrict__ x, int64_t ldx, int M, int N,
                                                               int K, float* __restrict__ part) {
+  constexpr int NW = 8 * NJ, LDS_ = NW + 1;
   const int rows_per = (M + (int)gridDim.y - 1) / (int)gridDim.y;        // <= 64 (host-checked)
-  __shared__ float ds[64 * 33];
+  __shared__ float ds[64 * LDS_];
   const int t = threadIdx.x, k4 = t & 31, q = t >> 5;
   const int m0 = blockIdx.y * rows_per, m1 = (m0 + rows_per < M) ? m0 + rows_per : M;
   const int k = blockIdx.x * kTK + 4 * k4;
-  for (int e = t; e < (m1 - m0) * 32; e += 256) {
-    const int row = e >> 5, n = e & 31;
-    ds[row * 33 + n] = n < N ? dy[(int64_t)(m0 + row) * ldy + n] : 0.f;
+  for (int e = t; e < (m1 - m0) * NW; e += 256) {
+    const int row = e / NW, n = e % NW;
+    ds[row * LDS_ + n] = n < N ? dy[(int64_t)(m0 + row) * ldy + n] : 0.f;
   }
   __syncthreads();
   if (k >= K) return;
-  float4 acc[4];
+  float4 acc[NJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j = 0; j < NJ; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int m = m0; m < m1; ++m) {
     const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)m * ldx + k);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float g = ds[(m - m0) * 33 + q + 8 * j];
+    for (int j = 0; j < NJ; ++j) {
+      const float g = ds[(m - m0) * LDS_ + q + 8 * j];
       acc[j].x += g * xv.x; acc[j].y += g * xv.y; acc[j].z += g * xv.z; acc[j].w += g * xv.w;
     }
   }
   float* __restrict__ p = part + (int64_t)blockIdx.y * N * K + k;
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < NJ; ++j)
     if (q + 8 * j < N) *reinterpret_cast<float4*>(p + (int64_t)(q + 8 * j) * K) = acc[j];
 }
 
@@ -310,6 +312,8 @@ static bool skinny_dispatch(int N, A... a) {
   else if (N <= 16) Launch<16>::go(a...);
   else if (N <= 24) Launch<24>::go(a...);
   else if (N <= 32) Launch<32>::go(a...);
+  else if (N <= 48) Launch<48>::go(a...);
+  else if (N <= 64) Launch<64>::go(a...);
   else return false;
   return true;
 }
@@ -359,16 +363,18 @@ extern "C" int mapx_skinny_linear_fwd(const float* x, int64_t ldx, const float* 
 extern "C" int mapx_skinny_linear_dw(const float* dy, int64_t ldy, const float* x, int64_t ldx, int M, int N, int K,
                                      float* part, int chunks, hipStream_t stream) {
   using namespace mapx;
-  MAPX_REQUIRE(dy && x && part && M >= 1 && N >= 1 && (N <= 32 || (N <= 64 && K <= 64)) && K >= 4 && K % 4 == 0 &&
-                   ldy >= N && chunks >= 1 && chunks <= 65535,
-               "skinny_linear_dw: bad sizes (N <= 32, or N <= 64 with K <= 64)");
+  MAPX_REQUIRE(dy && x && part && M >= 1 && N >= 1 && N <= 64 && K >= 4 && K % 4 == 0 && ldy >= N && chunks >= 1 &&
+                   chunks <= 65535, "skinny_linear_dw: bad sizes (N <= 64)");
   MAPX_REQUIRE(al16(x, ldx) && (uintptr_t)part % 16 == 0, "skinny_linear_dw: rows of x must be 16-byte aligned");
   const int rows_per = (M + chunks - 1) / chunks;
   if (K <= 64 && (N > 32 || (N > 8 && rows_per > 64)))
     hipLaunchKernelGGL(skinny_dw_tall_kernel, dim3(1, chunks), dim3(256), 0, stream, dy, ldy, x, ldx, M, N, K, part);
+  else if (N > 32 && rows_per <= 64)
+    hipLaunchKernelGGL(skinny_dw_tiled_kernel<8>, dim3(grid_for(K, kTK), chunks), dim3(256), 0, stream, dy, ldy, x, ldx,
+                       M, N, K, part);
   else if (N > 8 && rows_per <= 64)
-    hipLaunchKernelGGL(skinny_dw_tiled_kernel, dim3(grid_for(K, kTK), chunks), dim3(256), 0, stream, dy, ldy, x, ldx, M,
-                       N, K, part);
+    hipLaunchKernelGGL(skinny_dw_tiled_kernel<4>, dim3(grid_for(K, kTK), chunks), dim3(256), 0, stream, dy, ldy, x, ldx,
+                       M, N, K, part);
   else
     skinny_dispatch<DwLaunch>(N, dy, ldy, x, ldx, M, N, K, part, chunks, stream);
   return check_launch("skinny_linear_dw");
@@ -377,7 +383,7 @@ extern "C" int mapx_skinny_linear_dw(const float* dy, int64_t ldy, const float* 
 extern "C" int mapx_skinny_linear_dx(const float* dy, int64_t ldy, const float* w, int64_t ldw, int M, int N, int K,
                                      float* dx, int64_t lddx, hipStream_t stream) {
   using namespace mapx;
-  MAPX_REQUIRE(dy && w && dx && M >= 0 && N >= 1 && N <= 32 && K >= 4 && K % 4 == 0 && ldy >= N,
+  MAPX_REQUIRE(dy && w && dx && M >= 0 && N >= 1 && N <= 64 && K >= 4 && K % 4 == 0 && ldy >= N,
                "skinny_linear_dx: bad sizes");
   MAPX_REQUIRE(al16(w, ldw) && al16(dx, lddx), "skinny_linear_dx: rows of w and dx must be 16-byte aligned");
   if (M == 0) return MAPX_OK;

@@ -879,7 +879,7 @@ def _rows16(t):
 
 _TALL_ROWS = int(os.environ.get("MAPX_TALL_ROWS", "128"))
 SKINNY_MAX = int(os.environ.get("MAPX_SKINNY_MAX", "8"))            # forward: wider layers measured faster on the GEMM
-SKINNY_MAX_BWD = int(os.environ.get("MAPX_SKINNY_MAX_BWD", "32"))   # dW / dX (RFD's 23-wide layer: 14.6 / 8.6 vs 28 / 12 us)
+SKINNY_MAX_BWD = int(os.environ.get("MAPX_SKINNY_MAX_BWD", "64"))   # dW / dX (RFD's 23- / 39-wide layer: 14.6 / 8.6 vs 28 / 12 us at 23)
 
 
 def _skinny(Nn, K, *mats, bwd=False):
@@ -969,13 +969,16 @@ def linear_bwd_weight(dy, x, out=None, defer=False):
     Bn, Nn = dy.shape
     K = x.shape[1]
     # (also: both dimensions small over many rows — AutoInt's attention projections, dW [40, 16 | 40] over B*F rows)
-    tall = SKINNY and 32 < Nn <= 64 and 4 <= K <= 64 and K % 4 == 0 and Bn >= 8192 and _rows16(x)
-    if Bn >= 1 and (_skinny(Nn, K, x, bwd=True) or tall) and dy.dtype == torch.float32 and dy.dim() == 2 \
+    ok = _skinny(Nn, K, x, bwd=True)
+    rows_cap = 64 if (Nn > 32 and K > 64) else _TALL_ROWS     # (33..64 outputs x many columns: the LDS-tiled form only)
+    if ok and Nn > 32 and K > 64 and Bn > 64 * 2048:
+        ok = False
+    if Bn >= 1 and ok and dy.dtype == torch.float32 and dy.dim() == 2 \
             and dy.stride(1) == 1 \
             and (out is None or (out.dtype == torch.float32 and out.is_contiguous())):
         require_gpu(dy, x)
         chunks = lib.mapx_skinny_chunks()
-        while Bn // chunks > _TALL_ROWS and chunks < 2048:  # tall problems: a chunk is a workgroup
+        while -(-Bn // chunks) > rows_cap and chunks < 2048:  # tall problems: a chunk is a workgroup
             chunks *= 2
         dw = out if out is not None else torch.empty(Nn, K, dtype=torch.float32, device=dy.device)
         part = torch.empty(chunks, Nn * K, dtype=torch.float32, device=dy.device)

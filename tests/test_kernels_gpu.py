@@ -1035,7 +1035,8 @@ def test_take_rows_cuts_a_batch_behind_a_device_cursor(ops):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K", [(4096, 1, 1368), (4096, 23, 736), (777, 32, 64), (5, 7, 4), (64, 24, 2004),
-                                   (8500, 23, 40), (94208, 40, 16), (9000, 64, 64), (10000, 12, 40)])
+                                   (8500, 23, 40), (94208, 40, 16), (9000, 64, 64), (10000, 12, 40), (4096, 39, 1248),
+                                   (20000, 48, 200)])
 def test_skinny_linear_kernels_vs_fp64(ops, monkeypatch, M, N, K):
     """Narrow layers (the finetune head's single output; the kernels take up to 32) run as fp32 streaming
     kernels (csrc/skinny.hip): forward (+ bias, ReLU, strided destination), weight gradient (row-chunk partials
@@ -1049,10 +1050,14 @@ def test_skinny_linear_kernels_vs_fp64(ops, monkeypatch, M, N, K):
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
     b = torch.randn(N, generator=g).to(DEV)
     dy = torch.randn(M, N, generator=g).to(DEV)
-    if N > 32:                      # the tall weight-gradient form only (both dimensions small, many rows)
+    if N > 32:                      # 33..64 outputs: weight and input gradients only
+        monkeypatch.setattr(ops, "SKINNY_MAX_BWD", 64)
         dw_ref = dy.double().T @ x.double()
         dw = ops.linear_bwd_weight(dy, x)
         assert float((dw.double() - dw_ref).abs().max()) <= 3e-6 * float(dw_ref.abs().max())
+        dx_ref = dy.double() @ w.double()
+        dx = ops.linear_bwd_input(dy, w)
+        assert float((dx.double() - dx_ref).abs().max()) <= 2e-6 * float(dx_ref.abs().max())
         return
     assert ops._skinny(N, K, x, w)
     ref = x.double() @ w.double().T + b.double()
