@@ -218,6 +218,7 @@ class _Gather(Function):
             ops.dense_ready[0], ops.dense_ready[1] = ops.record_event(), torch.cuda.current_stream()
         plan = ctx.plan.get()
         g = g.contiguous().view(-1, ctx.width)           # bf16 rows in bf16 mode: summed in fp32
+        ops.dbg_sleep("gather_bwd")
         g2, link = None, getattr(ctx.table, "x0_link", None)
         if link is not None and link.g is not None:
             # the cross tower's dL/dX0, left aside by its backward node (_X0Link): summed with the deep tower's
@@ -506,11 +507,13 @@ def join_bwd_input(dz, w, final, link):
     side = ops.aux_stream("tower", dz.device) if dz.is_cuda else None
     forked = ops.stream_wait(side, main) if dz.is_cuda else False
     with (torch.cuda.stream(side) if forked else contextlib.nullcontext()):
+        ops.dbg_sleep("join_cross")
         g, t, dx0, part = ops.gemm_bwd_fused(dz, w[:, :D], D, x0=link.x0, u=link.u, plus_v=link.plus_v)
         ops.defer_part_rows(link.sb_cross, part, 0, D)
     if forked:
         dz.record_stream(side)
         ops.pending_joins.append((main, side))
+    ops.dbg_sleep("join_deep")
     dzr = ops.linear_bwd_input(dz, w[:, D:], relu_of=final[:, D:], colsum_to=link.relu.sb)
     link.relu.premasked = True
     link.t, link.dx0, link.g, link.dz = t, dx0, g, dzr
@@ -723,6 +726,7 @@ class _CrossTower(Function):
         if not ops.row_sliceable(g):
             g = g.contiguous()                   # else read in place: a slice of d(concat) costs no copy
         ops.run_side_tasks()                     # this chain has slack against the deep tower's
+        ops.dbg_sleep("cross_bwd")
         grads = [None] * (2 * n)
         D = x0.shape[1]
         t = dx0 = None
@@ -771,6 +775,7 @@ class _CrossTower(Function):
             # dL/dX0 goes to the gather's backward through the link, with an event HERE: the gather waits for the
             # dX chain above, not for the weight gradients and late tasks below
             cur = torch.cuda.current_stream()
+            ops.dbg_sleep("x0_event")
             xl.g, xl.event, xl.stream = g, ops.record_event(), cur
             if cur.cuda_stream != xl.consumer_stream.cuda_stream:
                 ops.pending_joins.append((xl.consumer_stream, cur))

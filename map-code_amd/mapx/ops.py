@@ -173,6 +173,16 @@ def clear_side_tasks():
     _main_tasks.clear()
 
 
+_DBG_SLEEP = os.environ.get("MAPX_DBG_SLEEP", "")
+
+
+def dbg_sleep(site):
+    """Race hunting: MAPX_DBG_SLEEP=<site>[,<site>] parks the CURRENT stream for ~0.5 ms at the named sites (a missing
+    cross-stream dependency then shows as a graph != eager or a parity failure instead of depending on timing)."""
+    if _DBG_SLEEP and site in _DBG_SLEEP.split(",") and torch.cuda.is_available():
+        torch.cuda._sleep(1_000_000)
+
+
 def reset_aux_streams():
     """Forget the named side streams (new ones are made on demand) and everything a backward pass may have
     left queued on them: after a failed graph capture the streams may be stuck in the invalidated capture,
