@@ -207,8 +207,17 @@ __global__ void __launch_bounds__(256) skinny_dw_tall_kernel(const float* __rest
           const float gg[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
+            // One v_fmac_f32 per term, by hand.  Left to the compiler this loop is 32 v_pk_fma_f32, the e == 1 ones
+            // taking dy from the HIGH half of a ds_read_b128 result for their LOW lane (op_sel:[0,1,0]).  Inside a
+            // captured step, beside the cross tower's MFMA kernels, the low halves of exactly those sums (outputs
+            // n % 4 == 1 at columns k % 2 == 0, lanes 48-63) were off by about one row's term once in ~10 steps,
+            // while eager mode and a graph of this kernel alone stayed bit-exact.
+            // 45 vs 43.5 us for AutoInt's 94 208 x 40 x 16 projection.
             float4& a = acc[4 * j4 + e];
-            a.x += gg[e] * xv.x; a.y += gg[e] * xv.y; a.z += gg[e] * xv.z; a.w += gg[e] * xv.w;
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a.x) : "v"(gg[e]), "v"(xv.x));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a.y) : "v"(gg[e]), "v"(xv.y));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a.z) : "v"(gg[e]), "v"(xv.z));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a.w) : "v"(gg[e]), "v"(xv.w));
           }
         }
       }

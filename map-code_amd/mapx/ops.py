@@ -890,8 +890,8 @@ def _rows16(t):
 _TALL_ROWS = int(os.environ.get("MAPX_TALL_ROWS", "128"))
 SKINNY_MAX = int(os.environ.get("MAPX_SKINNY_MAX", "8"))            # forward: wider layers measured faster on the GEMM
 # dW / dX (RFD's 23-wide layer: 14.6 / 8.6 vs 28 / 12 us).  The kernels take up to 64 outputs (Criteo's 39-wide layer:
-# dW 45 -> 26 us, its RFD step -2.3 %), but with 33..64 on, a captured step and the eager step of the small test models
-# (64-wide hidden layers) stopped agreeing bit for bit (1-ulp differences, cause not found): opt-in only.
+# dW 45 -> 26 us, its RFD step -2.3 %): opt-in.  (With 33..64 on, the captured step of the 64-wide test models stopped
+# agreeing with the eager one — traced to the packed FMAs of skinny_dw_tall_kernel, see there; now a test of its own.)
 SKINNY_MAX_BWD = int(os.environ.get("MAPX_SKINNY_MAX_BWD", "32"))
 
 
