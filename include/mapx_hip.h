@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 42
+#define MAPX_ABI_VERSION 43
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -249,11 +249,33 @@ int mapx_scale_inplace(float* x, int64_t n, const float* g, hipStream_t stream);
  * *nsplit_deferred receives the slab count (0 = C already final): the caller sums them later
  * with mapx_sum_tasks, together with every other deferred sum of the backward pass. */
 size_t mapx_gemm_splitk_workspace_bytes(int M, int N, int nsplit);
+/* Magnitude records (8 bytes of device memory each, zero-initialised by the caller once: the fp32 bit pattern of
+ * max |x| over a tensor's finite elements in the low word, an epoch tag in the high word; only ever raised, by
+ * integer atomicMax, so order-independent and never reset — a later epoch outranks an earlier one;
+ * csrc/amax.h).  A product whose two operands come with their records (amax_a, amax_b) is formed by the two-piece
+ * fp16 arithmetic (csrc/gemm_h2.hip: operands scaled by a power of two into fp16's range, hi + 2^-11 lo, three
+ * MFMAs per product, the error bound of the six-product arithmetic on tensors whose values lie within 2^29 of
+ * their maximum); without them, or where that kernel family does not build the case, by the six-product bf16
+ * arithmetic (csrc/gemm_x3.hip), which carries fp32's exponent range per element.  amax_c / amax_c2 (optional):
+ * records the launch raises with max |C| (mapx_gemm_f32_bwd_fused: of C's columns >= c0) and max |t|, for the
+ * product that reads those tensors next. */
+typedef struct mapx_gemm_scale {
+  const float* amax_a;
+  const float* amax_b;
+  void* amax_c;
+  void* amax_c2;
+} mapx_gemm_scale;
+/* The device int32 whose current value tags the records written from now on (the optimizer's update counter:
+ * a captured step then never needs to reset a record); NULL: tag 0. */
+int mapx_amax_epoch_source(const int32_t* device_counter_opt);
+/* record = max(record, max |x|) over x [rows, cols] (row stride ld); reset != 0: the record is zeroed first. */
+int mapx_amax_f32(const float* x, int64_t rows, int64_t cols, int64_t ld, void* record, int reset,
+                  hipStream_t stream);
 int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, int64_t lda,
                   const float* B, int64_t ldb, float* C, int64_t ldc, int epi, const float* bias,
                   const float* aux1, int64_t ld1, const float* aux2, int64_t ld2, float* out2,
                   int64_t ldo2, int nsplit, int tile_hint, void* ws, size_t ws_bytes,
-                  int* nsplit_deferred, hipStream_t stream);
+                  int* nsplit_deferred, const mapx_gemm_scale* scale_opt, hipStream_t stream);
 /* The input-gradient GEMM  v = dY W (+ add)  (a_kc = 1, b_kc = 0: dY [M,K], W [K,N]) whose epilogue also does the
  * elementwise backward that follows it in DCNv2's backward pass, on the tile while it is still in LDS:
  *   columns n >= c0:  v = mask[m,n] > 0 ? v : 0        ReLU backward of the layer whose OUTPUT `mask` is

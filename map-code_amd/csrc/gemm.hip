@@ -379,7 +379,8 @@ extern "C" int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
                              const float* B, int64_t ldb, float* C, int64_t ldc, int epi,
                              const float* bias, const float* aux1, int64_t ld1, const float* aux2,
                              int64_t ld2, float* out2, int64_t ldo2, int nsplit, int tile_hint,
-                             void* ws, size_t ws_bytes, int* nsplit_deferred, hipStream_t stream) {
+                             void* ws, size_t ws_bytes, int* nsplit_deferred, const mapx_gemm_scale* scale_opt,
+                             hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm_f32: negative size");
   if (M == 0 || N == 0) return MAPX_OK;
@@ -398,8 +399,15 @@ extern "C" int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
   MAPX_REQUIRE(epi >= MAPX_EPI_NONE && epi <= MAPX_EPI_RELU_MASK_COLSUM, "gemm_f32: unknown epilogue %d", epi);
   if (nsplit < 1) nsplit = 1;
   MAPX_REQUIRE(nsplit == 1 || epi == MAPX_EPI_NONE, "gemm_f32: split-K needs EPI_NONE");
+  GemmX3Extra ex{};
+  ex.batch = 1;
+  if (scale_opt) {
+    ex.amax_a = scale_opt->amax_a; ex.amax_b = scale_opt->amax_b;
+    ex.amax_c = static_cast<unsigned long long*>(scale_opt->amax_c);
+    ex.amax_c2 = static_cast<unsigned long long*>(scale_opt->amax_c2);
+  }
   return gemm_f32x3_launch(a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, epi, bias, aux1, ld1, aux2, ld2, out2, ldo2,
-                           nsplit, tile_hint, ws, ws_bytes, nsplit_deferred, stream);
+                           nsplit, tile_hint, ws, ws_bytes, nsplit_deferred, stream, scale_opt ? &ex : nullptr);
 }
 
 extern "C" int mapx_gemm_f32_bwd_fused(int M, int N, int K, const float* dY, int64_t lda, const float* W, int64_t ldw,

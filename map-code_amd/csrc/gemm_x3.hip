@@ -21,6 +21,7 @@
 // ds_read_b128 per fragment, conflict-free at the 80-byte row stride; k-strided: [k][rows + 32], two
 // ds_read_b64_tr_b16 per fragment).  One barrier per K-step, two LDS buffers; the epilogue goes
 // through LDS as fp32 rows and moves every operand with 16-byte accesses.
+#include "amax.h"
 #include "gemm_x3_common.h"
 #include "gemm_grouped.h"
 
@@ -482,34 +483,7 @@ __global__ void __launch_bounds__(64 * WR * WC) gemm_f32x3_kernel(GemmX3Args a_i
       for (int r = 0; r < 16; ++r)
         tile[(abase + 32 * i + 4 * kh + (r & 3) + 8 * (r >> 2)) * LDT + bbase + 32 * j + l31] = acc[i][j][r] + cor[i][j][r];
   __syncthreads();
-  auto al16 = [](const void* p, int64_t ld) { return p == nullptr || ((uintptr_t)p % 16 == 0 && ld % 4 == 0); };
-  const bool vio = a.N % 4 == 0 && al16(C, a.ldc) && al16(a.aux1, a.ld1) && al16(a.aux2, a.ld2) && al16(a.out2, a.ldo2) &&
-                   al16(a.bias, 0);
-  if (vio) {
-    switch (a.epi) {
-      case MAPX_EPI_BIAS: epilogue_rows_x3_vec<MAPX_EPI_BIAS, BM, BN, NT>(a, C, tile, m0, n0); break;
-      case MAPX_EPI_BIAS_RELU: epilogue_rows_x3_vec<MAPX_EPI_BIAS_RELU, BM, BN, NT>(a, C, tile, m0, n0); break;
-      case MAPX_EPI_BIAS_CROSS: epilogue_rows_x3_vec<MAPX_EPI_BIAS_CROSS, BM, BN, NT>(a, C, tile, m0, n0); break;
-      case MAPX_EPI_ADD: epilogue_rows_x3_vec<MAPX_EPI_ADD, BM, BN, NT>(a, C, tile, m0, n0); break;
-      case MAPX_EPI_RELU_MASK: epilogue_rows_x3_vec<MAPX_EPI_RELU_MASK, BM, BN, NT>(a, C, tile, m0, n0); break;
-      case MAPX_EPI_RELU_MASK_COLSUM:
-        if constexpr (BM == 128) epilogue_rows_x3_vec<MAPX_EPI_RELU_MASK_COLSUM, BM, BN, NT>(a, C, tile, m0, n0);
-        break;
-      case MAPX_EPI_BWD_FUSED:
-        if constexpr (BM == 128) epilogue_bwd_fused<BM, BN, NT>(a, C, tile, m0, n0);
-        break;
-      default: epilogue_rows_x3_vec<MAPX_EPI_NONE, BM, BN, NT>(a, C, tile, m0, n0); break;
-    }
-  } else {
-    switch (a.epi) {
-      case MAPX_EPI_BIAS: epilogue_rows_x3<MAPX_EPI_BIAS, BM, BN, NT>(a, C, tile, m0, n0, vio); break;
-      case MAPX_EPI_BIAS_RELU: epilogue_rows_x3<MAPX_EPI_BIAS_RELU, BM, BN, NT>(a, C, tile, m0, n0, vio); break;
-      case MAPX_EPI_BIAS_CROSS: epilogue_rows_x3<MAPX_EPI_BIAS_CROSS, BM, BN, NT>(a, C, tile, m0, n0, vio); break;
-      case MAPX_EPI_ADD: epilogue_rows_x3<MAPX_EPI_ADD, BM, BN, NT>(a, C, tile, m0, n0, vio); break;
-      case MAPX_EPI_RELU_MASK: epilogue_rows_x3<MAPX_EPI_RELU_MASK, BM, BN, NT>(a, C, tile, m0, n0, vio); break;
-      default: epilogue_rows_x3<MAPX_EPI_NONE, BM, BN, NT>(a, C, tile, m0, n0, vio); break;
-    }
-  }
+  epilogue_dispatch<BM, BN, NT>(a, C, tile, m0, n0);
 }
 
 template <int WR, int WC, int WMT, int WNT, bool A_KC, bool B_KC, bool VEC>
@@ -577,6 +551,9 @@ __global__ void __launch_bounds__(256) splitk_reduce_x3_v4_kernel(const float* _
   }
 }
 
+bool gemm_f32h2_try(GemmX3Args& g, int a_kc, int b_kc, bool vec, int tile, int nsplit, int batch, hipStream_t stream,
+                    hipError_t* err);      // gemm_h2.hip
+
 static bool xcd_slices_enabled() {
   static const bool on = [] { const char* e = getenv("MAPX_XCD_SLICES"); return !e || atoi(e) != 0; }();
   return on;
@@ -592,8 +569,13 @@ int gemm_f32x3_launch(int a_kc, int b_kc, int M, int N, int K, const float* A, i
   if (ex) {
     g.aux3 = ex->aux3; g.ld3 = ex->ld3; g.mask = ex->mask; g.ldm = ex->ldm; g.out3 = ex->out3; g.ldo3 = ex->ldo3;
     g.out4 = ex->out4; g.ldo4 = ex->ldo4; g.c0 = ex->c0; g.flags = ex->flags;
-    for (int z = 0; z < batch && batch > 1; ++z) { g.Az[z] = ex->Az[z]; g.Bz[z] = ex->Bz[z]; g.Cz[z] = ex->Cz[z]; }
+    g.amax_a = ex->amax_a; g.amax_b = ex->amax_b; g.amax_c = ex->amax_c; g.amax_c2 = ex->amax_c2;
+    for (int z = 0; z < batch && batch > 1; ++z) {
+      g.Az[z] = ex->Az[z]; g.Bz[z] = ex->Bz[z]; g.Cz[z] = ex->Cz[z];
+      g.amax_az[z] = ex->amax_az[z]; g.amax_bz[z] = ex->amax_bz[z];
+    }
   }
+  g.epoch = amax_epoch_ptr();
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
   g.M = M; g.N = N; g.K = K; g.epi = epi; g.bias = bias;
   g.aux1 = aux1; g.ld1 = ld1; g.aux2 = aux2; g.ld2 = ld2; g.out2 = out2; g.ldo2 = ldo2;
@@ -643,10 +625,15 @@ int gemm_f32x3_launch(int a_kc, int b_kc, int M, int N, int K, const float* A, i
     const int64_t nb1 = ceil_div(M, bm) * ceil_div(N, bn);
     g.xcd_slices = (8 % nsplit == 0 && nb1 % (8 / nsplit) == 0 && (nb1 * nsplit) % 8 == 0) ? 1 : 0;
   }
-  hipError_t e;
-  if (a_kc && b_kc) e = launch_layout_x3<true, true>(g, vec, tile, nsplit, stream, batch);
-  else if (a_kc) e = launch_layout_x3<true, false>(g, vec, tile, nsplit, stream, batch);
-  else e = launch_layout_x3<false, false>(g, vec, tile, nsplit, stream, batch);
+  hipError_t e = hipSuccess;
+  // both operands with a magnitude record: the two-piece fp16 arithmetic (gemm_h2.hip), where it builds the case
+  bool scaled = batch > 1 ? true : (g.amax_a && g.amax_b);
+  for (int z = 0; z < batch && batch > 1; ++z) scaled = scaled && g.amax_az[z] && g.amax_bz[z];
+  if (!(scaled && gemm_f32h2_try(g, a_kc, b_kc, vec, tile, nsplit, batch, stream, &e))) {
+    if (a_kc && b_kc) e = launch_layout_x3<true, true>(g, vec, tile, nsplit, stream, batch);
+    else if (a_kc) e = launch_layout_x3<true, false>(g, vec, tile, nsplit, stream, batch);
+    else e = launch_layout_x3<false, false>(g, vec, tile, nsplit, stream, batch);
+  }
   MAPX_HIP(e);
   if (batch > 1) {            // the caller sums the slabs of all problems with one launch (mapx_gemm_f32_batched)
     if (nsplit_deferred) *nsplit_deferred = nsplit > 1 ? nsplit : 0;

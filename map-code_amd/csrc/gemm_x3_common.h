@@ -41,6 +41,17 @@ struct GemmX3Args {
   float* Cz[4];
   int64_t batch_slabs;
   int xcd_slices;        // split-K blocks dealt so that an XCD works on ONE k-slice (see the kernel's tile order)
+  // Per-tensor magnitudes (include/mapx_hip.h: mapx_gemm_scale).  amax_a / amax_b: max |x| of the operands, read by
+  // the two-piece fp16 kernels (gemm_h2.hip) to place them in fp16's range; amax_c / amax_c2: where this launch
+  // leaves max |.| of what it stores (C — in EPI_BWD_FUSED its columns >= c0 — and out3), for the product that
+  // reads it next.  Batched launches: operands of problem z.
+  const float* amax_a;
+  const float* amax_b;
+  unsigned long long* amax_c;
+  unsigned long long* amax_c2;
+  const float* amax_az[4];
+  const float* amax_bz[4];
+  const int32_t* epoch;  // tag of the amax records written (amax.h)
 };
 
 // what the plain mapx_gemm_f32 contract does not carry (fused backward epilogue, batched launch)
@@ -54,6 +65,12 @@ struct GemmX3Extra {
   const float* Az[4];
   const float* Bz[4];
   float* Cz[4];
+  const float* amax_az[4];
+  const float* amax_bz[4];
+  const float* amax_a;            // mapx_gemm_scale of the (unbatched) product
+  const float* amax_b;
+  unsigned long long* amax_c;
+  unsigned long long* amax_c2;
 };
 
 #define MAPX_EPI_BWD_FUSED 7        // internal to the library: reached through mapx_gemm_f32_bwd_fused only
@@ -329,6 +346,40 @@ __device__ inline void epilogue_bwd_fused(const GemmX3Args& a, float* __restrict
       s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
     }
     *reinterpret_cast<float4*>(a.out2 + (int64_t)(m0 / 128) * a.ldo2 + n) = s;
+  }
+}
+
+// Second pass of every dense GEMM kernel (gemm_x3.hip, gemm_h2.hip): the fp32 tile in LDS -> C through the epilogue
+template <int BM, int BN, int NT>
+__device__ inline void epilogue_dispatch(const GemmX3Args& a, float* __restrict__ C, const float* __restrict__ tile,
+                                         int m0, int n0) {
+  auto al16 = [](const void* p, int64_t ld) { return p == nullptr || ((uintptr_t)p % 16 == 0 && ld % 4 == 0); };
+  const bool vio = a.N % 4 == 0 && al16(C, a.ldc) && al16(a.aux1, a.ld1) && al16(a.aux2, a.ld2) && al16(a.out2, a.ldo2) &&
+                   al16(a.bias, 0);
+  if (vio) {
+    switch (a.epi) {
+      case MAPX_EPI_BIAS: epilogue_rows_x3_vec<MAPX_EPI_BIAS, BM, BN, NT>(a, C, tile, m0, n0); break;
+      case MAPX_EPI_BIAS_RELU: epilogue_rows_x3_vec<MAPX_EPI_BIAS_RELU, BM, BN, NT>(a, C, tile, m0, n0); break;
+      case MAPX_EPI_BIAS_CROSS: epilogue_rows_x3_vec<MAPX_EPI_BIAS_CROSS, BM, BN, NT>(a, C, tile, m0, n0); break;
+      case MAPX_EPI_ADD: epilogue_rows_x3_vec<MAPX_EPI_ADD, BM, BN, NT>(a, C, tile, m0, n0); break;
+      case MAPX_EPI_RELU_MASK: epilogue_rows_x3_vec<MAPX_EPI_RELU_MASK, BM, BN, NT>(a, C, tile, m0, n0); break;
+      case MAPX_EPI_RELU_MASK_COLSUM:
+        if constexpr (BM == 128) epilogue_rows_x3_vec<MAPX_EPI_RELU_MASK_COLSUM, BM, BN, NT>(a, C, tile, m0, n0);
+        break;
+      case MAPX_EPI_BWD_FUSED:
+        if constexpr (BM == 128) epilogue_bwd_fused<BM, BN, NT>(a, C, tile, m0, n0);
+        break;
+      default: epilogue_rows_x3_vec<MAPX_EPI_NONE, BM, BN, NT>(a, C, tile, m0, n0); break;
+    }
+  } else {
+    switch (a.epi) {
+      case MAPX_EPI_BIAS: epilogue_rows_x3<MAPX_EPI_BIAS, BM, BN, NT>(a, C, tile, m0, n0, vio); break;
+      case MAPX_EPI_BIAS_RELU: epilogue_rows_x3<MAPX_EPI_BIAS_RELU, BM, BN, NT>(a, C, tile, m0, n0, vio); break;
+      case MAPX_EPI_BIAS_CROSS: epilogue_rows_x3<MAPX_EPI_BIAS_CROSS, BM, BN, NT>(a, C, tile, m0, n0, vio); break;
+      case MAPX_EPI_ADD: epilogue_rows_x3<MAPX_EPI_ADD, BM, BN, NT>(a, C, tile, m0, n0, vio); break;
+      case MAPX_EPI_RELU_MASK: epilogue_rows_x3<MAPX_EPI_RELU_MASK, BM, BN, NT>(a, C, tile, m0, n0, vio); break;
+      default: epilogue_rows_x3<MAPX_EPI_NONE, BM, BN, NT>(a, C, tile, m0, n0, vio); break;
+    }
   }
 }
 

@@ -19,6 +19,17 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace mapx
 
+namespace mapx {
+// amax.h: the device word whose value tags the magnitude records written from now on (one process = one GPU)
+static const int32_t* g_amax_epoch = nullptr;
+const int32_t* amax_epoch_ptr() { return g_amax_epoch; }
+}  // namespace mapx
+
+extern "C" int mapx_amax_epoch_source(const int32_t* device_counter_opt) {
+  mapx::g_amax_epoch = device_counter_opt;
+  return MAPX_OK;
+}
+
 extern "C" const char* mapx_last_error(void) { return mapx::g_err; }
 
 extern "C" int mapx_abi_version(void) { return MAPX_ABI_VERSION; }

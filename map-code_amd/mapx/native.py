@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmapx_hip.so")
 
-MAPX_ABI_VERSION = 42
+MAPX_ABI_VERSION = 43
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_CROSS, EPI_ADD, EPI_RELU_MASK, EPI_RELU_MASK_COLSUM = range(7)
 
 _p, _i, _i64, _u64, _f, _d, _sz = (C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double,
@@ -58,7 +58,9 @@ SIGNATURES = {
     "mapx_scale_inplace": (_i, [_p, _i64, _p, _p]),
     "mapx_gemm_splitk_workspace_bytes": (_sz, [_i, _i, _i]),
     "mapx_gemm_f32": (_i, [_i, _i, _i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _i, _p, _p, _i64, _p,
-                           _i64, _p, _i64, _i, _i, _p, _sz, _p, _p]),
+                           _i64, _p, _i64, _i, _i, _p, _sz, _p, _p, _p]),
+    "mapx_amax_epoch_source": (_i, [_p]),
+    "mapx_amax_f32": (_i, [_p, _i64, _i64, _i64, _p, _i, _p]),
     "mapx_gemm_f32_bwd_fused": (_i, [_i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i, _p, _i64, _p, _i64,
                                      _p, _i64, _p, _i64, _i, _i, _p, _i64, _p]),
     "mapx_gemm_f32_batched": (_i, [_i, _i, _i, _i, _i, _i, _p, _i64, _p, _i64, _p, _i, _p, _sz, _p]),
@@ -122,6 +124,11 @@ class SumTask(C.Structure):
     """mapx_sum_task (include/mapx_hip.h)."""
     _fields_ = [("dst", _p), ("src", _p), ("stride", _i64), ("n", _i64), ("nsplit", C.c_int32),
                 ("pad_", C.c_int32)]
+
+
+class GemmScale(C.Structure):
+    """mapx_gemm_scale (include/mapx_hip.h): magnitude records of a product's operands and outputs."""
+    _fields_ = [("amax_a", _p), ("amax_b", _p), ("amax_c", _p), ("amax_c2", _p)]
 
 
 class MapxError(RuntimeError):

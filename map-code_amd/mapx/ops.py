@@ -839,10 +839,48 @@ def gemm_bf16(a, b, a_kc, b_kc, M, N, K, out=None, out_dtype=BF16, ldc=None, epi
     return out
 
 
+def amax_record(device):
+    """A zeroed magnitude record (include/mapx_hip.h: mapx_gemm_scale; csrc/amax.h): 8 bytes."""
+    return torch.zeros(2, dtype=torch.int32, device=device)
+
+
+def amax(x, rec=None, reset=True):
+    """The magnitude record of a tensor no mapx kernel produced: one pass over x [rows, cols] (or 1-D)."""
+    require_gpu(x)
+    if x.dtype != torch.float32:
+        raise TypeError("amax: fp32 tensors")
+    if rec is None:
+        rec = torch.empty(2, dtype=torch.int32, device=x.device)
+        reset = True
+    x2 = x if x.dim() == 2 else x.reshape(1, -1)
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    check(lib.mapx_amax_f32(x2.data_ptr(), x2.shape[0], x2.shape[1], x2.stride(0), rec.data_ptr(), int(reset), stream()))
+    return rec
+
+
+def amax_value(rec):
+    """Host value of a record (tests)."""
+    return float(rec[:1].view(torch.float32).item())
+
+
+def _scale_arg(amax_a, amax_b, amax_c=None, amax_c2=None):
+    if amax_a is None and amax_b is None and amax_c is None and amax_c2 is None:
+        return None
+    sc = N.GemmScale()
+    sc.amax_a = amax_a.data_ptr() if amax_a is not None else None
+    sc.amax_b = amax_b.data_ptr() if amax_b is not None else None
+    sc.amax_c = amax_c.data_ptr() if amax_c is not None else None
+    sc.amax_c2 = amax_c2.data_ptr() if amax_c2 is not None else None
+    return sc
+
+
 def gemm(a, b, a_kc, b_kc, M, N, K, out=None, ldc=None, epi=N.EPI_NONE, bias=None, aux1=None,
-         aux2=None, out2=None, nsplit=1, lda=None, ldb=None, tile=-1, defer=False, out_dtype=None):
+         aux2=None, out2=None, nsplit=1, lda=None, ldb=None, tile=-1, defer=False, out_dtype=None,
+         amax_a=None, amax_b=None, amax_c=None):
     """C[M,N] = epi(sum_k A(m,k) B(k,n)); see include/mapx_hip.h: mapx_gemm_f32 (fp32 operands) /
-    mapx_gemm_bf16 (bf16 operands; `out_dtype` picks a bf16 or fp32 result)."""
+    mapx_gemm_bf16 (bf16 operands; `out_dtype` picks a bf16 or fp32 result).  amax_a / amax_b: the operands'
+    magnitude records (both given: the two-piece fp16 arithmetic); amax_c: record raised with max |C|."""
     require_gpu(a, b)
     if is_bf16(a):
         return gemm_bf16(a, b, a_kc, b_kc, M, N, K, out=out, out_dtype=out_dtype or BF16, ldc=ldc, epi=epi,
@@ -864,6 +902,7 @@ def gemm(a, b, a_kc, b_kc, M, N, K, out=None, ldc=None, epi=N.EPI_NONE, bias=Non
     ld2 = aux2.stride(0) if aux2 is not None else 0
     ldo2 = out2.stride(0) if out2 is not None else 0
     kind = "gemm_fwd_nt" if (a_kc and b_kc) else ("gemm_dx_nn" if a_kc else "gemm_dw_tn")
+    sc = _scale_arg(amax_a, amax_b, amax_c)
     with _timed(kind, 2.0 * M * N * K):
         check(lib.mapx_gemm_f32(int(a_kc), int(b_kc), M, N, K, a.data_ptr(), lda, b.data_ptr(), ldb,
                                 out.data_ptr(), ldc, epi, ptr(bias),
@@ -871,7 +910,8 @@ def gemm(a, b, a_kc, b_kc, M, N, K, out=None, ldc=None, epi=N.EPI_NONE, bias=Non
                                 aux2.data_ptr() if aux2 is not None else None, ld2,
                                 out2.data_ptr() if out2 is not None else None, ldo2, nsplit, tile,
                                 ws.data_ptr() if ws is not None else None, wsn,
-                                None if got is None else native_byref(got), stream()))
+                                None if got is None else native_byref(got),
+                                None if sc is None else native_byref(sc), stream()))
     if got is not None and got.value > 1:
         defer_sum(out, ws.view(torch.float32), M * N, got.value, M * N)
     return out

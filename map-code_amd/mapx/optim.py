@@ -303,25 +303,31 @@ class MapxOptimizer:
     def load_state_dict(self, sd):
         self.steps_done = int(sd["steps_done"])
         self.done.copy_(sd["done"])
-        pad = int(sd.get("flat_pad", 4))      # (states written before the key existed used slots of 4 elements)
+        saved_pad = sd.get("flat_pad")
         for g, s in zip(self.groups, sd["groups"]):
             if g["names"] != s["names"]:
                 raise ValueError("optimizer state: the parameter list changed since the state was saved")
-            if pad != self.FLAT_PAD or s["m"].numel() != g["m"].numel():
-                # another slot size: the flat moments do not line up — re-pack them parameter by parameter
-                sizes = g["numels"]
-                if sum((n + pad - 1) // pad * pad for n in sizes) != s["m"].numel() or s["v"].numel() != s["m"].numel():
-                    raise ValueError(f"optimizer state: flat moments of {s['m'].numel()} elements do not match the "
-                                     f"parameters at a slot size of {pad}")
-                src_off = dst_off = 0
-                for n in sizes:
-                    for key in ("m", "v"):
-                        g[key][dst_off:dst_off + n].copy_(s[key][src_off:src_off + n])
-                    src_off += (n + pad - 1) // pad * pad
-                    dst_off += (n + self.FLAT_PAD - 1) // self.FLAT_PAD * self.FLAT_PAD
+            sizes = g["numels"]
+            if s["v"].numel() != s["m"].numel():
+                raise ValueError("optimizer state: m and v of a group differ in length")
+            if s["m"].numel() == g["m"].numel() and saved_pad in (None, self.FLAT_PAD):
+                g["m"].copy_(s["m"])
+                g["v"].copy_(s["v"])
                 continue
-            g["m"].copy_(s["m"])
-            g["v"].copy_(s["v"])
+            # another slot size: the flat moments do not line up — re-pack them parameter by parameter.  States
+            # written before the `flat_pad` key existed used slots of 4, then of 8 elements: take the one that fits.
+            fits = [pad for pad in ([int(saved_pad)] if saved_pad is not None else [8, 4])
+                    if sum((n + pad - 1) // pad * pad for n in sizes) == s["m"].numel()]
+            if not fits:
+                raise ValueError(f"optimizer state: flat moments of {s['m'].numel()} elements do not match the "
+                                 f"parameters at a slot size of {saved_pad if saved_pad is not None else '8 or 4'}")
+            pad = fits[0]
+            src_off = dst_off = 0
+            for n in sizes:
+                for key in ("m", "v"):
+                    g[key][dst_off:dst_off + n].copy_(s[key][src_off:src_off + n])
+                src_off += (n + pad - 1) // pad * pad
+                dst_off += (n + self.FLAT_PAD - 1) // self.FLAT_PAD * self.FLAT_PAD
         for t, s in zip(self.tables, sd["tables"]):
             assert t.table.name == s["name"]
             t.m0.copy_(s["m0"]); t.v0.copy_(s["v0"]); t.last.copy_(s["last"])
