@@ -47,9 +47,10 @@ int mapx_abi_version(void);
 /* ------------------------------------------------------------------ embedding (a3)
  * layers.py:97-102 (nn.Embedding forward) + models.py:308 flatten: out[i,:] = table[ids[i],:].
  * ids [n] (= [B,F] flattened), table [V,E], out [n,E] (= [B, F*E]).  An out-of-range id
- * sets *err_flag (may be NULL) and yields a zero row (reference: IndexError). */
+ * sets *err_flag (may be NULL) and yields a zero row (reference: IndexError).  amax_out_opt: the magnitude record
+ * of `out` (mapx_gemm_scale below), raised with max |out|. */
 int mapx_emb_gather_fwd(const int64_t* ids, int64_t n, const float* table, int64_t V, int E,
-                        float* out, int* err_flag, hipStream_t stream);
+                        float* out, int* err_flag, void* amax_out_opt, hipStream_t stream);
 
 /* int64 ids -> int32 row keys, range-checked against V. */
 int mapx_ids_to_i32(const int64_t* ids, int64_t n, int64_t V, int32_t* out, int* err_flag,
@@ -209,10 +210,11 @@ int mapx_nce_fwd(const float* enc, int64_t B, int L, int F, int P, const int64_t
 /* Backward of the field gather: denc[b, f*P+p] = g * sum_{l: mi[b,l]==f} dh[b,l,p]; denc
  * [B, F*P] fully written.  gscale_opt: device scalar (upstream dLoss) or NULL = 1.
  * partials_ws_opt (with n_partials, loss_out_opt [2], acc_out_opt [1]): the forward's workspace when its totals
- * were left to this launch, which then writes them (same summation order as the forward's own finalize step). */
+ * were left to this launch, which then writes them (same summation order as the forward's own finalize step).
+ * amax_out_opt: magnitude record of denc (mapx_gemm_scale). */
 int mapx_nce_scatter_dh(const float* dh, const int64_t* masked_index, const float* gscale_opt,
                         int64_t B, int L, int F, int P, float* denc, const void* partials_ws_opt, int n_partials,
-                        float* loss_out_opt, int32_t* acc_out_opt, hipStream_t stream);
+                        float* loss_out_opt, int32_t* acc_out_opt, void* amax_out_opt, hipStream_t stream);
 /* Output-table gradient rows for the plan over idx.flatten() (n = B*L*(K+1)):
  * out_emb[u,:] = sum dlogit*h, out_bias[u] = sum dlogit over run u. */
 size_t mapx_nce_table_grad_workspace_bytes(int64_t n, int P);
@@ -249,25 +251,26 @@ int mapx_scale_inplace(float* x, int64_t n, const float* g, hipStream_t stream);
  * *nsplit_deferred receives the slab count (0 = C already final): the caller sums them later
  * with mapx_sum_tasks, together with every other deferred sum of the backward pass. */
 size_t mapx_gemm_splitk_workspace_bytes(int M, int N, int nsplit);
-/* Magnitude records (8 bytes of device memory each, zero-initialised by the caller once: the fp32 bit pattern of
- * max |x| over a tensor's finite elements in the low word, an epoch tag in the high word; only ever raised, by
- * integer atomicMax, so order-independent and never reset — a later epoch outranks an earlier one;
- * csrc/amax.h).  A product whose two operands come with their records (amax_a, amax_b) is formed by the two-piece
+/* Magnitude records (MAPX_AMAX_RECORD_BYTES of device memory each, zero-initialised by the caller once: 64 slots of
+ * {fp32 bit pattern of a maximum over finite elements, epoch tag}; only ever raised, by integer atomicMax, so
+ * order-independent and never reset — a later epoch outranks an earlier one; the tensor's max |x| is the maximum
+ * over the slots; csrc/amax.h).  A product whose two operands come with their records (amax_a, amax_b) is formed by the two-piece
  * fp16 arithmetic (csrc/gemm_h2.hip: operands scaled by a power of two into fp16's range, hi + 2^-11 lo, three
  * MFMAs per product, the error bound of the six-product arithmetic on tensors whose values lie within 2^29 of
  * their maximum); without them, or where that kernel family does not build the case, by the six-product bf16
  * arithmetic (csrc/gemm_x3.hip), which carries fp32's exponent range per element.  amax_c / amax_c2 (optional):
  * records the launch raises with max |C| (mapx_gemm_f32_bwd_fused: of C's columns >= c0) and max |t|, for the
  * product that reads those tensors next. */
+#define MAPX_AMAX_RECORD_BYTES 512
 typedef struct mapx_gemm_scale {
   const float* amax_a;
   const float* amax_b;
   void* amax_c;
   void* amax_c2;
 } mapx_gemm_scale;
-/* The device int32 whose current value tags the records written from now on (the optimizer's update counter:
- * a captured step then never needs to reset a record); NULL: tag 0. */
-int mapx_amax_epoch_source(const int32_t* device_counter_opt);
+/* The device int32 whose current value tags the records written from now on; mapx_step_advance adds 1 to it, so a
+ * captured step never needs to reset a record.  Process-wide (one process drives one GPU); NULL: tag 0. */
+int mapx_amax_epoch_source(int32_t* device_word_opt);
 /* record = max(record, max |x|) over x [rows, cols] (row stride ld); reset != 0: the record is zeroed first. */
 int mapx_amax_f32(const float* x, int64_t rows, int64_t cols, int64_t ld, void* record, int reset,
                   hipStream_t stream);
@@ -291,15 +294,15 @@ int mapx_gemm_f32_bwd_fused(int M, int N, int K, const float* dY, int64_t lda, c
                             float* C, int64_t ldc, const float* add_opt, int64_t ld_add, const float* mask_opt,
                             int64_t ld_mask, int c0, const float* x0, int64_t ld_x0, const float* u, int64_t ld_u,
                             float* t, int64_t ld_t, float* dx0, int64_t ld_dx0, int accumulate, int plus_v,
-                            float* part, int64_t ld_part, hipStream_t stream);
+                            float* part, int64_t ld_part, const mapx_gemm_scale* scale_opt, hipStream_t stream);
 /* `count` (<= 4) products of ONE shape in one launch (the cross layers' weight gradients, layers.py:197-201:
  * three 368 x 368 x 4096 products fill the GPU together, none of them alone): C[z] [M,N] dense = A[z] . B[z],
  * operands described as in mapx_gemm_f32 (a_kc / b_kc, lda, ldb).  nsplit > 1: split-K through `ws`
  * (count * mapx_gemm_splitk_workspace_bytes(M, N, nsplit) bytes), the slabs of all problems summed by one launch.
- * The pointer arrays are HOST memory. */
+ * The pointer arrays are HOST memory; scales_opt: `count` records (amax_a, amax_b of problem z), host memory. */
 int mapx_gemm_f32_batched(int count, int a_kc, int b_kc, int M, int N, int K, const float* const* A,
                           int64_t lda, const float* const* B, int64_t ldb, float* const* C, int nsplit,
-                          void* ws, size_t ws_bytes, hipStream_t stream);
+                          void* ws, size_t ws_bytes, const mapx_gemm_scale* scales_opt, hipStream_t stream);
 /* dst[i] = sum_{s < nsplit} src[s*stride + i], i < n, for up to 32 tasks in ONE launch.  The
  * task list is HOST memory (copied into the kernel arguments). */
 typedef struct mapx_sum_task {
@@ -334,11 +337,13 @@ int mapx_skinny_linear_dx(const float* dy, int64_t ldy, const float* w, int64_t 
  * mapx_gemm_f32_bwd_fused and mapx_gemm_f32's EPI_RELU_MASK_COLSUM do for wide heads):  v = dz w [M, D+H];
  * columns < D: g = v, t = v x0, dx0 = v u (+ v when plus_v), part_cross [ceil(M/128)][D] = column sums of t per
  * 128-row tile; columns >= D: dzr = final > 0 ? v : 0, part_deep [ceil(M/128)][H] likewise (mapx_sum_tasks adds the
- * tiles into the bias gradients).  D % 4 == H % 4 == 0, rows 16-byte aligned. */
+ * tiles into the bias gradients).  D % 4 == H % 4 == 0, rows 16-byte aligned.  amax_t_opt / amax_dzr_opt: magnitude
+ * records of t and dzr (mapx_gemm_scale). */
 int mapx_skinny_join_bwd(const float* dz, int64_t lddz, const float* w, int64_t ldw, int M, int N, int D, int H,
                          const float* final_act, int64_t ldf, const float* x0, int64_t ldx0, const float* u, int64_t ldu,
                          int plus_v, float* g, int64_t ldg, float* t, int64_t ldt, float* dx0, int64_t lddx0, float* dzr,
-                         int64_t lddzr, float* part_cross, float* part_deep, hipStream_t stream);
+                         int64_t lddzr, float* part_cross, float* part_deep, void* amax_t_opt, void* amax_dzr_opt,
+                         hipStream_t stream);
 /* row chunks of the column-sum kernels: with out/db == NULL they leave `chunks` partial rows
  * [chunks][N] in `ws` for a later mapx_sum_tasks (stride N, nsplit = chunks). */
 int mapx_colsum_chunks(void);
@@ -378,11 +383,12 @@ int mapx_cross_bwd_pre(const float* g, const float* x0, const float* u, int64_t 
  * are dense [M,N]; dy, y and g carry a leading dimension (column slices of the concatenated
  * trunk output and of its gradient are read in place).  cross: `accumulate` bit 0 adds to the dx0
  * already stored, bit 1 adds g as well (layer 0, whose Xi is X0). */
+/* amax_out_opt: the magnitude record of dz / t (mapx_gemm_scale), raised with the maximum of what is stored. */
 int mapx_relu_mask_colsum(const float* dy, int64_t ld_dy, const float* y, int64_t ld_y, int M, int N, float* dz,
-                          float* db, void* ws, size_t ws_bytes, hipStream_t stream);
+                          float* db, void* ws, size_t ws_bytes, void* amax_out_opt, hipStream_t stream);
 int mapx_cross_bwd_pre_colsum(const float* g, int64_t ld_g, const float* x0, const float* u, int M, int N,
                               float* t, float* dx0, int accumulate, float* db, void* ws, size_t ws_bytes,
-                              hipStream_t stream);
+                              void* amax_out_opt, hipStream_t stream);
 /* ReLU backward: out = y > 0 ? dy : 0 (y = activated output of layers.py:178-185). */
 int mapx_relu_mask(const float* dy, const float* y, int64_t n, float* out, hipStream_t stream);
 
@@ -437,9 +443,13 @@ int mapx_dynamic_mask_rfd(const int64_t* ids, int64_t B, int F, int L,
 /* ------------------------------------------------------------------ optimizer (a13)
  * transformers-4.26 AdamW semantics (trainer.py:60-85).  sched [sched_len][2] f32 =
  * {lr_s*sqrt(1-b2^s)/(1-b1^s), lr_s} for update s = index+1; *done = updates applied. */
+/* seg_off_opt [nseg + 1] (device; element offsets of the parameters inside the flat buffer, ascending, multiples of 8,
+ * seg_off[nseg] >= n) with seg_amax_opt [nseg] consecutive magnitude records (mapx_gemm_scale): the launch raises parameter z's
+ * record with max |p| of what it writes, tagged for the NEXT epoch — the weights are the next step's GEMM operands. */
 int mapx_adamw_dense(float* p, const float* g, float* m, float* v, int64_t n, const float* sched,
                      int sched_len, const int32_t* done, double beta1, double beta2, double eps,
-                     double weight_decay, hipStream_t stream);
+                     double weight_decay, const int64_t* seg_off_opt, int nseg, void* seg_amax_opt,
+                     hipStream_t stream);
 /* *done += 1 (scheduler.step(), trainer.py:141,329,453); cursor_opt: the device-side batch cursor of a
  * step that walks the epoch's permutation (the DataLoader's next batch, trainer.py:306), moved by
  * cursor_stride rows in the same launch. */

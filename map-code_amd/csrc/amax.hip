@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(256) amax_f32_kernel(const float* __restrict__
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
       m = max(m, finite_abs_bits(x[(i / cols) * ld + i % cols]));
   }
-  amax_publish_wave(rec, m, epoch, ahead);
+  amax_publish_block(rec, m, epoch, ahead);
 }
 
 }  // namespace mapx
@@ -29,7 +29,7 @@ extern "C" int mapx_amax_f32(const float* x, int64_t rows, int64_t cols, int64_t
                              hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(record && rows >= 0 && cols >= 0 && ld >= cols, "amax_f32: bad arguments");
-  if (reset) MAPX_HIP(hipMemsetAsync(record, 0, sizeof(amax_rec), stream));
+  if (reset) MAPX_HIP(hipMemsetAsync(record, 0, kAmaxSlots * sizeof(amax_rec), stream));
   if (rows == 0 || cols == 0) return MAPX_OK;
   MAPX_REQUIRE(x, "amax_f32: null tensor");
   hipLaunchKernelGGL(amax_f32_kernel, dim3(grid_for(rows * cols / 4 + 1, 256, 1024)), dim3(256), 0, stream, x, rows, cols,

@@ -1,6 +1,7 @@
 // Embedding row gather (reference code/layers.py:97-102 -> nn.Embedding forward, flattened
 // to [B, F*E] in models.py:308) and its helpers.  HBM-bound: 8 B of id + 2*E*4 B per row.
 #include "../../include/mapx_hip.h"
+#include "amax.h"
 #include "common.h"
 
 namespace mapx {
@@ -13,9 +14,11 @@ template <int VEC>
 __global__ void __launch_bounds__(256) emb_gather_kernel(const int64_t* __restrict__ ids,
                                                          int64_t n, const float* __restrict__ table,
                                                          int64_t V, int E, float* __restrict__ out,
-                                                         int* __restrict__ err) {
+                                                         int* __restrict__ err, amax_rec* __restrict__ amax_out,
+                                                         const int32_t* __restrict__ epoch) {
   const int per_row = E / VEC;
   const int64_t total = n * per_row;
+  uint32_t amx = 0;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = t / per_row;
@@ -27,10 +30,14 @@ __global__ void __launch_bounds__(256) emb_gather_kernel(const int64_t* __restri
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ok) v = *reinterpret_cast<const float4*>(table + id * E + c);
       *reinterpret_cast<float4*>(out + row * E + c) = v;
+      amx = amax4(amx, v.x, v.y, v.z, v.w);
     } else {
-      out[row * E + c] = ok ? table[id * E + c] : 0.f;
+      const float v = ok ? table[id * E + c] : 0.f;
+      out[row * E + c] = v;
+      amx = max(amx, finite_abs_bits(v));
     }
   }
+  if (amax_out) amax_publish_block(amax_out, amx, epoch);      // max |out| for the products that read it (amax.h)
 }
 
 // The same gather with bf16 output rows (bf16 compute mode: the trunk's first GEMMs read bf16; the
@@ -76,7 +83,7 @@ __global__ void __launch_bounds__(256) ids_to_i32_kernel(const int64_t* __restri
 }  // namespace mapx
 
 extern "C" int mapx_emb_gather_fwd(const int64_t* ids, int64_t n, const float* table, int64_t V,
-                                   int E, float* out, int* err_flag, hipStream_t stream) {
+                                   int E, float* out, int* err_flag, void* amax_out_opt, hipStream_t stream) {
   MAPX_REQUIRE(n >= 0 && V > 0 && E > 0, "emb_gather_fwd: bad sizes n=%lld V=%lld E=%d",
                (long long)n, (long long)V, E);
   if (n == 0) return MAPX_OK;
@@ -86,10 +93,10 @@ extern "C" int mapx_emb_gather_fwd(const int64_t* ids, int64_t n, const float* t
   const int grid = mapx::grid_for(total, 256);
   if (vec)
     hipLaunchKernelGGL(mapx::emb_gather_kernel<4>, dim3(grid), dim3(256), 0, stream, ids, n, table,
-                       V, E, out, err_flag);
+                       V, E, out, err_flag, static_cast<mapx::amax_rec*>(amax_out_opt), mapx::amax_epoch_ptr());
   else
     hipLaunchKernelGGL(mapx::emb_gather_kernel<1>, dim3(grid), dim3(256), 0, stream, ids, n, table,
-                       V, E, out, err_flag);
+                       V, E, out, err_flag, static_cast<mapx::amax_rec*>(amax_out_opt), mapx::amax_epoch_ptr());
   return mapx::check_launch("emb_gather_fwd");
 }
 

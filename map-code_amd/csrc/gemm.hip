@@ -13,6 +13,7 @@
 //   dW = dY^T X             : A k-strided (dY [B,out] read as [K=B, M=out]), B k-strided (X [B,in])
 #include "../../include/mapx_hip.h"
 #include "common.h"
+#include "amax.h"
 #include "gemm_grouped.h"
 #include "gemm_x3_common.h"
 
@@ -305,7 +306,8 @@ __global__ void __launch_bounds__(256) ew_colsum_kernel(const float* __restrict_
                                                         const float* __restrict__ b, int64_t ldb,
                                                         const float* __restrict__ c, int M, int N,
                                                         float* __restrict__ o1, float* __restrict__ o2,
-                                                        int accumulate, float* __restrict__ part) {
+                                                        int accumulate, float* __restrict__ part,
+                                                        amax_rec* __restrict__ amax_o1, const int32_t* __restrict__ epoch) {
   // CL lanes x float4 columns per block row; RL row lanes; N % 4 == 0, lda % 4 == 0 (host-checked)
   constexpr int RL = 256 / CL;
   const int cl = threadIdx.x % CL;
@@ -315,6 +317,7 @@ __global__ void __launch_bounds__(256) ew_colsum_kernel(const float* __restrict_
   const int r0 = blockIdx.y * rows_per;
   const int r1 = (r0 + rows_per < M) ? r0 + rows_per : M;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  uint32_t amx = 0;                     // max |o1| (dz or t) for the products that read it next (amax.h)
   if (col < N) {
 #pragma unroll 4
     for (int r = r0 + rl; r < r1; r += RL) {
@@ -325,6 +328,7 @@ __global__ void __launch_bounds__(256) ew_colsum_kernel(const float* __restrict_
         const float4 dz = make_float4(bv.x > 0.f ? av.x : 0.f, bv.y > 0.f ? av.y : 0.f,
                                       bv.z > 0.f ? av.z : 0.f, bv.w > 0.f ? av.w : 0.f);
         reinterpret_cast<float4*>(o1)[i] = dz;
+        amx = amax4(amx, dz.x, dz.y, dz.z, dz.w);
         v.x += dz.x; v.y += dz.y; v.z += dz.z; v.w += dz.w;
       } else {
         const float4 cv = reinterpret_cast<const float4*>(c)[i];
@@ -338,11 +342,13 @@ __global__ void __launch_bounds__(256) ew_colsum_kernel(const float* __restrict_
           d.x += av.x; d.y += av.y; d.z += av.z; d.w += av.w;
         }
         reinterpret_cast<float4*>(o1)[i] = t;
+        amx = amax4(amx, t.x, t.y, t.z, t.w);
         reinterpret_cast<float4*>(o2)[i] = d;
         v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
       }
     }
   }
+  if (amax_o1) amax_publish_block(amax_o1, amx, epoch);
   __shared__ float4 s[RL][CL];
   s[rl][cl] = v;
   __syncthreads();
@@ -415,7 +421,7 @@ extern "C" int mapx_gemm_f32_bwd_fused(int M, int N, int K, const float* dY, int
                                        const float* mask_opt, int64_t ld_mask, int c0, const float* x0, int64_t ld_x0,
                                        const float* u, int64_t ld_u, float* t, int64_t ld_t, float* dx0,
                                        int64_t ld_dx0, int accumulate, int plus_v, float* part, int64_t ld_part,
-                                       hipStream_t stream) {
+                                       const mapx_gemm_scale* scale_opt, hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(M >= 0 && N > 0 && K > 0 && dY && W && C && part, "gemm_f32_bwd_fused: bad arguments");
   if (M == 0) return MAPX_OK;
@@ -434,13 +440,19 @@ extern "C" int mapx_gemm_f32_bwd_fused(int M, int N, int K, const float* dY, int
   GemmX3Extra ex{};
   ex.aux3 = u; ex.ld3 = ld_u; ex.mask = mask_opt; ex.ldm = ld_mask; ex.out3 = t; ex.ldo3 = ld_t; ex.out4 = dx0;
   ex.ldo4 = ld_dx0; ex.c0 = c0; ex.flags = (accumulate ? 1 : 0) | (plus_v ? 2 : 0); ex.batch = 1;
+  if (scale_opt) {
+    ex.amax_a = scale_opt->amax_a; ex.amax_b = scale_opt->amax_b;
+    ex.amax_c = static_cast<unsigned long long*>(scale_opt->amax_c);
+    ex.amax_c2 = static_cast<unsigned long long*>(scale_opt->amax_c2);
+  }
   return gemm_f32x3_launch(1, 0, M, N, K, dY, lda, W, ldw, C, ldc, MAPX_EPI_BWD_FUSED, nullptr, add_opt, ld_add, x0,
                            ld_x0, part, ld_part, 1, -1, nullptr, 0, nullptr, stream, &ex);
 }
 
 extern "C" int mapx_gemm_f32_batched(int count, int a_kc, int b_kc, int M, int N, int K, const float* const* A,
                                      int64_t lda, const float* const* B, int64_t ldb, float* const* C, int nsplit,
-                                     void* ws, size_t ws_bytes, hipStream_t stream) {
+                                     void* ws, size_t ws_bytes, const mapx_gemm_scale* scales_opt,
+                                     hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(count >= 1 && count <= 4 && A && B && C, "gemm_f32_batched: 1 to 4 problems");
   MAPX_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_f32_batched: empty problem");
@@ -451,10 +463,13 @@ extern "C" int mapx_gemm_f32_batched(int count, int a_kc, int b_kc, int M, int N
   for (int z = 0; z < count; ++z) {
     MAPX_REQUIRE(A[z] && B[z] && C[z], "gemm_f32_batched: null operand");
     ex.Az[z] = A[z]; ex.Bz[z] = B[z]; ex.Cz[z] = C[z];
+    if (scales_opt) { ex.amax_az[z] = scales_opt[z].amax_a; ex.amax_bz[z] = scales_opt[z].amax_b; }
   }
-  if (count == 1)
+  if (count == 1) {
+    ex.amax_a = ex.amax_az[0]; ex.amax_b = ex.amax_bz[0];
     return gemm_f32x3_launch(a_kc, b_kc, M, N, K, A[0], lda, B[0], ldb, C[0], N, MAPX_EPI_NONE, nullptr, nullptr, 0,
-                             nullptr, 0, nullptr, 0, nsplit, -1, ws, ws_bytes, nullptr, stream, nullptr);
+                             nullptr, 0, nullptr, 0, nsplit, -1, ws, ws_bytes, nullptr, stream, &ex);
+  }
   int got = 0;
   // every problem with the vector-load conditions of problem 0 (same shapes and leading dimensions; bases checked)
   for (int z = 1; z < count; ++z)
@@ -583,8 +598,8 @@ extern "C" int mapx_colsum(const float* x, int64_t ld, int M, int N, float* out,
 }
 
 extern "C" int mapx_relu_mask_colsum(const float* dy, int64_t ld_dy, const float* y, int64_t ld_y, int M, int N,
-                                     float* dz, float* db,
-                                      void* ws, size_t ws_bytes, hipStream_t stream) {
+                                     float* dz, float* db, void* ws, size_t ws_bytes, void* amax_out_opt,
+                                     hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(dy && y && dz && M >= 0 && N > 0, "relu_mask_colsum: bad arguments");
   MAPX_REQUIRE(N % 4 == 0 && ld_dy % 4 == 0 && ld_dy >= N && (uintptr_t)dy % 16 == 0 && ld_y % 4 == 0 &&
@@ -597,17 +612,19 @@ extern "C" int mapx_relu_mask_colsum(const float* dy, int64_t ld_dy, const float
   float* part = static_cast<float*>(ws);
   if (ew_narrow_lanes(N))
     hipLaunchKernelGGL((ew_colsum_kernel<0, 32>), dim3((N + 127) / 128, kColChunks), dim3(256), 0, stream, dy, ld_dy, y,
-                       ld_y, (const float*)nullptr, M, N, dz, (float*)nullptr, 0, part);
+                       ld_y, (const float*)nullptr, M, N, dz, (float*)nullptr, 0, part, static_cast<amax_rec*>(amax_out_opt),
+                       amax_epoch_ptr());
   else
     hipLaunchKernelGGL((ew_colsum_kernel<0, 64>), dim3((N + 255) / 256, kColChunks), dim3(256), 0, stream, dy, ld_dy, y,
-                       ld_y, (const float*)nullptr, M, N, dz, (float*)nullptr, 0, part);
+                       ld_y, (const float*)nullptr, M, N, dz, (float*)nullptr, 0, part, static_cast<amax_rec*>(amax_out_opt),
+                       amax_epoch_ptr());
   if (db) hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, db);
   return check_launch("relu_mask_colsum");
 }
 
 extern "C" int mapx_cross_bwd_pre_colsum(const float* g, int64_t ld_g, const float* x0, const float* u, int M, int N,
                                          float* t, float* dx0, int accumulate, float* db, void* ws,
-                                         size_t ws_bytes, hipStream_t stream) {
+                                         size_t ws_bytes, void* amax_out_opt, hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(g && x0 && u && t && dx0 && M >= 0 && N > 0, "cross_bwd_pre_colsum: bad arguments");
   MAPX_REQUIRE(N % 4 == 0 && ld_g % 4 == 0 && ld_g >= N && (uintptr_t)g % 16 == 0,
@@ -619,10 +636,10 @@ extern "C" int mapx_cross_bwd_pre_colsum(const float* g, int64_t ld_g, const flo
   float* part = static_cast<float*>(ws);
   if (ew_narrow_lanes(N))
     hipLaunchKernelGGL((ew_colsum_kernel<1, 32>), dim3((N + 127) / 128, kColChunks), dim3(256), 0, stream, g, ld_g, x0,
-                       (int64_t)N, u, M, N, t, dx0, accumulate, part);
+                       (int64_t)N, u, M, N, t, dx0, accumulate, part, static_cast<amax_rec*>(amax_out_opt), amax_epoch_ptr());
   else
     hipLaunchKernelGGL((ew_colsum_kernel<1, 64>), dim3((N + 255) / 256, kColChunks), dim3(256), 0, stream, g, ld_g, x0,
-                       (int64_t)N, u, M, N, t, dx0, accumulate, part);
+                       (int64_t)N, u, M, N, t, dx0, accumulate, part, static_cast<amax_rec*>(amax_out_opt), amax_epoch_ptr());
   if (db) hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, part, N, db);
   return check_launch("cross_bwd_pre_colsum");
 }

@@ -594,6 +594,7 @@ int gemm_f32x3_launch(int a_kc, int b_kc, int M, int N, int K, const float* A, i
     for (int z = 0; z < batch && batch > 1; ++z) g.Cz[z] = static_cast<float*>(ws);
     g.ldc = N;
     g.slab_stride = (int64_t)M * N;
+    g.amax_c = g.amax_c2 = nullptr;          // slabs hold partial sums: their maxima say nothing about C
   }
 
   const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) &&

@@ -2,6 +2,7 @@
 // fp32 values into three bf16 planes, and the row-major epilogue pass over the fp32 tile in LDS.
 #pragma once
 #include "../../include/mapx_hip.h"
+#include "amax.h"
 #include "common.h"
 #include <utility>
 
@@ -140,6 +141,7 @@ __device__ inline void epilogue_rows_x3(const GemmX3Args& a, float* __restrict__
   constexpr int LDT = BN + 4;
   constexpr bool kBias = EPI >= MAPX_EPI_BIAS && EPI <= MAPX_EPI_BIAS_CROSS;
   constexpr bool kAux1 = EPI == MAPX_EPI_BIAS_CROSS || EPI == MAPX_EPI_ADD || EPI == MAPX_EPI_RELU_MASK;
+  uint32_t amx = 0;                    // max |C| this thread stores (amax.h)
   for (int idx = threadIdx.x; idx < BM * BN / 4; idx += NT) {
     const int row = idx / (BN / 4), c0 = (idx % (BN / 4)) * 4;
     const int m = m0 + row, n = n0 + c0;
@@ -181,16 +183,19 @@ __device__ inline void epilogue_rows_x3(const GemmX3Args& a, float* __restrict__
     if (vio) {
       *reinterpret_cast<float4*>(C + oc) = make_float4(v[0], v[1], v[2], v[3]);
       if (EPI == MAPX_EPI_BIAS_CROSS) *reinterpret_cast<float4*>(a.out2 + oo) = make_float4(u[0], u[1], u[2], u[3]);
+      amx = amax4(amx, v[0], v[1], v[2], v[3]);
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if (n + e < a.N) {
           C[oc + e] = v[e];
           if (EPI == MAPX_EPI_BIAS_CROSS) a.out2[oo + e] = u[e];
+          amx = max(amx, finite_abs_bits(v[e]));
         }
       }
     }
   }
+  if (a.amax_c) amax_publish_block(a.amax_c, amx, a.epoch);
 }
 
 // The same pass for 16-byte-aligned operands, without control flow between a load and its use: a thread's
@@ -209,6 +214,7 @@ __device__ inline void epilogue_rows_x3_vec(const GemmX3Args& a, float* __restri
   constexpr bool kAux2 = EPI == MAPX_EPI_BIAS_CROSS;
   const int c0 = (threadIdx.x % CPR) * 4, r0 = threadIdx.x / CPR;
   float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);        // kColsum: this thread's 4 columns over its rows
+  uint32_t amx = 0;                                     // max |C| this thread stores (amax.h)
   const int n = n0 + c0;
   const bool ncol = n < a.N;
   const int ns = ncol ? n : 0;
@@ -245,9 +251,11 @@ __device__ inline void epilogue_rows_x3_vec(const GemmX3Args& a, float* __restri
       if (ok[u]) {
         *reinterpret_cast<float4*>(C + mrow[u] * a.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
         if (kAux2) *reinterpret_cast<float4*>(a.out2 + mrow[u] * a.ldo2 + n) = make_float4(w[0], w[1], w[2], w[3]);
+        amx = amax4(amx, v[0], v[1], v[2], v[3]);
       }
     }
   }
+  if (a.amax_c) amax_publish_block(a.amax_c, amx, a.epoch);
   if (kColsum) {
     // column sums of the tile's (masked) rows: the RPI threads of a column group meet in LDS behind the
     // fp32 tile and are added in a fixed order; one partial row per 128-row tile, summed later
@@ -285,6 +293,7 @@ __device__ inline void epilogue_bwd_fused(const GemmX3Args& a, float* __restrict
   const bool relu = ns >= a.c0;                       // this thread's four columns: ReLU-masked, or the cross layer's
   const bool has_add = a.aux1 != nullptr, accum = (a.flags & 1) != 0, plus_v = (a.flags & 2) != 0;
   float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+  uint32_t amx_dz = 0, amx_t = 0;       // max |dz| (columns >= c0 of C) and max |t| this thread stores (amax.h)
 #pragma unroll
   for (int it0 = 0; it0 < NIT; it0 += U) {
     float4 t[U], pa[U], p1[U], p2[U], p3[U];
@@ -315,6 +324,7 @@ __device__ inline void epilogue_bwd_fused(const GemmX3Args& a, float* __restrict
         if (ok[u]) {
           csum.x += v[0]; csum.y += v[1]; csum.z += v[2]; csum.w += v[3];
           *reinterpret_cast<float4*>(C + mrow[u] * a.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+          amx_dz = amax4(amx_dz, v[0], v[1], v[2], v[3]);
         }
       } else {
         const float q2[4] = {p2[u].x, p2[u].y, p2[u].z, p2[u].w}, q3[4] = {p3[u].x, p3[u].y, p3[u].z, p3[u].w};
@@ -331,10 +341,13 @@ __device__ inline void epilogue_bwd_fused(const GemmX3Args& a, float* __restrict
           *reinterpret_cast<float4*>(C + mrow[u] * a.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
           *reinterpret_cast<float4*>(a.out3 + mrow[u] * a.ldo3 + n) = make_float4(tt[0], tt[1], tt[2], tt[3]);
           *reinterpret_cast<float4*>(a.out4 + mrow[u] * a.ldo4 + n) = make_float4(d[0], d[1], d[2], d[3]);
+          amx_t = amax4(amx_t, tt[0], tt[1], tt[2], tt[3]);
         }
       }
     }
   }
+  if (a.amax_c) amax_publish_block(a.amax_c, amx_dz, a.epoch);
+  if (a.amax_c2) amax_publish_block(a.amax_c2, amx_t, a.epoch);
   float4* const red = reinterpret_cast<float4*>(const_cast<float*>(tile) + BM * LDT);
   red[r0 * CPR + threadIdx.x % CPR] = csum;
   __syncthreads();

@@ -9,6 +9,7 @@
 // logit, the loss, and dL/dh; the table gradient is a reduce-by-key over (dlogit, h) that
 // never materialises per-pair rows (segreduce.h: NceContrib).
 #include "../../include/mapx_hip.h"
+#include "amax.h"
 #include "common.h"
 #include "segreduce.h"
 
@@ -303,7 +304,8 @@ __global__ void __launch_bounds__(256) nce_scatter_dh_kernel(const float* __rest
                                                              const float* __restrict__ partial,
                                                              const int32_t* __restrict__ acc_partial, int n_partial,
                                                              float invT, float* __restrict__ loss,
-                                                             int32_t* __restrict__ acc) {
+                                                             int32_t* __restrict__ acc, amax_rec* __restrict__ amax_out,
+                                                             const int32_t* __restrict__ epoch) {
   if (partial && blockIdx.x == 0 && threadIdx.x < kWave) {
     float v = 0.f;
     int a = 0;
@@ -321,6 +323,7 @@ __global__ void __launch_bounds__(256) nce_scatter_dh_kernel(const float* __rest
   }
   const float g = gscale ? *gscale : 1.f;
   const int64_t total = B * P;
+  uint32_t amx = 0;
   for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total;
        w += (int64_t)gridDim.x * blockDim.x) {
     const int64_t b = w / P;
@@ -331,7 +334,10 @@ __global__ void __launch_bounds__(256) nce_scatter_dh_kernel(const float* __rest
       const int64_t f = masked_index[b * L + l];
       row[f * P + p] += g * dh[(b * L + l) * P + p];
     }
+    if (amax_out)
+      for (int l = 0; l < L; ++l) amx = max(amx, finite_abs_bits(row[masked_index[b * L + l] * P + p]));
   }
+  if (amax_out) amax_publish_block(amax_out, amx, epoch);      // max |denc| for the encoder's input-gradient product
 }
 
 // scale rows in place by a device scalar (upstream gradient of the loss)
@@ -442,7 +448,7 @@ extern "C" int mapx_nce_fwd(const float* enc, int64_t B, int L, int F, int P,
 extern "C" int mapx_nce_scatter_dh(const float* dh, const int64_t* masked_index,
                                    const float* gscale_opt, int64_t B, int L, int F, int P,
                                    float* denc, const void* partials_ws_opt, int n_partials, float* loss_out_opt,
-                                   int32_t* acc_out_opt, hipStream_t stream) {
+                                   int32_t* acc_out_opt, void* amax_out_opt, hipStream_t stream) {
   MAPX_REQUIRE(dh && masked_index && denc, "nce_scatter_dh: null pointer");
   MAPX_REQUIRE(!partials_ws_opt || (n_partials >= 1 && n_partials <= mapx::kNceBlocks && loss_out_opt && acc_out_opt),
                "nce_scatter_dh: loss totals need 1..%d partials and both outputs", mapx::kNceBlocks);
@@ -451,7 +457,8 @@ extern "C" int mapx_nce_scatter_dh(const float* dh, const int64_t* masked_index,
   const int32_t* acc_partial = partial ? reinterpret_cast<const int32_t*>(partial + mapx::kNceBlocks) : nullptr;
   hipLaunchKernelGGL(mapx::nce_scatter_dh_kernel, dim3(mapx::grid_for(B * P, 256)), dim3(256), 0,
                      stream, dh, masked_index, gscale_opt, B, L, F, P, denc, partial, acc_partial, n_partials,
-                     1.0f / (float)(B * L), loss_out_opt, acc_out_opt);
+                     1.0f / (float)(B * L), loss_out_opt, acc_out_opt, static_cast<mapx::amax_rec*>(amax_out_opt),
+                     mapx::amax_epoch_ptr());
   return mapx::check_launch("nce_scatter_dh");
 }
 

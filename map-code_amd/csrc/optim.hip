@@ -25,6 +25,7 @@
 // in fp64 by 2e-14).  Only gaps that run past the end of the tables (steps beyond the schedule)
 // are replayed step by step, with a closed-form tail once the Adam term can no longer move p.
 #include "../../include/mapx_hip.h"
+#include "amax.h"
 #include "common.h"
 
 namespace mapx {
@@ -153,14 +154,43 @@ __global__ void __launch_bounds__(256) adamw_dense_kernel(float* __restrict__ p,
                                                           float* __restrict__ m, float* __restrict__ v,
                                                           int64_t n, const float2* __restrict__ sched,
                                                           int sched_len, const int32_t* __restrict__ done,
-                                                          AdamHyper h, float wd, __bf16* __restrict__ shadow) {
+                                                          AdamHyper h, float wd, __bf16* __restrict__ shadow,
+                                                          const int64_t* __restrict__ seg_off, int nseg,
+                                                          amax_rec* __restrict__ seg_amax,
+                                                          const int32_t* __restrict__ epoch) {
   int s = *done;  // updates applied so far; this is update s+1 -> sched[s]
   if (s >= sched_len) s = sched_len - 1;
   const float2 sc = sched[s];
   const float step = sc.x, decay = sc.y * wd;
   const int64_t n4 = n / 4;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-       i += (int64_t)gridDim.x * blockDim.x) {
+  // A block takes ONE contiguous range of float4s.  With magnitude records to keep (amax.h: the parameters this launch
+  // writes are the next step's GEMM operands; parameter z = elements [seg_off[z], seg_off[z + 1]), starts multiples of 8)
+  // a thread tracks the maximum of the parameter it is in, the block's threads meet in LDS (a range touches a few
+  // parameters), and one thread per touched parameter raises its record: ~1 global atomic per block.  (One atomic per
+  // wave and float4 — 15 k on twenty addresses — made this kernel 90 us instead of 9.)
+  const int64_t per = (n4 + gridDim.x - 1) / gridDim.x, i0 = (int64_t)blockIdx.x * per;
+  const int64_t i1 = i0 + per < n4 ? i0 + per : n4;
+  constexpr int kSlots = 16;
+  __shared__ uint32_t smax[kSlots];
+  int seg = 0, seg_first = 0;
+  uint32_t mx = 0;
+  if (seg_amax) {
+    if (threadIdx.x < kSlots) smax[threadIdx.x] = 0;
+    int lo = 0, hi = nseg;
+    while (hi - lo > 1) {                       // the parameter the block's range starts in
+      const int mid = (lo + hi) >> 1;
+      if (seg_off[mid] <= 4 * i0) lo = mid; else hi = mid;
+    }
+    seg = seg_first = lo;
+    __syncthreads();
+  }
+  auto flush = [&]() {
+    if (mx == 0) return;
+    if (seg - seg_first < kSlots) atomicMax(&smax[seg - seg_first], mx);
+    else amax_publish(seg_amax + (int64_t)seg * kAmaxSlots, mx, epoch, 1, blockIdx.x);
+    mx = 0;
+  };
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
     float4 pv = reinterpret_cast<float4*>(p)[i];
     float4 mv = reinterpret_cast<float4*>(m)[i];
     float4 vv = reinterpret_cast<float4*>(v)[i];
@@ -172,6 +202,13 @@ __global__ void __launch_bounds__(256) adamw_dense_kernel(float* __restrict__ p,
     reinterpret_cast<float4*>(p)[i] = pv;
     reinterpret_cast<float4*>(m)[i] = mv;
     reinterpret_cast<float4*>(v)[i] = vv;
+    if (seg_amax) {
+      while (seg + 1 < nseg && 4 * i >= seg_off[seg + 1]) {
+        flush();
+        ++seg;
+      }
+      mx = amax4(mx, pv.x, pv.y, pv.z, pv.w);
+    }
     if (SHADOW) {
       typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
       bf16x4_t o;
@@ -179,19 +216,28 @@ __global__ void __launch_bounds__(256) adamw_dense_kernel(float* __restrict__ p,
       reinterpret_cast<bf16x4_t*>(shadow)[i] = o;
     }
   }
-  // tail (n % 4)
-  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    adam_elem(p[i], m[i], v[i], g[i], step, decay, h);
-    if (SHADOW) shadow[i] = (__bf16)p[i];
+  if (seg_amax) {
+    flush();
+    __syncthreads();
+    if (threadIdx.x < kSlots && smax[threadIdx.x] != 0 && seg_first + threadIdx.x < nseg)
+      amax_publish(seg_amax + (int64_t)(seg_first + threadIdx.x) * kAmaxSlots, smax[threadIdx.x], epoch, 1, blockIdx.x);
   }
+  // tail (n % 4)
+  if (blockIdx.x == 0)
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
+      adam_elem(p[i], m[i], v[i], g[i], step, decay, h);
+      if (SHADOW) shadow[i] = (__bf16)p[i];
+      if (seg_amax) amax_publish(seg_amax + (int64_t)(nseg - 1) * kAmaxSlots, finite_abs_bits(p[i]), epoch, 1, threadIdx.x);
+    }
 }
 
 // ... and, when the step walks an epoch's permutation by a device-side cursor (trainer.GraphedStep), the
 // cursor's move to the next batch: one launch at the end of a step instead of two.
-__global__ void step_advance_kernel(int32_t* done, int64_t* cursor, int64_t stride) {
+// ... and the epoch of the magnitude records (amax.h): what the next step's kernels write outranks this step's.
+__global__ void step_advance_kernel(int32_t* done, int64_t* cursor, int64_t stride, int32_t* amax_epoch) {
   *done += 1;
   if (cursor) *cursor += stride;
+  if (amax_epoch) *amax_epoch += 1;
 }
 
 // ---------------------------------------------------------------------------- lazy tables
@@ -400,16 +446,18 @@ static AdamHyper make_hyper(double b1, double b2, double eps) {
 extern "C" int mapx_adamw_dense(float* p, const float* g, float* m, float* v, int64_t n,
                                 const float* sched, int sched_len, const int32_t* done,
                                 double beta1, double beta2, double eps, double weight_decay,
-                                hipStream_t stream) {
+                                const int64_t* seg_off_opt, int nseg, void* seg_amax_opt, hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(p && g && m && v && sched && done && n >= 0 && sched_len > 0, "adamw_dense: bad arguments");
+  MAPX_REQUIRE(!seg_amax_opt || (seg_off_opt && nseg >= 1), "adamw_dense: magnitude records need the segment table");
   MAPX_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
                    ((uintptr_t)v % 16 == 0),
                "adamw_dense: pointers must be 16-byte aligned");
   if (n == 0) return MAPX_OK;
   hipLaunchKernelGGL(adamw_dense_kernel<false>, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, stream, p, g, m,
                      v, n, reinterpret_cast<const float2*>(sched), sched_len, done,
-                     make_hyper(beta1, beta2, eps), (float)weight_decay, (__bf16*)nullptr);
+                     make_hyper(beta1, beta2, eps), (float)weight_decay, (__bf16*)nullptr, seg_off_opt, nseg,
+                     static_cast<amax_rec*>(seg_amax_opt), amax_epoch_ptr());
   return check_launch("adamw_dense");
 }
 
@@ -425,13 +473,15 @@ extern "C" int mapx_adamw_dense_shadow(float* p, const float* g, float* m, float
   if (n == 0) return MAPX_OK;
   hipLaunchKernelGGL(adamw_dense_kernel<true>, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, stream, p, g, m,
                      v, n, reinterpret_cast<const float2*>(sched), sched_len, done,
-                     make_hyper(beta1, beta2, eps), (float)weight_decay, reinterpret_cast<__bf16*>(shadow));
+                     make_hyper(beta1, beta2, eps), (float)weight_decay, reinterpret_cast<__bf16*>(shadow),
+                     (const int64_t*)nullptr, 0, (amax_rec*)nullptr, (const int32_t*)nullptr);
   return check_launch("adamw_dense_shadow");
 }
 
 extern "C" int mapx_step_advance(int32_t* done, int64_t* cursor_opt, int64_t cursor_stride, hipStream_t stream) {
   MAPX_REQUIRE(done, "step_advance: null");
-  hipLaunchKernelGGL(mapx::step_advance_kernel, dim3(1), dim3(1), 0, stream, done, cursor_opt, cursor_stride);
+  hipLaunchKernelGGL(mapx::step_advance_kernel, dim3(1), dim3(1), 0, stream, done, cursor_opt, cursor_stride,
+                     const_cast<int32_t*>(mapx::amax_epoch_ptr()));
   return mapx::check_launch("step_advance");
 }
 

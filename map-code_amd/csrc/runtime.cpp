@@ -21,12 +21,12 @@ void set_error(const char* fmt, ...) {
 
 namespace mapx {
 // amax.h: the device word whose value tags the magnitude records written from now on (one process = one GPU)
-static const int32_t* g_amax_epoch = nullptr;
+static int32_t* g_amax_epoch = nullptr;
 const int32_t* amax_epoch_ptr() { return g_amax_epoch; }
 }  // namespace mapx
 
-extern "C" int mapx_amax_epoch_source(const int32_t* device_counter_opt) {
-  mapx::g_amax_epoch = device_counter_opt;
+extern "C" int mapx_amax_epoch_source(int32_t* device_word_opt) {
+  mapx::g_amax_epoch = device_word_opt;
   return MAPX_OK;
 }
 

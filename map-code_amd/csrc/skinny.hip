@@ -8,6 +8,7 @@
 //   dX   dx[m, k] = sum_n dy[m, n] w[n, k]                a thread per 4 rows x 4 columns
 // K % 4 == 0, rows 16-byte aligned (host-checked).  Results are plain fp32 sums (not the six-product arithmetic of
 // gemm_x3.hip): closer to the fp64 value, not bit-identical to the GEMM path.
+#include "amax.h"
 #include "common.h"
 
 namespace mapx {
@@ -257,8 +258,10 @@ __global__ void __launch_bounds__(256) skinny_join_bwd_kernel(
     const float* __restrict__ fin, int64_t ldf, const float* __restrict__ x0, int64_t ldx0, const float* __restrict__ u,
     int64_t ldu, int plus_v, float* __restrict__ g, int64_t ldg, float* __restrict__ t, int64_t ldt,
     float* __restrict__ dx0, int64_t lddx0, float* __restrict__ dzr, int64_t lddzr, float* __restrict__ part_cross,
-    float* __restrict__ part_deep) {
+    float* __restrict__ part_deep, amax_rec* __restrict__ amax_t, amax_rec* __restrict__ amax_dzr,
+    const int32_t* __restrict__ epoch) {
   constexpr int CL = 32, RL = 8;
+  uint32_t amx_t = 0, amx_z = 0;        // max |t|, max |dzr|: what the towers' weight / input gradient products read
   const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
   const int c = 4 * (blockIdx.x * CL + cl);
   const int m0 = blockIdx.y * 128, m1 = (m0 + 128 < M) ? m0 + 128 : M;
@@ -289,15 +292,19 @@ __global__ void __launch_bounds__(256) skinny_join_bwd_kernel(
         *reinterpret_cast<float4*>(t + (int64_t)m * ldt + c) = tt;
         *reinterpret_cast<float4*>(dx0 + (int64_t)m * lddx0 + c) = dd;
         sum.x += tt.x; sum.y += tt.y; sum.z += tt.z; sum.w += tt.w;
+        amx_t = amax4(amx_t, tt.x, tt.y, tt.z, tt.w);
       } else {
         const float4 f = *reinterpret_cast<const float4*>(fin + (int64_t)m * ldf + c);
         const float4 z = make_float4(f.x > 0.f ? v.x : 0.f, f.y > 0.f ? v.y : 0.f, f.z > 0.f ? v.z : 0.f,
                                      f.w > 0.f ? v.w : 0.f);
         *reinterpret_cast<float4*>(dzr + (int64_t)m * lddzr + (c - D)) = z;
         sum.x += z.x; sum.y += z.y; sum.z += z.z; sum.w += z.w;
+        amx_z = amax4(amx_z, z.x, z.y, z.z, z.w);
       }
     }
   }
+  if (amax_t) amax_publish_block(amax_t, amx_t, epoch);
+  if (amax_dzr) amax_publish_block(amax_dzr, amx_z, epoch);
   __shared__ float4 red[RL][CL];
   red[rl][cl] = sum;
   __syncthreads();
@@ -404,7 +411,8 @@ extern "C" int mapx_skinny_join_bwd(const float* dz, int64_t lddz, const float* 
                                     int H, const float* final_act, int64_t ldf, const float* x0, int64_t ldx0,
                                     const float* u, int64_t ldu, int plus_v, float* g, int64_t ldg, float* t,
                                     int64_t ldt, float* dx0, int64_t lddx0, float* dzr, int64_t lddzr,
-                                    float* part_cross, float* part_deep, hipStream_t stream) {
+                                    float* part_cross, float* part_deep, void* amax_t_opt, void* amax_dzr_opt,
+                                    hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(dz && w && final_act && x0 && u && g && t && dx0 && dzr && part_cross && part_deep,
                "skinny_join_bwd: null pointer");
@@ -416,7 +424,8 @@ extern "C" int mapx_skinny_join_bwd(const float* dz, int64_t lddz, const float* 
   const dim3 grid(grid_for((D + H) / 4, 32), (M + 127) / 128);
 #define MAPX_SJ(NT)                                                                                                   \
   hipLaunchKernelGGL(skinny_join_bwd_kernel<NT>, grid, dim3(256), 0, stream, dz, lddz, w, ldw, M, N, D, H, final_act, \
-                     ldf, x0, ldx0, u, ldu, plus_v, g, ldg, t, ldt, dx0, lddx0, dzr, lddzr, part_cross, part_deep)
+                     ldf, x0, ldx0, u, ldu, plus_v, g, ldg, t, ldt, dx0, lddx0, dzr, lddzr, part_cross, part_deep,         \
+                     static_cast<amax_rec*>(amax_t_opt), static_cast<amax_rec*>(amax_dzr_opt), amax_epoch_ptr())
   if (N == 1) MAPX_SJ(1);
   else if (N <= 4) MAPX_SJ(4);
   else MAPX_SJ(8);

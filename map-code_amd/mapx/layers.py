@@ -508,13 +508,13 @@ def join_bwd_input(dz, w, final, link):
     forked = ops.stream_wait(side, main) if dz.is_cuda else False
     with (torch.cuda.stream(side) if forked else contextlib.nullcontext()):
         ops.dbg_sleep("join_cross")
-        g, t, dx0, part = ops.gemm_bwd_fused(dz, w[:, :D], D, x0=link.x0, u=link.u, plus_v=link.plus_v)
+        g, t, dx0, part = ops.gemm_bwd_fused(dz, ops.cols(w, 0, D), D, x0=link.x0, u=link.u, plus_v=link.plus_v)
         ops.defer_part_rows(link.sb_cross, part, 0, D)
     if forked:
         dz.record_stream(side)
         ops.pending_joins.append((main, side))
     ops.dbg_sleep("join_deep")
-    dzr = ops.linear_bwd_input(dz, w[:, D:], relu_of=final[:, D:], colsum_to=link.relu.sb)
+    dzr = ops.linear_bwd_input(dz, ops.cols(w, D, None), relu_of=final[:, D:], colsum_to=link.relu.sb)
     link.relu.premasked = True
     link.t, link.dx0, link.g, link.dz = t, dx0, g, dzr
     return torch.empty(1, 1, dtype=final.dtype, device=final.device).expand(final.shape[0], Nn)    # never read
@@ -544,12 +544,14 @@ class _Linear(Function):
         ctx.link_in, ctx.link_out = link_in, (link_out if relu else None)
         if ctx.link_out is not None:
             ctx.link_out.sb = ctx.slots[1]
+        ctx.amax = ops.amax_pack(x, wop)
         ctx.save_for_backward(x, wop, y if relu else None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
+        ops.amax_unpack((x, w), ctx.amax)
         sw, sb = ctx.slots
         if ctx.half and gy.dtype == torch.float32:
             gy = ops.cast_bf16(gy)                 # the fp32 gradient of a head's logits enters the bf16 trunk
@@ -710,6 +712,7 @@ class _CrossTower(Function):
         ctx.n = n
         ctx.slots = [(_grad_slot(wb[2 * i]), _grad_slot(wb[2 * i + 1])) for i in range(n)]
         ctx.link, ctx.x0_link = link, x0_link
+        ctx.amax = ops.amax_pack(x0, *xs[1:], *us, *wops)        # (records of the saved tensors, in their order)
         if link is not None:                 # what the consumer of the towers' output needs (see _JoinLink)
             link.x0, link.u, link.sb_cross, link.plus_v = x0, us[-1], ctx.slots[n - 1][1], n == 1
         ctx.save_for_backward(x0, *xs[1:], *us, *wops)
@@ -719,6 +722,7 @@ class _CrossTower(Function):
     def backward(ctx, g):
         n = ctx.n
         saved = ctx.saved_tensors
+        ops.amax_unpack(saved, ctx.amax)
         x0 = saved[0]
         xs = (x0,) + tuple(saved[1:n])
         us = saved[n:2 * n]

@@ -230,7 +230,7 @@ class DCNV2(BaseModel):
 
     def forward(self, input_ids, labels=None, masked_index=None, noise_samples=None):
         groups, nce_idx, join = None, None, None
-        feat_embed = self.embed(input_ids).flatten(start_dim=1)
+        feat_embed = ops.flat_rows(self.embed(input_ids))
         if self.config.num_hidden_layers > 0:
             # Three independent chains leave the gather: the cross tower (small D x D GEMMs on a
             # second stream that fill the tails of the deep tower's big ones; autograd replays the
@@ -257,6 +257,9 @@ class DCNV2(BaseModel):
                 x0_link = _X0Link(main)        # cross tower -> the gather's backward (no elementwise add, no wait)
             self.embed.table.x0_link = x0_link
             final_buf = torch.empty(feat_embed.shape[0], D + H, dtype=feat_embed.dtype, device=feat_embed.device)
+            if feat_embed.dtype == torch.float32:
+                # ONE magnitude record for the concatenated output: both towers' last kernels raise it (ops.out_record)
+                ops.tag(final_buf, ops.amax_record(final_buf.device))
             if LAYOUT_ON_MAIN and self._grouped_head(masked_index):
                 # the grouped encoder's slot layout (one 15-us launch) ahead of the deep tower, which by now
                 # has ~45 us of slack against the cross tower's stream (round 1 had it the other way round)
@@ -315,7 +318,7 @@ class DCNV2(BaseModel):
                 if nce_idx is not None:
                     labels.record_stream(tower)
                     nce_idx.record_stream(main)
-            final_output = _JoinColumns.apply(cross_output, dnn_output, final_buf, join) if direct \
+            final_output = ops.carry(_JoinColumns.apply(cross_output, dnn_output, final_buf, join), final_buf) if direct \
                 else torch.cat([cross_output, dnn_output], dim=-1)
             if self._mfp_head(masked_index):
                 # the towers' join node and the cross tower's node run behind the head's backward: it may leave them
@@ -349,7 +352,7 @@ class DNN(BaseModel):
             self.fc_out = HipLinear(config.hidden_size, 1, out_fp32=True)
 
     def forward(self, input_ids, labels=None, masked_index=None, noise_samples=None):
-        feat_embed = self.embed(input_ids).flatten(start_dim=1)
+        feat_embed = ops.flat_rows(self.embed(input_ids))
         nce_idx, early = self._sample_early(labels, masked_index, noise_samples)
         nn_output = self.dnn(feat_embed)
         self._plans_and_join(nce_idx, early)     # the sort(s) fork from the ids, enqueued behind the trunk
@@ -408,7 +411,7 @@ class DeepFM(BaseModel):
     def forward(self, input_ids, labels=None, masked_index=None, noise_samples=None):
         x3, lr = self.embed.forward_with_linear(input_ids, self.lr_layer.embed_w.weight)
         nce_idx, early = self._sample_early(labels, masked_index, noise_samples)
-        dnn_vec = self.dnn(x3.flatten(start_dim=1))
+        dnn_vec = self.dnn(ops.flat_rows(x3))
         self._plans_and_join(nce_idx, early)
         lr_fm = lr.view(-1, 1) + self.lr_layer.bias + fm_product_sum(x3)
         if self.config.pretrain:
@@ -487,7 +490,7 @@ class xDeepFM(BaseModel):
         else:
             x3 = self.embed(input_ids)
         nce_idx, early = self._sample_early(labels, masked_index, noise_samples)
-        final_vec = torch.cat([self.cin(x3), self.dnn(x3.flatten(start_dim=1))], dim=1)
+        final_vec = torch.cat([self.cin(x3), self.dnn(ops.flat_rows(x3))], dim=1)
         self._plans_and_join(nce_idx, early)
         if self.config.pretrain:
             return self.get_outputs(final_vec, labels, masked_index, noise_samples=noise_samples, nce_idx=nce_idx)

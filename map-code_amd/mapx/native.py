@@ -21,7 +21,7 @@ _p, _i, _i64, _u64, _f, _d, _sz = (C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C
 SIGNATURES = {
     "mapx_last_error": (C.c_char_p, []),
     "mapx_abi_version": (_i, []),
-    "mapx_emb_gather_fwd": (_i, [_p, _i64, _p, _i64, _i, _p, _p, _p]),
+    "mapx_emb_gather_fwd": (_i, [_p, _i64, _p, _i64, _i, _p, _p, _p, _p]),
     "mapx_ids_to_i32": (_i, [_p, _i64, _i64, _p, _p, _p]),
     "mapx_seg_plan_workspace_bytes": (_sz, [_i64, _i64]),
     "mapx_seg_plan": (_i, [_p, _i64, _i64, _p, _sz, _p, _p, _p, _p, _p, _p, _p]),
@@ -52,7 +52,7 @@ SIGNATURES = {
     "mapx_nce_fwd_workspace_bytes": (_sz, []),
     "mapx_nce_fwd": (_i, [_p, _i64, _i, _i, _i, _p, _p, _i, _p, _p, _p, _i64, _p, _p, _p, _p, _p,
                           _p, _p, _sz, _p, _p, _p, _p]),
-    "mapx_nce_scatter_dh": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p, _p, _i, _p, _p, _p]),
+    "mapx_nce_scatter_dh": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p]),
     "mapx_nce_table_grad_workspace_bytes": (_sz, [_i64, _i]),
     "mapx_nce_table_grad": (_i, [_i64, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _sz, _p, _p]),
     "mapx_scale_inplace": (_i, [_p, _i64, _p, _p]),
@@ -62,8 +62,8 @@ SIGNATURES = {
     "mapx_amax_epoch_source": (_i, [_p]),
     "mapx_amax_f32": (_i, [_p, _i64, _i64, _i64, _p, _i, _p]),
     "mapx_gemm_f32_bwd_fused": (_i, [_i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i, _p, _i64, _p, _i64,
-                                     _p, _i64, _p, _i64, _i, _i, _p, _i64, _p]),
-    "mapx_gemm_f32_batched": (_i, [_i, _i, _i, _i, _i, _i, _p, _i64, _p, _i64, _p, _i, _p, _sz, _p]),
+                                     _p, _i64, _p, _i64, _i, _i, _p, _i64, _p, _p]),
+    "mapx_gemm_f32_batched": (_i, [_i, _i, _i, _i, _i, _i, _p, _i64, _p, _i64, _p, _i, _p, _sz, _p, _p]),
     "mapx_gemm_bf16": (_i, [_i, _i, _i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _i, _i, _p, _p, _i64, _i, _p, _i64,
                             _p, _i64, _i, _i, _p, _sz, _p]),
     "mapx_cast_f32_bf16": (_i, [_p, _i64, _p, _p]),
@@ -85,7 +85,7 @@ SIGNATURES = {
     "mapx_skinny_linear_dw": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _p, _i, _p]),
     "mapx_skinny_linear_dx": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _p, _i64, _p]),
     "mapx_skinny_join_bwd": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _i, _p, _i64, _p, _i64,
-                                  _p, _i64, _p, _i64, _p, _p, _p]),
+                                  _p, _i64, _p, _i64, _p, _p, _p, _p, _p]),
     "mapx_enc_group_layout": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "mapx_enc_grouped_fwd": (_i, [_p, _i64, _i, _i, _p, _i64, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "mapx_enc_grouped_dw": (_i, [_p, _p, _i64, _i, _i, _p, _p, _i, _p, _p, _i64, _p]),
@@ -94,8 +94,8 @@ SIGNATURES = {
     "mapx_colsum": (_i, [_p, _i64, _i, _i, _p, _p, _sz, _p]),
     "mapx_cross_bwd_pre": (_i, [_p, _p, _p, _i64, _p, _p, _i, _p]),
     "mapx_relu_mask": (_i, [_p, _p, _i64, _p, _p]),
-    "mapx_relu_mask_colsum": (_i, [_p, _i64, _p, _i64, _i, _i, _p, _p, _p, _sz, _p]),
-    "mapx_cross_bwd_pre_colsum": (_i, [_p, _i64, _p, _p, _i, _i, _p, _p, _i, _p, _p, _sz, _p]),
+    "mapx_relu_mask_colsum": (_i, [_p, _i64, _p, _i64, _i, _i, _p, _p, _p, _sz, _p, _p]),
+    "mapx_cross_bwd_pre_colsum": (_i, [_p, _i64, _p, _p, _i, _i, _p, _p, _i, _p, _p, _sz, _p, _p]),
     "mapx_bce_workspace_bytes": (_sz, []),
     "mapx_bce_with_logits": (_i, [_p, _p, _i64, _p, _p, _p, _sz, _p]),
     "mapx_eval_metrics_workspace_bytes": (_sz, [_i64]),
@@ -104,7 +104,7 @@ SIGNATURES = {
     "mapx_dynamic_mask_mfp_rows": (_i, [_p, _i64, _p, _p, _i64, _i, _i, _p, _u64, _u64, _p, _p, _p, _p, _p, _p]),
     "mapx_dynamic_mask_rfd": (_i, [_p, _i64, _i, _i, _p, _p, _p, _i64, _i, _p, _p, _i64, _u64, _u64, _p, _p, _p,
                                   _p, _p]),
-    "mapx_adamw_dense": (_i, [_p, _p, _p, _p, _i64, _p, _i, _p, _d, _d, _d, _d, _p]),
+    "mapx_adamw_dense": (_i, [_p, _p, _p, _p, _i64, _p, _i, _p, _d, _d, _d, _d, _p, _i, _p, _p]),
     "mapx_step_advance": (_i, [_p, _p, _i64, _p]),
     "mapx_take_rows_i64": (_i, [_p, _i64, _i, _p, _p, _i64, _p, _p, _p]),
     "mapx_act_fwd": (_i, [_i, _p, _i64, _i, _p, _i64, _p]),

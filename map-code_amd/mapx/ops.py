@@ -353,10 +353,15 @@ def emb_gather(ids, table, validate=False, out_dtype=torch.float32):
     ids = ids.contiguous()
     out = torch.empty(*ids.shape, table.shape[1], dtype=out_dtype, device=table.device)
     err = _err_flag(table.device) if validate else None
-    fn = lib.mapx_emb_gather_fwd_bf16 if out_dtype == BF16 else lib.mapx_emb_gather_fwd
+    rec = amax_record(table.device) if out_dtype != BF16 else None
     with _timed("emb_gather", ids.numel() * (8 + (4 + out.element_size()) * table.shape[1])):
-        check(fn(ptr(ids), ids.numel(), ptr(table), table.shape[0], table.shape[1],
-                 ptr(out), ptr(err), stream()))
+        if out_dtype == BF16:
+            check(lib.mapx_emb_gather_fwd_bf16(ptr(ids), ids.numel(), ptr(table), table.shape[0], table.shape[1],
+                                               ptr(out), ptr(err), stream()))
+        else:
+            check(lib.mapx_emb_gather_fwd(ptr(ids), ids.numel(), ptr(table), table.shape[0], table.shape[1],
+                                          ptr(out), ptr(err), ptr(rec), stream()))
+    tag(out, rec)
     if validate and int(err.item()):
         raise IndexError("index out of range in self")          # reference CPU behaviour
     return out
@@ -769,9 +774,10 @@ def nce_scatter_dh(dh, masked_index, F, P, gscale=None, totals=None):
     B, L = masked_index.shape
     denc = torch.empty(B, F * P, dtype=torch.float32, device=dh.device)
     ws, n, loss, acc = totals if totals is not None else (None, 0, None, None)
+    rec = amax_record(dh.device)
     check(lib.mapx_nce_scatter_dh(ptr(dh), ptr(masked_index.contiguous()), ptr(gscale), B, L, F, P,
-                                  ptr(denc), ptr(ws), n, ptr(loss), ptr(acc), stream()))
-    return denc
+                                  ptr(denc), ptr(ws), n, ptr(loss), ptr(acc), ptr(rec), stream()))
+    return tag(denc, rec)
 
 
 def nce_table_grad(plan, dlogit, h, K, P, gscale=None):
@@ -839,9 +845,117 @@ def gemm_bf16(a, b, a_kc, b_kc, M, N, K, out=None, out_dtype=BF16, ldc=None, epi
     return out
 
 
+# Magnitude records (include/mapx_hip.h: mapx_gemm_scale; csrc/amax.h): every kernel that writes a tensor a GEMM will
+# read leaves max |x| in the tensor's 8-byte record; a product whose two operands carry one is formed by the two-piece
+# fp16 arithmetic (csrc/gemm_h2.hip), any other by the six-product bf16 one (csrc/gemm_x3.hip).  Here a record travels
+# as the attribute `_amax` of the tensor object: outputs of autograd Functions, saved INPUTS and gradients handed from
+# one backward node to the next keep their attributes; saved OUTPUTS and slices do not (carry / amax_pack below).
+H2 = os.environ.get("MAPX_GEMM_H2", "1") == "1"          # A/B switch: 0 = no records anywhere, x3 arithmetic only
+_epoch_word = {}
+_cap_pool = [None, 0]          # records of the capture in progress: (int32 [2 n] tensor, next free)
+_cap_pools = []                # ... of finished captures: a replayed graph has their addresses baked in
+_ring, _RING = {}, 1 << 12     # eager records
+REC = 128                      # int32 words of a record (MAPX_AMAX_RECORD_BYTES / 4: 64 slots of {bits, epoch})
+
+
+def _ensure_epoch(device):
+    """The process-wide epoch word of the records (mapx_amax_epoch_source): allocated once, never freed."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _epoch_word:
+        w = torch.zeros(1, dtype=torch.int32, device=device)
+        check(lib.mapx_amax_epoch_source(w.data_ptr()))
+        _epoch_word[key] = w
+    return _epoch_word[key]
+
+
+def amax_capture_begin(device, n=1024):
+    """Called right before a hipGraph capture: the records handed out during the capture come from one zeroed
+    block allocated HERE (a record allocated inside the capture would be a memset node of its own; the epoch tags
+    make resets unnecessary)."""
+    if H2:
+        _ensure_epoch(device)
+        _cap_pool[0], _cap_pool[1] = torch.zeros(REC * n, dtype=torch.int32, device=device), 0
+        _cap_pools.append(_cap_pool[0])
+
+
+def amax_capture_end():
+    _cap_pool[0] = None
+
+
 def amax_record(device):
-    """A zeroed magnitude record (include/mapx_hip.h: mapx_gemm_scale; csrc/amax.h): 8 bytes."""
-    return torch.zeros(2, dtype=torch.int32, device=device)
+    """A zeroed magnitude record, or None where none can be had (records switched off; inside a capture that
+    did not announce itself: the product then simply takes the six-product arithmetic)."""
+    if not H2:
+        return None
+    if torch.cuda.is_current_stream_capturing():
+        pool, i = _cap_pool
+        if pool is None or REC * (i + 1) > pool.numel():
+            return None
+        _cap_pool[1] = i + 1
+        return pool[REC * i:REC * (i + 1)]
+    _ensure_epoch(device)
+    # eager launches: a ring of records that is never freed (a record outlives the tensor object it hangs on
+    # whenever a side stream still runs the kernel that raises it), each zeroed when it is handed out
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    ring = _ring.get(key)
+    if ring is None:
+        ring = _ring[key] = [torch.zeros(REC * _RING, dtype=torch.int32, device=device), 0]
+    i = ring[1]
+    ring[1] = (i + 1) % _RING
+    rec = ring[0][REC * i:REC * (i + 1)]
+    rec.zero_()
+    return rec
+
+
+def amax_of(t):
+    """The record of tensor `t`, or None.  A parameter's record is kept by the optimizer's kernel; when something else
+    wrote the parameter through torch (load_state_dict, copy_: its version counter moved) it is recomputed here."""
+    if not H2 or t is None:
+        return None
+    rec = getattr(t, "_amax", None)
+    if rec is not None:
+        ver = getattr(t, "_amax_ver", None)
+        if ver is not None and ver != t._version:
+            amax(t.detach(), rec=rec, reset=True)
+            t._amax_ver = t._version
+    return rec
+
+
+def tag(t, rec):
+    if rec is not None and t is not None:
+        t._amax = rec
+    return t
+
+
+def carry(dst, src):
+    """`dst` is a slice / view / alias of `src`: the maximum over src bounds the maximum over dst."""
+    return tag(dst, amax_of(src))
+
+
+def flat_rows(x):
+    """x.flatten(start_dim=1) with x's record (the flattened embedding rows are the towers' first operand)."""
+    return carry(x.flatten(start_dim=1), x)
+
+
+def cols(t, c0, c1):
+    """t[:, c0:c1] with t's record."""
+    return carry(t[:, c0:c1], t)
+
+
+def amax_pack(*ts):
+    return tuple(amax_of(t) for t in ts)
+
+
+def amax_unpack(ts, recs):
+    for t, r in zip(ts, recs):
+        tag(t, r)
+
+
+def out_record(out, device):
+    """The record a kernel raises for its output: the one the caller put on `out` (several kernels writing
+    column ranges of one buffer share the buffer's record), else a fresh one."""
+    rec = amax_of(out)
+    return rec if rec is not None else amax_record(device)
 
 
 def amax(x, rec=None, reset=True):
@@ -849,8 +963,9 @@ def amax(x, rec=None, reset=True):
     require_gpu(x)
     if x.dtype != torch.float32:
         raise TypeError("amax: fp32 tensors")
+    _ensure_epoch(x.device)
     if rec is None:
-        rec = torch.empty(2, dtype=torch.int32, device=x.device)
+        rec = torch.empty(REC, dtype=torch.int32, device=x.device)
         reset = True
     x2 = x if x.dim() == 2 else x.reshape(1, -1)
     if x2.stride(1) != 1:
@@ -861,7 +976,25 @@ def amax(x, rec=None, reset=True):
 
 def amax_value(rec):
     """Host value of a record (tests)."""
-    return float(rec[:1].view(torch.float32).item())
+    return float(rec[0::2].max().view(1).view(torch.float32).item())      # (bit patterns of values >= 0 order as the values)
+
+
+# MAPX_AMAX_CHECK=1 (tests): every record a product is given is compared with the operand on the host — a record
+# below the operand's true maximum would overflow fp16, one far above it wastes precision.  H2_USED counts the
+# products that were handed both records (tests assert that the hot path really takes the new arithmetic).
+AMAX_CHECK = os.environ.get("MAPX_AMAX_CHECK", "0") == "1"
+H2_USED = [0, 0]               # products with both records / without
+
+
+def _check_record(x, rec, what):
+    if rec is None:
+        return
+    xs = x.detach().float()
+    xs = xs[torch.isfinite(xs)]
+    true = float(xs.abs().max()) if xs.numel() else 0.0
+    got = amax_value(rec)
+    if not (got >= true and (true == 0.0 or got <= true * 64.0 or got < 1e-30)):
+        raise AssertionError(f"magnitude record of operand {what}: {got!r} for a tensor whose max |x| is {true!r}")
 
 
 def _scale_arg(amax_a, amax_b, amax_c=None, amax_c2=None):
@@ -877,7 +1010,7 @@ def _scale_arg(amax_a, amax_b, amax_c=None, amax_c2=None):
 
 def gemm(a, b, a_kc, b_kc, M, N, K, out=None, ldc=None, epi=N.EPI_NONE, bias=None, aux1=None,
          aux2=None, out2=None, nsplit=1, lda=None, ldb=None, tile=-1, defer=False, out_dtype=None,
-         amax_a=None, amax_b=None, amax_c=None):
+         amax_a=None, amax_b=None, amax_c=None, record=True):
     """C[M,N] = epi(sum_k A(m,k) B(k,n)); see include/mapx_hip.h: mapx_gemm_f32 (fp32 operands) /
     mapx_gemm_bf16 (bf16 operands; `out_dtype` picks a bf16 or fp32 result).  amax_a / amax_b: the operands'
     magnitude records (both given: the two-piece fp16 arithmetic); amax_c: record raised with max |C|."""
@@ -902,6 +1035,14 @@ def gemm(a, b, a_kc, b_kc, M, N, K, out=None, ldc=None, epi=N.EPI_NONE, bias=Non
     ld2 = aux2.stride(0) if aux2 is not None else 0
     ldo2 = out2.stride(0) if out2 is not None else 0
     kind = "gemm_fwd_nt" if (a_kc and b_kc) else ("gemm_dx_nn" if a_kc else "gemm_dw_tn")
+    amax_a = amax_a if amax_a is not None else amax_of(a)
+    amax_b = amax_b if amax_b is not None else amax_of(b)
+    if amax_c is None and record and nsplit == 1:      # (split-K outputs are weight gradients: nobody multiplies them)
+        amax_c = out_record(out, dev)
+    H2_USED[0 if (amax_a is not None and amax_b is not None) else 1] += 1
+    if AMAX_CHECK and not torch.cuda.is_current_stream_capturing():
+        _check_record(a, amax_a, "A")
+        _check_record(b, amax_b, "B")
     sc = _scale_arg(amax_a, amax_b, amax_c)
     with _timed(kind, 2.0 * M * N * K):
         check(lib.mapx_gemm_f32(int(a_kc), int(b_kc), M, N, K, a.data_ptr(), lda, b.data_ptr(), ldb,
@@ -914,7 +1055,7 @@ def gemm(a, b, a_kc, b_kc, M, N, K, out=None, ldc=None, epi=N.EPI_NONE, bias=Non
                                 None if sc is None else native_byref(sc), stream()))
     if got is not None and got.value > 1:
         defer_sum(out, ws.view(torch.float32), M * N, got.value, M * N)
-    return out
+    return tag(out, amax_c)
 
 
 # Layers with at most 32 outputs (RFD's last predictor layer, the finetune head) as fp32 streaming kernels instead of
@@ -1051,7 +1192,8 @@ def linear_bwd_weight(dy, x, out=None, defer=False):
         ns = 1
     if is_bf16(dy):                          # fp32 gradient from bf16 operands
         return gemm_bf16(dy, x, False, False, Nn, K, Bn, out=out, out_dtype=torch.float32, nsplit=ns)
-    return gemm(dy, x, False, False, Nn, K, Bn, out=out, nsplit=ns, defer=DEFER and defer and out is not None)
+    return gemm(dy, x, False, False, Nn, K, Bn, out=out, nsplit=ns, defer=DEFER and defer and out is not None,
+                record=False)
 
 
 def _partials_h(Nn, device, defer):
@@ -1099,7 +1241,7 @@ def cross_layer_fwd(x0, xi, w, b, out=None):
     M, D = xi.shape
     u = torch.empty(M, D, dtype=xi.dtype, device=xi.device)
     y = gemm(xi, w, True, True, M, D, D, out=out, epi=N.EPI_BIAS_CROSS, bias=b, aux1=xi, aux2=x0,
-             out2=u)
+             out2=u)            # (y carries its record: the next layer's operand; u is read elementwise only)
     return y, u
 
 
@@ -1118,8 +1260,8 @@ def alias_cols(buf, col0, ncols):
     """A tensor over columns [col0, col0+ncols) of the 2-D buffer `buf` that shares its memory but
     is NOT an autograd view of it: kernels write a layer's output straight into its slot of a
     concatenated buffer, and autograd's view+in-place bookkeeping never sees a relationship."""
-    return torch.empty(0, dtype=buf.dtype, device=buf.device).set_(
-        buf.untyped_storage(), buf.storage_offset() + col0, (buf.shape[0], ncols), (buf.stride(0), 1))
+    return carry(torch.empty(0, dtype=buf.dtype, device=buf.device).set_(
+        buf.untyped_storage(), buf.storage_offset() + col0, (buf.shape[0], ncols), (buf.stride(0), 1)), buf)
 
 
 def row_sliceable(x):
@@ -1157,11 +1299,12 @@ def relu_mask_colsum(dy, y, db=None, defer=False):
     if db is None:
         db = torch.empty(Nn, dtype=torch.float32, device=dy.device)
     ws = _partials(Nn, dy.device, defer)
+    rec = amax_record(dy.device)
     check(lib.mapx_relu_mask_colsum(dy.data_ptr(), dy.stride(0), y.data_ptr(), y.stride(0), M, Nn, ptr(dz),
-                                    None if defer else ptr(db), ptr(ws), ws.numel(), stream()))
+                                    None if defer else ptr(db), ptr(ws), ws.numel(), ptr(rec), stream()))
     if defer:
         defer_sum(db, ws.view(torch.float32), Nn, COLSUM_CHUNKS, Nn)
-    return dz, db
+    return tag(dz, rec), db
 
 
 def cross_bwd_pre_colsum(g, x0, u, dx0=None, db=None, defer=False, plus_g=False):
@@ -1196,12 +1339,13 @@ def cross_bwd_pre_colsum(g, x0, u, dx0=None, db=None, defer=False, plus_g=False)
     if db is None:
         db = torch.empty(Nn, dtype=torch.float32, device=g.device)
     ws = _partials(Nn, g.device, defer)
+    rec = amax_record(g.device)
     check(lib.mapx_cross_bwd_pre_colsum(g.data_ptr(), g.stride(0), ptr(x0), ptr(u), M, Nn, ptr(t), ptr(dx0),
                                         int(acc) | (2 if plus_g else 0),
-                                        None if defer else ptr(db), ptr(ws), ws.numel(), stream()))
+                                        None if defer else ptr(db), ptr(ws), ws.numel(), ptr(rec), stream()))
     if defer:
         defer_sum(db, ws.view(torch.float32), Nn, COLSUM_CHUNKS, Nn)
-    return t, dx0, db
+    return tag(t, rec), dx0, db
 
 
 JOIN_FUSE = os.environ.get("MAPX_JOIN_FUSE", "1") == "1"      # the heads' dX as one product per tower with fused epilogues
@@ -1227,12 +1371,19 @@ def gemm_bwd_fused(dy, w, c0, add=None, mask=None, x0=None, u=None, dx0=None, pl
         dx0 = torch.empty(M, c0, dtype=torch.float32, device=dev)
     part = torch.empty((M + 127) // 128, Nn, dtype=torch.float32, device=dev)
     sd = lambda x: (x.data_ptr(), x.stride(0)) if x is not None else (None, 0)
+    # records: C's ReLU-masked columns (>= c0: the deep tower's dZ) and t, the operands of the products that follow
+    rec_c = amax_record(dev) if c0 < Nn else None
+    rec_t = amax_record(dev) if c0 > 0 else None
+    sc = _scale_arg(amax_of(dy), amax_of(w), rec_c, rec_t)
     with _timed("gemm_dx_nn", 2.0 * M * Nn * K):
         check(lib.mapx_gemm_f32_bwd_fused(M, Nn, K, dy.data_ptr(), dy.stride(0), w.data_ptr(), w.stride(0),
                                           C.data_ptr(), C.stride(0), *sd(add), *sd(mask), c0, *sd(x0), *sd(u), *sd(t),
                                           *sd(dx0), int(accumulate), int(plus_v), part.data_ptr(), part.stride(0),
-                                          stream()))
-    return C, t, dx0, part
+                                          None if sc is None else native_byref(sc), stream()))
+    if c0 == 0:
+        tag(C, rec_c)            # (0 < c0 < N: C mixes g and dZ — callers slice it and tag the slices)
+    C._amax_dz = rec_c
+    return C, tag(t, rec_t), dx0, part
 
 
 def skinny_join_bwd(dz, w, final, D, x0, u, plus_v):
@@ -1247,11 +1398,13 @@ def skinny_join_bwd(dz, w, final, D, x0, u, plus_v):
     dzr = torch.empty(M, H, **f32)
     tiles = (M + 127) // 128
     pc, pd = torch.empty(tiles, D, **f32), torch.empty(tiles, H, **f32)
+    rec_t, rec_z = amax_record(dz.device), amax_record(dz.device)
     with _timed("skinny_linear", 4.0 * (3.0 * M * (D + H) + 3.0 * M * D)):
         check(lib.mapx_skinny_join_bwd(ptr(dz), dz.stride(0), ptr(w), w.stride(0), M, Nn, D, H, final.data_ptr(),
                                        final.stride(0), ptr(x0), x0.stride(0), ptr(u), u.stride(0), int(plus_v), ptr(g),
-                                       D, ptr(t), D, ptr(dx0), D, ptr(dzr), H, ptr(pc), ptr(pd), stream()))
-    return g, t, dx0, dzr, pc, pd
+                                       D, ptr(t), D, ptr(dx0), D, ptr(dzr), H, ptr(pc), ptr(pd), ptr(rec_t), ptr(rec_z),
+                                       stream()))
+    return g, tag(t, rec_t), dx0, tag(dzr, rec_z), pc, pd
 
 
 def defer_part_rows(dst, part, col0, ncols):
@@ -1277,11 +1430,16 @@ def linear_bwd_weight_batched(dys, xs, outs):
         ns *= 2
     ws = scratch(cnt * lib.mapx_gemm_splitk_workspace_bytes(Nn, K, ns), dys[0].device) if ns > 1 else None
     PP = C.c_void_p * cnt
+    scales = None
+    if all(amax_of(d) is not None and amax_of(x) is not None for d, x in zip(dys, xs)):
+        scales = (N.GemmScale * cnt)()
+        for z, (d, x) in enumerate(zip(dys, xs)):
+            scales[z].amax_a, scales[z].amax_b = amax_of(d).data_ptr(), amax_of(x).data_ptr()
     with _timed("gemm_dw_tn", 2.0 * cnt * Nn * K * Bn):
         check(lib.mapx_gemm_f32_batched(cnt, 0, 0, Nn, K, Bn, PP(*[d.data_ptr() for d in dys]), Nn,
                                         PP(*[x.data_ptr() for x in xs]), K, PP(*[o.data_ptr() for o in outs]), ns,
                                         ws.data_ptr() if ws is not None else None,
-                                        ws.numel() if ws is not None else 0, stream()))
+                                        ws.numel() if ws is not None else 0, scales, stream()))
     return outs
 
 
@@ -1491,13 +1649,17 @@ def make_replay_aux(lr0, lambdas, beta1, beta2, wd):
     return torch.stack(rows).contiguous()
 
 
-def adamw_dense(p, g, m, v, sched, done, beta1, beta2, eps, wd, shadow=None):
-    """`shadow`: bf16 [n] copy of the updated parameters, written by the same kernel (bf16 mode)."""
+def adamw_dense(p, g, m, v, sched, done, beta1, beta2, eps, wd, shadow=None, seg_off=None, seg_amax=None):
+    """`shadow`: bf16 [n] copy of the updated parameters, written by the same kernel (bf16 mode).
+    seg_off (int64 [n_params + 1]) / seg_amax (int32 [n_params, 2]): the parameters' magnitude records, raised
+    with what this launch writes (fp32 mode: the weights are the next step's GEMM operands)."""
     require_gpu(p, g, m, v, sched, done)
     with _timed("adamw_dense", p.numel() * (28.0 if shadow is None else 30.0)):
         if shadow is None:
+            nseg = seg_off.numel() - 1 if (seg_off is not None and seg_amax is not None) else 0
             check(lib.mapx_adamw_dense(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(sched), sched.shape[0],
-                                       ptr(done), beta1, beta2, eps, wd, stream()))
+                                       ptr(done), beta1, beta2, eps, wd, ptr(seg_off) if nseg else None, nseg,
+                                       ptr(seg_amax) if nseg else None, stream()))
         else:
             check(lib.mapx_adamw_dense_shadow(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(sched),
                                               sched.shape[0], ptr(done), beta1, beta2, eps, wd, ptr(shadow),

@@ -177,8 +177,16 @@ class MapxOptimizer:
         flat_p = torch.zeros(total, device=dev)
         flat_g = torch.zeros(total, device=dev)
         flat_h = torch.zeros(total, dtype=torch.bfloat16, device=dev) if bf16 else None
+        # fp32 mode: every parameter's magnitude record (ops: "Magnitude records"), kept current by the AdamW kernel
+        # with what it writes — `p._amax` is what the GEMMs that read p as an operand look at
+        recs = None if (bf16 or not ops.H2) else torch.zeros(len(members), ops.REC, dtype=torch.int32, device=dev)
+        offs = [0]
+        for sz in sizes:
+            offs.append(offs[-1] + sz)
         off = 0
-        for (_, p), sz in zip(members, sizes):
+        for i, ((_, p), sz) in enumerate(zip(members, sizes)):
+            if recs is not None:
+                p._amax = recs[i]
             view = flat_p[off:off + p.numel()].view_as(p)
             view.copy_(p.data)
             p.data = view
@@ -187,11 +195,19 @@ class MapxOptimizer:
             p._mapx_bf16 = flat_h[off:off + p.numel()].view_as(p) if bf16 else None
             off += sz
         return dict(p=flat_p, g=flat_g, m=torch.zeros_like(flat_p), v=torch.zeros_like(flat_p), wd=wd,
-                    names=[n for n, _ in members], numels=[p.numel() for _, p in members], h=flat_h)
+                    names=[n for n, _ in members], numels=[p.numel() for _, p in members], h=flat_h,
+                    amax=recs, seg_off=torch.tensor(offs, dtype=torch.int64, device=dev) if recs is not None else None,
+                    params=[p for _, p in members])
 
     def refresh_bf16(self):
-        """Re-derive the bf16 weight shadows from the fp32 master weights: after anything other than
-        step() wrote the parameters (construction, load_model / load_state_dict, a test poking .data)."""
+        """Re-derive what the optimizer keeps beside the fp32 master weights — the bf16 shadows (bf16 mode), the
+        magnitude records (fp32 mode) — after anything other than step() wrote the parameters (construction,
+        load_model / load_state_dict, a test poking .data)."""
+        for g in self.groups:
+            if g.get("amax") is not None:
+                for p, rec in zip(g["params"], g["amax"]):
+                    ops.amax(p.data.reshape(1, -1) if p.dim() != 2 else p.data, rec=rec, reset=True)
+                    p._amax_ver = p._version
         if not self.bf16:
             return
         for g in self.groups:
@@ -274,7 +290,7 @@ class MapxOptimizer:
         b1, b2, eps = self.hyper
         for g in self.groups:
             ops.adamw_dense(g["p"], g["g"], g["m"], g["v"], self.sched, self.done, b1, b2, eps, g["wd"],
-                            shadow=g["h"])
+                            shadow=g["h"], seg_off=g.get("seg_off"), seg_amax=g.get("amax"))
 
     def zero_grad(self):
         """Dense gradients are overwritten by the next backward (see layers._grad_slot); only

@@ -133,10 +133,12 @@ def _capture(graph):
     was_enabled = gc.isenabled()
     gc.collect()
     gc.disable()
+    ops.amax_capture_begin(torch.device("cuda", torch.cuda.current_device()))     # the capture's magnitude records
     try:
         with torch.cuda.graph(graph, **kw):
             yield
     finally:
+        ops.amax_capture_end()
         if was_enabled:
             gc.enable()
 

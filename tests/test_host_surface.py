@@ -186,3 +186,43 @@ def test_no_cpu_path():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError):
         TrainingArguments(output_dir="o").device
+
+
+def test_optimizer_state_slot_size_is_inferred_when_the_key_is_missing():
+    """dense moments are saved as flat buffers whose per-parameter slots were 4, then 8 elements before the
+    state recorded `flat_pad`.  A keyless state in slots of 8 that holds a one-element parameter (the bias of a
+    one-output layer) does not fit slots of 4: the slot size is the one that fits, 8 tried first; nothing fits: ValueError."""
+    import pytest
+    import torch
+    try:
+        from mapx.optim import MapxOptimizer
+    except ImportError as e:          # the HIP library is not built here
+        pytest.skip(str(e))
+    numels = [736, 1, 23, 64]
+
+    def flat(pad, fill):
+        parts = []
+        for i, n in enumerate(numels):
+            piece = torch.zeros((n + pad - 1) // pad * pad)
+            piece[:n] = fill + i + torch.arange(n) * 1e-3
+            parts.append(piece)
+        return torch.cat(parts)
+
+    def blank():
+        opt = object.__new__(MapxOptimizer)
+        opt.done, opt.steps_done, opt.tables, opt.bf16 = torch.zeros(1, dtype=torch.int32), 0, [], False
+        opt.groups = [dict(names=["a", "b", "c", "d"], numels=numels, m=torch.zeros_like(flat(8, 0.0)),
+                           v=torch.zeros_like(flat(8, 0.0)))]
+        return opt
+
+    for pad in (8, 4):
+        opt = blank()
+        sd = dict(steps_done=3, done=torch.tensor([3], dtype=torch.int32), tables=[],
+                  groups=[dict(names=["a", "b", "c", "d"], m=flat(pad, 1.0), v=flat(pad, 2.0))])
+        opt.load_state_dict(sd)
+        assert torch.equal(opt.groups[0]["m"], flat(8, 1.0)) and torch.equal(opt.groups[0]["v"], flat(8, 2.0)), pad
+    opt = blank()
+    sd["groups"][0]["m"] = sd["groups"][0]["m"][:-1]
+    sd["groups"][0]["v"] = sd["groups"][0]["v"][:-1]
+    with pytest.raises(ValueError):
+        opt.load_state_dict(sd)

@@ -844,9 +844,8 @@ def test_optimizer_state_with_another_flat_slot_size_is_repacked(tmp_path):
     bad["groups"] = [dict(names=s["names"], m=s["m"][:-4], v=s["v"][:-4]) for s in old["groups"]]
     with pytest.raises(ValueError):
         opt.load_state_dict(bad)
-    # a state WITHOUT the key but already in slots of 8 (written between the two changes), with
-    # one-element parameters in it (biases of one-output layers): the slot size is inferred, not assumed to be 4
-    assert any(n % 8 in (1, 2, 3, 4) for g in opt.groups for n in g["numels"])
+    # a state WITHOUT the key but already in slots of 8 (written between the two changes): inferred, not assumed 4
+    # (with a one-element parameter in it: tests/test_host_surface.py)
     keyless8 = dict(sd)
     keyless8.pop("flat_pad")
     for g in opt.groups:
