@@ -267,7 +267,27 @@ typedef struct mapx_gemm_scale {
   const float* amax_b;
   void* amax_c;
   void* amax_c2;
+  const void* b_planes;     /* operand B pre-cut by mapx_h2_weight_planes (same orientation b_kc, same N, K), or NULL */
 } mapx_gemm_scale;
+/* A weight matrix cut ONCE per optimizer step into the two fp16 pieces of the two-piece arithmetic, stored in the
+ * order the matrix instruction reads its B fragments (csrc/gemm_h2w.hip: blocks of 32 columns x 16 k, zero-padded),
+ * with the power-of-two scale taken from its magnitude record at the time of the call.  W as operand B of
+ * mapx_gemm_f32: b_kc != 0: B(k,n) = W[n*ldw + k] (forward, W [N,K]); b_kc == 0: B(k,n) = W[k*ldw + n] (input
+ * gradient, W [K,N]; a column slice of a wider matrix is fine).  A product that is handed the planes
+ * (mapx_gemm_scale.b_planes, with amax_a) and is large enough (>= 128 tiles of 128 x 128, A k-contiguous, no
+ * split-K) reads B from them instead of cutting it per row tile; any other product ignores them. */
+size_t mapx_h2_weight_planes_bytes(int N, int K);
+/* ... and up to 16 matrices in one launch (the task list is HOST memory, copied into the kernel arguments). */
+typedef struct mapx_plane_task {
+  const float* W;
+  int64_t ldw;
+  int32_t N, K, b_kc, pad_;
+  const void* amax_record;
+  void* planes;
+} mapx_plane_task;
+int mapx_h2_weight_planes_multi(const mapx_plane_task* tasks_host, int ntasks, hipStream_t stream);
+int mapx_h2_weight_planes(const float* W, int64_t ldw, int N, int K, int b_kc, const void* amax_record, void* planes,
+                          hipStream_t stream);
 /* The device int32 whose current value tags the records written from now on; mapx_step_advance adds 1 to it, so a
  * captured step never needs to reset a record.  Process-wide (one process drives one GPU); NULL: tag 0. */
 int mapx_amax_epoch_source(int32_t* device_word_opt);

@@ -411,6 +411,7 @@ extern "C" int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const floa
     ex.amax_a = scale_opt->amax_a; ex.amax_b = scale_opt->amax_b;
     ex.amax_c = static_cast<unsigned long long*>(scale_opt->amax_c);
     ex.amax_c2 = static_cast<unsigned long long*>(scale_opt->amax_c2);
+    ex.b_planes = scale_opt->b_planes;
   }
   return gemm_f32x3_launch(a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, epi, bias, aux1, ld1, aux2, ld2, out2, ldo2,
                            nsplit, tile_hint, ws, ws_bytes, nsplit_deferred, stream, scale_opt ? &ex : nullptr);
@@ -444,6 +445,7 @@ extern "C" int mapx_gemm_f32_bwd_fused(int M, int N, int K, const float* dY, int
     ex.amax_a = scale_opt->amax_a; ex.amax_b = scale_opt->amax_b;
     ex.amax_c = static_cast<unsigned long long*>(scale_opt->amax_c);
     ex.amax_c2 = static_cast<unsigned long long*>(scale_opt->amax_c2);
+    ex.b_planes = scale_opt->b_planes;
   }
   return gemm_f32x3_launch(1, 0, M, N, K, dY, lda, W, ldw, C, ldc, MAPX_EPI_BWD_FUSED, nullptr, add_opt, ld_add, x0,
                            ld_x0, part, ld_part, 1, -1, nullptr, 0, nullptr, stream, &ex);

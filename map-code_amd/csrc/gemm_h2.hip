@@ -451,12 +451,27 @@ static hipError_t launch_layout_h2(GemmX3Args& a, int tile, int nsplit, hipStrea
 // slabs, k_chunk) when both operands come with a magnitude record.  Returns false when this family does not
 // build the case (scalar-load operands, a slab of one K-step, the 8-wave layout asked for): the caller goes on
 // with its own kernels.
-bool gemm_f32h2_try(GemmX3Args& g, int a_kc, int b_kc, bool vec, int tile, int nsplit, int batch, hipStream_t stream,
-                    hipError_t* err) {
+bool gemm_f32h2_try(GemmX3Args& g, int a_kc, int b_kc, bool vec, int tile, bool hinted, bool xcd_on, int nsplit,
+                    int batch, hipStream_t stream, hipError_t* err) {
   static const bool on = [] { const char* e = getenv("MAPX_GEMM_H2"); return !e || atoi(e) != 0; }();
   if (!on || !vec) return false;
   if (g.K - (int64_t)g.k_chunk * (nsplit - 1) <= kXBK) return false;        // every slab >= 2 K-steps
   if (tile != 0 && tile != 1 && tile != 2) tile = 3;
+  if (!hinted && g.epi != MAPX_EPI_BWD_FUSED && g.epi != MAPX_EPI_RELU_MASK_COLSUM) {
+    // This family's own choice of layout (tools/gemm_h2_bench.py, round 4): with half the MFMA time per K-step the
+    // 128 x 128 tile pays from 128 workgroups on (the six-product kernels: 160), and a problem too narrow for it
+    // (N = 368) takes 128 x 64 before 64 x 64 when that gives >= 160 workgroups (1000 x 1000 x 4096 unsplit: 128
+    // of them took 83 us, 256 tiles of 64 x 64 take 71).  (The two epilogues that leave one partial row per 128-row tile keep
+    // what the caller chose.)
+    auto blocks = [&](int bm, int bn) { return ceil_div(g.M, bm) * ceil_div(g.N, bn) * nsplit * batch; };
+    const int mine = blocks(128, 128) >= 128 ? 3 : (blocks(128, 64) >= 160 ? 1 : 0);
+    if (mine != tile && nsplit > 1 && batch == 1) {       // the k-slice dealing depends on the tile grid (gemm_x3.hip)
+      const int bm = mine == 0 ? 64 : 128, bn = mine == 3 ? 128 : 64;
+      const int64_t nb1 = ceil_div(g.M, bm) * ceil_div(g.N, bn);
+      g.xcd_slices = (xcd_on && 8 % nsplit == 0 && nb1 % (8 / nsplit) == 0 && (nb1 * nsplit) % 8 == 0) ? 1 : 0;
+    }
+    tile = mine;
+  }
   if (a_kc && b_kc) *err = launch_layout_h2<true, true>(g, tile, nsplit, stream, batch);
   else if (a_kc) *err = launch_layout_h2<true, false>(g, tile, nsplit, stream, batch);
   else *err = launch_layout_h2<false, false>(g, tile, nsplit, stream, batch);

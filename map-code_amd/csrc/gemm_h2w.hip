@@ -1,0 +1,405 @@
+// The two-piece fp16 product (gemm_h2.hip) for the case that matters most: operand B is a WEIGHT matrix.  A weight is
+// cut once per optimizer step, not once per row tile of every product that reads it: mapx_h2_weight_planes leaves its
+// two fp16 pieces in HBM in the order the matrix instruction wants its B fragments — for column tile t (32 columns) and
+// k16 step s one 2-KB block [piece hi | lo][lane][8 halves], lane (r, h) holding B(k = 16 s + 8 h + j, n = 32 t + r) —
+// zero-padded to whole tiles and to K % 32 == 0, with the scale exponent in a header.  The product kernel then
+//   * reads its B fragments straight from global memory into registers, one fully coalesced 1-KB load per fragment
+//     (rows of a row-major matrix fetched 32 at a time by one load instruction run at a third of that: round 3,
+//     tools/experiments/grouped_ra), two K-steps ahead of their use;
+//   * stages only operand A (activations / upstream gradients, fp32 in HBM, cut between the global load and the LDS
+//     store as in gemm_h2.hip) through LDS: half the ds_write_b128 traffic, half the cut's VALU work, no LDS reads
+//     for B.  What bounds gemm_h2.hip's K-step is exactly that (tools/h2_ablate.sh: MFMAs alone 0.46 us, staging
+//     alone 0.55, together 1.05 — the LDS store path, 79 B/clk per CU, and VALU issue beside MFMAs do not overlap
+//     the matrix pipe; with operand B not staged at all: 0.73);
+//   * gives each of its 4 waves all 128 rows of A and 32 columns of B (wave tile 128 x 32: the B fragments of the
+//     four waves are disjoint, nothing is fetched twice).
+// Forward products Y = X W^T (B(k, n) = W[n][k]) and input gradients dX = dY W (B(k, n) = W[k][n]) take the planes
+// of the matching orientation; weight gradients (both operands activations) stay on gemm_h2.hip.
+// Reference sites: MLPBlock layers.py:173-188, CrossNetV2 layers.py:197-201, heads models.py:74,119-124.
+#include "amax.h"
+#include "gemm_x3_common.h"
+
+namespace mapx {
+
+typedef _Float16 f16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kPlaneHeader = 256;        // bytes: int32 scale exponent n (pieces are those of 2^n B), then padding
+
+// gemm_h2.hip: the cut of two pairs of floats, four asm blocks of four full-rate VALU instructions
+struct CutRegs {
+  float sx[4], r[4];
+};
+__device__ __forceinline__ void w_unit0(float x0a, float x1a, float x0b, float x1b, float s, CutRegs& c) {
+  asm volatile("v_mul_f32 %0, %8, %4\n\t"
+               "v_mul_f32 %1, %8, %5\n\t"
+               "v_mul_f32 %2, %8, %6\n\t"
+               "v_mul_f32 %3, %8, %7"
+               : "=&v"(c.sx[0]), "=&v"(c.sx[1]), "=&v"(c.sx[2]), "=&v"(c.sx[3])
+               : "v"(x0a), "v"(x1a), "v"(x0b), "v"(x1b), "s"(s));
+}
+__device__ __forceinline__ void w_unit1(CutRegs& c, uint32_t& Ha, uint32_t& Hb) {
+  asm volatile("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+               "v_cvt_pk_f16_f32 %1, %6, %7\n\t"
+               "v_fma_mix_f32 %2, %4, 1.0, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+               "v_fma_mix_f32 %3, %6, 1.0, -%1 op_sel:[0,0,0] op_sel_hi:[0,0,1]"
+               : "=&v"(Ha), "=&v"(Hb), "=&v"(c.r[0]), "=&v"(c.r[2])
+               : "v"(c.sx[0]), "v"(c.sx[1]), "v"(c.sx[2]), "v"(c.sx[3]));
+}
+__device__ __forceinline__ void w_unit2(CutRegs& c, uint32_t Ha, uint32_t Hb, float k2048) {
+  asm volatile("v_fma_mix_f32 %0, %4, 1.0, -%6 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+               "v_fma_mix_f32 %1, %5, 1.0, -%7 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+               "v_mul_f32 %2, %8, %2\n\t"
+               "v_mul_f32 %3, %8, %3"
+               : "=&v"(c.r[1]), "=&v"(c.r[3]), "+v"(c.r[0]), "+v"(c.r[2])
+               : "v"(c.sx[1]), "v"(c.sx[3]), "v"(Ha), "v"(Hb), "s"(k2048));
+}
+__device__ __forceinline__ void w_unit3(CutRegs& c, float k2048, uint32_t& La, uint32_t& Lb) {
+  asm volatile("v_mul_f32 %2, %4, %2\n\t"
+               "v_mul_f32 %3, %4, %3\n\t"
+               "v_cvt_pk_f16_f32 %0, %5, %2\n\t"
+               "v_cvt_pk_f16_f32 %1, %6, %3"
+               : "=&v"(La), "=&v"(Lb), "+v"(c.r[1]), "+v"(c.r[3])
+               : "s"(k2048), "v"(c.r[0]), "v"(c.r[2]));
+}
+__device__ inline void w_cut8(const float (&x)[8], float s, uint4& hi, uint4& lo) {
+  uint32_t H[4], L[4];
+#pragma unroll
+  for (int e = 0; e < 4; e += 2) {
+    CutRegs c;
+    w_unit0(x[2 * e], x[2 * e + 1], x[2 * e + 2], x[2 * e + 3], s, c);
+    w_unit1(c, H[e], H[e + 1]);
+    w_unit2(c, H[e], H[e + 1], 2048.f);
+    w_unit3(c, 2048.f, L[e], L[e + 1]);
+  }
+  hi = make_uint4(H[0], H[1], H[2], H[3]);
+  lo = make_uint4(L[0], L[1], L[2], L[3]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// W -> planes.  One wave per (column tile t, k16 step s) block; K padded to whole K-steps of 32, N to tiles of 32.
+__global__ void __launch_bounds__(256) h2_weight_planes_kernel(const float* __restrict__ W, int64_t ldw, int N, int K,
+                                                               int b_kc, const float* __restrict__ amax,
+                                                               unsigned char* __restrict__ planes) {
+  const int KS = ((K + 31) / 32) * 2, NT32 = (N + 31) / 32;
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int n_exp = h2_scale_exp(amax);
+  const float s = pow2f(n_exp);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<int32_t*>(planes) = n_exp;
+  const int64_t blocks = (int64_t)NT32 * KS;
+  for (int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); blk < blocks; blk += (int64_t)gridDim.x * 4) {
+    const int t = (int)(blk / KS), sidx = (int)(blk % KS);
+    const int n = 32 * t + r, k0 = 16 * sidx + 8 * h;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + j;
+      const bool in = n < N && k < K;
+      x[j] = in ? (b_kc ? W[(int64_t)n * ldw + k] : W[(int64_t)k * ldw + n]) : 0.f;
+    }
+    uint4 hi, lo;
+    w_cut8(x, s, hi, lo);
+    unsigned char* dst = planes + kPlaneHeader + blk * 2048 + lane * 16;
+    *reinterpret_cast<uint4*>(dst) = hi;
+    *reinterpret_cast<uint4*>(dst + 1024) = lo;
+  }
+}
+
+// The same for up to kMaxPlaneTasks matrices in ONE launch (the optimizer re-cuts every registered weight behind its
+// update: six launches of 5 us each sat at the end of the step).
+constexpr int kMaxPlaneTasks = 16;
+struct PlaneTasks {
+  mapx_plane_task t[kMaxPlaneTasks];
+  int64_t first[kMaxPlaneTasks + 1];          // first block of task i in the launch's numbering
+  int n;
+};
+__global__ void __launch_bounds__(256) h2_weight_planes_multi_kernel(PlaneTasks tasks) {
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int64_t total = tasks.first[tasks.n];
+  for (int64_t gb = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); gb < total; gb += (int64_t)gridDim.x * 4) {
+    int ti = 0;
+    while (ti + 1 < tasks.n && gb >= tasks.first[ti + 1]) ++ti;
+    const mapx_plane_task tk = tasks.t[ti];
+    const int64_t blk = gb - tasks.first[ti];
+    const int KS = ((tk.K + 31) / 32) * 2;
+    const int n_exp = h2_scale_exp(static_cast<const float*>(tk.amax_record));
+    const float s = pow2f(n_exp);
+    unsigned char* const planes = static_cast<unsigned char*>(tk.planes);
+    if (blk == 0 && lane == 0) *reinterpret_cast<int32_t*>(planes) = n_exp;
+    const int t = (int)(blk / KS), sidx = (int)(blk % KS);
+    const int n = 32 * t + r, k0 = 16 * sidx + 8 * h;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + j;
+      const bool in = n < tk.N && k < tk.K;
+      x[j] = in ? (tk.b_kc ? tk.W[(int64_t)n * tk.ldw + k] : tk.W[(int64_t)k * tk.ldw + n]) : 0.f;
+    }
+    uint4 hi, lo;
+    w_cut8(x, s, hi, lo);
+    unsigned char* dst = planes + kPlaneHeader + blk * 2048 + lane * 16;
+    *reinterpret_cast<uint4*>(dst) = hi;
+    *reinterpret_cast<uint4*>(dst + 1024) = lo;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Operand A: as gemm_h2.hip's k-contiguous operand (XOR-swizzled [row][32] planes in LDS)
+template <int ROWS, int NT>
+struct OperandA {
+  static constexpr int LD = kXBK, PLANE = ROWS * LD, LDS_ELEMS = 2 * PLANE, CPR = kXBK / 8;
+  static constexpr int TOTAL = ROWS * kXBK / 8, NV = TOTAL / NT;
+  static_assert(TOTAL % NT == 0, "whole rounds of chunks");
+  float4 r[NV][2];
+  __device__ static inline void coords(int f, int& row, int& col) {
+    row = f / CPR;
+    col = (f % CPR) * 8;
+  }
+  __device__ static inline int lds_off(int row, int col) {
+    return row * LD + (((col >> 3) ^ ((row >> 2) & 3)) << 3);
+  }
+  __device__ static inline f16x8 frag1(const f16_t* __restrict__ s, int pl, int lane, int s2, int t) {
+    const int l31 = lane & 31, kh = lane >> 5;
+    return *reinterpret_cast<const f16x8*>(s + pl * PLANE + lds_off(32 * t + l31, 16 * s2 + 8 * kh));
+  }
+};
+
+// 128 x 128 tile, 4 waves of 128 x 32.  A k-contiguous [M][K] (lda % 4 == 0, 16-byte aligned, K % 8 == 0), B = planes.
+__global__ void __launch_bounds__(256) gemm_f32h2w_kernel(GemmX3Args a, const unsigned char* __restrict__ planes) {
+  constexpr int BM = 128, BN = 128, NT = 256, WMT = 4;
+  using OpA = OperandA<BM, NT>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  f16_t* const smem = reinterpret_cast<f16_t*>(smem_raw);
+  constexpr int kBuf = OpA::LDS_ELEMS;
+
+  const int na = __builtin_amdgcn_readfirstlane(h2_scale_exp(a.amax_a));
+  const int nb = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int32_t*>(planes));
+  const float sA = pow2f(na), k2048 = 2048.f;
+
+  const int nb_tiles = a.tiles_m * a.tiles_n, per = nb_tiles / 8;
+  int lin = blockIdx.x;
+  if (lin < per * 8) lin = (lin % 8) * per + lin / 8;      // XCD-aware tile order
+  const int tm = lin / a.tiles_n, tn = lin % a.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, kh = lane >> 5;
+
+  f32x16 acc[WMT], cor[WMT];
+#pragma unroll
+  for (int i = 0; i < WMT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = cor[i][r] = 0.f;
+
+  const int nk = (a.K + kXBK - 1) / kXBK;                  // K-steps; the planes are zero beyond K
+  const int KS = nk * 2;
+  // this wave's B blocks: column tile 4 tn + wave, k16 steps 2 kt, 2 kt + 1: 4 KB per K-step, contiguous
+  const unsigned char* const bbase =
+      planes + kPlaneHeader + ((int64_t)(tn * 4 + wave) * KS) * 2048 + lane * 16;
+  u32x4 fb[4][2][2];                                       // [set = kt & 3][k16 half][piece hi / lo]
+#define MAPX_W_BLOAD(SET, t)                                                                           \
+  do {                                                                                                 \
+    const int tc_ = (t) < nk ? (t) : nk - 1;                                                           \
+    const unsigned char* const q_ = bbase + (int64_t)tc_ * 4096;                                       \
+    fb[SET][0][0] = *reinterpret_cast<const u32x4*>(q_);                                               \
+    fb[SET][0][1] = *reinterpret_cast<const u32x4*>(q_ + 1024);                                        \
+    fb[SET][1][0] = *reinterpret_cast<const u32x4*>(q_ + 2048);                                        \
+    fb[SET][1][1] = *reinterpret_cast<const u32x4*>(q_ + 3072);                                        \
+  } while (0)
+
+  // operand A: chunk offsets (rows past M clamped to row 0, chunks past K to column 0: what they contribute meets
+  // zeros of B or lands in rows the epilogue does not store), LDS offsets
+  OpA la[2];
+  int64_t goffA[OpA::NV];
+  int soffA[OpA::NV], kcolA[OpA::NV];
+#pragma unroll
+  for (int i = 0; i < OpA::NV; ++i) {
+    int tr, tc;
+    OpA::coords(threadIdx.x + i * NT, tr, tc);
+    const bool in = m0 + tr < a.M;
+    goffA[i] = (int64_t)(in ? m0 + tr : 0) * a.lda;
+    kcolA[i] = tc;
+    soffA[i] = OpA::lds_off(tr, tc);
+  }
+#define MAPX_W_ALOAD(SET, i, hf, t)                                                                    \
+  do {                                                                                                 \
+    const int tc_ = (t) < nk ? (t) : nk - 1;                                                           \
+    const int k_ = tc_ * kXBK + kcolA[i];                                                              \
+    la[SET].r[i][hf] = *reinterpret_cast<const float4*>(a.A + goffA[i] + (k_ < a.K ? k_ : 0) + 4 * (hf)); \
+  } while (0)
+
+  // prologue: A tiles 0, 1 (tile 0 cut + stored), B sets 0, 1
+#pragma unroll
+  for (int i = 0; i < OpA::NV; ++i) { MAPX_W_ALOAD(0, i, 0, 0); MAPX_W_ALOAD(0, i, 1, 0); }
+#pragma unroll
+  for (int i = 0; i < OpA::NV; ++i) { MAPX_W_ALOAD(1, i, 0, 1); MAPX_W_ALOAD(1, i, 1, 1); }
+  MAPX_W_BLOAD(0, 0);
+  MAPX_W_BLOAD(1, 1);
+#pragma unroll
+  for (int i = 0; i < OpA::NV; ++i) {
+    const float x[8] = {la[0].r[i][0].x, la[0].r[i][0].y, la[0].r[i][0].z, la[0].r[i][0].w,
+                        la[0].r[i][1].x, la[0].r[i][1].y, la[0].r[i][1].z, la[0].r[i][1].w};
+    uint4 hi, lo;
+    w_cut8(x, sA, hi, lo);
+    *reinterpret_cast<uint4*>(smem + soffA[i]) = hi;
+    *reinterpret_cast<uint4*>(smem + soffA[i] + OpA::PLANE) = lo;
+  }
+#pragma unroll
+  for (int i = 0; i < OpA::NV; ++i) { MAPX_W_ALOAD(0, i, 0, 2); MAPX_W_ALOAD(0, i, 1, 2); }
+  __syncthreads();
+
+  // K-step kt on LDS buffer CUR = kt & 1, B set BS = kt & 3.  Slots: 24 MFMAs (k16 half h, A tile i, term); the cut
+  // of A's tile kt + 1 (2 chunks = 16 units of 4 VALU) in slots 0..15, its 4 LDS stores and the 4 loads of A's tile
+  // kt + 3 behind them; the 4 loads of B's K-step kt + 2 in slots 0..3; the second half's 8 A fragments in slots 0..7.
+  constexpr int kNM = 24, kU = 8 * OpA::NV;
+  static_assert(OpA::NV == 2, "two chunks of A per thread");
+#define MAPX_W_UNIT(CUR, u)                                                                            \
+  do {                                                                                                 \
+    constexpr int c_ = (u) / 8, pg_ = ((u) % 8) / 4, st_ = (u) % 4;                                    \
+    if (st_ == 0) {                                                                                    \
+      const float4 v_ = la[(CUR) ^ 1].r[c_][pg_];                                                      \
+      w_unit0(v_.x, v_.y, v_.z, v_.w, sA, cr);                                                         \
+    }                                                                                                  \
+    if (st_ == 1) w_unit1(cr, cH[c_][2 * pg_], cH[c_][2 * pg_ + 1]);                                   \
+    if (st_ == 2) w_unit2(cr, cH[c_][2 * pg_], cH[c_][2 * pg_ + 1], k2048);                            \
+    if (st_ == 3) w_unit3(cr, k2048, cL[c_][2 * pg_], cL[c_][2 * pg_ + 1]);                            \
+  } while (0)
+#define MAPX_W_KSTEP(CUR, BS, kt)                                                                      \
+  do {                                                                                                 \
+    const f16_t* const As_cur = smem + (CUR) * kBuf;                                                   \
+    f16_t* const As_nxt = smem + ((CUR) ^ 1) * kBuf;                                                   \
+    f16x8 fa[2][2][WMT];                          /* [k16 half][piece hi / lo][A row tile] */          \
+    _Pragma("unroll") for (int i = 0; i < WMT; ++i) {                                                  \
+      fa[0][1][i] = OpA::frag1(As_cur, 1, lane, 0, i);                                                 \
+      fa[0][0][i] = OpA::frag1(As_cur, 0, lane, 0, i);                                                 \
+    }                                                                                                  \
+    uint32_t cH[2][4], cL[2][4];                                                                       \
+    CutRegs cr;                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    unroll_seq([&](auto zc) __attribute__((always_inline)) {                                           \
+      constexpr int z = decltype(zc)::value;                                                           \
+      constexpr int h = z / 12, i = (z % 12) / 3, term = z % 3;                                        \
+      const f16x8 bh_ = __builtin_bit_cast(f16x8, fb[BS][h][0]), bl_ = __builtin_bit_cast(f16x8, fb[BS][h][1]); \
+      if (term == 0) cor[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[h][1][i], bh_, cor[i], 0, 0, 0); \
+      if (term == 1) cor[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[h][0][i], bl_, cor[i], 0, 0, 0); \
+      if (term == 2) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[h][0][i], bh_, acc[i], 0, 0, 0); \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+      if constexpr (z < 8) {                      /* second half's A fragments */                      \
+        constexpr int pl = 1 - (z & 1), t = z >> 1;                                                    \
+        fa[1][pl][t] = OpA::frag1(As_cur, pl, lane, 1, t);                                             \
+      }                                                                                                \
+      if constexpr (z < kU) MAPX_W_UNIT(CUR, z);                                                       \
+      if constexpr (z >= 8 && z < 12) {           /* B fragments of K-step kt + 2 */                   \
+        constexpr int q = z - 8;                                                                       \
+        const int tc_ = (kt) + 2 < nk ? (kt) + 2 : nk - 1;                                             \
+        fb[((BS) + 2) & 3][q >> 1][q & 1] =                                                            \
+            *reinterpret_cast<const u32x4*>(bbase + (int64_t)tc_ * 4096 + q * 1024);                   \
+      }                                                                                                \
+      if constexpr (z >= 12 && z < 16) {          /* chunk 0's stores (its cut ended with unit 7), then its loads */ \
+        constexpr int q = z - 12;                                                                      \
+        if (q < 2) *reinterpret_cast<uint4*>(As_nxt + soffA[0] + q * OpA::PLANE) =                     \
+            q == 0 ? make_uint4(cH[0][0], cH[0][1], cH[0][2], cH[0][3]) : make_uint4(cL[0][0], cL[0][1], cL[0][2], cL[0][3]); \
+        else MAPX_W_ALOAD((CUR) ^ 1, 0, (q >= 2 ? q - 2 : 0), (kt) + 3);                               \
+      }                                                                                                \
+      if constexpr (z >= 16 && z < 20) {          /* chunk 1's */                                      \
+        constexpr int q = z - 16;                                                                      \
+        if (q < 2) *reinterpret_cast<uint4*>(As_nxt + soffA[1] + q * OpA::PLANE) =                     \
+            q == 0 ? make_uint4(cH[1][0], cH[1][1], cH[1][2], cH[1][3]) : make_uint4(cL[1][0], cL[1][1], cL[1][2], cL[1][3]); \
+        else MAPX_W_ALOAD((CUR) ^ 1, 1, (q >= 2 ? q - 2 : 0), (kt) + 3);                               \
+      }                                                                                                \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+    }, std::make_integer_sequence<int, kNM>{});                                                        \
+    __syncthreads();                                                                                   \
+  } while (0)
+
+  int kt = 0;
+  for (; kt + 3 < nk; kt += 4) {
+    MAPX_W_KSTEP(0, 0, kt);
+    MAPX_W_KSTEP(1, 1, kt + 1);
+    MAPX_W_KSTEP(0, 2, kt + 2);
+    MAPX_W_KSTEP(1, 3, kt + 3);
+  }
+  if (kt < nk) { MAPX_W_KSTEP(0, 0, kt); ++kt; }
+  if (kt < nk) { MAPX_W_KSTEP(1, 1, kt); ++kt; }
+  if (kt < nk) { MAPX_W_KSTEP(0, 2, kt); ++kt; }
+#undef MAPX_W_KSTEP
+#undef MAPX_W_UNIT
+#undef MAPX_W_ALOAD
+#undef MAPX_W_BLOAD
+
+  float* const tile = reinterpret_cast<float*>(smem_raw);
+  constexpr int LDT = BN + 4;
+  const int dn = -(na + nb);
+#pragma unroll
+  for (int i = 0; i < WMT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      tile[(32 * i + 4 * kh + (r & 3) + 8 * (r >> 2)) * LDT + 32 * wave + l31] =
+          __builtin_ldexpf(__builtin_fmaf(cor[i][r], 0x1p-11f, acc[i][r]), dn);
+  __syncthreads();
+  epilogue_dispatch<BM, BN, NT>(a, a.C, tile, m0, n0);
+}
+
+// Called by gemm_f32x3_launch (gemm_x3.hip) when the caller handed the weight operand's planes.  false: not this
+// kernel's case (the caller goes on with gemm_h2.hip / gemm_x3.hip).
+bool gemm_f32h2w_try(GemmX3Args& g, int a_kc, bool vec, const void* planes, int nsplit, int batch, hipStream_t stream,
+                     hipError_t* err) {
+  static const bool on = [] { const char* e = getenv("MAPX_GEMM_H2W"); return !e || atoi(e) != 0; }();
+  if (!on || !planes || !a_kc || !vec || nsplit != 1 || batch != 1 || !g.amax_a) return false;
+  if (g.K < 2 * kXBK || g.K % 8 != 0 || (uintptr_t)planes % 16 != 0) return false;
+  const int64_t tiles = ceil_div(g.M, 128) * ceil_div(g.N, 128);
+  if (tiles < 128) return false;                     // narrow products: gemm_h2.hip's smaller tiles fill the chip
+  g.tiles_m = (int)ceil_div(g.M, 128);
+  g.tiles_n = (int)ceil_div(g.N, 128);
+  constexpr size_t ops = (size_t)2 * OperandA<128, 256>::LDS_ELEMS * sizeof(f16_t);
+  constexpr size_t epi = ((size_t)128 * 132 + 4 * 256) * sizeof(float);
+  constexpr size_t lds = ops > epi ? ops : epi;
+  static hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32h2w_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (raised != hipSuccess) { *err = raised; return true; }
+  hipLaunchKernelGGL(gemm_f32h2w_kernel, dim3(g.tiles_m * g.tiles_n), dim3(256), lds, stream, g,
+                     static_cast<const unsigned char*>(planes));
+  *err = hipSuccess;
+  return true;
+}
+
+}  // namespace mapx
+
+extern "C" size_t mapx_h2_weight_planes_bytes(int N, int K) {
+  const size_t KS = (size_t)((K + 31) / 32) * 2, NT32 = (size_t)((N + 127) / 128) * 4;     // whole 128-column tiles
+  return mapx::kPlaneHeader + NT32 * KS * 2048;
+}
+
+extern "C" int mapx_h2_weight_planes(const float* W, int64_t ldw, int N, int K, int b_kc, const void* amax_record,
+                                     void* planes, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(W && planes && amax_record && N > 0 && K > 0, "h2_weight_planes: bad arguments");
+  MAPX_REQUIRE((uintptr_t)planes % 16 == 0, "h2_weight_planes: planes must be 16-byte aligned");
+  const int Np = ((N + 127) / 128) * 128;                   // tiles of the padding columns are written too (zeros)
+  const int64_t blocks = (int64_t)(Np / 32) * (((K + 31) / 32) * 2);
+  hipLaunchKernelGGL(h2_weight_planes_kernel, dim3(grid_for(blocks, 4, 4096)), dim3(256), 0, stream, W, ldw, N, K, b_kc,
+                     static_cast<const float*>(amax_record), static_cast<unsigned char*>(planes));
+  return check_launch("h2_weight_planes");
+}
+
+extern "C" int mapx_h2_weight_planes_multi(const mapx_plane_task* tasks_host, int ntasks, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(ntasks >= 0 && ntasks <= kMaxPlaneTasks, "h2_weight_planes_multi: at most %d matrices per call", kMaxPlaneTasks);
+  if (ntasks == 0) return MAPX_OK;
+  MAPX_REQUIRE(tasks_host, "h2_weight_planes_multi: null task list");
+  PlaneTasks pt;
+  memset(&pt, 0, sizeof(pt));
+  pt.n = ntasks;
+  int64_t run = 0;
+  for (int i = 0; i < ntasks; ++i) {
+    const mapx_plane_task& t = tasks_host[i];
+    MAPX_REQUIRE(t.W && t.planes && t.amax_record && t.N > 0 && t.K > 0 && (uintptr_t)t.planes % 16 == 0,
+                 "h2_weight_planes_multi: bad task %d", i);
+    pt.t[i] = t;
+    pt.first[i] = run;
+    run += (int64_t)(((t.N + 127) / 128) * 4) * (((t.K + 31) / 32) * 2);
+  }
+  pt.first[ntasks] = run;
+  hipLaunchKernelGGL(h2_weight_planes_multi_kernel, dim3(grid_for(run, 4, 4096)), dim3(256), 0, stream, pt);
+  return check_launch("h2_weight_planes_multi");
+}

@@ -551,8 +551,11 @@ __global__ void __launch_bounds__(256) splitk_reduce_x3_v4_kernel(const float* _
   }
 }
 
-bool gemm_f32h2_try(GemmX3Args& g, int a_kc, int b_kc, bool vec, int tile, int nsplit, int batch, hipStream_t stream,
-                    hipError_t* err);      // gemm_h2.hip
+bool gemm_f32h2_try(GemmX3Args& g, int a_kc, int b_kc, bool vec, int tile, bool hinted, bool xcd_on, int nsplit,
+                    int batch, hipStream_t stream, hipError_t* err);      // gemm_h2.hip
+
+bool gemm_f32h2w_try(GemmX3Args& g, int a_kc, bool vec, const void* planes, int nsplit, int batch, hipStream_t stream,
+                     hipError_t* err);     // gemm_h2w.hip
 
 static bool xcd_slices_enabled() {
   static const bool on = [] { const char* e = getenv("MAPX_XCD_SLICES"); return !e || atoi(e) != 0; }();
@@ -630,7 +633,11 @@ int gemm_f32x3_launch(int a_kc, int b_kc, int M, int N, int K, const float* A, i
   // both operands with a magnitude record: the two-piece fp16 arithmetic (gemm_h2.hip), where it builds the case
   bool scaled = batch > 1 ? true : (g.amax_a && g.amax_b);
   for (int z = 0; z < batch && batch > 1; ++z) scaled = scaled && g.amax_az[z] && g.amax_bz[z];
-  if (!(scaled && gemm_f32h2_try(g, a_kc, b_kc, vec, tile, nsplit, batch, stream, &e))) {
+  const bool hinted = tile_hint >= 0 && (tile_hint & 255) <= 3;
+  // operand B's pieces already in HBM (a weight matrix: gemm_h2w.hip), else both operands cut in the kernel
+  if (!hinted && ex && ex->b_planes && gemm_f32h2w_try(g, a_kc, vec, ex->b_planes, nsplit, batch, stream, &e)) {
+  } else
+  if (!(scaled && gemm_f32h2_try(g, a_kc, b_kc, vec, tile, hinted, xcd_slices_enabled(), nsplit, batch, stream, &e))) {
     if (a_kc && b_kc) e = launch_layout_x3<true, true>(g, vec, tile, nsplit, stream, batch);
     else if (a_kc) e = launch_layout_x3<true, false>(g, vec, tile, nsplit, stream, batch);
     else e = launch_layout_x3<false, false>(g, vec, tile, nsplit, stream, batch);

@@ -72,6 +72,7 @@ struct GemmX3Extra {
   const float* amax_b;
   unsigned long long* amax_c;
   unsigned long long* amax_c2;
+  const void* b_planes;
 };
 
 #define MAPX_EPI_BWD_FUSED 7        // internal to the library: reached through mapx_gemm_f32_bwd_fused only

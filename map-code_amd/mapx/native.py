@@ -60,6 +60,9 @@ SIGNATURES = {
     "mapx_gemm_f32": (_i, [_i, _i, _i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _i, _p, _p, _i64, _p,
                            _i64, _p, _i64, _i, _i, _p, _sz, _p, _p, _p]),
     "mapx_amax_epoch_source": (_i, [_p]),
+    "mapx_h2_weight_planes_bytes": (_sz, [_i, _i]),
+    "mapx_h2_weight_planes": (_i, [_p, _i64, _i, _i, _i, _p, _p, _p]),
+    "mapx_h2_weight_planes_multi": (_i, [_p, _i, _p]),
     "mapx_amax_f32": (_i, [_p, _i64, _i64, _i64, _p, _i, _p]),
     "mapx_gemm_f32_bwd_fused": (_i, [_i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i, _p, _i64, _p, _i64,
                                      _p, _i64, _p, _i64, _i, _i, _p, _i64, _p, _p]),
@@ -126,9 +129,15 @@ class SumTask(C.Structure):
                 ("pad_", C.c_int32)]
 
 
+class PlaneTask(C.Structure):
+    """mapx_plane_task (include/mapx_hip.h)."""
+    _fields_ = [("W", _p), ("ldw", _i64), ("N", C.c_int32), ("K", C.c_int32), ("b_kc", C.c_int32), ("pad_", C.c_int32),
+                ("amax_record", _p), ("planes", _p)]
+
+
 class GemmScale(C.Structure):
     """mapx_gemm_scale (include/mapx_hip.h): magnitude records of a product's operands and outputs."""
-    _fields_ = [("amax_a", _p), ("amax_b", _p), ("amax_c", _p), ("amax_c2", _p)]
+    _fields_ = [("amax_a", _p), ("amax_b", _p), ("amax_c", _p), ("amax_c2", _p), ("b_planes", _p)]
 
 
 class MapxError(RuntimeError):

@@ -918,6 +918,7 @@ def amax_of(t):
         if ver is not None and ver != t._version:
             amax(t.detach(), rec=rec, reset=True)
             t._amax_ver = t._version
+            refresh_weight_planes(t)
     return rec
 
 
@@ -938,8 +939,11 @@ def flat_rows(x):
 
 
 def cols(t, c0, c1):
-    """t[:, c0:c1] with t's record."""
-    return carry(t[:, c0:c1], t)
+    """t[:, c0:c1] with t's record (and, for a weight, the note which columns of which parameter it is)."""
+    v = carry(t[:, c0:c1], t)
+    if getattr(t, "_planes", None) is not None:
+        v._wslice = (t, c0, c1)
+    return v
 
 
 def amax_pack(*ts):
@@ -997,10 +1001,76 @@ def _check_record(x, rec, what):
         raise AssertionError(f"magnitude record of operand {what}: {got!r} for a tensor whose max |x| is {true!r}")
 
 
-def _scale_arg(amax_a, amax_b, amax_c=None, amax_c2=None):
+# Weight planes (include/mapx_hip.h: mapx_h2_weight_planes; csrc/gemm_h2w.hip): a weight that is operand B of large
+# products is cut into its two fp16 pieces once per optimizer step instead of once per row tile of every product.  The
+# optimizer owns the cache: `p._planes` {(b_kc, c0, c1): planes} on a parameter, filled at first use, refreshed by
+# MapxOptimizer right after the AdamW kernel (and by refresh_bf16 after anything else wrote the parameter).
+H2W = os.environ.get("MAPX_GEMM_H2W", "1") == "1"
+
+
+def h2_weight_planes(w, b_kc, rec, out=None):
+    """The planes of w as operand B (b_kc: B(k,n) = w[n,k], forward; else B(k,n) = w[k,n], input gradient; w may
+    be a column slice) at the scale its record `rec` gives now."""
+    require_gpu(w)
+    Nn, K = (w.shape[0], w.shape[1]) if b_kc else (w.shape[1], w.shape[0])
+    if out is None:
+        out = torch.empty(lib.mapx_h2_weight_planes_bytes(Nn, K), dtype=torch.uint8, device=w.device)
+    check(lib.mapx_h2_weight_planes(w.data_ptr(), w.stride(0), Nn, K, int(b_kc), rec.data_ptr(), out.data_ptr(), stream()))
+    return out
+
+
+def planes_wanted(M, Nn, K):
+    """Would gemm_h2w.hip take a product of this shape?  (>= 128 tiles of 128 x 128, K >= 64, K % 8 == 0)"""
+    return math.ceil(M / 128) * math.ceil(Nn / 128) >= 128 and K >= 64 and K % 8 == 0
+
+
+def weight_planes(w, b_kc, M):
+    """The cached planes of weight (or weight slice, ops.cols) `w` for a product with M rows, or None: no optimizer
+    owns the parameter, records are off, or the product is not one gemm_h2w.hip takes."""
+    if not (H2 and H2W) or w is None or w.dim() != 2 or w.dtype != torch.float32:
+        return None
+    base, c0, c1 = getattr(w, "_wslice", (w, 0, None))
+    reg = getattr(base, "_planes", None)
+    rec = amax_of(base)
+    if reg is None or rec is None:
+        return None
+    Nn, K = (w.shape[0], w.shape[1]) if b_kc else (w.shape[1], w.shape[0])
+    if not planes_wanted(M, Nn, K):
+        return None
+    key = (bool(b_kc), c0, c1)
+    pl = reg.get(key)
+    if pl is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None               # (registered by the eager steps that precede a capture)
+        pl = reg[key] = h2_weight_planes(base.detach()[:, c0:c1] if (c0, c1) != (0, None) else base.detach(), b_kc, rec)
+    return pl
+
+
+def refresh_weight_planes(params):
+    """Re-cut every registered plane set of the parameters (their records must be current on this stream): one
+    launch per 16 sets."""
+    if isinstance(params, torch.Tensor):
+        params = [params]
+    todo = []
+    for p in params:
+        for (b_kc, c0, c1), pl in (getattr(p, "_planes", None) or {}).items():
+            w = p.detach()[:, c0:c1] if (c0, c1) != (0, None) else p.detach()
+            Nn, K = (w.shape[0], w.shape[1]) if b_kc else (w.shape[1], w.shape[0])
+            todo.append((w, Nn, K, b_kc, p._amax, pl))
+    for i in range(0, len(todo), 16):
+        part = todo[i:i + 16]
+        arr = (N.PlaneTask * len(part))()
+        for j, (w, Nn, K, b_kc, rec, pl) in enumerate(part):
+            arr[j].W, arr[j].ldw, arr[j].N, arr[j].K, arr[j].b_kc = w.data_ptr(), w.stride(0), Nn, K, int(b_kc)
+            arr[j].amax_record, arr[j].planes = rec.data_ptr(), pl.data_ptr()
+        check(lib.mapx_h2_weight_planes_multi(arr, len(part), stream()))
+
+
+def _scale_arg(amax_a, amax_b, amax_c=None, amax_c2=None, b_planes=None):
     if amax_a is None and amax_b is None and amax_c is None and amax_c2 is None:
         return None
     sc = N.GemmScale()
+    sc.b_planes = b_planes.data_ptr() if (b_planes is not None and amax_a is not None) else None
     sc.amax_a = amax_a.data_ptr() if amax_a is not None else None
     sc.amax_b = amax_b.data_ptr() if amax_b is not None else None
     sc.amax_c = amax_c.data_ptr() if amax_c is not None else None
@@ -1010,7 +1080,7 @@ def _scale_arg(amax_a, amax_b, amax_c=None, amax_c2=None):
 
 def gemm(a, b, a_kc, b_kc, M, N, K, out=None, ldc=None, epi=N.EPI_NONE, bias=None, aux1=None,
          aux2=None, out2=None, nsplit=1, lda=None, ldb=None, tile=-1, defer=False, out_dtype=None,
-         amax_a=None, amax_b=None, amax_c=None, record=True):
+         amax_a=None, amax_b=None, amax_c=None, record=True, b_planes=None):
     """C[M,N] = epi(sum_k A(m,k) B(k,n)); see include/mapx_hip.h: mapx_gemm_f32 (fp32 operands) /
     mapx_gemm_bf16 (bf16 operands; `out_dtype` picks a bf16 or fp32 result).  amax_a / amax_b: the operands'
     magnitude records (both given: the two-piece fp16 arithmetic); amax_c: record raised with max |C|."""
@@ -1043,7 +1113,8 @@ def gemm(a, b, a_kc, b_kc, M, N, K, out=None, ldc=None, epi=N.EPI_NONE, bias=Non
     if AMAX_CHECK and not torch.cuda.is_current_stream_capturing():
         _check_record(a, amax_a, "A")
         _check_record(b, amax_b, "B")
-    sc = _scale_arg(amax_a, amax_b, amax_c)
+    sc = _scale_arg(amax_a, amax_b, amax_c, b_planes=b_planes if b_planes is not None else
+                    (weight_planes(b, b_kc, M) if (a_kc and nsplit == 1 and tile < 0) else None))
     with _timed(kind, 2.0 * M * N * K):
         check(lib.mapx_gemm_f32(int(a_kc), int(b_kc), M, N, K, a.data_ptr(), lda, b.data_ptr(), ldb,
                                 out.data_ptr(), ldc, epi, ptr(bias),
@@ -1074,6 +1145,7 @@ SKINNY_MAX = int(os.environ.get("MAPX_SKINNY_MAX", "8"))            # forward: w
 # dW 45 -> 26 us, its RFD step -2.3 %): opt-in.  (With 33..64 on, the captured step of the 64-wide test models stopped
 # agreeing with the eager one — traced to the packed FMAs of skinny_dw_tall_kernel, see there; now a test of its own.)
 SKINNY_MAX_BWD = int(os.environ.get("MAPX_SKINNY_MAX_BWD", "32"))
+SKINNY_TALL = os.environ.get("MAPX_SKINNY_TALL", "0") == "1"
 
 
 def _skinny(Nn, K, *mats, bwd=False):
@@ -1162,9 +1234,11 @@ def linear_bwd_weight(dy, x, out=None, defer=False):
     """dW = dY^T X.  dy [B,N], x [B,K] -> [N,K].  defer: leave split-K slabs for flush_deferred()."""
     Bn, Nn = dy.shape
     K = x.shape[1]
-    # (also: both dimensions small over many rows — AutoInt's attention projections, dW [40, 16 | 40] over B*F rows)
-    # (also: both dimensions small over many rows — AutoInt's attention projections, dW [40, 16 | 40] over B*F rows)
-    tall = SKINNY and 32 < Nn <= 64 and 4 <= K <= 64 and K % 4 == 0 and Bn >= 8192 and _rows16(x)
+    # (also: both dimensions small over many rows — AutoInt's attention projections, dW [40, 16 | 40] over B*F rows.
+    # Opt-in since round 4 (MAPX_SKINNY_TALL=1; ADVICE r3): this is the kernel whose compiler-generated packed FMAs
+    # gave a timing-dependent wrong result beside MFMA kernels in round 3; the re-written loop has passed every
+    # bitwise graph == eager run since, but the mechanism was never found (DESIGN §8), so the default is the GEMM.)
+    tall = SKINNY and SKINNY_TALL and 32 < Nn <= 64 and 4 <= K <= 64 and K % 4 == 0 and Bn >= 8192 and _rows16(x)
     ok = _skinny(Nn, K, x, bwd=True) or tall
     rows_cap = 64 if (Nn > 32 and K > 64) else _TALL_ROWS     # (33..64 outputs x many columns: the LDS-tiled form only)
     if ok and Nn > 32 and K > 64 and Bn > 64 * 2048:
@@ -1374,7 +1448,7 @@ def gemm_bwd_fused(dy, w, c0, add=None, mask=None, x0=None, u=None, dx0=None, pl
     # records: C's ReLU-masked columns (>= c0: the deep tower's dZ) and t, the operands of the products that follow
     rec_c = amax_record(dev) if c0 < Nn else None
     rec_t = amax_record(dev) if c0 > 0 else None
-    sc = _scale_arg(amax_of(dy), amax_of(w), rec_c, rec_t)
+    sc = _scale_arg(amax_of(dy), amax_of(w), rec_c, rec_t, b_planes=weight_planes(w, False, M))
     with _timed("gemm_dx_nn", 2.0 * M * Nn * K):
         check(lib.mapx_gemm_f32_bwd_fused(M, Nn, K, dy.data_ptr(), dy.stride(0), w.data_ptr(), w.stride(0),
                                           C.data_ptr(), C.stride(0), *sd(add), *sd(mask), c0, *sd(x0), *sd(u), *sd(t),

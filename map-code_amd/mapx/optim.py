@@ -148,7 +148,8 @@ class MapxOptimizer:
         # Round 3 (tools/flag_sweep.py, one box each): in fp32, with the table gradients on the tower stream's late
         # tasks, the early row updates LOSE (0.8058 vs 0.7975 ms per step: the updates run in step(), beside the
         # optimizer's dense half); in the bf16 mode, whose GEMM chains are half as long, they WIN (0.5931 vs 0.6318).
-        early_default = "1" if self.bf16 else "0"
+        # Round 4 (two-piece fp16 GEMMs: the fp32 chains are a third shorter): early wins in fp32 as well, 0.7075 vs 0.7175.
+        early_default = "1"
         early = (os.environ.get("MAPX_EARLY_TABLE_UPDATE", early_default) == "1" and self.max_grad_norm <= 0
                  and not parallel.exchanging())
         for t in self.tables:
@@ -187,6 +188,8 @@ class MapxOptimizer:
         for i, ((_, p), sz) in enumerate(zip(members, sizes)):
             if recs is not None:
                 p._amax = recs[i]
+                if p.dim() == 2:
+                    p._planes = {}           # ops.weight_planes: filled at first use, refreshed behind every update
             view = flat_p[off:off + p.numel()].view_as(p)
             view.copy_(p.data)
             p.data = view
@@ -208,6 +211,7 @@ class MapxOptimizer:
                 for p, rec in zip(g["params"], g["amax"]):
                     ops.amax(p.data.reshape(1, -1) if p.dim() != 2 else p.data, rec=rec, reset=True)
                     p._amax_ver = p._version
+                    ops.refresh_weight_planes(p)
         if not self.bf16:
             return
         for g in self.groups:
@@ -291,6 +295,8 @@ class MapxOptimizer:
         for g in self.groups:
             ops.adamw_dense(g["p"], g["g"], g["m"], g["v"], self.sched, self.done, b1, b2, eps, g["wd"],
                             shadow=g["h"], seg_off=g.get("seg_off"), seg_amax=g.get("amax"))
+            if g.get("amax") is not None:
+                ops.refresh_weight_planes(g["params"])       # the weights' fp16 pieces for the next step's products
 
     def zero_grad(self):
         """Dense gradients are overwritten by the next backward (see layers._grad_slot); only

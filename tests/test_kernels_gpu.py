@@ -1052,6 +1052,7 @@ def test_skinny_linear_kernels_vs_fp64(ops, monkeypatch, M, N, K):
     dy = torch.randn(M, N, generator=g).to(DEV)
     if N > 32:                      # 33..64 outputs: weight and input gradients only
         monkeypatch.setattr(ops, "SKINNY_MAX_BWD", 64)
+        monkeypatch.setattr(ops, "SKINNY_TALL", True)        # (the tall weight-gradient kernel is opt-in since round 4)
         dw_ref = dy.double().T @ x.double()
         dw = ops.linear_bwd_weight(dy, x)
         assert float((dw.double() - dw_ref).abs().max()) <= 3e-6 * float(dw_ref.abs().max())

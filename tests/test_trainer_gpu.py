@@ -304,8 +304,10 @@ def test_graph_replay_equals_eager_bitwise_with_streaming_hidden_layers(monkeypa
     weight gradient."""
     from mapx import ops
     monkeypatch.setattr(ops, "SKINNY_MAX_BWD", 64)
-    for _ in range(3):
-        _graph_equals_eager(0.0, "DCNv2", 18, 1, tail=0)
+    monkeypatch.setattr(ops, "SKINNY_TALL", True)
+    # one run (not a loop: a result that comes and goes with timing is not chased by repetition — the instruction form
+    # behind it is kept out of every shipped kernel by tests/test_isa_guard.py instead)
+    _graph_equals_eager(0.0, "DCNv2", 18, 1, tail=0)
 
 
 def _graph_equals_eager(max_grad_norm, backbone, full, epochs, tail=100):

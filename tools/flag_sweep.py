@@ -38,7 +38,7 @@ def mean2(env):
 cur = {k: d for k, d, _ in FLAGS}
 best, runs = mean2(cur)
 print(f"defaults: {best:.4f} {runs}", flush=True)
-for sweep in (1, 2):
+for sweep in range(1, int(os.environ.get('SWEEP_PASSES', '2')) + 1):
     changed = False
     for k, d, alt in FLAGS:
         trial = dict(cur)

@@ -34,7 +34,10 @@ def run(name, a_kc, b_kc, M, N, K, epi=EPI_NONE, nsplit=1, tile=-1, check=True, 
     out = torch.empty(M, N, device="cuda")
     ra, rb = ops.amax(A), ops.amax(B)
     res = {}
-    for mode, kw in (("x3", {}), ("h2", dict(amax_a=ra, amax_b=rb))):
+    modes = [("x3", {}), ("h2", dict(amax_a=ra, amax_b=rb))]
+    if a_kc and nsplit == 1 and tile < 0 and ops.planes_wanted(M, N, K):
+        modes.append(("h2w", dict(amax_a=ra, amax_b=rb, b_planes=ops.h2_weight_planes(B, b_kc, rb))))
+    for mode, kw in modes:
         fn = lambda: ops.gemm(A, B, a_kc, b_kc, M, N, K, out=out, epi=epi, bias=bias, nsplit=nsplit, tile=tile, **kw)
         us = timeit(fn)
         err = float("nan")
@@ -47,8 +50,9 @@ def run(name, a_kc, b_kc, M, N, K, epi=EPI_NONE, nsplit=1, tile=-1, check=True, 
             err = float(((o[rows].double() - ref).abs() / mag).max())
         res[mode] = (us, 2.0 * M * N * K / us / 1e6, err)
     x, h = res["x3"], res["h2"]
+    w = res.get("h2w")
     print(f"  {name:28s} tile {tile:2d}: x3 {x[0]:7.1f} us {x[1]:6.1f} TF err {x[2]:.2e} | h2 {h[0]:7.1f} us {h[1]:6.1f} TF err {h[2]:.2e}"
-          f" | x{ x[0] / h[0]:.2f}", flush=True)
+          f" | x{ x[0] / h[0]:.2f}" + (f" | h2w {w[0]:7.1f} us {w[1]:6.1f} TF err {w[2]:.2e} x{x[0] / w[0]:.2f}" if w else ""), flush=True)
 
 
 if __name__ == "__main__":
