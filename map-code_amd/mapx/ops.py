@@ -987,6 +987,9 @@ def amax_value(rec):
 # below the operand's true maximum would overflow fp16, one far above it wastes precision.  H2_USED counts the
 # products that were handed both records (tests assert that the hot path really takes the new arithmetic).
 AMAX_CHECK = os.environ.get("MAPX_AMAX_CHECK", "0") == "1"
+# tests: a product whose operand comes without a record gets one computed on the spot (and its weight-like operand B
+# its planes), so that every GEMM test also runs through the two-piece fp16 kernels
+AUTO_AMAX = os.environ.get("MAPX_AUTO_AMAX", "0") == "1"
 H2_USED = [0, 0]               # products with both records / without
 
 
@@ -1066,6 +1069,11 @@ def refresh_weight_planes(params):
         check(lib.mapx_h2_weight_planes_multi(arr, len(part), stream()))
 
 
+def _as2d(t, ld):
+    """The [rows, ld] matrix an operand pointer + leading dimension describes (AUTO_AMAX: a superset of the operand)."""
+    return t if t.dim() == 2 else t.reshape(-1, ld)
+
+
 def _scale_arg(amax_a, amax_b, amax_c=None, amax_c2=None, b_planes=None):
     if amax_a is None and amax_b is None and amax_c is None and amax_c2 is None:
         return None
@@ -1107,6 +1115,12 @@ def gemm(a, b, a_kc, b_kc, M, N, K, out=None, ldc=None, epi=N.EPI_NONE, bias=Non
     kind = "gemm_fwd_nt" if (a_kc and b_kc) else ("gemm_dx_nn" if a_kc else "gemm_dw_tn")
     amax_a = amax_a if amax_a is not None else amax_of(a)
     amax_b = amax_b if amax_b is not None else amax_of(b)
+    if AUTO_AMAX and H2:
+        amax_a = amax_a if amax_a is not None else amax(_as2d(a, lda))
+        amax_b = amax_b if amax_b is not None else amax(_as2d(b, ldb))
+        if b_planes is None and H2W and a_kc and nsplit == 1 and tile < 0 and planes_wanted(M, N, K) \
+                and b.dim() == 2 and b.stride(1) == 1:
+            b_planes = h2_weight_planes(b[:N, :K] if b_kc else b[:K, :N], b_kc, amax_b)
     if amax_c is None and record and nsplit == 1:      # (split-K outputs are weight gradients: nobody multiplies them)
         amax_c = out_record(out, dev)
     H2_USED[0 if (amax_a is not None and amax_b is not None) else 1] += 1
@@ -1448,7 +1462,13 @@ def gemm_bwd_fused(dy, w, c0, add=None, mask=None, x0=None, u=None, dx0=None, pl
     # records: C's ReLU-masked columns (>= c0: the deep tower's dZ) and t, the operands of the products that follow
     rec_c = amax_record(dev) if c0 < Nn else None
     rec_t = amax_record(dev) if c0 > 0 else None
-    sc = _scale_arg(amax_of(dy), amax_of(w), rec_c, rec_t, b_planes=weight_planes(w, False, M))
+    ra, rb, pl = amax_of(dy), amax_of(w), weight_planes(w, False, M)
+    if AUTO_AMAX and H2:
+        ra = ra if ra is not None else amax(dy)
+        rb = rb if rb is not None else amax(w)
+        if pl is None and H2W and planes_wanted(M, Nn, K) and w.stride(1) == 1:
+            pl = h2_weight_planes(w, False, rb)
+    sc = _scale_arg(ra, rb, rec_c, rec_t, b_planes=pl)
     with _timed("gemm_dx_nn", 2.0 * M * Nn * K):
         check(lib.mapx_gemm_f32_bwd_fused(M, Nn, K, dy.data_ptr(), dy.stride(0), w.data_ptr(), w.stride(0),
                                           C.data_ptr(), C.stride(0), *sd(add), *sd(mask), c0, *sd(x0), *sd(u), *sd(t),
@@ -1505,6 +1525,10 @@ def linear_bwd_weight_batched(dys, xs, outs):
     ws = scratch(cnt * lib.mapx_gemm_splitk_workspace_bytes(Nn, K, ns), dys[0].device) if ns > 1 else None
     PP = C.c_void_p * cnt
     scales = None
+    if AUTO_AMAX and H2:
+        for t_ in list(dys) + list(xs):
+            if amax_of(t_) is None:
+                tag(t_, amax(t_))
     if all(amax_of(d) is not None and amax_of(x) is not None for d, x in zip(dys, xs)):
         scales = (N.GemmScale * cnt)()
         for z, (d, x) in enumerate(zip(dys, xs)):

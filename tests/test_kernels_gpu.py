@@ -238,9 +238,19 @@ def _ref_mm(a, b):
     return (a.double() @ b.double())
 
 
+@pytest.fixture(params=["x3", "h2"])
+def arith(request, monkeypatch, ops):
+    """Every GEMM test runs twice: through the six-product bf16 arithmetic (csrc/gemm_x3.hip: operands without
+    magnitude records) and through the two-piece fp16 one (csrc/gemm_h2.hip, and gemm_h2w.hip where operand B is
+    weight-like and the product large: ops.AUTO_AMAX computes the records — and planes — the step's own kernels
+    would have left).  Same bounds for both."""
+    monkeypatch.setattr(ops, "AUTO_AMAX", request.param == "h2")
+    return request.param
+
+
 @pytest.mark.parametrize("M,N,K", [(7, 368, 368), (64, 1000, 400), (4096, 1000, 368), (256, 736, 1368),
                                    (100, 23, 736), (129, 1, 1368), (4096, 368, 368), (65, 130, 17)])
-def test_gemm_linear_forward(ops, M, N, K):
+def test_gemm_linear_forward(ops, arith, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
     x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
     ref = _ref_mm(x, w.t()) + b.double()
@@ -254,7 +264,7 @@ def test_gemm_linear_forward(ops, M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(7, 368, 400), (4096, 1000, 368), (64, 23, 736), (300, 1, 1368),
                                    (4096, 368, 368), (33, 65, 129)])
-def test_gemm_backward_products(ops, M, N, K):
+def test_gemm_backward_products(ops, arith, M, N, K):
     """dX = dY W (a_kc, b_nc) and dW = dY^T X (a_mc, b_nc), incl. deterministic split-K."""
     g = torch.Generator().manual_seed(M * N + K)
     dy, w, x = torch.randn(M, N, generator=g), torch.randn(N, K, generator=g), torch.randn(M, K, generator=g)
@@ -277,7 +287,7 @@ def test_gemm_backward_products(ops, M, N, K):
 
 @pytest.mark.parametrize("M,N,K,ns", [(128, 192, 512, 1), (128, 192, 512, 2), (1000, 1000, 256, 1), (1000, 1000, 4096, 1),
                                       (64, 64, 384, 1), (100, 68, 256, 1), (1000, 368, 2048, 2)])
-def test_gemm_weight_gradient_shapes(ops, M, N, K, ns):
+def test_gemm_weight_gradient_shapes(ops, arith, M, N, K, ns):
     """Weight-gradient products (both operands k-strided) with K a multiple of 128: edge tiles
     (1000 = 7 x 128 + 104, 100 x 68), split-K slabs, padded leading dimensions, an output with a row stride of its
     own, and bit-reproducibility."""
@@ -301,7 +311,7 @@ def test_gemm_weight_gradient_shapes(ops, M, N, K, ns):
 @pytest.mark.parametrize("a_kc,b_kc,M,N,K", [(1, 1, 4096, 1000, 368), (1, 1, 4096, 1000, 1000), (1, 0, 4096, 1368, 736),
                                              (0, 0, 1000, 1000, 4096), (1, 1, 300, 200, 200), (0, 0, 300, 200, 520),
                                              (1, 0, 777, 1624, 1248), (1, 1, 256, 128, 64), (1, 0, 130, 72, 40)])
-def test_gemm_every_tile_layout(ops, a_kc, b_kc, M, N, K):
+def test_gemm_every_tile_layout(ops, arith, a_kc, b_kc, M, N, K):
     """Every tile layout of the fp32 GEMM (hints 0-3: 64x64, 128x64, 128x128 by 8 waves, 128x128 by 4
     waves with the hand-woven K-step) on the step's shapes and on the woven loop's corner cases: a K
     remainder (the partial tile goes first), edge tiles in both dimensions (out-of-range rows are read from
@@ -322,7 +332,7 @@ def test_gemm_every_tile_layout(ops, a_kc, b_kc, M, N, K):
 @pytest.mark.parametrize("M,N,K,c0", [(4096, 1368, 736, 368), (300, 432, 96, 368), (129, 368, 368, 368),
                                       (260, 1000, 200, 0), (64, 72, 40, 40)])
 @pytest.mark.parametrize("add,accumulate,plus_v", [(False, False, False), (True, True, False), (True, True, True)])
-def test_gemm_bwd_fused_epilogue(ops, M, N, K, c0, add, accumulate, plus_v):
+def test_gemm_bwd_fused_epilogue(ops, arith, M, N, K, c0, add, accumulate, plus_v):
     """mapx_gemm_f32_bwd_fused: the dX GEMM whose epilogue does the ReLU backward right of column c0 and the
     cross layer's backward (t = v x0, dx0 (+)= v u (+ v)) left of it, plus one partial row of the bias
     gradients per 128-row tile — against fp64 on the step's shapes (the heads' concatenated input: N = D + H,
@@ -376,7 +386,7 @@ def test_gemm_bwd_fused_epilogue(ops, M, N, K, c0, add, accumulate, plus_v):
 
 
 @pytest.mark.parametrize("cnt,Bn,Nn,K", [(3, 4096, 368, 368), (2, 777, 72, 40), (4, 512, 128, 136), (1, 300, 64, 64)])
-def test_linear_bwd_weight_batched(ops, cnt, Bn, Nn, K):
+def test_linear_bwd_weight_batched(ops, arith, cnt, Bn, Nn, K):
     """mapx_gemm_f32_batched: the cross layers' weight gradients (equal shapes) from one launch + one slab sum."""
     g = torch.Generator().manual_seed(cnt + Bn + Nn + K)
     dys = [torch.randn(Bn, Nn, generator=g) for _ in range(cnt)]
@@ -437,7 +447,7 @@ def test_gemm_x3_operand_magnitudes(ops):
 
 
 @pytest.mark.parametrize("M,N,K", [(4096, 1000, 1000), (300, 368, 200), (129, 72, 1000)])
-def test_gemm_relu_mask_colsum_epilogue(ops, M, N, K):
+def test_gemm_relu_mask_colsum_epilogue(ops, arith, M, N, K):
     """EPI_RELU_MASK_COLSUM (an MLP layer's dX GEMM doing the upstream layer's ReLU backward): the masked
     product, and one partial row of its column sums per 128-row tile that add up to the bias gradient."""
     from mapx.native import EPI_RELU_MASK_COLSUM
@@ -495,7 +505,7 @@ def test_mask_rows_with_device_cursor(ops):
             assert torch.equal(x_, y_)
 
 
-def test_gemm_writes_into_column_slice(ops):
+def test_gemm_writes_into_column_slice(ops, arith):
     x, w, b = torch.randn(50, 64, device=DEV), torch.randn(40, 64, device=DEV), torch.randn(40, device=DEV)
     final = torch.full((50, 100), 7.0, device=DEV)
     ops.linear_fwd(x, w, b, out=final[:, 60:])
