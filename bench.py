@@ -31,8 +31,11 @@ MFMA_PEAK_TFLOPS = {"f32": 157.3,     # v_mfma_f32_32x32x2_f32, dense fp32 matri
                     "bf16": 2500.0,   # v_mfma_f32_32x32x16_bf16, dense bf16 peak (no 2:1 sparsity)
                     # fp32 products formed from six bf16 MFMAs (csrc/gemm_x3.hip: operands cut into three bf16
                     # pieces): the instruction-level ceiling of that algorithm in fp32-equivalent flop/s
-                    "f32x3": 2500.0 / 6}
-ROUND = "r03"                # profiles/<ROUND>_pmc_hbm_traffic[_bf16].json is this round's PMC summary
+                    "f32x3": 2500.0 / 6,
+                    # ... from three fp16 MFMAs (csrc/gemm_h2.hip, gemm_h2w.hip: operands scaled by their magnitude
+                    # records and cut into two fp16 pieces); the fp16 forms issue at the bf16 rate
+                    "f32h2": 2500.0 / 3}
+ROUND = "r04"                # profiles/<ROUND>_pmc_hbm_traffic[_bf16].json is this round's PMC summary
 
 WORKLOADS = {
     "avazu": dict(F=23, V=9449445),
@@ -43,9 +46,13 @@ WORKLOADS = {
 
 # kernel class (ops.Timers name) -> substrings of the rocprof kernel names it launches
 PMC_MAP = {
-    "gemm_fwd_nt": [["gemm_f32x3_kernel<", ", true, true, true>"], ["gemm_bf16_kernel<", ", true, true, "]],
-    "gemm_dx_nn": [["gemm_f32x3_kernel<", ", true, false, true>"], ["gemm_bf16_kernel<", ", true, false, "]],
-    "gemm_dw_tn": [["gemm_f32x3_kernel<", ", false, false, true>"], ["gemm_bf16_kernel<", ", false, false, "]],
+    "gemm_fwd_nt": [["gemm_f32x3_kernel<", ", true, true, true>"], ["gemm_f32h2_kernel<", ", true, true>"],
+                    ["gemm_bf16_kernel<", ", true, true, "]],
+    "gemm_dx_nn": [["gemm_f32x3_kernel<", ", true, false, true>"], ["gemm_f32h2_kernel<", ", true, false>"],
+                   ["gemm_bf16_kernel<", ", true, false, "]],
+    "gemm_dw_tn": [["gemm_f32x3_kernel<", ", false, false, true>"], ["gemm_f32h2_kernel<", ", false, false>"],
+                   ["gemm_bf16_kernel<", ", false, false, "]],
+    "gemm_weight_planes": [["gemm_f32h2w_kernel"]],      # (forward and input-gradient products alike: one kernel)
     "gemm_enc_grouped_fwd": [["gemm_grouped_x3_kernel<false>"]],
     "gemm_enc_grouped_dw": [["gemm_grouped_x3_kernel<true>"]],
     "nce_fwd": ["nce_fwd_"],
@@ -106,10 +113,33 @@ def pmc_traffic(name, dtype="f32"):
             continue
         pats = PMC_MAP[name]
         pats = pats if isinstance(pats[0], list) else [pats]        # alternatives, each a list of substrings
+        if name in ("gemm_fwd_nt", "gemm_dx_nn"):                   # (their large products run as the one weight-planes kernel)
+            pats = pats + PMC_MAP["gemm_weight_planes"]
         if any(all(sub in k for sub in alt) for alt in pats):
             tot += v["hbm_bytes_per_launch"] * v["launches"]
             n += v["launches"]
     return tot / n if n else None
+
+
+def mfma_busy(name, dtype="f32"):
+    """Share of the matrix pipe's cycles the class's kernels kept it busy (SQ_VALU_MFMA_BUSY_CYCLES over
+    GRBM_GUI_ACTIVE x SIMDs, one rocprofv3 --pmc pass of the serial step: tools/pmc_mfma_summary.py), or None."""
+    path = os.path.join(ROOT, "profiles", f"{ROUND}_pmc_mfma_busy{'' if dtype == 'f32' else '_' + dtype}.json")
+    if path not in _PMC:
+        _PMC[path] = json.load(open(path)) if os.path.exists(path) else {}
+    data = _PMC[path]
+    names = [name] + (["gemm_weight_planes"] if name in ("gemm_fwd_nt", "gemm_dx_nn") else [])
+    busy = cyc = 0.0
+    for nm in names:
+        if nm not in PMC_MAP:
+            continue
+        pats = PMC_MAP[nm]
+        pats = pats if isinstance(pats[0], list) else [pats]
+        for k, v in data.items():
+            if k != "_meta" and any(all(sub in k for sub in alt) for alt in pats):
+                busy += v["mfma_busy_cycles"]
+                cyc += v["simd_cycles"]
+    return busy / cyc if cyc else None
 
 
 def parse():
@@ -463,8 +493,9 @@ def main():
     # committed PMC passes measured per launch
     data_dependent = ("table_adam_update", "table_adam_catchup", "nce_table_grad", "seg_reduce_rows")
     # the grouped feat_encoder kernels compute in fp32 in either mode; the dense GEMM classes follow --dtype
-    f32_kind = "f32x3"
-    mfma_peak = lambda name: MFMA_PEAK_TFLOPS[f32_kind if ("grouped" in name or args.dtype == "f32") else args.dtype]
+    from mapx import ops as _ops
+    f32_kind = "f32h2" if _ops.H2 else "f32x3"          # the dense classes; the grouped encoder kernels: six products
+    mfma_peak = lambda name: MFMA_PEAK_TFLOPS["f32x3" if "grouped" in name else (f32_kind if args.dtype == "f32" else args.dtype)]
     gemm_flops = 0.0
     for name, s in ksum.items():
         per_launch = s["work"] / s["launches"]
@@ -476,11 +507,17 @@ def main():
             gemm_flops += s["work"] / ksteps
             kernels[name] = dict(bound="mfma", achieved=rate / 1e12, peak=mfma_peak(name), unit="TFLOP/s",
                                  frac=rate / 1e12 / mfma_peak(name))
-            if mfma_peak(name) == MFMA_PEAK_TFLOPS["f32x3"]:
-                # algorithmic fp32 flop/s; `peak` = bf16 dense peak / 6 MFMAs per product; for comparison the
-                # same rate against the fp32 MFMA instruction's own peak (what gemm.hip's kernels are bound by)
-                kernels[name].update(peak_is="bf16 dense MFMA peak / 6 (three-piece bf16 split, six MFMAs per product)",
+            if mfma_peak(name) in (MFMA_PEAK_TFLOPS["f32x3"], MFMA_PEAK_TFLOPS["f32h2"]):
+                # algorithmic fp32 flop/s; `peak` = the 16-bit dense MFMA peak / MFMAs per product; for comparison the
+                # same rate against the fp32 MFMA instruction's own peak
+                six = mfma_peak(name) == MFMA_PEAK_TFLOPS["f32x3"]
+                kernels[name].update(peak_is="bf16 dense MFMA peak / 6 (three-piece bf16 split, six MFMAs per product)" if six else
+                                     "fp16 dense MFMA peak / 3 (operands scaled by their magnitude records and cut into two "
+                                     "fp16 pieces, three MFMAs per product)",
                                      frac_of_f32_mfma_peak=rate / 1e12 / MFMA_PEAK_TFLOPS["f32"])
+            mb = mfma_busy(name, args.dtype)
+            if mb is not None:
+                kernels[name]["mfma_busy"] = mb
         else:
             kernels[name] = dict(bound="hbm", achieved=rate / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                                  frac=rate / 1e9 / HBM_PEAK_GBS)
@@ -490,7 +527,7 @@ def main():
                              bytes_from="pmc" if measured else "model")
     dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
     roofline = dict(kernel=dominant, **{k: kernels[dominant][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic",
-                                                                         "peak_is", "frac_of_f32_mfma_peak")
+                                                                         "peak_is", "frac_of_f32_mfma_peak", "mfma_busy")
                                         if k in kernels[dominant]})
     hbm_name = "nce_fwd"
     out = {
@@ -503,7 +540,10 @@ def main():
                                f"V={cfg.input_size}, E=16, H=1000x3, cross x3, P=32, K=25, mask_ratio 0.3"
                                + (", bf16 GEMM operands / activations over fp32 master weights, tables and optimizer"
                                   if args.dtype == "bf16" else
-                                  ", fp32 GEMMs as six bf16 MFMAs per product (operands cut into three bf16 pieces, fp32 accumulation)"),
+                                  (", fp32 GEMMs as three fp16 MFMAs per product (operands scaled by per-tensor magnitude records "
+                                   "and cut into two fp16 pieces, fp32 accumulation; weights cut once per optimizer step)"
+                                   if _ops.H2 else
+                                   ", fp32 GEMMs as six bf16 MFMAs per product (operands cut into three bf16 pieces, fp32 accumulation)")),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "launch": ("eager" if not tr.use_graph else
                               "hipGraph replay of mask + forward + backward; pack and merge + optimizer replayed per message size, RCCL calls eager"

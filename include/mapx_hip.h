@@ -438,7 +438,7 @@ int mapx_dynamic_mask_mfp(const int64_t* ids, int64_t B, int F, int L,
  * front of every step).  Same outputs as mapx_dynamic_mask_mfp(split_ids[sel], ...).
  * sel_cursor_dev_opt (device int64, may be NULL): the batch is sel[*cursor .. *cursor + B) — `sel` is then a
  * whole epoch's permutation and a captured step walks it by itself (the caller advances the cursor). */
-int mapx_dynamic_mask_mfp_rows(const int64_t* split_ids, int64_t N, const int64_t* sel,
+int mapx_dynamic_mask_mfp_rows(const int64_t* split_ids, int64_t N, const int64_t* sel, int64_t sel_len,
                                const int64_t* sel_cursor_dev_opt, int64_t B, int F, int L,
                                const int64_t* masked_index_in, uint64_t seed, uint64_t offset,
                                const int32_t* offset_dev, int64_t* ids_out, int64_t* labels,
@@ -448,7 +448,7 @@ int mapx_dynamic_mask_mfp_rows(const int64_t* split_ids, int64_t N, const int64_
  * 122-129, 431-438 — so that a captured step walks an epoch's permutation by itself (mapx_step_advance moves the
  * cursor).  Labels: F = 1; out_f32_opt (then `out` may be NULL): the values as fp32 — the finetune step's
  * labels.float() (models.py:91) without a launch of its own.  Row numbers outside [0, N) are clamped. */
-int mapx_take_rows_i64(const int64_t* src, int64_t N, int F, const int64_t* sel,
+int mapx_take_rows_i64(const int64_t* src, int64_t N, int F, const int64_t* sel, int64_t sel_len,
                        const int64_t* sel_cursor_dev_opt, int64_t B, int64_t* out, float* out_f32_opt,
                        hipStream_t stream);
 /* trainer.py:233-262 (RFD).  mode = RFD_replace: 0 Unigram, 1 Uniform (idx_low/idx_high [F]),

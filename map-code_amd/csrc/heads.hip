@@ -69,17 +69,21 @@ __global__ void __launch_bounds__(256) mask_mfp_kernel(const int64_t* __restrict
                                                        int64_t* __restrict__ mi_out,
                                                        int32_t* __restrict__ keys_out,
                                                        const int64_t* __restrict__ sel,
-                                                       const int64_t* __restrict__ sel_cursor, int64_t nrows) {
+                                                       const int64_t* __restrict__ sel_cursor, int64_t nrows,
+                                                       int64_t sel_len) {
   // sel (optional): batch row b is row sel[b] of `ids` — the batch is cut out of the HBM-resident
   // split here instead of by two index kernels and two copies in front of every step
   if (offset_dev) offset += (uint64_t)(uint32_t)*offset_dev;   // graph-replay safe stream offset
   // sel_cursor (optional): `sel` is a whole epoch's permutation and the batch starts at *sel_cursor — a
   // captured step then walks the epoch by itself, with no copy of row numbers in front of each replay
-  if (sel && sel_cursor) sel += *sel_cursor;
-  // (row numbers outside the split — a cursor walked past its permutation, a corrupt selection — are clamped:
-  // the caller checks its cursor on the host, GraphedStep.__call__; a stray row must not become a page fault)
+  const int64_t c0 = (sel && sel_cursor) ? *sel_cursor : 0;
+  // (positions outside the selection and row numbers outside the split — a device cursor that walked past its
+  // permutation or diverged from the host's bookkeeping, a corrupt selection — are clamped: the caller checks its
+  // cursor on the host, GraphedStep.__call__, but a stray index must not become a page fault)
   auto row_of = [&](int64_t b) {
-    const int64_t r = sel[b];
+    int64_t i = c0 + b;
+    i = i < 0 ? 0 : (i < sel_len ? i : sel_len - 1);
+    const int64_t r = sel[i];
     return r < 0 ? (int64_t)0 : (r < nrows ? r : nrows - 1);
   };
   for (int64_t b0 = (int64_t)blockIdx.x * kMaskRows; b0 < B; b0 += (int64_t)gridDim.x * kMaskRows) {
@@ -217,22 +221,22 @@ extern "C" int mapx_dynamic_mask_mfp(const int64_t* ids, int64_t B, int F, int L
   if (B == 0) return MAPX_OK;
   hipLaunchKernelGGL(mask_mfp_kernel, dim3(grid_for(B, kMaskRows)), dim3(256), 0, stream, ids, B, F, L,
                      masked_index_in, seed, offset, offset_dev, ids_out, labels, masked_index_out, keys_out_opt,
-                     (const int64_t*)nullptr, (const int64_t*)nullptr, (int64_t)0);
+                     (const int64_t*)nullptr, (const int64_t*)nullptr, (int64_t)0, (int64_t)0);
   return check_launch("dynamic_mask_mfp");
 }
 
-extern "C" int mapx_dynamic_mask_mfp_rows(const int64_t* split_ids, int64_t N, const int64_t* sel,
+extern "C" int mapx_dynamic_mask_mfp_rows(const int64_t* split_ids, int64_t N, const int64_t* sel, int64_t sel_len,
                                           const int64_t* sel_cursor_dev_opt, int64_t B, int F,
                                           int L, const int64_t* masked_index_in, uint64_t seed, uint64_t offset,
                                           const int32_t* offset_dev, int64_t* ids_out, int64_t* labels,
                                           int64_t* masked_index_out, int32_t* keys_out_opt, hipStream_t stream) {
   using namespace mapx;
-  MAPX_REQUIRE(split_ids && sel && ids_out && labels && B >= 0 && N > 0 && F > 0 && L >= 0,
+  MAPX_REQUIRE(split_ids && sel && ids_out && labels && B >= 0 && N > 0 && F > 0 && L >= 0 && sel_len >= 1,
                "dynamic_mask_mfp_rows: bad arguments");
   if (B == 0) return MAPX_OK;
   hipLaunchKernelGGL(mask_mfp_kernel, dim3(grid_for(B, kMaskRows)), dim3(256), 0, stream, split_ids, B, F, L,
                      masked_index_in, seed, offset, offset_dev, ids_out, labels, masked_index_out, keys_out_opt, sel,
-                     sel_cursor_dev_opt, N);
+                     sel_cursor_dev_opt, N, sel_len);
   return check_launch("dynamic_mask_mfp_rows");
 }
 
@@ -240,7 +244,7 @@ namespace mapx {
 // out[b, :] = src[sel[cursor + b], :] — the batch of an RFD / finetune step cut from the resident split inside the
 // step (the MFP mask kernel reads its rows through `sel` itself).  One thread per element.
 __global__ void __launch_bounds__(256) take_rows_i64_kernel(const int64_t* __restrict__ src, int64_t N, int F,
-                                                            const int64_t* __restrict__ sel,
+                                                            const int64_t* __restrict__ sel, int64_t sel_len,
                                                             const int64_t* __restrict__ cursor, int64_t B,
                                                             int64_t* __restrict__ out, float* __restrict__ out_f32) {
   const int64_t c0 = cursor ? *cursor : 0;
@@ -248,8 +252,10 @@ __global__ void __launch_bounds__(256) take_rows_i64_kernel(const int64_t* __res
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t b = e / F;
-    int64_t r = sel[c0 + b];
-    r = r < 0 ? 0 : (r >= N ? N - 1 : r);           // (caller-checked; a wrong cursor must not read out of bounds)
+    int64_t i = c0 + b;                             // (caller-checked; a wrong cursor must not read out of bounds:
+    i = i < 0 ? 0 : (i >= sel_len ? sel_len - 1 : i);   //  neither past the selection nor, below, past the split)
+    int64_t r = sel[i];
+    r = r < 0 ? 0 : (r >= N ? N - 1 : r);
     const int64_t v = src[r * F + (e - b * F)];
     if (out_f32) out_f32[e] = (float)v;
     else out[e] = v;
@@ -257,13 +263,13 @@ __global__ void __launch_bounds__(256) take_rows_i64_kernel(const int64_t* __res
 }
 }  // namespace mapx
 
-extern "C" int mapx_take_rows_i64(const int64_t* src, int64_t N, int F, const int64_t* sel,
+extern "C" int mapx_take_rows_i64(const int64_t* src, int64_t N, int F, const int64_t* sel, int64_t sel_len,
                                   const int64_t* sel_cursor_dev_opt, int64_t B, int64_t* out, float* out_f32_opt,
                                   hipStream_t stream) {
   using namespace mapx;
-  MAPX_REQUIRE(src && sel && (out || out_f32_opt) && N > 0 && F > 0 && B >= 0, "take_rows_i64: bad arguments");
+  MAPX_REQUIRE(src && sel && (out || out_f32_opt) && N > 0 && F > 0 && B >= 0 && sel_len >= 1, "take_rows_i64: bad arguments");
   if (B == 0) return MAPX_OK;
-  hipLaunchKernelGGL(take_rows_i64_kernel, dim3(grid_for(B * F, 256)), dim3(256), 0, stream, src, N, F, sel,
+  hipLaunchKernelGGL(take_rows_i64_kernel, dim3(grid_for(B * F, 256)), dim3(256), 0, stream, src, N, F, sel, sel_len,
                      sel_cursor_dev_opt, B, out, out_f32_opt);
   return check_launch("take_rows_i64");
 }

@@ -104,12 +104,12 @@ SIGNATURES = {
     "mapx_eval_metrics_workspace_bytes": (_sz, [_i64]),
     "mapx_eval_metrics": (_i, [_p, _p, _i64, _p, _p, _sz, _p]),
     "mapx_dynamic_mask_mfp": (_i, [_p, _i64, _i, _i, _p, _u64, _u64, _p, _p, _p, _p, _p, _p]),
-    "mapx_dynamic_mask_mfp_rows": (_i, [_p, _i64, _p, _p, _i64, _i, _i, _p, _u64, _u64, _p, _p, _p, _p, _p, _p]),
+    "mapx_dynamic_mask_mfp_rows": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _i, _p, _u64, _u64, _p, _p, _p, _p, _p, _p]),
     "mapx_dynamic_mask_rfd": (_i, [_p, _i64, _i, _i, _p, _p, _p, _i64, _i, _p, _p, _i64, _u64, _u64, _p, _p, _p,
                                   _p, _p]),
     "mapx_adamw_dense": (_i, [_p, _p, _p, _p, _i64, _p, _i, _p, _d, _d, _d, _d, _p, _i, _p, _p]),
     "mapx_step_advance": (_i, [_p, _p, _i64, _p]),
-    "mapx_take_rows_i64": (_i, [_p, _i64, _i, _p, _p, _i64, _p, _p, _p]),
+    "mapx_take_rows_i64": (_i, [_p, _i64, _i, _p, _i64, _p, _i64, _p, _p, _p]),
     "mapx_act_fwd": (_i, [_i, _p, _i64, _i, _p, _i64, _p]),
     "mapx_act_bwd": (_i, [_i, _p, _i64, _p, _i64, _i, _p, _p]),
     "mapx_vocab_table_init": (_i, [_p, _p, _p, _i64, _p]),

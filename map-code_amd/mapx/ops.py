@@ -1664,7 +1664,7 @@ def dynamic_mask_mfp(ids, L, masked_index=None, seed=0, offset=0, offset_dev=Non
         mi_out = torch.empty(B, L, dtype=torch.int64, device=ids.device)
         mi_in = masked_index.contiguous() if masked_index is not None else None
         keys = torch.empty(B * F, dtype=torch.int32, device=ids.device)
-        check(lib.mapx_dynamic_mask_mfp_rows(ptr(ids), ids.shape[0], ptr(sel), ptr(sel_cursor), B, F, L, ptr(mi_in), seed, offset,
+        check(lib.mapx_dynamic_mask_mfp_rows(ptr(ids), ids.shape[0], ptr(sel), sel.numel(), ptr(sel_cursor), B, F, L, ptr(mi_in), seed, offset,
                                              ptr(offset_dev), ptr(out), ptr(labels), ptr(mi_out), ptr(keys), stream()))
         _keys_of[0], _keys_of[1] = out, keys
         return out, labels, mi_out
@@ -1781,7 +1781,7 @@ def take_rows(src, sel, cursor=None, batch=None, as_f32=False):
                       device=src.device)
     if B == 0:
         return out
-    check(lib.mapx_take_rows_i64(ptr(src), src.shape[0], F, ptr(sel), ptr(cursor), B, None if as_f32 else ptr(out),
+    check(lib.mapx_take_rows_i64(ptr(src), src.shape[0], F, ptr(sel), sel.numel(), ptr(cursor), B, None if as_f32 else ptr(out),
                                  ptr(out) if as_f32 else None, stream()))
     return out
 

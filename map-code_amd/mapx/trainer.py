@@ -258,6 +258,12 @@ class GraphedBackward:
         try:
             with _capture(self.graph):
                 self.out = fwd_bwd_fn(self.X, self.Y)
+                # task queues a backward node may have left for a later node (the encoder's dW / db, a head's dW, the
+                # NCE table's gradient): run HERE, inside the graph — left to optimizer.step() they would run once,
+                # eagerly, and every replay would miss that gradient
+                ops.run_main_tasks()
+                ops.run_side_tasks()
+                ops.run_late_tasks()
                 # deferred partial sums (bias gradients) belong to this graph: the list that names them
                 # exists only while the capture runs, a replay would leave them unsummed for the tail
                 ops.flush_deferred()

@@ -21,6 +21,9 @@ RESERVED = ("<pad>", "<cls>", "<sep>", "<mask>", "<unused0>", "<unused1>", "<unu
             "<unused5>")                                  # proc_avazu.py:213-220: ids 0..9
 
 
+_HEX = __import__("re").compile(r"[0-9a-f]*")
+
+
 def encode_column(values):
     """A raw column -> (int64 codes, decode) with decode(code) = the value as the reference's f-string prints
     it (proc_avazu.py:249: f'{name}-{k}').  Integer columns are their own codes; columns of hexadecimal
@@ -30,15 +33,12 @@ def encode_column(values):
         return a.astype(np.int64), (lambda c: str(int(c)))
     if a.dtype.kind in "USO":
         strs = [str(x) for x in a.tolist()]
-        try:
-            if all(0 < len(s) <= 15 and s == s.lower() for s in strs[:64]):
-                codes = np.array([int(s, 16) for s in strs], dtype=np.int64)
-                width = {len(s) for s in strs}
-                if len(width) == 1:                   # fixed-width lower-case hex: code <-> string is a bijection
-                    w = width.pop()
-                    return codes, (lambda c, w=w: format(int(c), f"0{w}x"))
-        except ValueError:
-            pass
+        # fixed-width lower-case hexadecimal — EVERY string matches [0-9a-f]{w} (int(s, 16) alone also takes '1A',
+        # ' 1f', '1_0', '+1f', which would merge values the reference's Counter keeps apart): code <-> string is a bijection
+        w = len(strs[0]) if strs else 0
+        if 0 < w <= 15 and all(len(s) == w for s in strs) and _HEX.fullmatch("".join(strs)) is not None:
+            codes = np.array([int(s, 16) for s in strs], dtype=np.int64)
+            return codes, (lambda c, w=w: format(int(c), f"0{w}x"))
         first = {}
         codes = np.fromiter((first.setdefault(s, len(first)) for s in strs), dtype=np.int64, count=len(strs))
         names = list(first)

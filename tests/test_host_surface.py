@@ -226,3 +226,21 @@ def test_optimizer_state_slot_size_is_inferred_when_the_key_is_missing():
     sd["groups"][0]["v"] = sd["groups"][0]["v"][:-1]
     with pytest.raises(ValueError):
         opt.load_state_dict(sd)
+
+
+def test_vocab_hex_path_needs_every_string_to_be_fixed_width_lower_case_hex():
+    """encode_column's hexadecimal fast path (exact integer codes for the 8-digit hashes of Avazu / Criteo)
+    looked at the first 64 strings only; '1A' vs '1a', ' 1f' vs '01f' or '1_0' all parse with int(s, 16) and would have
+    merged into one vocabulary entry where the reference's Counter (proc_avazu.py:237-251, keyed by the raw string)
+    keeps them apart.  Every string must match [0-9a-f]{w}; anything else is numbered by first occurrence."""
+    import numpy as np
+    import pytest
+    try:
+        from mapx.vocab import encode_column
+    except ImportError as e:
+        pytest.skip(str(e))
+    codes, dec = encode_column(np.array(["0a1f", "ffff", "0a1f"] + ["00ff"] * 70))
+    assert codes[0] == codes[2] == 0x0a1f and codes[1] == 0xffff and dec(codes[0]) == "0a1f"
+    late = ["0a1f"] * 70 + ["0A1F", " a1f", "1_0f", "+a1f"]            # the odd ones come after the first 64
+    codes, dec = encode_column(np.array(late))
+    assert len(set(codes.tolist())) == 5 and [dec(c) for c in codes[-4:]] == late[-4:]

@@ -5,7 +5,7 @@
 # one-rank RCCL rehearsal of the data-parallel step and of the RFD / finetune steps (tools/step_bench.py).
 # Copy gpurun_out/prof_rNN/out/* into profiles/.
 set -e
-R=${1:-r03}
+R=${1:-r04}
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
 O=gpurun_out/prof_$R
@@ -18,6 +18,8 @@ for DT in f32 bf16; do
   P="python3 bench.py --steps 10 --warmup 2 --preroll 60 --no-cpu-baseline --dtype $DT"
   MAPX_GRAPH=0 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch$S -o f -- $P > $O/fetch$S.log 2>&1
   MAPX_GRAPH=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write$S -o w -- $P > $O/write$S.log 2>&1
+  MAPX_GRAPH=0 MAPX_SERIAL=1 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/mfma$S -o m -- $P > $O/mfma$S.log 2>&1
+  python3 tools/pmc_mfma_summary.py $(find $O/mfma$S -name '*counter_collection.csv' | head -1) $O/out/${R}_pmc_mfma_busy$S.json > $O/out/mfma$S.txt
   cp $(find $O/graph$S -name '*kernel_stats.csv' | head -1) $O/out/${R}_bench_kernel_stats$S.csv
   cp $(find $O/serial$S -name '*kernel_stats.csv' | head -1) $O/out/${R}_bench_kernel_stats_serial$S.csv
   python3 tools/pmc_summary.py $(find $O/fetch$S -name '*counter_collection.csv' | head -1) \
