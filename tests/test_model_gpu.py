@@ -68,8 +68,19 @@ def _check_grads(z, model, pattern=None, tag=None):
         np.testing.assert_allclose(g.cpu().numpy(), ref[n], rtol=2e-5, atol=2e-5 * scale + 1e-12, err_msg=n)
 
 
+@pytest.fixture(params=["x3", "h2"])
+def arith(request, monkeypatch):
+    """The golden and full-batch tests run twice: a model nobody optimizes has no magnitude records, so its products
+    take the six-product bf16 arithmetic ("x3"); with ops.AUTO_AMAX every product gets the records — and weight
+    planes — a training step's kernels leave, and takes the two-piece fp16 arithmetic the Trainer's steps run on
+    ("h2": csrc/gemm_h2.hip, gemm_h2w.hip).  Same fixtures, same tolerances."""
+    from mapx import ops
+    monkeypatch.setattr(ops, "AUTO_AMAX", request.param == "h2")
+    return "" if request.param == "x3" else "/h2"
+
+
 @pytest.mark.parametrize("case", CASES)
-def test_mfp_golden(case):
+def test_mfp_golden(case, arith):
     cfg, z, inp, params = load_case(case, "MFP")
     model = build_model(cfg, "MFP", params, inp["feat_count"])
     from util import hook_relu_pattern
@@ -91,7 +102,7 @@ def test_mfp_golden(case):
     np.testing.assert_allclose(float(loss.detach()), float(z["out/loss"]), rtol=1e-5)
     assert count == int(z["out/count"]) and int(acc) == int(z["out/total_acc"])
     loss.backward()
-    _check_grads(z, model, (masks, "MFP", cfg, params, inp), tag=f"DCNv2/MFP/{case}")
+    _check_grads(z, model, (masks, "MFP", cfg, params, inp), tag=f"DCNv2/MFP/{case}{arith}")
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -112,7 +123,7 @@ def test_mfp_logits_golden(case):
 
 
 @pytest.mark.parametrize("case", CASES)
-def test_rfd_golden(case):
+def test_rfd_golden(case, arith):
     cfg, z, inp, params = load_case(case, "RFD")
     model = build_model(cfg, "RFD", params, None)
     from util import hook_relu_pattern
@@ -130,11 +141,11 @@ def test_rfd_golden(case):
     np.testing.assert_allclose(float(acc), float(z["out/acc"]), rtol=1e-6)
     np.testing.assert_allclose(float(pos), float(z["out/pos_ratio"]), rtol=1e-6)
     loss.backward()
-    _check_grads(z, model, (masks, "RFD", cfg, params, inp), tag=f"DCNv2/RFD/{case}")
+    _check_grads(z, model, (masks, "RFD", cfg, params, inp), tag=f"DCNv2/RFD/{case}{arith}")
 
 
 @pytest.mark.parametrize("case", CASES)
-def test_ctr_golden(case):
+def test_ctr_golden(case, arith):
     cfg, z, inp, params = load_case(case, "CTR")
     model = build_model(cfg, "CTR", params, None)
     from util import hook_relu_pattern
@@ -151,7 +162,7 @@ def test_ctr_golden(case):
     np.testing.assert_allclose(float(loss.detach()), float(z["out/loss"]), rtol=1e-5)
     np.testing.assert_allclose(logits.detach().cpu().numpy(), z["out/logits"], rtol=1e-5, atol=1e-5)
     loss.backward()
-    _check_grads(z, model, (dict(masks), "CTR", cfg, params, inp), tag=f"DCNv2/CTR/{case}")
+    _check_grads(z, model, (dict(masks), "CTR", cfg, params, inp), tag=f"DCNv2/CTR/{case}{arith}")
     (logits_only,) = model(input_ids=ids)
     np.testing.assert_allclose(logits_only.detach().cpu().numpy(), z["out/logits"], rtol=1e-5, atol=1e-5)
 
@@ -195,7 +206,7 @@ def _oracle_pass(mode, P, model_inputs, cfg, cnt, dtype, relu_masks=None, preact
 
 @pytest.mark.parametrize("mode,B,F", [("MFP", 4096, 23), ("RFD", 4096, 23), ("CTR", 4096, 23), ("MFP", 777, 39),
                                       ("RFD", 777, 39)])
-def test_full_batch_vs_fp64_oracle(mode, B, F):
+def test_full_batch_vs_fp64_oracle(mode, B, F, arith):
     """BASELINE configs[1], [3], [4] at their real batch size (4096 x 23, K = 25, P = 32, H = 1000):
     generated masks / negatives / replacements of the GPU step are fed to the oracle, which runs
     twice — in fp64 (the exact answer) and in fp32 (the reference's CPU arithmetic).  Loss, logits
