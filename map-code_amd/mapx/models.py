@@ -30,8 +30,9 @@ JOINT_PLAN = os.environ.get("MAPX_JOINT_PLAN", "auto")
 # the joint plan in forward waits for the deep tower's GEMMs to be on their way (see above)
 # the grouped encoder's slot layout ahead of the deep tower (main stream) or on the cross tower's stream.  Round 2: main
 # won (0.869 / 0.873 vs 0.876 / 0.882 ms); round 3, after the backward pass changed (tools/flag_sweep.py): the tower
-# stream wins, 0.8058 vs 0.8223 ms; round 4, with the two-piece fp16 GEMMs (shorter towers): main again, 0.7175 vs 0.7307
-LAYOUT_ON_MAIN = os.environ.get("MAPX_LAYOUT_ON_MAIN", "1") == "1"
+# stream wins, 0.8058 vs 0.8223 ms; round 4: with the two-piece fp16 GEMMs cutting both operands main won (0.7175 vs
+# 0.7307), with the weights' planes (gemm_h2w.hip) the tower stream again (0.7120 vs 0.7175) — kept there
+LAYOUT_ON_MAIN = os.environ.get("MAPX_LAYOUT_ON_MAIN", "0") == "1"
 PLAN_AFTER_DNN = os.environ.get("MAPX_PLAN_AFTER_DNN", "1")       # 1 | tower | 0: what the joint plan goes behind
 # RFD / finetune steps: what the one table's sort goes behind: auto | main | tower | 0 (A/B switch)
 PLAN_AFTER_TRUNK = os.environ.get("MAPX_PLAN_AFTER_TRUNK", "auto")

@@ -148,8 +148,9 @@ class MapxOptimizer:
         # Round 3 (tools/flag_sweep.py, one box each): in fp32, with the table gradients on the tower stream's late
         # tasks, the early row updates LOSE (0.8058 vs 0.7975 ms per step: the updates run in step(), beside the
         # optimizer's dense half); in the bf16 mode, whose GEMM chains are half as long, they WIN (0.5931 vs 0.6318).
-        # Round 4 (two-piece fp16 GEMMs: the fp32 chains are a third shorter): early wins in fp32 as well, 0.7075 vs 0.7175.
-        early_default = "1"
+        # Round 4, two sweeps: with gemm_h2.hip alone early won in fp32 too (0.7075 vs 0.7175), with the weights' planes
+        # (gemm_h2w.hip, the shipped default) it loses again (0.7315 vs 0.7120).
+        early_default = "1" if self.bf16 else "0"
         early = (os.environ.get("MAPX_EARLY_TABLE_UPDATE", early_default) == "1" and self.max_grad_norm <= 0
                  and not parallel.exchanging())
         for t in self.tables:
