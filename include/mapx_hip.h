@@ -202,8 +202,10 @@ int mapx_nce_fwd(const float* enc, int64_t B, int L, int F, int P, const int64_t
                  const int32_t* idx, int K, const float* emb, const float* bias,
                  const float* logq, int64_t V, float* h_out, float* dlogit, float* dh,
                  float* logits_opt, float* loss_out, int32_t* acc_out, void* ws, size_t ws_bytes,
-                 const int32_t* hpos_opt, float* dh_slots_opt, int* partials_left_opt, hipStream_t stream);
-/* partials_left_opt != NULL: the loss / accuracy totals are NOT formed by this call (loss_out / acc_out stay
+                 const int32_t* hpos_opt, float* dh_slots_opt, int* partials_left_opt, void* amax_dh_opt,
+                 hipStream_t stream);
+/* amax_dh_opt: magnitude record of dh (and dh_slots: the same values), for mapx_enc_grouped_dw.
+ * partials_left_opt != NULL: the loss / accuracy totals are NOT formed by this call (loss_out / acc_out stay
  * unwritten); *partials_left_opt receives the number of per-block partials left in `ws`, which the caller keeps alive
  * and hands to the mapx_nce_scatter_dh that follows (a training step: trainer.py:317-322 runs loss.backward() right
  * behind the forward pass) — one launch less between the loss and the head's backward. */
@@ -380,16 +382,18 @@ int mapx_colsum_chunks(void);
  *   (the layout's [F+1] array, or NULL) only orders the tiles over the workgroups — tiles that hold the
  *   same batch rows go to the same XCD's L2 — and never changes a result.
  * mapx_enc_grouped_dw:  dW[f*32 + p, :] = sum_{slot in group f} dh_slots[slot, p] * final[rowmap[slot], :]
- *   (all F*32 rows written; dh_slots must be zero in unused slots), times *gscale_opt if given. */
+ *   (all F*32 rows written; dh_slots must be zero in unused slots), times *gscale_opt if given.
+ * scale_opt (both): amax_a / amax_b = the magnitude records of the first / second operand (fwd: final_act, W; dw:
+ *   dh_slots, final_act); both given: the two-piece fp16 arithmetic (csrc/gemm_grouped_h2.hip), else six products. */
 int mapx_enc_group_layout(const int64_t* masked_index, int T, int L, int F, int cap_slots, int32_t* rowmap,
                           int32_t* hpos, int32_t* tile_group, int32_t* group_start, hipStream_t stream);
 int mapx_enc_grouped_fwd(const float* final_act, int64_t ld_final, int nrows, int K, const float* W,
                          int64_t ldw, const float* bias, const int32_t* rowmap,
                          const int32_t* tile_group, const int32_t* group_start_opt, int F, int cap_slots,
-                         float* h_slots, float* zero_slots_opt, hipStream_t stream);
+                         float* h_slots, float* zero_slots_opt, const mapx_gemm_scale* scale_opt, hipStream_t stream);
 int mapx_enc_grouped_dw(const float* dh_slots, const float* final_act, int64_t ld_final, int nrows, int N,
                         const int32_t* rowmap, const int32_t* group_start, int F, const float* gscale_opt,
-                        float* dW, int64_t ldw, hipStream_t stream);
+                        float* dW, int64_t ldw, const mapx_gemm_scale* scale_opt, hipStream_t stream);
 /* out[n] = sum_m x[m*ld + n]  (bias gradients), deterministic two-stage. */
 size_t mapx_colsum_workspace_bytes(int N);
 int mapx_colsum(const float* x, int64_t ld, int M, int N, float* out, void* ws, size_t ws_bytes,

@@ -529,7 +529,8 @@ extern "C" int mapx_enc_group_layout(const int64_t* masked_index, int T, int L, 
 extern "C" int mapx_enc_grouped_fwd(const float* final_act, int64_t ld_final, int nrows, int K, const float* W,
                                     int64_t ldw, const float* bias, const int32_t* rowmap,
                                     const int32_t* tile_group, const int32_t* group_start_opt, int F,
-                                    int cap_slots, float* h_slots, float* zero_slots_opt, hipStream_t stream) {
+                                    int cap_slots, float* h_slots, float* zero_slots_opt,
+                                    const mapx_gemm_scale* scale_opt, hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(final_act && W && bias && rowmap && tile_group && h_slots, "enc_grouped_fwd: null pointer");
   MAPX_REQUIRE(K % 4 == 0 && ld_final % 4 == 0 && ldw % 4 == 0 && cap_slots % 128 == 0,
@@ -541,13 +542,20 @@ extern "C" int mapx_enc_grouped_fwd(const float* final_act, int64_t ld_final, in
   g.zero_out = zero_slots_opt;
   MAPX_REQUIRE(K % 8 == 0 && ld_final % 4 == 0 && ldw % 4 == 0 && (uintptr_t)final_act % 16 == 0 && (uintptr_t)W % 16 == 0,
                "enc_grouped_fwd: K %% 8 != 0 or operands not 16-byte aligned (use the dense encoder GEMM)");
-  MAPX_HIP(enc_grouped_fwd_x3_launch(g, cap_slots, stream));
+  static const bool h2 = [] { const char* e = getenv("MAPX_GEMM_H2"); return !e || atoi(e) != 0; }();
+  if (h2 && scale_opt && scale_opt->amax_a && scale_opt->amax_b) {      // both records: the two-piece fp16 arithmetic
+    g.amax_a = scale_opt->amax_a; g.amax_b = scale_opt->amax_b;
+    MAPX_HIP(enc_grouped_fwd_h2_launch(g, cap_slots, stream));
+  } else {
+    MAPX_HIP(enc_grouped_fwd_x3_launch(g, cap_slots, stream));
+  }
   return check_launch("enc_grouped_fwd");
 }
 
 extern "C" int mapx_enc_grouped_dw(const float* dh_slots, const float* final_act, int64_t ld_final, int nrows,
                                    int N, const int32_t* rowmap, const int32_t* group_start, int F,
-                                   const float* gscale_opt, float* dW, int64_t ldw, hipStream_t stream) {
+                                   const float* gscale_opt, float* dW, int64_t ldw, const mapx_gemm_scale* scale_opt,
+                                   hipStream_t stream) {
   using namespace mapx;
   MAPX_REQUIRE(dh_slots && final_act && rowmap && group_start && dW, "enc_grouped_dw: null pointer");
   MAPX_REQUIRE(N % 4 == 0 && ld_final % 4 == 0 && F >= 1, "enc_grouped_dw: N, ld %% 4 must be 0");
@@ -557,7 +565,13 @@ extern "C" int mapx_enc_grouped_dw(const float* dh_slots, const float* final_act
   g.gscale = gscale_opt;
   MAPX_REQUIRE(N % 8 == 0 && (uintptr_t)final_act % 16 == 0 && (uintptr_t)dh_slots % 16 == 0,
                "enc_grouped_dw: N %% 8 != 0 or operands not 16-byte aligned (use the dense encoder GEMM)");
-  MAPX_HIP(enc_grouped_dw_x3_launch(g, F, stream));
+  static const bool h2 = [] { const char* e = getenv("MAPX_GEMM_H2"); return !e || atoi(e) != 0; }();
+  if (h2 && scale_opt && scale_opt->amax_a && scale_opt->amax_b) {
+    g.amax_a = scale_opt->amax_a; g.amax_b = scale_opt->amax_b;
+    MAPX_HIP(enc_grouped_dw_h2_launch(g, F, stream));
+  } else {
+    MAPX_HIP(enc_grouped_dw_x3_launch(g, F, stream));
+  }
   return check_launch("enc_grouped_dw");
 }
 

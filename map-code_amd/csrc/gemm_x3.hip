@@ -661,48 +661,6 @@ int gemm_f32x3_launch(int a_kc, int b_kc, int M, int N, int K, const float* A, i
   return check_launch("gemm_f32 (3 x bf16)");
 }
 
-// FWD: block -> 128-slot tile, XCD-aware (8 waves; every thread of the block gets the same answer, -1 = no tile).
-// Tiles sorted by (eighth of their group they lie in, field, index in the group): a group's slots are in
-// batch-row order, so equal eighths of different groups hold the same batch rows.  Block b takes sorted position
-// (b % 8) * per + b / 8 — a bijection on [0, 8 per) that covers the used tiles.  (Computed by the whole block at
-// once: wave x sums the tiles below key x over the fields, its lanes.)
-__device__ inline int grouped_fwd_tile(const GroupedArgs& a, int lane, int wave) {
-  constexpr int BM = 128;
-  int tile = blockIdx.x;
-  if (a.group_start) {
-    const int used = a.group_start[a.F] / BM, per = (used + 7) / 8;
-    if ((int)gridDim.x >= 8 * per && a.F <= 64) {
-      const int i = blockIdx.x / 8, pos = (blockIdx.x % 8) * per + i;
-      if (i >= per || pos >= used) return -1;
-      __shared__ int below[8];                     // tiles with key < x:  sum_f ceil(x nf / 8)
-      const int gs0 = lane < a.F ? a.group_start[lane] : 0, gs1 = lane < a.F ? a.group_start[lane + 1] : 0;
-      const int nf = (gs1 - gs0) / BM;
-      int v = (wave * nf + 7) >> 3;
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-      if (lane == 0) below[wave] = v;
-      __syncthreads();
-      int X = 0;
-#pragma unroll
-      for (int x = 1; x < 8; ++x)
-        if (below[x] <= pos) X = x;
-      const int q = pos - below[X];                // index among the tiles of key X, ordered by (field, j)
-      const int j0 = (X * nf + 7) >> 3, c = (((X + 1) * nf + 7) >> 3) - j0;
-      int incl = c;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int u = __shfl_up(incl, d);
-        if (lane >= d) incl += u;
-      }
-      const bool hit = q >= incl - c && q < incl;
-      const unsigned long long m = __ballot(hit);
-      if (m == 0) return -1;
-      tile = __shfl(gs0 / BM + j0 + (q - (incl - c)), __ffsll((long long)m) - 1);
-    }
-  }
-  return tile;
-}
-
 // ------------------------------------------------------------------------------------------
 // Grouped feat_encoder products (gemm.hip, "Grouped GEMMs": models.py:74-75) on the bf16 matrix cores.
 // Same slot layout, same two products, same outputs as gemm_grouped_kernel:

@@ -169,8 +169,10 @@ __global__ void __launch_bounds__(256) nce_fwd_p32_kernel(
     const float* __restrict__ bias, const float* __restrict__ logq, float lnV, float lnK,
     float invT, float* __restrict__ h_out, float* __restrict__ dlogit, float* __restrict__ dh,
     float* __restrict__ logits, float* __restrict__ loss_partial, int* __restrict__ acc_partial,
-    const int32_t* __restrict__ hpos, float* __restrict__ dh_slots) {
+    const int32_t* __restrict__ hpos, float* __restrict__ dh_slots, amax_rec* __restrict__ amax_dh,
+    const int32_t* __restrict__ epoch) {
   constexpr int LG = 8, P = 32, GPB = 256 / LG, MAXB = 4;   // up to 32 rows per target
+  uint32_t amx = 0;                                          // max |dh| (the grouped encoder's weight gradient reads it)
   const int lane = threadIdx.x & 63;
   const int sub = lane & 7, gbase = lane & ~7;
   const int gib = threadIdx.x / LG;
@@ -249,6 +251,7 @@ __global__ void __launch_bounds__(256) nce_fwd_p32_kernel(
     }
     *reinterpret_cast<float4*>(dh + t * P + 4 * sub) = dh4;
     if (dh_slots) *reinterpret_cast<float4*>(dh_slots + (int64_t)hpos[t] * P + 4 * sub) = dh4;
+    amx = amax4(amx, dh4.x, dh4.y, dh4.z, dh4.w);
     const float loss_t = group_sum<LG>(loss_l);
     float smax = smax_l;
 #pragma unroll
@@ -269,6 +272,7 @@ __global__ void __launch_bounds__(256) nce_fwd_p32_kernel(
     loss_partial[blockIdx.x] = l;
     acc_partial[blockIdx.x] = a;      // summed by the finalize kernel: no atomics, no zero-fill launch
   }
+  if (amax_dh) amax_publish_block(amax_dh, amx, epoch);
 }
 
 __global__ void nce_loss_finalize_kernel(const float* __restrict__ partial, const int32_t* __restrict__ acc_partial,
@@ -391,7 +395,7 @@ extern "C" int mapx_nce_fwd(const float* enc, int64_t B, int L, int F, int P,
                             float* h_out, float* dlogit, float* dh, float* logits_opt,
                             float* loss_out, int32_t* acc_out, void* ws, size_t ws_bytes,
                             const int32_t* hpos_opt, float* dh_slots_opt, int* partials_left_opt,
-                            hipStream_t stream) {
+                            void* amax_dh_opt, hipStream_t stream) {
   MAPX_REQUIRE(enc && masked_index && idx && emb && bias && logq && h_out && dlogit && dh &&
                    loss_out && acc_out && ws,
                "nce_fwd: null pointer");
@@ -429,7 +433,8 @@ extern "C" int mapx_nce_fwd(const float* enc, int64_t B, int L, int F, int P,
       if (K + 1 <= 32)
         hipLaunchKernelGGL(mapx::nce_fwd_p32_kernel, dim3(grid), dim3(256), 0, stream, enc, enc_stride,
                            masked_index, L, idx, T, K + 1, emb, bias, logq, lnV, lnK, invT, h_out, dlogit,
-                           dh, logits_opt, partial, acc_partial, hpos_opt, dh_slots_opt);
+                           dh, logits_opt, partial, acc_partial, hpos_opt, dh_slots_opt,
+                           static_cast<mapx::amax_rec*>(amax_dh_opt), mapx::amax_epoch_ptr());
       else
         MAPX_NCE(8);
       break;

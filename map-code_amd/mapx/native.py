@@ -51,7 +51,7 @@ SIGNATURES = {
     "mapx_nce_pack_idx": (_i, [_p, _p, _i64, _i, _i64, _p, _p, _p]),
     "mapx_nce_fwd_workspace_bytes": (_sz, []),
     "mapx_nce_fwd": (_i, [_p, _i64, _i, _i, _i, _p, _p, _i, _p, _p, _p, _i64, _p, _p, _p, _p, _p,
-                          _p, _p, _sz, _p, _p, _p, _p]),
+                          _p, _p, _sz, _p, _p, _p, _p, _p]),
     "mapx_nce_scatter_dh": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p]),
     "mapx_nce_table_grad_workspace_bytes": (_sz, [_i64, _i]),
     "mapx_nce_table_grad": (_i, [_i64, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _sz, _p, _p]),
@@ -90,8 +90,8 @@ SIGNATURES = {
     "mapx_skinny_join_bwd": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _i, _p, _i64, _p, _i64,
                                   _p, _i64, _p, _i64, _p, _p, _p, _p, _p]),
     "mapx_enc_group_layout": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
-    "mapx_enc_grouped_fwd": (_i, [_p, _i64, _i, _i, _p, _i64, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
-    "mapx_enc_grouped_dw": (_i, [_p, _p, _i64, _i, _i, _p, _p, _i, _p, _p, _i64, _p]),
+    "mapx_enc_grouped_fwd": (_i, [_p, _i64, _i, _i, _p, _i64, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p]),
+    "mapx_enc_grouped_dw": (_i, [_p, _p, _i64, _i, _i, _p, _p, _i, _p, _p, _i64, _p, _p]),
     "mapx_colsum_chunks": (_i, []),
     "mapx_colsum_workspace_bytes": (_sz, [_i]),
     "mapx_colsum": (_i, [_p, _i64, _i, _i, _p, _p, _sz, _p]),

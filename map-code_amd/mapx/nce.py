@@ -156,7 +156,7 @@ class _EncNceLoss(Function):
         ctx.crit, ctx.F, ctx.P, ctx.K, ctx.groups, ctx.join = crit, F, P, idx.shape[1] - 1, groups, join
         ctx.plan = crit.table.plan
         ctx.slots = (getattr(w_enc, "_mapx_grad", None), getattr(b_enc, "_mapx_grad", None))
-        ctx.amax = ops.amax_pack(final, w_enc)
+        ctx.amax = ops.amax_pack(final, w_enc, dh_slots)
         ctx.save_for_backward(final, w_enc, o["dlogit"], o["dh"], o["h"], masked_index, dh_slots)
         logits = o["logits"] if want_logits else torch.empty(0, device=final.device)
         ctx.mark_non_differentiable(o["acc"], logits)
@@ -167,7 +167,7 @@ class _EncNceLoss(Function):
     @staticmethod
     def backward(ctx, gl, _a, _l):
         final, w_enc, dlogit, dh, h, mi, dh_slots = ctx.saved_tensors
-        ops.amax_unpack((final, w_enc), ctx.amax)
+        ops.amax_unpack((final, w_enc, dh_slots), ctx.amax)
         sw, sb = ctx.slots
         gl = gl.contiguous().float()
         denc = ops.nce_scatter_dh(dh, mi, ctx.F, ctx.P, gscale=gl, totals=ctx.totals)          # dense [B, F*P]

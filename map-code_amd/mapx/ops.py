@@ -703,13 +703,16 @@ def nce_fwd(enc, masked_index, idx, emb, bias, logq, F, P, want_logits=False, hp
     # (partials that outlive this call get a buffer of their own, not the stream's shared scratch)
     ws = torch.empty(nws, dtype=torch.uint8, device=dev) if totals_later else scratch(nws, dev)
     left = native_int() if totals_later else None
+    rec = amax_record(dev) if (dh_slots is not None and P == 32 and K1 <= 32) else None     # (the p32 kernel writes it)
     # algorithmic bytes: per (target, sample) one table row + bias + log q + id
     with _timed("nce_fwd", T * K1 * (4.0 * P + 8 + 4)):
         check(lib.mapx_nce_fwd(ptr(enc), B, L, F, P, ptr(masked_index.contiguous()), ptr(idx), K1 - 1,
                                ptr(emb), ptr(bias), ptr(logq), emb.shape[0], ptr(out["h"]),
                                ptr(out["dlogit"]), ptr(out["dh"]), ptr(out["logits"]), ptr(out["loss"]),
                                ptr(out["acc"]), ptr(ws), ws.numel(), ptr(hpos), ptr(dh_slots),
-                               None if left is None else native_byref(left), stream()))
+                               None if left is None else native_byref(left), ptr(rec), stream()))
+    tag(dh_slots, rec)
+    tag(out["dh"], rec)
     out["totals"] = (ws, left.value, out["loss"], out["acc"]) if (left is not None and left.value > 0) else None
     return out
 
@@ -746,11 +749,16 @@ def enc_grouped_fwd(final, w, b, groups, zero_slots=None):
     zero_slots: a [cap, 32] buffer cleared by the same launch."""
     require_gpu(final, w, b)
     h = torch.empty(groups.cap, 32, dtype=torch.float32, device=final.device)
+    ra, rb = amax_of(final), amax_of(w)
+    if AUTO_AMAX and H2:
+        ra = ra if ra is not None else amax(final)
+        rb = rb if rb is not None else amax(w)
+    sc = _scale_arg(ra, rb) if (ra is not None and rb is not None) else None
     with _timed("gemm_enc_grouped_fwd", 2.0 * groups.T * 32 * final.shape[1]):
         check(lib.mapx_enc_grouped_fwd(final.data_ptr(), final.stride(0), final.shape[0], final.shape[1],
                                        ptr(w), w.stride(0), ptr(b), ptr(groups.rowmap), ptr(groups.tile_group),
                                        ptr(groups.group_start), groups.F, groups.cap, ptr(h), ptr(zero_slots),
-                                       stream()))
+                                       None if sc is None else native_byref(sc), stream()))
     return h
 
 
@@ -761,10 +769,15 @@ def enc_grouped_dw(dh_slots, final, groups, out=None, gscale=None):
     Nn = final.shape[1]
     if out is None:
         out = torch.empty(groups.F * 32, Nn, dtype=torch.float32, device=final.device)
+    ra, rb = amax_of(dh_slots), amax_of(final)
+    if AUTO_AMAX and H2:
+        ra = ra if ra is not None else amax(dh_slots)
+        rb = rb if rb is not None else amax(final)
+    sc = _scale_arg(ra, rb) if (ra is not None and rb is not None) else None
     with _timed("gemm_enc_grouped_dw", 2.0 * groups.T * 32 * Nn):
         check(lib.mapx_enc_grouped_dw(ptr(dh_slots), final.data_ptr(), final.stride(0), final.shape[0], Nn,
                                       ptr(groups.rowmap), ptr(groups.group_start), groups.F, ptr(gscale),
-                                      ptr(out), out.stride(0), stream()))
+                                      ptr(out), out.stride(0), None if sc is None else native_byref(sc), stream()))
     return out
 
 

@@ -831,7 +831,7 @@ def test_rfd_replacement_generators(ops):
 
 
 @pytest.mark.parametrize("B,F,D", [(64, 23, 432), (4096, 23, 1368), (100, 39, 688)])
-def test_grouped_feat_encoder_matches_dense(ops, B, F, D):
+def test_grouped_feat_encoder_matches_dense(ops, arith, B, F, D):
     """Grouped forward / dW of feat_encoder == dense GEMM + field gather (models.py:74-75)."""
     g = torch.Generator().manual_seed(B + F)
     P, L = 32, int(F * 0.3)
