@@ -165,9 +165,13 @@ struct OperandA {
   }
 };
 
-// 128 x 128 tile, 4 waves of 128 x 32.  A k-contiguous [M][K] (lda % 4 == 0, 16-byte aligned, K % 8 == 0), B = planes.
+// 128 x 128 tile by 4 waves of 128 x 32 (WMT = 4), or — products too narrow for 128 of those — 128 x 64 by 2 x 2 waves of
+// 64 x 32 (WMT = 2: the two waves of a column tile read the same B fragments, from L1).  A k-contiguous [M][K]
+// (lda % 4 == 0, 16-byte aligned, K % 8 == 0), B = planes.
+template <int WMT>
 __global__ void __launch_bounds__(256) gemm_f32h2w_kernel(GemmX3Args a, const unsigned char* __restrict__ planes) {
-  constexpr int BM = 128, BN = 128, NT = 256, WMT = 4;
+  constexpr int BM = 128, WCOLS = WMT == 4 ? 4 : 2, BN = 32 * WCOLS, NT = 256;
+  static_assert(WMT == 4 || WMT == 2, "wave tile 128 x 32 or 64 x 32");
   using OpA = OperandA<BM, NT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   f16_t* const smem = reinterpret_cast<f16_t*>(smem_raw);
@@ -184,6 +188,7 @@ __global__ void __launch_bounds__(256) gemm_f32h2w_kernel(GemmX3Args a, const un
   const int m0 = tm * BM, n0 = tn * BN;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, kh = lane >> 5;
+  const int wr = wave / WCOLS, wc = wave % WCOLS, tbase = wr * WMT;      // this wave's A row tiles tbase .. tbase + WMT - 1
 
   f32x16 acc[WMT], cor[WMT];
 #pragma unroll
@@ -193,9 +198,9 @@ __global__ void __launch_bounds__(256) gemm_f32h2w_kernel(GemmX3Args a, const un
 
   const int nk = (a.K + kXBK - 1) / kXBK;                  // K-steps; the planes are zero beyond K
   const int KS = nk * 2;
-  // this wave's B blocks: column tile 4 tn + wave, k16 steps 2 kt, 2 kt + 1: 4 KB per K-step, contiguous
+  // this wave's B blocks: column tile WCOLS tn + wc, k16 steps 2 kt, 2 kt + 1: 4 KB per K-step, contiguous
   const unsigned char* const bbase =
-      planes + kPlaneHeader + ((int64_t)(tn * 4 + wave) * KS) * 2048 + lane * 16;
+      planes + kPlaneHeader + ((int64_t)(tn * WCOLS + wc) * KS) * 2048 + lane * 16;
   u32x4 fb[4][2][2];                                       // [set = kt & 3][k16 half][piece hi / lo]
 #define MAPX_W_BLOAD(SET, t)                                                                           \
   do {                                                                                                 \
@@ -248,11 +253,13 @@ __global__ void __launch_bounds__(256) gemm_f32h2w_kernel(GemmX3Args a, const un
   for (int i = 0; i < OpA::NV; ++i) { MAPX_W_ALOAD(0, i, 0, 2); MAPX_W_ALOAD(0, i, 1, 2); }
   __syncthreads();
 
-  // K-step kt on LDS buffer CUR = kt & 1, B set BS = kt & 3.  Slots: 24 MFMAs (k16 half h, A tile i, term); the cut
-  // of A's tile kt + 1 (2 chunks = 16 units of 4 VALU) in slots 0..15, its 4 LDS stores and the 4 loads of A's tile
-  // kt + 3 behind them; the 4 loads of B's K-step kt + 2 in slots 0..3; the second half's 8 A fragments in slots 0..7.
-  constexpr int kNM = 24, kU = 8 * OpA::NV;
-  static_assert(OpA::NV == 2, "two chunks of A per thread");
+  // K-step kt on LDS buffer CUR = kt & 1, B set BS = kt & 3.  Slots: 6 WMT MFMAs (k16 half h, A tile i, term); the cut
+  // of A's tile kt + 1 (2 chunks = 16 units of 4 VALU), kUPS units per slot from slot 0; the second half's 2 WMT A
+  // fragments in the first slots; then the 4 loads of B's K-step kt + 2; a chunk's two LDS stores and the two loads of
+  // A's tile kt + 3 behind the slot that ends its cut.  WMT = 4: 24 slots, one unit each; WMT = 2: 12 slots, two each.
+  constexpr int kNM = 6 * WMT, kU = 8 * OpA::NV, kUPS = WMT == 4 ? 1 : 2, kFR = 2 * WMT;
+  constexpr int kC0 = 8 / kUPS + (WMT == 4 ? 4 : 0), kC1 = 16 / kUPS + (WMT == 4 ? 0 : 0);    // first memory slot of chunk 0 / 1
+  static_assert(OpA::NV == 2 && kC1 + 4 <= kNM && kC0 + 4 <= kC1 + 4, "two chunks of A per thread; slots");
 #define MAPX_W_UNIT(CUR, u)                                                                            \
   do {                                                                                                 \
     constexpr int c_ = (u) / 8, pg_ = ((u) % 8) / 4, st_ = (u) % 4;                                    \
@@ -270,39 +277,42 @@ __global__ void __launch_bounds__(256) gemm_f32h2w_kernel(GemmX3Args a, const un
     f16_t* const As_nxt = smem + ((CUR) ^ 1) * kBuf;                                                   \
     f16x8 fa[2][2][WMT];                          /* [k16 half][piece hi / lo][A row tile] */          \
     _Pragma("unroll") for (int i = 0; i < WMT; ++i) {                                                  \
-      fa[0][1][i] = OpA::frag1(As_cur, 1, lane, 0, i);                                                 \
-      fa[0][0][i] = OpA::frag1(As_cur, 0, lane, 0, i);                                                 \
+      fa[0][1][i] = OpA::frag1(As_cur, 1, lane, 0, tbase + i);                                         \
+      fa[0][0][i] = OpA::frag1(As_cur, 0, lane, 0, tbase + i);                                         \
     }                                                                                                  \
     uint32_t cH[2][4], cL[2][4];                                                                       \
     CutRegs cr;                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
     unroll_seq([&](auto zc) __attribute__((always_inline)) {                                           \
       constexpr int z = decltype(zc)::value;                                                           \
-      constexpr int h = z / 12, i = (z % 12) / 3, term = z % 3;                                        \
+      constexpr int h = z / (3 * WMT), i = (z % (3 * WMT)) / 3, term = z % 3;                          \
       const f16x8 bh_ = __builtin_bit_cast(f16x8, fb[BS][h][0]), bl_ = __builtin_bit_cast(f16x8, fb[BS][h][1]); \
       if (term == 0) cor[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[h][1][i], bh_, cor[i], 0, 0, 0); \
       if (term == 1) cor[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[h][0][i], bl_, cor[i], 0, 0, 0); \
       if (term == 2) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[h][0][i], bh_, acc[i], 0, 0, 0); \
       __builtin_amdgcn_sched_barrier(0);                                                               \
-      if constexpr (z < 8) {                      /* second half's A fragments */                      \
+      if constexpr (z < kFR) {                    /* second half's A fragments */                      \
         constexpr int pl = 1 - (z & 1), t = z >> 1;                                                    \
-        fa[1][pl][t] = OpA::frag1(As_cur, pl, lane, 1, t);                                             \
+        fa[1][pl][t] = OpA::frag1(As_cur, pl, lane, 1, tbase + t);                                     \
       }                                                                                                \
-      if constexpr (z < kU) MAPX_W_UNIT(CUR, z);                                                       \
-      if constexpr (z >= 8 && z < 12) {           /* B fragments of K-step kt + 2 */                   \
-        constexpr int q = z - 8;                                                                       \
+      if constexpr (z * kUPS < kU) {                                                                   \
+        MAPX_W_UNIT(CUR, z * kUPS);                                                                    \
+        if constexpr (kUPS == 2) MAPX_W_UNIT(CUR, (z * kUPS + 1 < kU ? z * kUPS + 1 : 0));             \
+      }                                                                                                \
+      if constexpr (z >= kFR && z < kFR + 4) {    /* B fragments of K-step kt + 2 */                   \
+        constexpr int q = z - kFR;                                                                     \
         const int tc_ = (kt) + 2 < nk ? (kt) + 2 : nk - 1;                                             \
         fb[((BS) + 2) & 3][q >> 1][q & 1] =                                                            \
             *reinterpret_cast<const u32x4*>(bbase + (int64_t)tc_ * 4096 + q * 1024);                   \
       }                                                                                                \
-      if constexpr (z >= 12 && z < 16) {          /* chunk 0's stores (its cut ended with unit 7), then its loads */ \
-        constexpr int q = z - 12;                                                                      \
+      if constexpr (z >= kC0 && z < kC0 + 4) {    /* chunk 0's stores (its cut ended with unit 7), then its loads */ \
+        constexpr int q = z - kC0;                                                                     \
         if (q < 2) *reinterpret_cast<uint4*>(As_nxt + soffA[0] + q * OpA::PLANE) =                     \
             q == 0 ? make_uint4(cH[0][0], cH[0][1], cH[0][2], cH[0][3]) : make_uint4(cL[0][0], cL[0][1], cL[0][2], cL[0][3]); \
         else MAPX_W_ALOAD((CUR) ^ 1, 0, (q >= 2 ? q - 2 : 0), (kt) + 3);                               \
       }                                                                                                \
-      if constexpr (z >= 16 && z < 20) {          /* chunk 1's */                                      \
-        constexpr int q = z - 16;                                                                      \
+      if constexpr (z >= kC1 && z < kC1 + 4) {    /* chunk 1's */                                      \
+        constexpr int q = z - kC1;                                                                     \
         if (q < 2) *reinterpret_cast<uint4*>(As_nxt + soffA[1] + q * OpA::PLANE) =                     \
             q == 0 ? make_uint4(cH[1][0], cH[1][1], cH[1][2], cH[1][3]) : make_uint4(cL[1][0], cL[1][1], cL[1][2], cL[1][3]); \
         else MAPX_W_ALOAD((CUR) ^ 1, 1, (q >= 2 ? q - 2 : 0), (kt) + 3);                               \
@@ -334,10 +344,25 @@ __global__ void __launch_bounds__(256) gemm_f32h2w_kernel(GemmX3Args a, const un
   for (int i = 0; i < WMT; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      tile[(32 * i + 4 * kh + (r & 3) + 8 * (r >> 2)) * LDT + 32 * wave + l31] =
+      tile[(32 * (tbase + i) + 4 * kh + (r & 3) + 8 * (r >> 2)) * LDT + 32 * wc + l31] =
           __builtin_ldexpf(__builtin_fmaf(cor[i][r], 0x1p-11f, acc[i][r]), dn);
   __syncthreads();
   epilogue_dispatch<BM, BN, NT>(a, a.C, tile, m0, n0);
+}
+
+template <int WMT>
+static hipError_t launch_h2w(const GemmX3Args& g, const void* planes, hipStream_t stream) {
+  constexpr int BN = WMT == 4 ? 128 : 64;
+  constexpr size_t ops = (size_t)2 * OperandA<128, 256>::LDS_ELEMS * sizeof(f16_t);
+  constexpr size_t epi = ((size_t)128 * (BN + 4) + 4 * 256) * sizeof(float);
+  constexpr size_t lds = ops > epi ? ops : epi;
+  static hipError_t raised = lds > 65536 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32h2w_kernel<WMT>),
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                         : hipSuccess;
+  if (raised != hipSuccess) return raised;
+  hipLaunchKernelGGL(gemm_f32h2w_kernel<WMT>, dim3(g.tiles_m * g.tiles_n), dim3(256), lds, stream, g,
+                     static_cast<const unsigned char*>(planes));
+  return hipSuccess;
 }
 
 // Called by gemm_f32x3_launch (gemm_x3.hip) when the caller handed the weight operand's planes.  false: not this
@@ -345,22 +370,21 @@ __global__ void __launch_bounds__(256) gemm_f32h2w_kernel(GemmX3Args a, const un
 bool gemm_f32h2w_try(GemmX3Args& g, int a_kc, bool vec, const void* planes, int nsplit, int batch, hipStream_t stream,
                      hipError_t* err) {
   static const bool on = [] { const char* e = getenv("MAPX_GEMM_H2W"); return !e || atoi(e) != 0; }();
+  static const bool narrow = [] { const char* e = getenv("MAPX_GEMM_H2W_NARROW"); return !e || atoi(e) != 0; }();
   if (!on || !planes || !a_kc || !vec || nsplit != 1 || batch != 1 || !g.amax_a) return false;
   if (g.K < 2 * kXBK || g.K % 8 != 0 || (uintptr_t)planes % 16 != 0) return false;
-  const int64_t tiles = ceil_div(g.M, 128) * ceil_div(g.N, 128);
-  if (tiles < 128) return false;                     // narrow products: gemm_h2.hip's smaller tiles fill the chip
   g.tiles_m = (int)ceil_div(g.M, 128);
-  g.tiles_n = (int)ceil_div(g.N, 128);
-  constexpr size_t ops = (size_t)2 * OperandA<128, 256>::LDS_ELEMS * sizeof(f16_t);
-  constexpr size_t epi = ((size_t)128 * 132 + 4 * 256) * sizeof(float);
-  constexpr size_t lds = ops > epi ? ops : epi;
-  static hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32h2w_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (raised != hipSuccess) { *err = raised; return true; }
-  hipLaunchKernelGGL(gemm_f32h2w_kernel, dim3(g.tiles_m * g.tiles_n), dim3(256), lds, stream, g,
-                     static_cast<const unsigned char*>(planes));
-  *err = hipSuccess;
-  return true;
+  if (ceil_div(g.M, 128) * ceil_div(g.N, 128) >= 128) {
+    g.tiles_n = (int)ceil_div(g.N, 128);
+    *err = launch_h2w<4>(g, planes, stream);
+    return true;
+  }
+  if (narrow && ceil_div(g.M, 128) * ceil_div(g.N, 64) >= 128) {      // narrow products (N = 368): 128 x 64 tiles
+    g.tiles_n = (int)ceil_div(g.N, 64);
+    *err = launch_h2w<2>(g, planes, stream);
+    return true;
+  }
+  return false;
 }
 
 }  // namespace mapx

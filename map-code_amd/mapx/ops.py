@@ -1036,8 +1036,8 @@ def h2_weight_planes(w, b_kc, rec, out=None):
 
 
 def planes_wanted(M, Nn, K):
-    """Would gemm_h2w.hip take a product of this shape?  (>= 128 tiles of 128 x 128, K >= 64, K % 8 == 0)"""
-    return math.ceil(M / 128) * math.ceil(Nn / 128) >= 128 and K >= 64 and K % 8 == 0
+    """Would gemm_h2w.hip take a product of this shape?  (>= 128 tiles of 128 x 128 — or of 128 x 64 —, K >= 64, K % 8 == 0)"""
+    return math.ceil(M / 128) * math.ceil(Nn / 64) >= 128 and K >= 64 and K % 8 == 0
 
 
 def weight_planes(w, b_kc, M):

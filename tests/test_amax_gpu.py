@@ -172,7 +172,8 @@ def test_gemm_h2_operand_magnitudes(ops):
 
 
 @pytest.mark.parametrize("b_kc,M,N,K", [(1, 4096, 1000, 1024), (0, 4096, 1000, 736), (1, 4096, 1000, 1000), (1, 4096, 1000, 368),
-                                        (0, 4097, 1368, 200), (1, 16384, 130, 72)])
+                                        (0, 4097, 1368, 200), (1, 16384, 130, 72),
+                                        (1, 4096, 368, 736), (0, 4096, 368, 1000), (1, 4100, 368, 368)])        # 128 x 64 tiles
 def test_weight_planes_products_equal_the_in_kernel_cut(ops, b_kc, M, N, K):
     """gemm_h2w.hip (operand B read from mapx_h2_weight_planes' fragment-ordered fp16 pieces) forms the very
     products gemm_h2.hip forms from the fp32 weight: same pieces, same scale, the same sums per k16 block in the same
@@ -188,7 +189,8 @@ def test_weight_planes_products_equal_the_in_kernel_cut(ops, b_kc, M, N, K):
     bias = torch.randn(N, generator=g).to(DEV)
     from mapx.native import EPI_BIAS_RELU
     got = ops.gemm(A, B, True, bool(b_kc), M, N, K, amax_a=ra, amax_b=rb, b_planes=pl, epi=EPI_BIAS_RELU, bias=bias)
-    want = ops.gemm(A, B, True, bool(b_kc), M, N, K, amax_a=ra, amax_b=rb, tile=3, epi=EPI_BIAS_RELU, bias=bias)
+    wide = math.ceil(M / 128) * math.ceil(N / 128) >= 128          # else the 128 x 64 form of both kernels
+    want = ops.gemm(A, B, True, bool(b_kc), M, N, K, amax_a=ra, amax_b=rb, tile=3 if wide else 1, epi=EPI_BIAS_RELU, bias=bias)
     ref = torch.relu(A.double() @ (B.double().t() if b_kc else B.double()) + bias.double())
     bound = 2e-6 * (A.abs().double() @ (B.abs().double().t() if b_kc else B.abs().double())) + 1e-6
     assert bool(((got.double() - ref).abs() <= bound).all())
