@@ -38,6 +38,11 @@ PLAN_AFTER_DNN = os.environ.get("MAPX_PLAN_AFTER_DNN", "1")       # 1 | tower | 
 PLAN_AFTER_TRUNK = os.environ.get("MAPX_PLAN_AFTER_TRUNK", "auto")
 
 X0_LINK = os.environ.get("MAPX_X0_LINK", "1") == "1"       # A/B switch of layers._X0Link
+# Round 4 (the two-piece fp16 GEMMs made the towers a third shorter): the NCE head's sampling + catch-up (HBM-bound,
+# 80 us in the graph) BEHIND the cross tower's GEMMs on the tower stream instead of in front of them — in front, the
+# cross tower ended 50 us after the deep one and the encoder waited for it; the main stream joins the tower stream at
+# the cross tower's end (an event), the loss kernel alone waits for the sampled ids (`nce_idx._ready`)
+NCE_AFTER_CROSS = os.environ.get("MAPX_NCE_AFTER_CROSS", "0") == "1"
 EARLY_NCE_ALL = os.environ.get("MAPX_EARLY_NCE_ALL", "1") == "1"   # A/B switch: BaseModel._sample_early
 
 _OTHER_BACKBONES = ("trans", "fignn", "fgcnn")
@@ -231,6 +236,15 @@ class DCNV2(BaseModel):
 
     def forward(self, input_ids, labels=None, masked_index=None, noise_samples=None):
         groups, nce_idx, join = None, None, None
+        planes_ev = None
+        if ops._dirty_planes and input_ids.is_cuda and self.config.num_hidden_layers > 0:
+            # the weights' planes of this step (ops.PLANES_AT_START): on the tower stream, beside the step's head (catch-up,
+            # gather: small grids); the deep tower's first product waits for them
+            tower0 = ops.aux_stream("tower", input_ids.device)
+            if ops.stream_wait(tower0, torch.cuda.current_stream()):
+                with torch.cuda.stream(tower0):
+                    ops.refresh_dirty_planes()
+                    planes_ev = ops.record_event()
         feat_embed = ops.flat_rows(self.embed(input_ids))
         if self.config.num_hidden_layers > 0:
             # Three independent chains leave the gather: the cross tower (small D x D GEMMs on a
@@ -243,6 +257,7 @@ class DCNV2(BaseModel):
             main = torch.cuda.current_stream()
             tower = ops.aux_stream("tower", feat_embed.device)
             forked = ops.stream_wait(tower, main)
+
             # both towers write their last layer straight into the concatenated buffer
             D, H = feat_embed.shape[1], self.config.hidden_size
             direct = self.config.num_cross_layers > 0
@@ -270,8 +285,10 @@ class DCNV2(BaseModel):
                     # the cross tower has ~70 us of slack against the deep one: the slot layout of
                     # the grouped encoder (one single-workgroup launch) rides on its stream
                     groups = ops.EncGroups(masked_index, self.config.num_fields)
-                if self._mfp_head(masked_index) and NCE_EARLY and labels is not None \
-                        and (groups is not None or self.embed.compute_dtype != torch.float32):
+                early_nce = self._mfp_head(masked_index) and NCE_EARLY and labels is not None \
+                    and (groups is not None or self.embed.compute_dtype != torch.float32)
+                after_cross = early_nce and NCE_AFTER_CROSS and groups is not None and direct
+                if early_nce and not after_cross:
                     # the NCE head's sampling and the lazy catch-up of the sampled rows need only
                     # the targets: HBM-bound kernels that run beside the deep tower's first GEMMs
                     # instead of alone between the towers and the loss (same branch, no new one).  (Round 2: BEHIND
@@ -280,6 +297,13 @@ class DCNV2(BaseModel):
                     nce_idx = self.mfp_criterion.sample_ids(labels, noise_samples)
                 cross_output = self.cross_net(feat_embed, out=ops.alias_cols(final_buf, 0, D) if direct else None,
                                               link=join, x0_link=x0_link)
+                cross_done = None
+                if after_cross:
+                    cross_done = ops.record_event()
+                    nce_idx = self.mfp_criterion.sample_ids(labels, noise_samples)
+                    nce_idx._ready = (ops.record_event(), tower)
+            if planes_ev is not None:
+                ops.stream_wait_event(main, planes_ev, tower)
             dnn_output = self.parallel_dnn(feat_embed, out=ops.alias_cols(final_buf, D, H) if direct else None,
                                            link_last=join.relu if join is not None else None)
             # Both tables' segment plans from ONE chain of launches (8 instead of 8 + 8), when the
@@ -308,7 +332,11 @@ class DCNV2(BaseModel):
                 # sort on its queue): finetune 0.636 -> 0.619 ms, RFD 0.768 -> 0.786 — so by the head.
                 where = PLAN_AFTER_TRUNK if PLAN_AFTER_TRUNK != "auto" else ("main" if self.config.pretrain else "tower")
                 self.embed.table.start_plan(after={"main": main, "tower": tower}.get(where))
-            ops.stream_wait(main, tower)
+            if cross_done is not None:
+                ops.stream_wait_event(main, cross_done, tower)       # (the sampled ids: waited for by the loss kernel)
+                ops.pending_joins.append((main, tower))
+            else:
+                ops.stream_wait(main, tower)
             if forked:
                 feat_embed.record_stream(tower)
                 final_buf.record_stream(tower)

@@ -149,6 +149,9 @@ class _EncNceLoss(Function):
         final = final.contiguous()
         dh_slots = torch.empty(groups.cap, P, dtype=torch.float32, device=final.device)
         h_slots = ops.enc_grouped_fwd(final, w_enc, b_enc, groups, zero_slots=dh_slots)
+        ready = getattr(idx, "_ready", None)
+        if ready is not None:           # sampled behind the cross tower (models.NCE_AFTER_CROSS): only this kernel waits
+            ops.stream_wait_event(torch.cuda.current_stream(), ready[0], ready[1])
         later = TOTALS_LATER and ops.step_window[0] and ctx.needs_input_grad[0]      # (see _NceLoss.forward)
         o = ops.nce_fwd(h_slots, masked_index, idx, emb_w, bias_w.view(-1), logq, F, P,
                         want_logits=want_logits, hpos=groups.hpos, dh_slots=dh_slots, totals_later=later)

@@ -1050,6 +1050,8 @@ def weight_planes(w, b_kc, M):
     rec = amax_of(base)
     if reg is None or rec is None:
         return None
+    if _dirty_planes:
+        refresh_dirty_planes()            # (nobody re-cut them at the start of this step: do it before the first reader)
     Nn, K = (w.shape[0], w.shape[1]) if b_kc else (w.shape[1], w.shape[0])
     if not planes_wanted(M, Nn, K):
         return None
@@ -1060,6 +1062,32 @@ def weight_planes(w, b_kc, M):
             return None               # (registered by the eager steps that precede a capture)
         pl = reg[key] = h2_weight_planes(base.detach()[:, c0:c1] if (c0, c1) != (0, None) else base.detach(), b_kc, rec)
     return pl
+
+
+# Where the planes are re-cut: right behind the AdamW kernel (end of the step, "0"), or at the START of the next step
+# ("1"): the optimizer only notes which parameters it wrote; the model's forward re-cuts them on a stream that is idle
+# while the step's head (mask, catch-up, gather) runs, and any product that asks for planes before that re-cuts on the
+# spot — a stale plane is never read.
+PLANES_AT_START = os.environ.get("MAPX_PLANES_AT_START", "0") == "1"
+_dirty_planes = []
+
+
+def planes_written(params):
+    """The optimizer wrote these parameters (their records are current): re-cut their planes now or note them."""
+    if PLANES_AT_START:
+        _dirty_planes.append(list(params))
+    else:
+        refresh_weight_planes(params)
+
+
+def refresh_dirty_planes():
+    """Re-cut the planes of every parameter noted by planes_written, on the current stream.  -> True if any."""
+    if not _dirty_planes:
+        return False
+    todo = [p for ps in _dirty_planes for p in ps]
+    del _dirty_planes[:]
+    refresh_weight_planes(todo)
+    return True
 
 
 def refresh_weight_planes(params):

@@ -296,8 +296,9 @@ class MapxOptimizer:
         for g in self.groups:
             ops.adamw_dense(g["p"], g["g"], g["m"], g["v"], self.sched, self.done, b1, b2, eps, g["wd"],
                             shadow=g["h"], seg_off=g.get("seg_off"), seg_amax=g.get("amax"))
+        for g in self.groups:
             if g.get("amax") is not None:
-                ops.refresh_weight_planes(g["params"])       # the weights' fp16 pieces for the next step's products
+                ops.planes_written(g["params"])              # the weights' fp16 pieces for the next step's products
 
     def zero_grad(self):
         """Dense gradients are overwritten by the next backward (see layers._grad_slot); only
