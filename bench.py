@@ -53,8 +53,8 @@ PMC_MAP = {
     "gemm_dw_tn": [["gemm_f32x3_kernel<", ", false, false, true>"], ["gemm_f32h2_kernel<", ", false, false>"],
                    ["gemm_bf16_kernel<", ", false, false, "]],
     "gemm_weight_planes": [["gemm_f32h2w_kernel"]],      # (forward and input-gradient products alike: one kernel)
-    "gemm_enc_grouped_fwd": [["gemm_grouped_x3_kernel<false>"]],
-    "gemm_enc_grouped_dw": [["gemm_grouped_x3_kernel<true>"]],
+    "gemm_enc_grouped_fwd": [["gemm_grouped_x3_kernel<false>"], ["gemm_grouped_h2_kernel<false>"]],
+    "gemm_enc_grouped_dw": [["gemm_grouped_x3_kernel<true>"], ["gemm_grouped_h2_kernel<true>"]],
     "nce_fwd": ["nce_fwd_"],
     "nce_table_grad": ["seg_reduce_pass_a<8, true"],
     "seg_reduce_rows": ["seg_reduce_pass_a<4, false"],
@@ -494,8 +494,8 @@ def main():
     data_dependent = ("table_adam_update", "table_adam_catchup", "nce_table_grad", "seg_reduce_rows")
     # the grouped feat_encoder kernels compute in fp32 in either mode; the dense GEMM classes follow --dtype
     from mapx import ops as _ops
-    f32_kind = "f32h2" if _ops.H2 else "f32x3"          # the dense classes; the grouped encoder kernels: six products
-    mfma_peak = lambda name: MFMA_PEAK_TFLOPS["f32x3" if "grouped" in name else (f32_kind if args.dtype == "f32" else args.dtype)]
+    f32_kind = "f32h2" if _ops.H2 else "f32x3"          # (the grouped encoder kernels compute in fp32 in either mode)
+    mfma_peak = lambda name: MFMA_PEAK_TFLOPS[f32_kind if ("grouped" in name or args.dtype == "f32") else args.dtype]
     gemm_flops = 0.0
     for name, s in ksum.items():
         per_launch = s["work"] / s["launches"]

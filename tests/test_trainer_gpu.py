@@ -595,7 +595,7 @@ def test_full_vocabulary_step_properties(F, V, pt, dtype):
             assert bool(moved[same].all()), n          # decayed rows did move, by exactly the predicted amount
 
 
-def test_pretrain_then_finetune_auc_on_10k_heldout_rows_vs_oracle():
+def test_pretrain_then_finetune_auc_on_12k_heldout_rows_batch_256_vs_oracle():
     """BASELINE configs[4]: "DCNv2 finetune after MFP — AUC parity vs reference within 1e-4"
     (reference flow: run.py:64-67 load_for_finetune, trainer.py:87-161 train, :163-215 eval).
     30 MFP steps -> name+shape transfer into the CTR model -> 40 finetune steps, on the GPU (HIP
