@@ -244,10 +244,11 @@ int mapx_scale_inplace(float* x, int64_t n, const float* g, hipStream_t stream);
 #define MAPX_EPI_BIAS_CROSS 3
 #define MAPX_EPI_ADD 4
 #define MAPX_EPI_RELU_MASK 5
-/* RELU_MASK plus the column sums of the masked result, one partial row per 128-row tile: out2 [ceil(M/128)][ldo2]
- * fp32 (the upstream layer's bias gradient: add the rows with mapx_sum_tasks).  mapx_gemm_bf16: `out2` then points to
- * those FP32 partial rows (ldo2 in floats) and the sums are those of the bf16 values stored.  16-byte aligned
- * operands, no split-K; else MAPX_EINVAL. */
+/* RELU_MASK plus the column sums of the masked result as partial rows (the upstream layer's bias gradient: add the
+ * rows with mapx_sum_tasks).  mapx_gemm_f32: out2 [ceil(M/64)][ldo2] fp32, one row per 64 rows of C, every row
+ * written (a kernel with 128-row tiles leaves the tile's sum in the first of its two rows and zeros in the second).
+ * mapx_gemm_bf16: `out2` points to FP32 partial rows [ceil(M/128)][ldo2 floats], one per 128 rows, and the sums are
+ * those of the bf16 values stored.  16-byte aligned operands, no split-K; else MAPX_EINVAL. */
 #define MAPX_EPI_RELU_MASK_COLSUM 6
 /* nsplit_deferred != NULL: the split-K slabs stay in `ws` ([nsplit][M*N], dense) and
  * *nsplit_deferred receives the slab count (0 = C already final): the caller sums them later
@@ -308,8 +309,8 @@ int mapx_gemm_f32(int a_kc, int b_kc, int M, int N, int K, const float* A, int64
  *   columns n <  c0:  t[m,n] = v x0[m,n];  dx0[m,n] = (accumulate ? dx0[m,n] : 0) + v u[m,n] (+ v if plus_v)
  *                                                       the cross layer's backward (layers.py:200:
  *                                                       X_{i+1} = X_i + X0 * u, u = W X_i + b)
- *   C[m,n] = v;  part[m / 128][n] = sum over the 128-row tile of (n >= c0 ? v : t[m,n])  (bias gradients: add the
- *   rows with mapx_sum_tasks).
+ *   C[m,n] = v;  part [ceil(M/64)][ld_part]: partial rows of the column sums of (n >= c0 ? v : t[m,n]), one per 64
+ *   rows of C, every row written (see MAPX_EPI_RELU_MASK_COLSUM; bias gradients: add the rows with mapx_sum_tasks).
  * c0 = 0: a ReLU layer's dZ only; c0 = N: a cross layer only; 0 < c0 < N: the concatenated input of the heads
  * (models.py:316-318), cross tower left of c0, deep tower right of it.  N, c0 % 4 == 0, 16-byte aligned operands. */
 int mapx_gemm_f32_bwd_fused(int M, int N, int K, const float* dY, int64_t lda, const float* W, int64_t ldw,

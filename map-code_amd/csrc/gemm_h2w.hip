@@ -350,6 +350,203 @@ __global__ void __launch_bounds__(256) gemm_f32h2w_kernel(GemmX3Args a, const un
   epilogue_dispatch<BM, BN, NT>(a, a.C, tile, m0, n0);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same product with EIGHT waves on a 64 x 256 tile: every wave takes all 64 rows of A and its own 32 columns of B.
+// Why: the 4-wave kernel above is bound by instruction issue, not by the matrix pipe — a slot of its K-step is one
+// MFMA + one 4-instruction unit of A's cut at ~8 cycles each beside MFMAs + a memory instruction, and after every
+// barrier its one wave per SIMD waits out the LDS latency of the first fragments (0.78 us per K-step measured, 0.46 for
+// the MFMAs alone).  Here the A tile is half as tall and shared by twice as many waves: per SIMD and K-step the same
+// 24 MFMAs, but 32 VALU instructions of cut instead of 64 and 8 KB of LDS stores instead of 16; waves 0-3 stage A (one
+// chunk each), waves 4-7 only multiply; and the LDS pipeline is one tile deeper — four buffers, tile t in buffer t & 3:
+// K-step kt multiplies tile kt, reads the first fragments of tile kt + 1 (stored during K-step kt - 1, visible since
+// the barrier that ended it) and stores tile kt + 2 — so that no MFMA waits for LDS behind a barrier.  B fragments are
+// read from the planes by twice as many workgroups.
+#ifndef MAPX_W8_ABLATE
+#define MAPX_W8_ABLATE 0      // tools/h2_ablate.sh: 1 no B loads, 2 no cut, 4 no MFMAs, 8 no LDS stores, 16 no A loads, 32 no fragment reads, 64 no barrier
+#endif
+__global__ void __launch_bounds__(512) gemm_f32h2w8_kernel(GemmX3Args a, const unsigned char* __restrict__ planes) {
+  constexpr int BM = 64, BN = 256, NT = 512, WMT = 2;
+  using OpA = OperandA<BM, 256>;                    // 256 chunks per K-step: one per thread of waves 0-3
+  static_assert(OpA::NV == 1, "one chunk per staging thread");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  f16_t* const smem = reinterpret_cast<f16_t*>(smem_raw);
+  constexpr int kBuf = OpA::LDS_ELEMS;
+
+  const int na = __builtin_amdgcn_readfirstlane(h2_scale_exp(a.amax_a));
+  const int nb = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int32_t*>(planes));
+  const float sA = pow2f(na), k2048 = 2048.f;
+
+  const int nb_tiles = a.tiles_m * a.tiles_n, per = nb_tiles / 8;
+  int lin = blockIdx.x;
+  if (lin < per * 8) lin = (lin % 8) * per + lin / 8;      // XCD-aware tile order
+  const int tm = lin / a.tiles_n, tn = lin % a.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l31 = lane & 31, kh = lane >> 5;
+  const bool stager = wave < 4;
+
+  f32x16 acc[WMT], cor[WMT];
+#pragma unroll
+  for (int i = 0; i < WMT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = cor[i][r] = 0.f;
+
+  const int nk = (a.K + kXBK - 1) / kXBK;
+  const int KS = nk * 2;
+  // (the planes hold whole 128-column tiles: a wave whose 32 columns lie past them reads the last tile's — its
+  // results fall in columns >= N, which the epilogue does not store)
+  const int ct_last = (a.N + 127) / 128 * 4 - 1, ct = tn * 8 + wave < ct_last ? tn * 8 + wave : ct_last;
+  const unsigned char* const bbase = planes + kPlaneHeader + ((int64_t)ct * KS) * 2048 + lane * 16;
+  u32x4 fb[4][2][2];                                       // [set = kt & 3][k16 half][piece hi / lo]
+#define MAPX_W8_BLOAD1(SET, q, t)                                                                      \
+  do {                                                                                                 \
+    const int tc_ = (t) < nk ? (t) : nk - 1;                                                           \
+    fb[SET][(q) >> 1][(q) & 1] = *reinterpret_cast<const u32x4*>(bbase + (int64_t)tc_ * 4096 + (q) * 1024); \
+  } while (0)
+
+  // operand A (waves 0-3): this thread's chunk
+  float4 ra[2][2];                                          // [register set = tile & 1][half of the chunk]
+  int tr, tc;
+  OpA::coords(threadIdx.x & 255, tr, tc);
+  const int64_t goffA = (int64_t)((m0 + tr < a.M) ? m0 + tr : 0) * a.lda;
+  const int soffA = OpA::lds_off(tr, tc);
+#define MAPX_W8_ALOAD(SET, hf, t)                                                                      \
+  do {                                                                                                 \
+    const int tc_ = (t) < nk ? (t) : nk - 1;                                                           \
+    const int k_ = tc_ * kXBK + tc;                                                                    \
+    ra[SET][hf] = *reinterpret_cast<const float4*>(a.A + goffA + (k_ < a.K ? k_ : 0) + 4 * (hf));      \
+  } while (0)
+
+  // prologue: B sets 0, 1, 2; A tiles 0, 1 cut and stored, tiles 2, 3 on their way; the first fragments of tile 0
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { MAPX_W8_BLOAD1(0, q, 0); MAPX_W8_BLOAD1(1, q, 1); MAPX_W8_BLOAD1(2, q, 2); }
+  if (stager) {
+    MAPX_W8_ALOAD(0, 0, 0); MAPX_W8_ALOAD(0, 1, 0);
+    MAPX_W8_ALOAD(1, 0, 1); MAPX_W8_ALOAD(1, 1, 1);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float x[8] = {ra[t][0].x, ra[t][0].y, ra[t][0].z, ra[t][0].w, ra[t][1].x, ra[t][1].y, ra[t][1].z, ra[t][1].w};
+      uint4 hi, lo;
+      w_cut8(x, sA, hi, lo);
+      *reinterpret_cast<uint4*>(smem + t * kBuf + soffA) = hi;
+      *reinterpret_cast<uint4*>(smem + t * kBuf + soffA + OpA::PLANE) = lo;
+    }
+    MAPX_W8_ALOAD(0, 0, 2); MAPX_W8_ALOAD(0, 1, 2);
+    MAPX_W8_ALOAD(1, 0, 3); MAPX_W8_ALOAD(1, 1, 3);
+  }
+  __syncthreads();
+  f16x8 fa0[2][WMT];                                       // [piece hi / lo][A row tile]: first k16 half of a tile
+#pragma unroll
+  for (int i = 0; i < WMT; ++i) {
+    fa0[1][i] = OpA::frag1(smem, 1, lane, 0, i);
+    fa0[0][i] = OpA::frag1(smem, 0, lane, 0, i);
+  }
+
+  // K-step kt on LDS buffer CUR = kt & 3 = B set: 12 slots (k16 half h, A tile i, term).  Every wave: tile kt's second
+  // half fragments in slots 0..3, tile kt + 1's first half in slots 7..10 (over the registers of tile kt's, whose
+  // MFMAs are slots 0..5), the 4 loads of B's K-step kt + 3 in slots 4..7 (into the set K-step kt - 1 used: three
+  // K-steps of latency — the planes of a long K do not fit L2).  Staging waves also: the 8 units of the cut of their
+  // chunk of tile kt + 2 in slots 0..7, its two LDS stores in slots 8, 9, its registers re-loaded with tile kt + 4 in
+  // slots 1 and 10.
+  constexpr int kNM = 6 * WMT;
+#define MAPX_W8_UNIT(CUR, u)                                                                           \
+  do {                                                                                                 \
+    constexpr int pg_ = (u) / 4, st_ = (u) % 4;                                                        \
+    if (st_ == 0) {                                                                                    \
+      const float4 v_ = ra[(CUR) & 1][pg_];                                                            \
+      w_unit0(v_.x, v_.y, v_.z, v_.w, sA, cr);                                                         \
+    }                                                                                                  \
+    if (st_ == 1) w_unit1(cr, cH[2 * pg_], cH[2 * pg_ + 1]);                                           \
+    if (st_ == 2) w_unit2(cr, cH[2 * pg_], cH[2 * pg_ + 1], k2048);                                    \
+    if (st_ == 3) w_unit3(cr, k2048, cL[2 * pg_], cL[2 * pg_ + 1]);                                    \
+  } while (0)
+#define MAPX_W8_KSTEP(CUR, kt, STG)                                                                    \
+  do {                                                                                                 \
+    const f16_t* const As_cur = smem + (CUR) * kBuf;                                                   \
+    const f16_t* const As_n1 = smem + (((CUR) + 1) & 3) * kBuf;                                        \
+    f16_t* const As_n2 = smem + (((CUR) + 2) & 3) * kBuf;                                              \
+    f16x8 fa1[2][WMT];                                                                                 \
+    uint32_t cH[4], cL[4];                                                                             \
+    CutRegs cr;                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    unroll_seq([&](auto zc) __attribute__((always_inline)) {                                           \
+      constexpr int z = decltype(zc)::value;                                                           \
+      constexpr int h = z / 6, i = (z % 6) / 3, term = z % 3;                                          \
+      const f16x8 bh_ = __builtin_bit_cast(f16x8, fb[CUR][h][0]), bl_ = __builtin_bit_cast(f16x8, fb[CUR][h][1]); \
+      const f16x8 ah_ = h == 0 ? fa0[0][i] : fa1[0][i], al_ = h == 0 ? fa0[1][i] : fa1[1][i];          \
+      if (!(MAPX_W8_ABLATE & 4)) {                                                                     \
+        if (term == 0) cor[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al_, bh_, cor[i], 0, 0, 0);     \
+        if (term == 1) cor[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bl_, cor[i], 0, 0, 0);     \
+        if (term == 2) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bh_, acc[i], 0, 0, 0);     \
+      }                                                                                                \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+      if constexpr (z < 4 && !(MAPX_W8_ABLATE & 32)) {                                                 \
+        constexpr int pl = 1 - (z & 1), t = z >> 1;                                                    \
+        fa1[pl][t] = OpA::frag1(As_cur, pl, lane, 1, t);                                               \
+      }                                                                                                \
+      if constexpr (z >= 7 && z < 11 && !(MAPX_W8_ABLATE & 32)) {   /* (the first half's MFMAs are slots 0..5) */ \
+        constexpr int q = z - 7, pl = 1 - (q & 1), t = q >> 1;                                         \
+        fa0[pl][t] = OpA::frag1(As_n1, pl, lane, 0, t);                                                \
+      }                                                                                                \
+      if constexpr (z >= 4 && z < 8 && !(MAPX_W8_ABLATE & 1)) MAPX_W8_BLOAD1(((CUR) + 3) & 3, z - 4, (kt) + 3); \
+      if constexpr (STG) {                                                                             \
+        if constexpr (z < 8 && !(MAPX_W8_ABLATE & 2)) MAPX_W8_UNIT(CUR, z);                            \
+        if constexpr (z == 8 && !(MAPX_W8_ABLATE & 8)) *reinterpret_cast<uint4*>(As_n2 + soffA) = make_uint4(cH[0], cH[1], cH[2], cH[3]); \
+        if constexpr (z == 9 && !(MAPX_W8_ABLATE & 8)) *reinterpret_cast<uint4*>(As_n2 + soffA + OpA::PLANE) = make_uint4(cL[0], cL[1], cL[2], cL[3]); \
+        if constexpr (z == 1 && !(MAPX_W8_ABLATE & 16)) MAPX_W8_ALOAD((CUR) & 1, 0, (kt) + 4);         \
+        if constexpr (z == 10 && !(MAPX_W8_ABLATE & 16)) MAPX_W8_ALOAD((CUR) & 1, 1, (kt) + 4);        \
+      }                                                                                                \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+    }, std::make_integer_sequence<int, kNM>{});                                                        \
+    if (!(MAPX_W8_ABLATE & 64)) __syncthreads();                                                       \
+  } while (0)
+#define MAPX_W8_LOOP(STG)                                                                              \
+  do {                                                                                                 \
+    int kt = 0;                                                                                        \
+    for (; kt + 3 < nk; kt += 4) {                                                                     \
+      MAPX_W8_KSTEP(0, kt, STG);                                                                       \
+      MAPX_W8_KSTEP(1, kt + 1, STG);                                                                   \
+      MAPX_W8_KSTEP(2, kt + 2, STG);                                                                   \
+      MAPX_W8_KSTEP(3, kt + 3, STG);                                                                   \
+    }                                                                                                  \
+    if (kt < nk) { MAPX_W8_KSTEP(0, kt, STG); ++kt; }                                                  \
+    if (kt < nk) { MAPX_W8_KSTEP(1, kt, STG); ++kt; }                                                  \
+    if (kt < nk) { MAPX_W8_KSTEP(2, kt, STG); ++kt; }                                                  \
+  } while (0)
+  if (stager) MAPX_W8_LOOP(true);
+  else MAPX_W8_LOOP(false);
+#undef MAPX_W8_LOOP
+#undef MAPX_W8_KSTEP
+#undef MAPX_W8_UNIT
+#undef MAPX_W8_ALOAD
+#undef MAPX_W8_BLOAD1
+  if (MAPX_W8_ABLATE & 64) __syncthreads();
+
+  float* const tile = reinterpret_cast<float*>(smem_raw);
+  constexpr int LDT = BN + 4;
+  const int dn = -(na + nb);
+#pragma unroll
+  for (int i = 0; i < WMT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      tile[(32 * i + 4 * kh + (r & 3) + 8 * (r >> 2)) * LDT + 32 * wave + l31] =
+          __builtin_ldexpf(__builtin_fmaf(cor[i][r], 0x1p-11f, acc[i][r]), dn);
+  __syncthreads();
+  epilogue_dispatch<BM, BN, NT>(a, a.C, tile, m0, n0);
+}
+
+static hipError_t launch_h2w8(const GemmX3Args& g, const void* planes, hipStream_t stream) {
+  constexpr size_t ops = (size_t)4 * OperandA<64, 256>::LDS_ELEMS * sizeof(f16_t);
+  constexpr size_t epi = ((size_t)64 * (256 + 4) + 4 * 512) * sizeof(float);
+  constexpr size_t lds = ops > epi ? ops : epi;
+  static hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32h2w8_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (raised != hipSuccess) return raised;
+  hipLaunchKernelGGL(gemm_f32h2w8_kernel, dim3(g.tiles_m * g.tiles_n), dim3(512), lds, stream, g,
+                     static_cast<const unsigned char*>(planes));
+  return hipSuccess;
+}
+
 template <int WMT>
 static hipError_t launch_h2w(const GemmX3Args& g, const void* planes, hipStream_t stream) {
   constexpr int BN = WMT == 4 ? 128 : 64;
@@ -373,6 +570,13 @@ bool gemm_f32h2w_try(GemmX3Args& g, int a_kc, bool vec, const void* planes, int 
   static const bool narrow = [] { const char* e = getenv("MAPX_GEMM_H2W_NARROW"); return !e || atoi(e) != 0; }();
   if (!on || !planes || !a_kc || !vec || nsplit != 1 || batch != 1 || !g.amax_a) return false;
   if (g.K < 2 * kXBK || g.K % 8 != 0 || (uintptr_t)planes % 16 != 0) return false;
+  static const bool eight = [] { const char* e = getenv("MAPX_GEMM_H2W8"); return !e || atoi(e) != 0; }();
+  if (eight && ceil_div(g.M, 64) * ceil_div(g.N, 256) >= 128) {     // 64 x 256 tiles by 8 waves
+    g.tiles_m = (int)ceil_div(g.M, 64);
+    g.tiles_n = (int)ceil_div(g.N, 256);
+    *err = launch_h2w8(g, planes, stream);
+    return true;
+  }
   g.tiles_m = (int)ceil_div(g.M, 128);
   if (ceil_div(g.M, 128) * ceil_div(g.N, 128) >= 128) {
     g.tiles_n = (int)ceil_div(g.N, 128);

@@ -199,6 +199,18 @@ __device__ inline void epilogue_rows_x3(const GemmX3Args& a, float* __restrict__
   if (a.amax_c) amax_publish_block(a.amax_c, amx, a.epoch);
 }
 
+// Partial rows of an epilogue's column sums (RELU_MASK_COLSUM, BWD_FUSED): out2 has one row per 64 rows of C,
+// ceil(M / 64) in all, and every one is written: a 64-row tile writes its own, a 128-row tile its sum into the first
+// of its two and zeros into the second (when that row exists) — the sum over the partial rows does not depend on which
+// kernel ran.
+template <int BM>
+__device__ inline void partial_row_store(const GemmX3Args& a, int m0, int n, float4 sum) {
+  static_assert(BM == 64 || BM == 128, "tile height");
+  float* const dst = a.out2 + (int64_t)(m0 / 64) * a.ldo2 + n;
+  *reinterpret_cast<float4*>(dst) = sum;
+  if (BM == 128 && m0 + 64 < a.M) *reinterpret_cast<float4*>(dst + a.ldo2) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // The same pass for 16-byte-aligned operands, without control flow between a load and its use: a thread's
 // column never changes (NT is a multiple of BN / 4), so the bias is fetched once; rows go in batches of
 // four whose auxiliary operands are all requested before the first of them is used; rows past M re-read
@@ -259,7 +271,7 @@ __device__ inline void epilogue_rows_x3_vec(const GemmX3Args& a, float* __restri
   if (a.amax_c) amax_publish_block(a.amax_c, amx, a.epoch);
   if (kColsum) {
     // column sums of the tile's (masked) rows: the RPI threads of a column group meet in LDS behind the
-    // fp32 tile and are added in a fixed order; one partial row per 128-row tile, summed later
+    // fp32 tile and are added in a fixed order; partial rows (partial_row_store), summed later
     float4* const red = reinterpret_cast<float4*>(const_cast<float*>(tile) + BM * LDT);
     red[r0 * CPR + threadIdx.x % CPR] = csum;
     __syncthreads();
@@ -270,7 +282,7 @@ __device__ inline void epilogue_rows_x3_vec(const GemmX3Args& a, float* __restri
         const float4 q = red[k * CPR + threadIdx.x % CPR];
         t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
       }
-      *reinterpret_cast<float4*>(a.out2 + (int64_t)(m0 / 128) * a.ldo2 + n) = t;
+      partial_row_store<BM>(a, m0, n, t);
     }
   }
 }
@@ -279,14 +291,14 @@ __device__ inline void epilogue_rows_x3_vec(const GemmX3Args& a, float* __restri
 // Epilogue of mapx_gemm_f32_bwd_fused (include/mapx_hip.h): the elementwise backward that follows a dX GEMM in
 // DCNv2's backward pass, done on the tile while it is in LDS instead of by one more launch on the chain:
 //   v = acc (+ add);   n >= c0:  v = mask > 0 ? v : 0 (ReLU backward);   n < c0:  t = v x0, dx0 (+)= v u (+ v)
-//   C = v;  one partial row per 128-row tile of the column sums of (n >= c0 ? v : t).
+//   C = v;  partial rows (partial_row_store) of the column sums of (n >= c0 ? v : t).
 // Same row pass as epilogue_rows_x3_vec (a thread's four columns never change, rows in batches of four whose
 // operands are all requested before the first is used); 16-byte aligned operands, N and c0 multiples of 4.
 template <int BM, int BN, int NT>
 __device__ inline void epilogue_bwd_fused(const GemmX3Args& a, float* __restrict__ C, const float* __restrict__ tile,
                                           int m0, int n0) {
   constexpr int LDT = BN + 4, CPR = BN / 4, RPI = NT / CPR, NIT = BM / RPI, U = NIT < 4 ? NIT : 4;
-  static_assert(NT % CPR == 0 && BM % RPI == 0 && NIT % U == 0 && BM == 128, "epilogue tiling");
+  static_assert(NT % CPR == 0 && BM % RPI == 0 && NIT % U == 0 && (BM == 128 || BM == 64), "epilogue tiling");
   const int c0 = (threadIdx.x % CPR) * 4, r0 = threadIdx.x / CPR;
   const int n = n0 + c0;
   const bool ncol = n < a.N;
@@ -359,7 +371,7 @@ __device__ inline void epilogue_bwd_fused(const GemmX3Args& a, float* __restrict
       const float4 q = red[k * CPR + threadIdx.x % CPR];
       s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
     }
-    *reinterpret_cast<float4*>(a.out2 + (int64_t)(m0 / 128) * a.ldo2 + n) = s;
+    partial_row_store<BM>(a, m0, n, s);
   }
 }
 
@@ -377,11 +389,11 @@ __device__ inline void epilogue_dispatch(const GemmX3Args& a, float* __restrict_
       case MAPX_EPI_BIAS_CROSS: epilogue_rows_x3_vec<MAPX_EPI_BIAS_CROSS, BM, BN, NT>(a, C, tile, m0, n0); break;
       case MAPX_EPI_ADD: epilogue_rows_x3_vec<MAPX_EPI_ADD, BM, BN, NT>(a, C, tile, m0, n0); break;
       case MAPX_EPI_RELU_MASK: epilogue_rows_x3_vec<MAPX_EPI_RELU_MASK, BM, BN, NT>(a, C, tile, m0, n0); break;
-      case MAPX_EPI_RELU_MASK_COLSUM:
-        if constexpr (BM == 128) epilogue_rows_x3_vec<MAPX_EPI_RELU_MASK_COLSUM, BM, BN, NT>(a, C, tile, m0, n0);
+      case MAPX_EPI_RELU_MASK_COLSUM:       // (launchers: tiles of 128 rows, or 64 x 256)
+        if constexpr (BM == 128 || BN == 256) epilogue_rows_x3_vec<MAPX_EPI_RELU_MASK_COLSUM, BM, BN, NT>(a, C, tile, m0, n0);
         break;
       case MAPX_EPI_BWD_FUSED:
-        if constexpr (BM == 128) epilogue_bwd_fused<BM, BN, NT>(a, C, tile, m0, n0);
+        if constexpr (BM == 128 || BN == 256) epilogue_bwd_fused<BM, BN, NT>(a, C, tile, m0, n0);
         break;
       default: epilogue_rows_x3_vec<MAPX_EPI_NONE, BM, BN, NT>(a, C, tile, m0, n0); break;
     }

@@ -1245,12 +1245,18 @@ def fused_mask_colsum_ok(dy, relu_of):
     return dy.dtype == torch.float32 and relu_of.shape[1] % 4 == 0 and row_sliceable(relu_of)
 
 
+def part_rows(M, dtype=torch.float32):
+    """Partial rows of a column-sum epilogue (EPI_RELU_MASK_COLSUM, mapx_gemm_f32_bwd_fused) over M rows: the fp32
+    kernels write one per 64 rows (tiles of 128 rows: the sum and a row of zeros), the bf16 ones one per 128."""
+    return (M + 63) // 64 if dtype == torch.float32 else (M + 127) // 128
+
+
 def linear_bwd_input(dy, w, out=None, add=None, relu_of=None, colsum_to=None):
     """dX = dY W  (+ add)  or masked by relu_of > 0.  dy [M,N], w [N,K] -> [M,K] (dtype of dy;
     bf16: `add` may be fp32 — the cross tower's running dL/dX0).
     colsum_to (with relu_of; see fused_mask_colsum_ok): the masked result is the upstream ReLU layer's dZ,
-    and its column sums — that layer's bias gradient — leave the same epilogue as one partial row per
-    128-row tile, summed into `colsum_to` by flush_deferred()."""
+    and its column sums — that layer's bias gradient — leave the same epilogue as partial rows (part_rows),
+    summed into `colsum_to` by flush_deferred()."""
     M, Nn = dy.shape
     K = w.shape[1]
     if add is None and relu_of is None and _skinny(Nn, K, w, bwd=True) and dy.dtype == torch.float32 and dy.dim() == 2 \
@@ -1266,7 +1272,7 @@ def linear_bwd_input(dy, w, out=None, add=None, relu_of=None, colsum_to=None):
         epi, aux = N.EPI_ADD, add
     elif relu_of is not None and colsum_to is not None:
         epi, aux = N.EPI_RELU_MASK_COLSUM, relu_of
-        out2 = torch.empty((M + 127) // 128, K, dtype=torch.float32, device=dy.device)
+        out2 = torch.empty(part_rows(M, dy.dtype), K, dtype=torch.float32, device=dy.device)
     elif relu_of is not None:
         epi, aux = N.EPI_RELU_MASK, relu_of
     dx = gemm(dy, w, True, False, M, K, Nn, out=out, epi=epi, aux1=aux, out2=out2)
@@ -1488,7 +1494,7 @@ def gemm_bwd_fused(dy, w, c0, add=None, mask=None, x0=None, u=None, dx0=None, pl
     """v = dy W (+ add) with the elementwise backward that follows it done in the GEMM's epilogue
     (include/mapx_hip.h: mapx_gemm_f32_bwd_fused): columns >= c0 masked by `mask` > 0 (the ReLU layer whose output
     `mask` is), columns < c0 the cross layer's  t = v x0,  dx0 (+)= v u (+ v).  fp32.
-    -> (C [M,N], t [M,c0] | None, dx0 [M,c0] | None, part [ceil(M/128), N]: partial rows of the bias gradients)."""
+    -> (C [M,N], t [M,c0] | None, dx0 [M,c0] | None, part [ceil(M/64), N]: partial rows of the bias gradients)."""
     require_gpu(dy, w)
     M, K = dy.shape
     Nn = w.shape[1]
@@ -1498,7 +1504,7 @@ def gemm_bwd_fused(dy, w, c0, add=None, mask=None, x0=None, u=None, dx0=None, pl
     accumulate = dx0 is not None
     if c0 > 0 and dx0 is None:
         dx0 = torch.empty(M, c0, dtype=torch.float32, device=dev)
-    part = torch.empty((M + 127) // 128, Nn, dtype=torch.float32, device=dev)
+    part = torch.empty(part_rows(M), Nn, dtype=torch.float32, device=dev)
     sd = lambda x: (x.data_ptr(), x.stride(0)) if x is not None else (None, 0)
     # records: C's ReLU-masked columns (>= c0: the deep tower's dZ) and t, the operands of the products that follow
     rec_c = amax_record(dev) if c0 < Nn else None

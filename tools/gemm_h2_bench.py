@@ -60,7 +60,9 @@ if __name__ == "__main__":
         mode, tile = sys.argv[sys.argv.index("once") + 1], int(sys.argv[sys.argv.index("once") + 2])
         M, Nn, K = 4096, 1000, 4096
         A, B = torch.randn(M, K, device="cuda"), torch.randn(Nn, K, device="cuda")
-        kw = dict(amax_a=ops.amax(A), amax_b=ops.amax(B)) if mode == "h2" else {}
+        kw = dict(amax_a=ops.amax(A), amax_b=ops.amax(B)) if mode in ("h2", "h2w") else {}
+        if mode == "h2w":             # (tile must be -1; MAPX_GEMM_H2W8=0: the 4-wave kernel)
+            kw["b_planes"] = ops.h2_weight_planes(B, True, kw["amax_b"])
         out = torch.empty(M, Nn, device="cuda")
         for _ in range(5):
             ops.gemm(A, B, True, True, M, Nn, K, out=out, tile=tile, **kw)
@@ -70,6 +72,10 @@ if __name__ == "__main__":
         for tile in (3, 2):
             for K in (2048, 4096):
                 run(f"K={K}", True, True, 4096, 1000, K, check=False, tile=tile)
+        sys.exit(0)
+    if "ablatew" in sys.argv:         # tools/h2_ablate.sh with H2_ABLATE_W8=1: the weight-planes kernels
+        for K in (2048, 4096):
+            run(f"K={K}", True, True, 4096, 1000, K, check=False)
         sys.exit(0)
     quick = "--quick" in sys.argv
     print("NT 4096 x 1000 x K, bias+relu")
