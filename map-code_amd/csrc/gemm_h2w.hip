@@ -570,8 +570,15 @@ bool gemm_f32h2w_try(GemmX3Args& g, int a_kc, bool vec, const void* planes, int 
   static const bool narrow = [] { const char* e = getenv("MAPX_GEMM_H2W_NARROW"); return !e || atoi(e) != 0; }();
   if (!on || !planes || !a_kc || !vec || nsplit != 1 || batch != 1 || !g.amax_a) return false;
   if (g.K < 2 * kXBK || g.K % 8 != 0 || (uintptr_t)planes % 16 != 0) return false;
-  static const bool eight = [] { const char* e = getenv("MAPX_GEMM_H2W8"); return !e || atoi(e) != 0; }();
-  if (eight && ceil_div(g.M, 64) * ceil_div(g.N, 256) >= 128) {     // 64 x 256 tiles by 8 waves
+  // Opt-in (MAPX_GEMM_H2W8=1, read at every call so that a test can switch it): alone and repeated, the 8-wave
+  // kernel is 5-9 % faster than the 4-wave one on N >= 736 (4096 x 1000 x 1000: 33.0 -> 30.9 us, K = 4096: 110 -> 101);
+  // inside the step, on the step's own operands, its classes measure 3-8 % SLOWER one kernel at a time and the step
+  // does not move (tools/experiments/gemm_h2/RESULTS.md, section 5).
+  const char* const e8 = getenv("MAPX_GEMM_H2W8");
+  const bool eight = e8 && atoi(e8) != 0;
+  // 64 x 256 tiles by 8 waves: where they cover the chip and N fills its 256-column tiles (N = 368 computes 512
+  // columns: slower than the 128-wide tiles, measured)
+  if (eight && ceil_div(g.M, 64) * ceil_div(g.N, 256) >= 128 && ceil_div(g.N, 256) * 256 * 100 <= (int64_t)g.N * 115) {
     g.tiles_m = (int)ceil_div(g.M, 64);
     g.tiles_n = (int)ceil_div(g.N, 256);
     *err = launch_h2w8(g, planes, stream);

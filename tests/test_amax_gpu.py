@@ -171,6 +171,45 @@ def test_gemm_h2_operand_magnitudes(ops):
     assert bool(((out[keep].double() - ref).abs() <= 2e-7 * (A[keep].abs().double() @ B.abs().double().t())).all())
 
 
+@pytest.mark.parametrize("b_kc,M,N,K", [(1, 4096, 1000, 1024), (0, 4096, 1000, 1000), (1, 4100, 736, 368), (0, 8192, 1368, 200)])
+def test_eight_wave_weight_planes_kernel_equals_the_four_wave_one(ops, monkeypatch, b_kc, M, N, K):
+    """gemm_f32h2w8_kernel (64 x 256 tiles by eight waves, opt-in: MAPX_GEMM_H2W8=1) forms the same sums in the same
+    order as the 4-wave kernel: bit-identical C through the plain, the bias + ReLU, the ReLU-mask + column-sum and the
+    fused-backward epilogues; its partial rows (one per 64 rows) and the 4-wave kernel's (sum + zero row per 128)
+    hold the same column sums grouped differently."""
+    from mapx.native import EPI_BIAS_RELU, EPI_RELU_MASK_COLSUM
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(DEV) * 0.3
+    B = (torch.randn((N, K) if b_kc else (K, N), generator=g) / math.sqrt(K)).to(DEV)
+    bias, y = torch.randn(N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+    ra, rb = ops.amax(A), ops.amax(B)
+    pl = ops.h2_weight_planes(B, b_kc, rb)
+    kw = dict(amax_a=ra, amax_b=rb, b_planes=pl)
+    c0 = 368 if N > 368 else 0
+    x0, u = torch.randn(M, max(c0, 4), generator=g).to(DEV), torch.randn(M, max(c0, 4), generator=g).to(DEV)
+    out = {}
+    for arm in ("0", "1"):
+        monkeypatch.setenv("MAPX_GEMM_H2W8", arm)
+        part = torch.full((ops.part_rows(M), N), 7.0, device=DEV)
+        res = [ops.gemm(A, B, True, bool(b_kc), M, N, K, **kw),
+               ops.gemm(A, B, True, bool(b_kc), M, N, K, epi=EPI_BIAS_RELU, bias=bias, **kw),
+               ops.gemm(A, B, True, bool(b_kc), M, N, K, epi=EPI_RELU_MASK_COLSUM, aux1=y, out2=part, **kw), part]
+        if not b_kc:
+            monkeypatch.setattr(ops, "AUTO_AMAX", True)          # (records and planes computed by the wrapper)
+            C, t, dx0, p2 = ops.gemm_bwd_fused(A, B, c0, mask=y, x0=x0 if c0 else None, u=u if c0 else None, plus_v=True)
+            res += [C, t if c0 else C, dx0 if c0 else C, p2]
+        out[arm] = res
+    for k, (a, b) in enumerate(zip(out["0"], out["1"])):
+        if a.shape[0] == ops.part_rows(M) and a.shape[0] != M:          # partial rows
+            assert bool((a[1::2] == 0).all()) and not bool((b[1::2] == 0).all())
+            sa, sb = a.double().sum(0), b.double().sum(0)
+            assert bool(((sa - sb).abs() <= 1e-5 * sa.abs() + 1e-4).all()), k
+        else:
+            assert torch.equal(a, b), k
+    ref = A.double() @ (B.double().t() if b_kc else B.double())
+    assert bool(((out["1"][0].double() - ref).abs() <= 2e-6 * (A.abs().double() @ (B.abs().double().t() if b_kc else B.abs().double())) + 1e-6).all())
+
+
 @pytest.mark.parametrize("b_kc,M,N,K", [(1, 4096, 1000, 1024), (0, 4096, 1000, 736), (1, 4096, 1000, 1000), (1, 4096, 1000, 368),
                                         (0, 4097, 1368, 200), (1, 16384, 130, 72),
                                         (1, 4096, 368, 736), (0, 4096, 368, 1000), (1, 4100, 368, 368)])        # 128 x 64 tiles
