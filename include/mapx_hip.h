@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 43
+#define MAPX_ABI_VERSION 44
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -197,13 +197,30 @@ int mapx_nce_pack_idx(const int64_t* targets, const int64_t* noise, int64_t T, i
  * acc_out[1] (# targets ranked first).
  * hpos_opt != NULL (grouped encoder, P = 32): `enc` is h_slots [slots, P] and target t reads
  * slot hpos_opt[t]; dh_slots_opt then also receives dh at the slot (for mapx_enc_grouped_dw). */
+/* The lazy-AdamW state of the rows `emb` / `bias` name (mapx_table_adam's arguments of the same names): with it the
+ * forward reads every sampled row THROUGH its pending zero-gradient updates — last[row] beside the row and, when the
+ * row is stale, its moments; the gap replayed in registers with the arithmetic mapx_table_adam's catch-up would have
+ * used (bit-identical) — and writes nothing: no catch-up pass before the forward, and the gradient update that ends
+ * the step is the row's only read-modify-write (reference: every row is updated every step, trainer.py:328 over
+ * index_linear.py:99-102's table).  coef_opt: mapx_replay_coef_table's output for the same *done (else the closed
+ * form's coefficients are derived from `aux` at every stale access).  P = 32 and K + 1 <= 32 only. */
+typedef struct mapx_lazy_rows {
+  const float* m0; const float* v0; int64_t ld_mv0; float wd0;
+  const float* m1; const float* v1; int64_t ld_mv1; float wd1;   /* the scalar table's (bias), or NULL */
+  const int32_t* last;
+  const float* sched; int sched_len;
+  const int32_t* done;
+  const double* aux; int aux_len; int aux_rows;
+  double beta1, beta2, eps;
+  const float* coef_opt;
+} mapx_lazy_rows;
 size_t mapx_nce_fwd_workspace_bytes(void);
 int mapx_nce_fwd(const float* enc, int64_t B, int L, int F, int P, const int64_t* masked_index,
                  const int32_t* idx, int K, const float* emb, const float* bias,
                  const float* logq, int64_t V, float* h_out, float* dlogit, float* dh,
                  float* logits_opt, float* loss_out, int32_t* acc_out, void* ws, size_t ws_bytes,
                  const int32_t* hpos_opt, float* dh_slots_opt, int* partials_left_opt, void* amax_dh_opt,
-                 hipStream_t stream);
+                 const mapx_lazy_rows* lazy_opt, hipStream_t stream);
 /* amax_dh_opt: magnitude record of dh (and dh_slots: the same values), for mapx_enc_grouped_dw.
  * partials_left_opt != NULL: the loss / accuracy totals are NOT formed by this call (loss_out / acc_out stay
  * unwritten); *partials_left_opt receives the number of per-block partials left in `ws`, which the caller keeps alive
@@ -494,6 +511,12 @@ int mapx_step_advance(int32_t* done, int64_t* cursor_opt, int64_t cursor_stride,
  * ld_mv0 / ld_mv1: row strides (floats) of m0, v0 / m1, v1 — W0 / 1 for separate dense arrays; a row's two
  * moments side by side in one record: v0 = m0 + W0 with ld_mv0 = 2 W0, v1 = m1 + 1 with ld_mv1 = 2 (random rows
  * cost per access, not per byte: 2 random places per row instead of 3). */
+/* The closed form's per-row coefficients for every gap that ends at *done, tabulated once per step for the readers
+ * that replay rows in registers (mapx_lazy_rows.coef_opt): coef [2][aux_len][12] f32 (decayed | undecayed;
+ * {P_e/P_s, beta1^n, beta2^n, T_0..T_6, 0, 0} at index `from`), entries from < *done written.  aux_rows = 17. */
+size_t mapx_replay_coef_table_bytes(int aux_len);
+int mapx_replay_coef_table(const double* aux, int aux_len, int aux_rows, double beta1, double beta2,
+                           const int32_t* done, float* coef, hipStream_t stream);
 int mapx_table_adam(float* p0, float* m0, float* v0, int64_t ld_mv0, int W0, float wd0, float* p1, float* m1,
                     float* v1, int64_t ld_mv1, float wd1, int32_t* last, const int32_t* rows, int64_t row_begin,
                     int64_t n_rows, const int32_t* n_rows_dev, const float* grad0,

@@ -11,6 +11,7 @@
 #include "../../include/mapx_hip.h"
 #include "amax.h"
 #include "common.h"
+#include "lazy_adam.h"
 #include "segreduce.h"
 
 namespace mapx {
@@ -163,6 +164,9 @@ __global__ void __launch_bounds__(256) nce_fwd_kernel(
 // for 8 rows) that leaves row j's score in lane j%8 — the lane that also loaded that row's
 // bias and log q — so logit, loss term and gradient are computed once per row, not once
 // per lane.
+// LAZY: the table rows are read through their pending zero-gradient updates (lazy_adam.h: LazyRows) — last[id] beside
+// the id's bias, the m | v record of a stale row beside the row, the gap replayed in registers; nothing is written.
+template <bool LAZY>
 __global__ void __launch_bounds__(256) nce_fwd_p32_kernel(
     const float* __restrict__ enc, int64_t enc_stride, const int64_t* __restrict__ masked_index,
     int L, const int32_t* __restrict__ idx, int64_t T, int K1, const float* __restrict__ emb,
@@ -170,8 +174,9 @@ __global__ void __launch_bounds__(256) nce_fwd_p32_kernel(
     float invT, float* __restrict__ h_out, float* __restrict__ dlogit, float* __restrict__ dh,
     float* __restrict__ logits, float* __restrict__ loss_partial, int* __restrict__ acc_partial,
     const int32_t* __restrict__ hpos, float* __restrict__ dh_slots, amax_rec* __restrict__ amax_dh,
-    const int32_t* __restrict__ epoch) {
+    const int32_t* __restrict__ epoch, LazyRows lz) {
   constexpr int LG = 8, P = 32, GPB = 256 / LG, MAXB = 4;   // up to 32 rows per target
+  const int target = LAZY ? *lz.done : 0;
   uint32_t amx = 0;                                          // max |dh| (the grouped encoder's weight gradient reads it)
   const int lane = threadIdx.x & 63;
   const int sub = lane & 7, gbase = lane & ~7;
@@ -191,10 +196,20 @@ __global__ void __launch_bounds__(256) nce_fwd_p32_kernel(
       const int j = 8 * c + sub;
       myid[c] = j < K1 ? ix[j] : 0;
     }
+    int myfrom[MAXB];                                   // LAZY: updates already applied to row myid[c]
 #pragma unroll
     for (int c = 0; c < MAXB; ++c) {
       mybq[c] = bias[myid[c]];
       mylq[c] = logq[myid[c]];
+      myfrom[c] = LAZY ? lz.last[myid[c]] : 0;
+    }
+    if (LAZY && lz.m1) {
+#pragma unroll
+      for (int c = 0; c < MAXB; ++c)
+        if (myfrom[c] >= 0 && myfrom[c] < target) {
+          const float m1 = lz.m1[(int64_t)myid[c] * lz.ld_mv1], v1 = lz.v1[(int64_t)myid[c] * lz.ld_mv1];
+          lazy_replay1(lz, mybq[c], m1, v1, myfrom[c], target);
+        }
     }
     float4 dh4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float loss_l = 0.f, smax_l = -INFINITY, s0 = 0.f;
@@ -202,14 +217,30 @@ __global__ void __launch_bounds__(256) nce_fwd_p32_kernel(
     for (int c = 0; c < MAXB; ++c) {
       if (8 * c >= K1) break;
       float4 r[8];
+      int rid[8], fr[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int id = __shfl(myid[c], gbase + u, kWave);
-        r[u] = *reinterpret_cast<const float4*>(emb + (int64_t)id * P + 4 * sub);
+        rid[u] = __shfl(myid[c], gbase + u, kWave);
+        fr[u] = LAZY ? __shfl(myfrom[c], gbase + u, kWave) : 0;
+        r[u] = *reinterpret_cast<const float4*>(emb + (int64_t)rid[u] * P + 4 * sub);
+      }
+      if (LAZY) {
+        // the stale rows' moments, all requested before the first replay
+        float4 m[8], v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (fr[u] >= 0 && fr[u] < target) {
+            m[u] = *reinterpret_cast<const float4*>(lz.m0 + (int64_t)rid[u] * lz.ld_mv0 + 4 * sub);
+            v[u] = *reinterpret_cast<const float4*>(lz.v0 + (int64_t)rid[u] * lz.ld_mv0 + 4 * sub);
+          }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (fr[u] >= 0 && fr[u] < target) lazy_replay4(lz, r[u], m[u], v[u], fr[u], target);
       }
       float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = h4.x * r[u].x + h4.y * r[u].y + h4.z * r[u].z + h4.w * r[u].w;
+      for (int u = 0; u < 8; ++u)          // (spelled out: both instantiations of this kernel must round alike)
+        v[u] = __builtin_fmaf(h4.w, r[u].w, __builtin_fmaf(h4.z, r[u].z, __builtin_fmaf(h4.y, r[u].y, __fmul_rn(h4.x, r[u].x))));
       // transposing butterfly: after 3 steps lane `sub` holds the full dot product of row `sub`
       float w4[4], w2[2];
 #pragma unroll
@@ -246,7 +277,8 @@ __global__ void __launch_bounds__(256) nce_fwd_p32_kernel(
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const float du = __shfl(d, gbase + u, kWave);     // 0 for rows beyond K1
-        dh4.x += du * r[u].x; dh4.y += du * r[u].y; dh4.z += du * r[u].z; dh4.w += du * r[u].w;
+        dh4.x = __builtin_fmaf(du, r[u].x, dh4.x); dh4.y = __builtin_fmaf(du, r[u].y, dh4.y);
+        dh4.z = __builtin_fmaf(du, r[u].z, dh4.z); dh4.w = __builtin_fmaf(du, r[u].w, dh4.w);
       }
     }
     *reinterpret_cast<float4*>(dh + t * P + 4 * sub) = dh4;
@@ -395,10 +427,27 @@ extern "C" int mapx_nce_fwd(const float* enc, int64_t B, int L, int F, int P,
                             float* h_out, float* dlogit, float* dh, float* logits_opt,
                             float* loss_out, int32_t* acc_out, void* ws, size_t ws_bytes,
                             const int32_t* hpos_opt, float* dh_slots_opt, int* partials_left_opt,
-                            void* amax_dh_opt, hipStream_t stream) {
+                            void* amax_dh_opt, const mapx_lazy_rows* lazy_opt, hipStream_t stream) {
   MAPX_REQUIRE(enc && masked_index && idx && emb && bias && logq && h_out && dlogit && dh &&
                    loss_out && acc_out && ws,
                "nce_fwd: null pointer");
+  mapx::LazyRows lz{};
+  if (lazy_opt) {
+    const mapx_lazy_rows& q = *lazy_opt;
+    MAPX_REQUIRE(P == 32 && K + 1 <= 32, "nce_fwd: rows are read through their pending updates for P = 32, K <= 31 only");
+    MAPX_REQUIRE(q.m0 && q.v0 && q.last && q.sched && q.done && q.aux && q.aux_len > 1 && q.sched_len > 0 &&
+                     (!q.m1) == (!q.v1) && q.ld_mv0 >= P && q.ld_mv0 % 4 == 0 && (uintptr_t)q.m0 % 16 == 0 &&
+                     (uintptr_t)q.v0 % 16 == 0 && (!q.m1 || q.ld_mv1 >= 1) && (uintptr_t)q.coef_opt % 16 == 0,
+                 "nce_fwd: incomplete lazy-row state");
+    MAPX_REQUIRE(q.aux_rows == 3 || q.aux_rows == 3 + 2 * (mapx::kJ + 1), "nce_fwd: aux must have 3 or %d rows",
+                 3 + 2 * (mapx::kJ + 1));
+    const double beta = sqrt(q.beta2);
+    lz = mapx::LazyRows{q.m0, q.v0, q.ld_mv0, q.wd0, q.m1, q.v1, q.ld_mv1, q.wd1, q.last,
+                        reinterpret_cast<const float2*>(q.sched), q.sched_len, q.done,
+                        mapx::make_hyper(q.beta1, q.beta2, q.eps),
+                        mapx::ReplayAux{q.aux, q.aux_len, q.aux_rows, q.beta1 / beta, 1.0 / beta},
+                        q.aux_rows > 3 ? q.coef_opt : nullptr};
+  }
   MAPX_REQUIRE(B >= 0 && L >= 1 && F >= 1 && K >= 1 && V > 0, "nce_fwd: bad sizes");
   MAPX_REQUIRE(P == 8 || P == 16 || P == 32 || P == 64 || P == 128,
                "nce_fwd: proj_size %d unsupported (8, 16, 32, 64, 128)", P);
@@ -430,11 +479,16 @@ extern "C" int mapx_nce_fwd(const float* enc, int64_t B, int L, int F, int P,
     case 2: MAPX_NCE(2); break;
     case 4: MAPX_NCE(4); break;
     case 8:
-      if (K + 1 <= 32)
-        hipLaunchKernelGGL(mapx::nce_fwd_p32_kernel, dim3(grid), dim3(256), 0, stream, enc, enc_stride,
+      if (K + 1 <= 32 && lazy_opt)
+        hipLaunchKernelGGL(mapx::nce_fwd_p32_kernel<true>, dim3(grid), dim3(256), 0, stream, enc, enc_stride,
                            masked_index, L, idx, T, K + 1, emb, bias, logq, lnV, lnK, invT, h_out, dlogit,
                            dh, logits_opt, partial, acc_partial, hpos_opt, dh_slots_opt,
-                           static_cast<mapx::amax_rec*>(amax_dh_opt), mapx::amax_epoch_ptr());
+                           static_cast<mapx::amax_rec*>(amax_dh_opt), mapx::amax_epoch_ptr(), lz);
+      else if (K + 1 <= 32)
+        hipLaunchKernelGGL(mapx::nce_fwd_p32_kernel<false>, dim3(grid), dim3(256), 0, stream, enc, enc_stride,
+                           masked_index, L, idx, T, K + 1, emb, bias, logq, lnV, lnK, invT, h_out, dlogit,
+                           dh, logits_opt, partial, acc_partial, hpos_opt, dh_slots_opt,
+                           static_cast<mapx::amax_rec*>(amax_dh_opt), mapx::amax_epoch_ptr(), lz);
       else
         MAPX_NCE(8);
       break;

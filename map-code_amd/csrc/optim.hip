@@ -27,124 +27,9 @@
 #include "../../include/mapx_hip.h"
 #include "amax.h"
 #include "common.h"
+#include "lazy_adam.h"
 
 namespace mapx {
-
-struct AdamHyper {
-  float beta1, beta2, eps;
-  float one_m_b1, one_m_b2;
-};
-
-__device__ inline void adam_elem(float& p, float& m, float& v, float g, float step, float decay,
-                                 const AdamHyper& h) {
-  m = m * h.beta1 + g * h.one_m_b1;
-  v = v * h.beta2 + (h.one_m_b2 * g) * g;
-  const float denom = sqrtf(v) + h.eps;
-  p = p + ((-step) * m) / denom;   // ATen addcdiv: self + (value * t1) / t2
-  if (decay != 0.f) p = p + (-decay) * p;
-}
-
-// Zero-gradient update (the replayed steps of the lazy tables).  The Adam term uses the
-// hardware sqrt / reciprocal (1 ulp each) instead of the correctly-rounded sequences: the
-// term is <= lr in magnitude, so the deviation from the reference's arithmetic is <= ~1e-7*lr
-// per replayed step, far inside the fp32 parity budget, at a third of the instruction count.
-// Returns true when the Adam term was too small to change p (|term| < 2^-26 |p|: the fp32
-// add is then a no-op, and stays one for all later zero-gradient steps because m shrinks by
-// beta1 per step while sqrt(v) shrinks only by sqrt(beta2)).
-__device__ inline bool adam_elem_zero_grad(float& p, float& m, float& v, float step, float decay,
-                                           const AdamHyper& h) {
-  m = m * h.beta1;
-  v = v * h.beta2;
-  const float denom = __builtin_amdgcn_sqrtf(v) + h.eps;
-  const float term = ((-step) * m) * __builtin_amdgcn_rcpf(denom);
-  const bool dead = fabsf(term) < 1.4901161e-8f * fabsf(p);
-  p = p + term;
-  if (decay != 0.f) p = p + (-decay) * p;
-  return dead;
-}
-
-// Prefix tables for the closed-form tail of a replay (host fp64):
-//   aux[0*len + s] = prod_{i<s} (1 - lr_i * wd)   (wd = the optimizer's weight decay)
-//   aux[1*len + n] = beta1^n,  aux[2*len + n] = beta2^n
-//   aux[(3 + i) * len + s]          = R_i[s] with the optimizer's weight decay, i = 0..kJ
-//   aux[(3 + kJ + 1 + i) * len + s] = R_i[s] without decay                      (see replay_coef)
-struct ReplayAux {
-  const double* t;
-  int len;
-  int rows;          // 3: prefix tables only (iterative replay + closed-form tail); 3 + 2(kJ+1): full closed form
-  double rho;        // beta1 / sqrt(beta2)
-  double inv_beta;   // 1 / sqrt(beta2)
-};
-
-// ---------------------------------------------------------------------------------------------
-// Closed form of n zero-gradient AdamW steps (updates s+1 .. e, n = e - s) on one element:
-//     m_k = b1^k m,  v_k = b2^k v,   p_k = (p_{k-1} - a_u m_k / (sqrt(v_k) + eps)) (1 - d_u),  u = s+k-1
-// with a_u the step size and d_u = lr_u * wd of update u+1.  With r = sqrt(v), beta = sqrt(b2),
-// y = eps / (r + eps) and delta_k = beta^-k - 1 (<= 0.07 while rho^k matters):
-//     1 / (r beta^k + eps) = beta^-k / ((r + eps) (1 + y delta_k)) = beta^-k/(r+eps) * sum_j (-y delta_k)^j
-// so the total Adam displacement is   m / (r + eps) * sum_j (-y)^j T_j,   with per-ROW coefficients
-//     T_j = sum_k a_u rho^k delta_k^j D_k = sum_i C(j,i) (-1)^(j-i) Q_i,      rho = b1 / beta,
-//     Q_i = sum_k a_u (rho beta^-i)^k D_k = q_i [ (P_e / P_s) R_i[s] - q_i^n R_i[e] ],   q_i = rho beta^-i,
-// D_k = prod_{j >= u}^{e-1} (1 - d_j), P = prefix product of (1 - d), and the host fp64 table
-//     R_i[s] = a_s + q_i / (1 - d_s) * R_i[s+1]        (backward recurrence: every quantity is O(a), no
-// underflow and no cancellation however long the gap or the schedule).  kJ + 1 = 7 terms leave a
-// relative error < 0.07^7 = 8e-9 of the displacement for ANY eps/r; against step-by-step replay
-// in fp64 the closed form agrees to 2e-14 (tests: lazy == dense reference AdamW), which is 8
-// orders closer than the reference's own fp32 stepwise rounding.  Cost: O(1) per element instead
-// of up to ~150 replayed steps — the catch-up kernels become HBM-bound.
-constexpr int kJ = 6;
-struct ReplayCoef {
-  float fp, fm, fv;
-  float T[kJ + 1];
-};
-
-__device__ inline void replay_coef(int s, int e, const ReplayAux& ax, bool decayed, ReplayCoef& c) {
-  const int n = e - s;
-  const double* __restrict__ P = ax.t;
-  const double* __restrict__ R = ax.t + (size_t)(3 + (decayed ? 0 : kJ + 1)) * ax.len;
-  const double pr = decayed ? P[e] / P[s] : 1.0;
-  const double b1n = ax.t[ax.len + n], b2n = ax.t[2 * ax.len + n];
-  const double binv_n = 1.0 / sqrt(b2n);                 // beta^-n
-  double Q[kJ + 1];
-  double qi = ax.rho, qn = b1n * binv_n;                 // q_i, q_i^n
-#pragma unroll
-  for (int i = 0; i <= kJ; ++i) {
-    Q[i] = qi * (pr * R[(size_t)i * ax.len + s] - qn * R[(size_t)i * ax.len + e]);
-    qi *= ax.inv_beta;
-    qn *= binv_n;
-  }
-  // T_j = j-th forward difference of Q at 0 (in place)
-#pragma unroll
-  for (int j = 1; j <= kJ; ++j)
-#pragma unroll
-    for (int i = kJ; i >= j; --i) Q[i] -= Q[i - 1];
-#pragma unroll
-  for (int j = 0; j <= kJ; ++j) c.T[j] = (float)Q[j];
-  c.fp = (float)pr;
-  c.fm = (float)b1n;
-  c.fv = (float)b2n;
-}
-
-__device__ inline void replay_elem_closed(float& p, float& m, float& v, const ReplayCoef& c, float eps) {
-  const float den = sqrtf(v) + eps;
-  const float y = eps / den;
-  float poly = c.T[kJ];
-#pragma unroll
-  for (int j = kJ - 1; j >= 0; --j) poly = c.T[j] - y * poly;
-  p = p * c.fp - (m / den) * poly;
-  m *= c.fm;
-  v *= c.fv;
-}
-
-__device__ inline void closed_form_tail(int s, int to, const ReplayAux& ax, bool decayed,
-                                        float& fp, float& fm, float& fv) {
-  const int n = to - s;
-  const int a = s < ax.len ? s : ax.len - 1, b = to < ax.len ? to : ax.len - 1;
-  const int nn = n < ax.len ? n : ax.len - 1;
-  fp = decayed ? (float)(ax.t[b] / ax.t[a]) : 1.f;
-  fm = (float)ax.t[ax.len + nn];
-  fv = (float)ax.t[2 * ax.len + nn];
-}
 
 // SHADOW: also store the updated parameter as bf16 (the weight operand of the bf16 GEMMs,
 // gemm_bf16.hip): the conversion rides on the one pass that touches every parameter anyway.
@@ -251,39 +136,6 @@ struct TableGroup {
   int32_t* last;                                        // [V] updates applied to each row
   int64_t ld_mv0, ld_mv1;                               // row stride (floats) of m0 / v0 and of m1 / v1
 };
-
-// Replay zero-gradient updates (from+1 .. to) on one float4 of a row.
-__device__ inline void replay4(float4& p, float4& m, float4& v, int from, int to,
-                               const float2* __restrict__ sched, int sched_len, float wd,
-                               const AdamHyper& h, const ReplayAux& ax) {
-  if (ax.rows > 3 && to < ax.len) {       // O(1): the whole gap in closed form
-    if (to <= from) return;
-    ReplayCoef c;
-    replay_coef(from, to, ax, wd != 0.f, c);
-    replay_elem_closed(p.x, m.x, v.x, c, h.eps);
-    replay_elem_closed(p.y, m.y, v.y, c, h.eps);
-    replay_elem_closed(p.z, m.z, v.z, c, h.eps);
-    replay_elem_closed(p.w, m.w, v.w, c, h.eps);
-    return;
-  }
-  int s = from;
-  for (; s < to; ++s) {  // update s+1 uses sched[s]
-    const float2 sc = sched[s < sched_len ? s : sched_len - 1];
-    const float decay = sc.y * wd;
-    bool dead = adam_elem_zero_grad(p.x, m.x, v.x, sc.x, decay, h);
-    dead &= adam_elem_zero_grad(p.y, m.y, v.y, sc.x, decay, h);
-    dead &= adam_elem_zero_grad(p.z, m.z, v.z, sc.x, decay, h);
-    dead &= adam_elem_zero_grad(p.w, m.w, v.w, sc.x, decay, h);
-    if (dead) { ++s; break; }
-  }
-  if (s < to) {
-    float fp, fm, fv;
-    closed_form_tail(s, to, ax, wd != 0.f, fp, fm, fv);
-    p.x *= fp; p.y *= fp; p.z *= fp; p.w *= fp;
-    m.x *= fm; m.y *= fm; m.z *= fm; m.w *= fm;
-    v.x *= fv; v.y *= fv; v.z *= fv; v.w *= fv;
-  }
-}
 
 constexpr int kRowBusy = -1;
 
@@ -431,15 +283,6 @@ __global__ void __launch_bounds__(256) table_adam_raw_kernel(TableGroup tg, cons
   }
 }
 
-// betas arrive as doubles: the reference computes (1 - beta) in Python double precision and
-// only then rounds to fp32 (1 - 0.999 != 1 - float(0.999) at the 1e-5 level).
-static AdamHyper make_hyper(double b1, double b2, double eps) {
-  AdamHyper h;
-  h.beta1 = (float)b1; h.beta2 = (float)b2; h.eps = (float)eps;
-  h.one_m_b1 = (float)(1.0 - b1);
-  h.one_m_b2 = (float)(1.0 - b2);
-  return h;
-}
 
 }  // namespace mapx
 
@@ -483,6 +326,41 @@ extern "C" int mapx_step_advance(int32_t* done, int64_t* cursor_opt, int64_t cur
   hipLaunchKernelGGL(mapx::step_advance_kernel, dim3(1), dim3(1), 0, stream, done, cursor_opt, cursor_stride,
                      const_cast<int32_t*>(mapx::amax_epoch_ptr()));
   return mapx::check_launch("step_advance");
+}
+
+namespace mapx {
+// coef[(decayed ? 0 : len) + from] = replay_coef(from, *done) for every from < *done (lazy_adam.h: LazyRows)
+__global__ void __launch_bounds__(256) replay_coef_table_kernel(ReplayAux ax, const int32_t* __restrict__ done,
+                                                                float* __restrict__ coef) {
+  const int to = *done;
+  if (!(ax.rows > 3 && to < ax.len)) return;           // (gaps past the schedule tables: readers replay step by step)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * (int64_t)to;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const bool decayed = i < to;
+    const int from = (int)(decayed ? i : i - to);
+    ReplayCoef c;
+    replay_coef(from, to, ax, decayed, c);
+    float4* q = reinterpret_cast<float4*>(coef + ((size_t)(decayed ? 0 : ax.len) + from) * kCoefFloats);
+    q[0] = make_float4(c.fp, c.fm, c.fv, c.T[0]);
+    q[1] = make_float4(c.T[1], c.T[2], c.T[3], c.T[4]);
+    q[2] = make_float4(c.T[5], c.T[6], 0.f, 0.f);
+  }
+}
+}  // namespace mapx
+
+extern "C" size_t mapx_replay_coef_table_bytes(int aux_len) {
+  return (size_t)2 * (size_t)(aux_len > 0 ? aux_len : 0) * mapx::kCoefFloats * sizeof(float);
+}
+
+extern "C" int mapx_replay_coef_table(const double* aux, int aux_len, int aux_rows, double beta1, double beta2,
+                                      const int32_t* done, float* coef, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(aux && done && coef && aux_len > 1 && (uintptr_t)coef % 16 == 0, "replay_coef_table: bad arguments");
+  MAPX_REQUIRE(aux_rows == 3 + 2 * (kJ + 1), "replay_coef_table: the closed form needs the %d-row tables", 3 + 2 * (kJ + 1));
+  const double beta = sqrt(beta2);
+  const ReplayAux ax{aux, aux_len, aux_rows, beta1 / beta, 1.0 / beta};
+  hipLaunchKernelGGL(replay_coef_table_kernel, dim3(64), dim3(256), 0, stream, ax, done, coef);
+  return check_launch("replay_coef_table");
 }
 
 extern "C" int mapx_table_adam(float* p0, float* m0, float* v0, int64_t ld_mv0, int W0, float wd0, float* p1,

@@ -49,7 +49,7 @@ class RowTable:
     def num_rows(self):
         return self.p0.shape[0]
 
-    def prepare(self, keys_i32, need_plan, defer_plan=False):
+    def prepare(self, keys_i32, need_plan, defer_plan=False, through_replay=False):
         """Called by the forward pass with this step's row ids (repeats allowed).
         * stale rows among them are brought up to date on the current stream, straight from the
           raw id list (ownership by atomicCAS in the kernel): nothing on the critical path
@@ -65,7 +65,12 @@ class RowTable:
         # (it is a read of last[] and nothing else for rows that are current).  Capturing right
         # after a flush (stale == False: first step of an epoch, or after eval / save) otherwise
         # gave a graph whose replays read rows that had missed their zero-gradient updates.
-        if self.lazy is not None and (self.lazy.stale or torch.cuda.is_current_stream_capturing()):
+        # through_replay: the kernel that reads these rows replays a stale row's missing updates in registers
+        # (ops.nce_fwd(lazy=)) and the gradient update that ends the step writes it once — no catch-up pass; what
+        # is refreshed instead is the step's table of replay coefficients (one tiny launch).
+        if self.lazy is not None and through_replay:
+            self.lazy.refresh_coef()
+        elif self.lazy is not None and (self.lazy.stale or torch.cuda.is_current_stream_capturing()):
             self.lazy.catch_up_raw(keys_i32)
         if need_plan and not defer_plan:
             self.plan.start()

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmapx_hip.so")
 
-MAPX_ABI_VERSION = 43
+MAPX_ABI_VERSION = 44
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_CROSS, EPI_ADD, EPI_RELU_MASK, EPI_RELU_MASK_COLSUM = range(7)
 
 _p, _i, _i64, _u64, _f, _d, _sz = (C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double,
@@ -51,7 +51,7 @@ SIGNATURES = {
     "mapx_nce_pack_idx": (_i, [_p, _p, _i64, _i, _i64, _p, _p, _p]),
     "mapx_nce_fwd_workspace_bytes": (_sz, []),
     "mapx_nce_fwd": (_i, [_p, _i64, _i, _i, _i, _p, _p, _i, _p, _p, _p, _i64, _p, _p, _p, _p, _p,
-                          _p, _p, _sz, _p, _p, _p, _p, _p]),
+                          _p, _p, _sz, _p, _p, _p, _p, _p, _p]),
     "mapx_nce_scatter_dh": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p]),
     "mapx_nce_table_grad_workspace_bytes": (_sz, [_i64, _i]),
     "mapx_nce_table_grad": (_i, [_i64, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _sz, _p, _p]),
@@ -118,6 +118,8 @@ SIGNATURES = {
     "mapx_vocab_rank_keys": (_i, [_p, _p, _i64, C.c_int32, _p, _p]),
     "mapx_vocab_assign": (_i, [_p, _p, _p, _p, _i64, C.c_int32, _p, _p, _p, _p, _p]),
     "mapx_vocab_map": (_i, [_p, _p, _p, _p, _i64, _i64, _p, _i64, _p]),
+    "mapx_replay_coef_table_bytes": (_sz, [_i]),
+    "mapx_replay_coef_table": (_i, [_p, _i, _i, _d, _d, _p, _p, _p]),
     "mapx_table_adam": (_i, [_p, _p, _p, _i64, _i, _f, _p, _p, _p, _i64, _f, _p, _p, _i64, _i64, _p, _p, _p, _p,
                              _i, _p, _p, _i, _i, _d, _d, _d, _i, _p]),
 }
@@ -138,6 +140,16 @@ class PlaneTask(C.Structure):
 class GemmScale(C.Structure):
     """mapx_gemm_scale (include/mapx_hip.h): magnitude records of a product's operands and outputs."""
     _fields_ = [("amax_a", _p), ("amax_b", _p), ("amax_c", _p), ("amax_c2", _p), ("b_planes", _p)]
+
+
+class LazyRows(C.Structure):
+    """mapx_lazy_rows (include/mapx_hip.h): the lazy-AdamW state of the table rows a forward kernel reads through
+    their pending zero-gradient updates."""
+    _fields_ = [("m0", _p), ("v0", _p), ("ld_mv0", _i64), ("wd0", _f),
+                ("m1", _p), ("v1", _p), ("ld_mv1", _i64), ("wd1", _f),
+                ("last", _p), ("sched", _p), ("sched_len", _i), ("done", _p),
+                ("aux", _p), ("aux_len", _i), ("aux_rows", _i),
+                ("beta1", _d), ("beta2", _d), ("eps", _d), ("coef_opt", _p)]
 
 
 class MapxError(RuntimeError):

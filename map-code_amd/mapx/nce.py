@@ -70,7 +70,7 @@ class _NceLoss(Function):
         # forms the loss totals, one launch less between the loss and the backward pass
         later = TOTALS_LATER and ops.step_window[0] and ctx.needs_input_grad[0]
         o = ops.nce_fwd(enc.contiguous(), masked_index, idx, emb_w, bias_w.view(-1), logq, F, P,
-                        want_logits=want_logits, totals_later=later)
+                        want_logits=want_logits, totals_later=later, lazy=getattr(idx, "_lazy", None))
         ctx.totals = o["totals"]
         ctx.crit, ctx.F, ctx.P, ctx.K = crit, F, P, idx.shape[1] - 1
         ctx.plan = crit.table.plan
@@ -136,6 +136,13 @@ HEAD_SIDE = os.environ.get("MAPX_HEAD_SIDE", "1") == "1"     # 0.871 vs 0.900 ms
 DEFER_PLAN_JOIN = os.environ.get("MAPX_DEFER_PLAN_JOIN", "1") == "1"    # the dense-encoder head: see _NceLoss.backward
 TOTALS_LATER = os.environ.get("MAPX_TOTALS_LATER", "1") == "1"     # loss totals formed by the head's first backward launch
 LATE_TABLE = os.environ.get("MAPX_LATE_TABLE", "1") == "1"
+# "1": a training step reads the sampled table rows through their pending zero-gradient updates (no catch-up pass; the
+# gradient update is a row's one read-modify-write of the step).  Built, bit-identical, and
+# measured slower on the step it was asked for (one box, tools/ab_env.sh): the loss kernel 19.5 -> 64 us (639 k row
+# accesses per step, 14 % of them stale and nearly all distinct: the replay runs in waves that are 70 % divergent, on
+# the loss's critical path), the update 2 x 12.8 -> 2 x 17.5 us, against the 31-us catch-up pass that ran beside the deep
+# tower's first GEMMs: 0.746 vs 0.730 ms per step.  Hence opt-in.
+LAZY_FOLD = os.environ.get("MAPX_LAZY_FOLD", "0") == "1"
 
 
 class _EncNceLoss(Function):
@@ -154,7 +161,8 @@ class _EncNceLoss(Function):
             ops.stream_wait_event(torch.cuda.current_stream(), ready[0], ready[1])
         later = TOTALS_LATER and ops.step_window[0] and ctx.needs_input_grad[0]      # (see _NceLoss.forward)
         o = ops.nce_fwd(h_slots, masked_index, idx, emb_w, bias_w.view(-1), logq, F, P,
-                        want_logits=want_logits, hpos=groups.hpos, dh_slots=dh_slots, totals_later=later)
+                        want_logits=want_logits, hpos=groups.hpos, dh_slots=dh_slots, totals_later=later,
+                        lazy=getattr(idx, "_lazy", None))
         ctx.totals = o["totals"]
         ctx.crit, ctx.F, ctx.P, ctx.K, ctx.groups, ctx.join = crit, F, P, idx.shape[1] - 1, groups, join
         ctx.plan = crit.table.plan
@@ -343,7 +351,13 @@ class IndexLinear(nn.Module):
         else:
             idx = self.get_noise_index(target)
         need_grad = torch.is_grad_enabled() and self.emb.weight.requires_grad
-        self.table.prepare(idx.view(-1), need_grad, defer_plan=True)
+        # a training step's rows are read through their pending updates by the loss kernel and written once, by the
+        # gradient update; without a gradient (eval) the catch-up pass brings them up to date
+        lazy = self.table.lazy
+        fold = (LAZY_FOLD and need_grad and lazy is not None and lazy.replay_in_readers()
+                and ops.lazy_rows_supported(self.proj_size, idx.shape[1]))
+        self.table.prepare(idx.view(-1), need_grad, defer_plan=True, through_replay=fold)
+        idx._lazy = lazy.lazy_rows() if fold else None
         return idx
 
     def forward_with_encoder(self, target, final, encoder, masked_index, noise_samples=None, groups=None,

@@ -683,10 +683,17 @@ def nce_pack_idx(targets, noise, V, validate=False):
     return idx
 
 
+def lazy_rows_supported(P, K1):
+    """mapx_nce_fwd reads rows through their pending updates (lazy=) for this proj_size / sample count."""
+    return P == 32 and K1 <= 32
+
+
 def nce_fwd(enc, masked_index, idx, emb, bias, logq, F, P, want_logits=False, hpos=None, dh_slots=None,
-            totals_later=False):
+            totals_later=False, lazy=None):
     """-> dict(loss [2] = {mean loss, accuracy}, acc [1] i32, h [T,P], dlogit [T,K+1], dh [T,P], logits or None).
     hpos (grouped encoder): `enc` is h_slots [slots,P]; dh_slots receives dh at the slots too.
+    lazy (a native.LazyRows: optim.TableAdam.lazy_rows()): emb / bias rows are read through their pending
+    zero-gradient updates — no catch-up pass ran before this call.
     totals_later: loss / acc are left UNWRITTEN and out["totals"] = (partials buffer, count, loss, acc) goes to the
     nce_scatter_dh that must follow (the head's backward inside a training step)."""
     require_gpu(enc, masked_index, idx, emb, bias, logq)
@@ -710,7 +717,8 @@ def nce_fwd(enc, masked_index, idx, emb, bias, logq, F, P, want_logits=False, hp
                                ptr(emb), ptr(bias), ptr(logq), emb.shape[0], ptr(out["h"]),
                                ptr(out["dlogit"]), ptr(out["dh"]), ptr(out["logits"]), ptr(out["loss"]),
                                ptr(out["acc"]), ptr(ws), ws.numel(), ptr(hpos), ptr(dh_slots),
-                               None if left is None else native_byref(left), ptr(rec), stream()))
+                               None if left is None else native_byref(left), ptr(rec),
+                               None if lazy is None else native_byref(lazy), stream()))
     tag(dh_slots, rec)
     tag(out["dh"], rec)
     out["totals"] = (ws, left.value, out["loss"], out["acc"]) if (left is not None and left.value > 0) else None
@@ -1839,6 +1847,18 @@ def step_advance(done, cursor=None, stride=0):
     if cursor is not None and (cursor.dtype != torch.int64 or not cursor.is_cuda):
         raise TypeError("step_advance: the cursor is an int64 device scalar")
     check(lib.mapx_step_advance(ptr(done), ptr(cursor), int(stride), stream()))
+
+
+def replay_coef_table(aux, beta1, beta2, done, coef=None):
+    """The closed-form replay's coefficients for every gap ending at *done (include/mapx_hip.h:
+    mapx_replay_coef_table) -> coef [2, aux_len, 12] f32 (allocated once by the caller, rewritten every step)."""
+    require_gpu(aux, done)
+    if coef is None:
+        coef = torch.zeros(lib.mapx_replay_coef_table_bytes(aux.shape[1]) // 4, dtype=torch.float32, device=aux.device)
+    with _timed("replay_coef_table", 0.0):
+        check(lib.mapx_replay_coef_table(ptr(aux), aux.shape[1], aux.shape[0], beta1, beta2, ptr(done), ptr(coef),
+                                         stream()))
+    return coef
 
 
 def table_adam(p0, m0, v0, wd0, last, sched, done, aux, beta1, beta2, eps, p1=None, m1=None, v1=None,

@@ -77,6 +77,31 @@ class TableAdam:
     def catch_up(self, plan):
         self._call(rows=plan.uniq, n_rows=plan.n, n_rows_dev=plan.n_uniq)
 
+    def replay_in_readers(self):
+        """The closed form is tabulated (17-row aux): a forward kernel may read rows through their pending updates."""
+        return self.aux.shape[0] > 3
+
+    def refresh_coef(self):
+        """This step's replay coefficients (ops.replay_coef_table) for the kernels that take lazy_rows()."""
+        self.coef = ops.replay_coef_table(self.aux, self.b1, self.b2, self.done, getattr(self, "coef", None))
+
+    def lazy_rows(self):
+        """native.LazyRows over this table's state (include/mapx_hip.h: mapx_lazy_rows)."""
+        from . import native as N
+        if getattr(self, "coef", None) is None:
+            self.refresh_coef()
+        lz = N.LazyRows()
+        lz.m0, lz.v0, lz.ld_mv0, lz.wd0 = self.m0.data_ptr(), self.v0.data_ptr(), self.m0.stride(0), self.wd0
+        if self.m1 is not None:
+            lz.m1, lz.v1, lz.ld_mv1, lz.wd1 = self.m1.data_ptr(), self.v1.data_ptr(), self.m1.stride(0), self.wd1
+        else:
+            lz.m1, lz.v1, lz.ld_mv1, lz.wd1 = None, None, 1, 0.0
+        lz.last, lz.sched, lz.sched_len, lz.done = self.last.data_ptr(), self.sched.data_ptr(), self.sched.shape[0], self.done.data_ptr()
+        lz.aux, lz.aux_len, lz.aux_rows = self.aux.data_ptr(), self.aux.shape[1], self.aux.shape[0]
+        lz.beta1, lz.beta2, lz.eps = self.b1, self.b2, self.eps
+        lz.coef_opt = self.coef.data_ptr()
+        return lz
+
     def catch_up_raw(self, keys_i32):
         """Catch-up straight from a raw id list (repeats allowed; no sort on the critical path)."""
         self._call(rows=keys_i32, n_rows=keys_i32.numel(), rows_may_repeat=True)

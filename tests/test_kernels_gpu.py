@@ -735,6 +735,82 @@ def test_lazy_replay_long_gap_closed_form_tail(ops):
     np.testing.assert_allclose(_cpu(m).numpy(), mr.numpy(), rtol=1e-4, atol=1e-12)
 
 
+@pytest.mark.parametrize("grouped", [False, True])
+def test_nce_forward_reads_rows_through_their_pending_updates(ops, grouped):
+    """mapx_nce_fwd(lazy=): the loss kernel reads every sampled row of the NCE table through its missing
+    zero-gradient updates (last[row], the m | v record, the closed form with this step's tabulated coefficients) and
+    writes nothing.  Bit-identical — loss, logits, dlogit, dh — to the catch-up pass followed by the plain kernel, on a
+    table whose rows are 0 .. 40 updates behind (hot ids current, the bias table included), and the table itself is
+    untouched.  Then the gradient update: from the stale table it leaves the very rows the catch-up + update pair
+    leaves (a row's one read-modify-write of the step)."""
+    from mapx import native as N
+    V, P, K, B, L, F = 3000, 32, 25, 64, 3, 5
+    T_done = 57
+    sched, lambdas = _sched(ops, 200, kind="cosine", warm=10)
+    aux = ops.make_replay_aux(1e-3, lambdas, 0.9, 0.999, 0.05).to(DEV)
+    g = torch.Generator().manual_seed(11)
+    emb = (0.3 * torch.randn(V, P, generator=g)).to(DEV)
+    bias = torch.randn(V, generator=g).to(DEV)
+    mv0 = torch.cat([0.01 * torch.randn(V, P, generator=g), 1e-4 * torch.rand(V, P, generator=g)], 1).to(DEV)
+    mv1 = torch.stack([0.01 * torch.randn(V, generator=g), 1e-4 * torch.rand(V, generator=g)], 1).to(DEV)
+    m0, v0, m1, v1 = mv0[:, :P], mv0[:, P:], mv1[:, 0], mv1[:, 1]
+    last = (T_done - torch.randint(0, 41, (V,), generator=g)).to(torch.int32).to(DEV)
+    last[:50] = T_done                                            # hot ids: current
+    done = torch.full((1,), T_done, dtype=torch.int32, device=DEV)
+    logq = torch.log_softmax(torch.randn(V, generator=g), 0).to(DEV)
+    masked_index = torch.stack([torch.randperm(F, generator=g)[:L] for _ in range(B)]).to(DEV)
+    idx = torch.randint(0, V, (B * L, K + 1), generator=g).to(torch.int32)
+    idx[:, 3] = idx[:, 3] % 50
+    idx = idx.to(DEV)
+    enc = torch.randn(B, F * P, generator=g).to(DEV)
+    kw = {}
+    if grouped:
+        groups = ops.EncGroups(masked_index, F)
+        h_slots = torch.zeros(groups.cap, P, device=DEV)
+        hsel = enc.view(B, F, P)[torch.arange(B, device=DEV)[:, None], masked_index].reshape(B * L, P)
+        h_slots[groups.hpos.long()] = hsel
+        kw = dict(hpos=groups.hpos)
+        src = h_slots
+    else:
+        src = enc
+
+    def fwd(e, b, lazy=None):
+        dh_slots = torch.zeros(groups.cap, P, device=DEV) if grouped else None
+        o = ops.nce_fwd(src, masked_index, idx, e, b, logq, F, P, want_logits=True, lazy=lazy,
+                        dh_slots=dh_slots, **kw)
+        return [o["loss"], o["acc"], o["h"], o["dlogit"], o["dh"], o["logits"]] + ([dh_slots] if grouped else [])
+
+    coef = ops.replay_coef_table(aux, 0.9, 0.999, done)
+    lz = N.LazyRows()
+    lz.m0, lz.v0, lz.ld_mv0, lz.wd0 = m0.data_ptr(), v0.data_ptr(), mv0.stride(0), 0.05
+    lz.m1, lz.v1, lz.ld_mv1, lz.wd1 = m1.data_ptr(), v1.data_ptr(), mv1.stride(0), 0.0
+    lz.last, lz.sched, lz.sched_len, lz.done = last.data_ptr(), sched.data_ptr(), sched.shape[0], done.data_ptr()
+    lz.aux, lz.aux_len, lz.aux_rows = aux.data_ptr(), aux.shape[1], aux.shape[0]
+    lz.beta1, lz.beta2, lz.eps, lz.coef_opt = 0.9, 0.999, 1e-8, coef.data_ptr()
+    before = [t.clone() for t in (emb, bias, mv0, mv1, last)]
+    got = fwd(emb, bias, lazy=lz)
+    for a, b in zip(before, (emb, bias, mv0, mv1, last)):
+        assert torch.equal(a, b)                                  # nothing written
+    # the catch-up pass on copies, then the plain kernel
+    e2, b2, mv0b, mv1b, last2 = [t.clone() for t in before]
+    ta = dict(p1=b2, m1=mv1b[:, 0], v1=mv1b[:, 1], wd1=0.0)
+    ops.table_adam(e2, mv0b[:, :P], mv0b[:, P:], 0.05, last2, sched, done, aux, 0.9, 0.999, 1e-8,
+                   rows=idx.view(-1), rows_may_repeat=True, **ta)
+    assert not torch.equal(e2, emb)
+    want = fwd(e2, b2)
+    for k, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), k
+    # the update: stale table + gradient == caught-up table + gradient
+    uniq = torch.unique(idx.view(-1).long()).to(torch.int32)
+    g0, g1 = 0.05 * torch.randn(uniq.numel(), P, generator=g).to(DEV), 0.05 * torch.randn(uniq.numel(), generator=g).to(DEV)
+    ops.table_adam(emb, m0, v0, 0.05, last, sched, done, aux, 0.9, 0.999, 1e-8, rows=uniq, grad0=g0, grad1=g1,
+                   p1=bias, m1=m1, v1=v1, wd1=0.0)
+    ops.table_adam(e2, mv0b[:, :P], mv0b[:, P:], 0.05, last2, sched, done, aux, 0.9, 0.999, 1e-8, rows=uniq,
+                   grad0=g0, grad1=g1, **ta)
+    for a, b in zip((emb, bias, mv0, mv1, last), (e2, b2, mv0b, mv1b, last2)):
+        assert torch.equal(a, b)
+
+
 def test_errors_are_loud(ops):
     from mapx.native import MapxError
     with pytest.raises(MapxError):
