@@ -17,6 +17,8 @@
 // No float atomics anywhere: sums are bit-reproducible, so data-parallel replicas that
 // apply the same merged gradient stay bit-identical.
 #pragma once
+#include <cstdlib>
+
 #include "common.h"
 
 namespace mapx {
@@ -27,7 +29,10 @@ constexpr int kSegChunk = 32;  // sorted positions per lane group in pass A ...
 // (13.5 us).  The NCE table's 639 k positions lose at 16 (37 -> 48 us: twice the partial rows and owners).
 constexpr int kSegChunkSmall = 16;
 constexpr int64_t kSegSmallN = 1 << 18;
-inline __host__ __device__ int seg_chunk_for(int64_t n) { return n <= kSegSmallN ? kSegChunkSmall : kSegChunk; }
+inline int seg_chunk_for(int64_t n) {
+  static const int64_t small_n = [] { const char* e = getenv("MAPX_SEG_SMALL_N"); return e ? atoll(e) : kSegSmallN; }();
+  return n <= small_n ? kSegChunkSmall : kSegChunk;
+}
 
 struct SegPlanView {
   int64_t n;
@@ -152,6 +157,10 @@ __global__ void __launch_bounds__(256) seg_reduce_pass_a(SegPlanView pl, Contrib
                                                          int32_t* __restrict__ owners,
                                                          int32_t* __restrict__ n_owners) {
   constexpr int NPL = CH / LG;          // entries each lane preloads; BATCH = contributions in flight per walk step
+  __shared__ int wg_owners, wg_base;    // this workgroup's owner chunks: counted in LDS, appended with ONE atomic
+  if (threadIdx.x == 0) wg_owners = 0;
+  __syncthreads();
+  int own_slot = -1;
   contrib.prepare();
   const int WS = EXTRA ? W + 4 : W;
   const int lane = threadIdx.x % kWave;
@@ -234,11 +243,20 @@ __global__ void __launch_bounds__(256) seg_reduce_pass_a(SegPlanView pl, Contrib
     } else {
       dst = part_tail + group * WS;
       dstx = part_tail + group * WS + W;
-      if (sub == 0) owners[atomicAdd(n_owners, 1)] = (int32_t)group;   // this chunk owns a spanning run
+      if (sub == 0) own_slot = atomicAdd(&wg_owners, 1);               // this chunk owns a spanning run
     }
     *reinterpret_cast<float4*>(dst + 4 * sub) = acc;
     if (EXTRA && sub == 0) *dstx = accx;
   }
+  // The owner list through one returning atomic per WORKGROUP (its chunks' owners counted in LDS).  Rounds 1-3: one per
+  // owner chunk, all on the same counter — 4.6 k same-address returning atomics per NCE step = 10 of the kernel's 30 us
+  // (tools/micro/seg_reduce_floor.hip, variants C and D; measured here: 30.0 -> 19.7 us).  One per wave (2.2 k) is as
+  // slow as one per chunk (28.9 us); per-chunk flags instead of a list made this pass as fast (18.5 us) and pass B,
+  // which then visits every chunk, 6-9 us slower.
+  __syncthreads();
+  if (threadIdx.x == 0 && wg_owners > 0) wg_base = atomicAdd(n_owners, wg_owners);
+  __syncthreads();
+  if (own_slot >= 0) owners[wg_base + own_slot] = (int32_t)group;
 }
 
 // One wave per OWNER chunk (listed by pass A): sum = tail[c] + head[c+1] + ... + head[c_last].
