@@ -168,7 +168,11 @@ struct OperandA {
 // 128 x 128 tile by 4 waves of 128 x 32 (WMT = 4), or — products too narrow for 128 of those — 128 x 64 by 2 x 2 waves of
 // 64 x 32 (WMT = 2: the two waves of a column tile read the same B fragments, from L1).  A k-contiguous [M][K]
 // (lda % 4 == 0, 16-byte aligned, K % 8 == 0), B = planes.
-template <int WMT>
+// DEEP: the LDS pipeline one tile deeper — four buffers, tile t in buffer t & 3: K-step kt multiplies tile kt (its first
+// fragments already in registers), reads the first fragments of tile kt + 1 (stored during K-step kt - 1, visible since
+// the barrier that ended it) and stores tile kt + 2, and B runs three K-steps ahead — so that the one wave of a SIMD
+// does not wait out an LDS round trip behind every barrier.  Same sums in the same order.
+template <int WMT, bool DEEP>
 __global__ void __launch_bounds__(256) gemm_f32h2w_kernel(GemmX3Args a, const unsigned char* __restrict__ planes) {
   constexpr int BM = 128, WCOLS = WMT == 4 ? 4 : 2, BN = 32 * WCOLS, NT = 256;
   static_assert(WMT == 4 || WMT == 2, "wave tile 128 x 32 or 64 x 32");
@@ -233,25 +237,62 @@ __global__ void __launch_bounds__(256) gemm_f32h2w_kernel(GemmX3Args a, const un
     la[SET].r[i][hf] = *reinterpret_cast<const float4*>(a.A + goffA[i] + (k_ < a.K ? k_ : 0) + 4 * (hf)); \
   } while (0)
 
-  // prologue: A tiles 0, 1 (tile 0 cut + stored), B sets 0, 1
+  f16x8 fa0[2][WMT];                          // DEEP: [piece hi / lo][A row tile], first k16 half of the running tile
+  if constexpr (!DEEP) {
+    // prologue: A tiles 0, 1 (tile 0 cut + stored), B sets 0, 1
+  #pragma unroll
+    for (int i = 0; i < OpA::NV; ++i) { MAPX_W_ALOAD(0, i, 0, 0); MAPX_W_ALOAD(0, i, 1, 0); }
+  #pragma unroll
+    for (int i = 0; i < OpA::NV; ++i) { MAPX_W_ALOAD(1, i, 0, 1); MAPX_W_ALOAD(1, i, 1, 1); }
+    MAPX_W_BLOAD(0, 0);
+    MAPX_W_BLOAD(1, 1);
+  #pragma unroll
+    for (int i = 0; i < OpA::NV; ++i) {
+      const float x[8] = {la[0].r[i][0].x, la[0].r[i][0].y, la[0].r[i][0].z, la[0].r[i][0].w,
+                          la[0].r[i][1].x, la[0].r[i][1].y, la[0].r[i][1].z, la[0].r[i][1].w};
+      uint4 hi, lo;
+      w_cut8(x, sA, hi, lo);
+      *reinterpret_cast<uint4*>(smem + soffA[i]) = hi;
+      *reinterpret_cast<uint4*>(smem + soffA[i] + OpA::PLANE) = lo;
+    }
+  #pragma unroll
+    for (int i = 0; i < OpA::NV; ++i) { MAPX_W_ALOAD(0, i, 0, 2); MAPX_W_ALOAD(0, i, 1, 2); }
+    __syncthreads();
+  } else {
+    // A tiles 0, 1 cut and stored; B sets 0, 1, 2 and A tiles 2, 3 on their way, requested in the K loop's own order
+    // (per K-step: a B set, then A's chunks) so that the wait counts the compiler merges at the loop head are the
+    // steady state's; then the first fragments of tile 0
 #pragma unroll
-  for (int i = 0; i < OpA::NV; ++i) { MAPX_W_ALOAD(0, i, 0, 0); MAPX_W_ALOAD(0, i, 1, 0); }
+    for (int i = 0; i < OpA::NV; ++i) { MAPX_W_ALOAD(0, i, 0, 0); MAPX_W_ALOAD(0, i, 1, 0); }
 #pragma unroll
-  for (int i = 0; i < OpA::NV; ++i) { MAPX_W_ALOAD(1, i, 0, 1); MAPX_W_ALOAD(1, i, 1, 1); }
-  MAPX_W_BLOAD(0, 0);
-  MAPX_W_BLOAD(1, 1);
+    for (int i = 0; i < OpA::NV; ++i) { MAPX_W_ALOAD(1, i, 0, 1); MAPX_W_ALOAD(1, i, 1, 1); }
+    MAPX_W_BLOAD(0, 0);
 #pragma unroll
-  for (int i = 0; i < OpA::NV; ++i) {
-    const float x[8] = {la[0].r[i][0].x, la[0].r[i][0].y, la[0].r[i][0].z, la[0].r[i][0].w,
-                        la[0].r[i][1].x, la[0].r[i][1].y, la[0].r[i][1].z, la[0].r[i][1].w};
-    uint4 hi, lo;
-    w_cut8(x, sA, hi, lo);
-    *reinterpret_cast<uint4*>(smem + soffA[i]) = hi;
-    *reinterpret_cast<uint4*>(smem + soffA[i] + OpA::PLANE) = lo;
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < OpA::NV; ++i) {
+        const float x[8] = {la[t].r[i][0].x, la[t].r[i][0].y, la[t].r[i][0].z, la[t].r[i][0].w,
+                            la[t].r[i][1].x, la[t].r[i][1].y, la[t].r[i][1].z, la[t].r[i][1].w};
+        uint4 hi, lo;
+        w_cut8(x, sA, hi, lo);
+        *reinterpret_cast<uint4*>(smem + t * kBuf + soffA[i]) = hi;
+        *reinterpret_cast<uint4*>(smem + t * kBuf + soffA[i] + OpA::PLANE) = lo;
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    MAPX_W_BLOAD(1, 1);
+#pragma unroll
+    for (int i = 0; i < OpA::NV; ++i) { MAPX_W_ALOAD(0, i, 0, 2); MAPX_W_ALOAD(0, i, 1, 2); }
+    MAPX_W_BLOAD(2, 2);
+#pragma unroll
+    for (int i = 0; i < OpA::NV; ++i) { MAPX_W_ALOAD(1, i, 0, 3); MAPX_W_ALOAD(1, i, 1, 3); }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < WMT; ++i) {
+      fa0[1][i] = OpA::frag1(smem, 1, lane, 0, tbase + i);
+      fa0[0][i] = OpA::frag1(smem, 0, lane, 0, tbase + i);
+    }
   }
-#pragma unroll
-  for (int i = 0; i < OpA::NV; ++i) { MAPX_W_ALOAD(0, i, 0, 2); MAPX_W_ALOAD(0, i, 1, 2); }
-  __syncthreads();
 
   // K-step kt on LDS buffer CUR = kt & 1, B set BS = kt & 3.  Slots: 6 WMT MFMAs (k16 half h, A tile i, term); the cut
   // of A's tile kt + 1 (2 chunks = 16 units of 4 VALU), kUPS units per slot from slot 0; the second half's 2 WMT A
@@ -260,11 +301,11 @@ __global__ void __launch_bounds__(256) gemm_f32h2w_kernel(GemmX3Args a, const un
   constexpr int kNM = 6 * WMT, kU = 8 * OpA::NV, kUPS = WMT == 4 ? 1 : 2, kFR = 2 * WMT;
   constexpr int kC0 = 8 / kUPS + (WMT == 4 ? 4 : 0), kC1 = 16 / kUPS + (WMT == 4 ? 0 : 0);    // first memory slot of chunk 0 / 1
   static_assert(OpA::NV == 2 && kC1 + 4 <= kNM && kC0 + 4 <= kC1 + 4, "two chunks of A per thread; slots");
-#define MAPX_W_UNIT(CUR, u)                                                                            \
+#define MAPX_W_UNIT(SET, u)                                                                            \
   do {                                                                                                 \
     constexpr int c_ = (u) / 8, pg_ = ((u) % 8) / 4, st_ = (u) % 4;                                    \
     if (st_ == 0) {                                                                                    \
-      const float4 v_ = la[(CUR) ^ 1].r[c_][pg_];                                                      \
+      const float4 v_ = la[SET].r[c_][pg_];                                                             \
       w_unit0(v_.x, v_.y, v_.z, v_.w, sA, cr);                                                         \
     }                                                                                                  \
     if (st_ == 1) w_unit1(cr, cH[c_][2 * pg_], cH[c_][2 * pg_ + 1]);                                   \
@@ -296,8 +337,8 @@ __global__ void __launch_bounds__(256) gemm_f32h2w_kernel(GemmX3Args a, const un
         fa[1][pl][t] = OpA::frag1(As_cur, pl, lane, 1, tbase + t);                                     \
       }                                                                                                \
       if constexpr (z * kUPS < kU) {                                                                   \
-        MAPX_W_UNIT(CUR, z * kUPS);                                                                    \
-        if constexpr (kUPS == 2) MAPX_W_UNIT(CUR, (z * kUPS + 1 < kU ? z * kUPS + 1 : 0));             \
+        MAPX_W_UNIT((CUR) ^ 1, z * kUPS);                                                                  \
+        if constexpr (kUPS == 2) MAPX_W_UNIT((CUR) ^ 1, (z * kUPS + 1 < kU ? z * kUPS + 1 : 0));             \
       }                                                                                                \
       if constexpr (z >= kFR && z < kFR + 4) {    /* B fragments of K-step kt + 2 */                   \
         constexpr int q = z - kFR;                                                                     \
@@ -322,16 +363,87 @@ __global__ void __launch_bounds__(256) gemm_f32h2w_kernel(GemmX3Args a, const un
     __syncthreads();                                                                                   \
   } while (0)
 
+  // DEEP K-step kt on LDS buffer CUR = kt & 3 = B set.  Slots as above, except: the cut is that of tile kt + 2 (register
+  // set kt & 1, re-loaded with tile kt + 4), stored into buffer (CUR + 2) & 3; B's loads are K-step kt + 3's (into the set
+  // K-step kt - 1 used); and behind the first half's MFMAs (slots 0 .. 3 WMT - 1) their fragment registers are re-read
+  // with tile kt + 1's first half from buffer (CUR + 1) & 3.
+  constexpr int kN0 = 3 * WMT;
+#define MAPX_WD_KSTEP(CUR, kt)                                                                         \
+  do {                                                                                                 \
+    const f16_t* const As_cur = smem + (CUR) * kBuf;                                                   \
+    const f16_t* const As_n1 = smem + (((CUR) + 1) & 3) * kBuf;                                        \
+    f16_t* const As_n2 = smem + (((CUR) + 2) & 3) * kBuf;                                              \
+    f16x8 fa1[2][WMT];                            /* [piece hi / lo][A row tile]: second k16 half */   \
+    uint32_t cH[2][4], cL[2][4];                                                                       \
+    CutRegs cr;                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    unroll_seq([&](auto zc) __attribute__((always_inline)) {                                           \
+      constexpr int z = decltype(zc)::value;                                                           \
+      constexpr int h = z / (3 * WMT), i = (z % (3 * WMT)) / 3, term = z % 3;                          \
+      const f16x8 bh_ = __builtin_bit_cast(f16x8, fb[CUR][h][0]), bl_ = __builtin_bit_cast(f16x8, fb[CUR][h][1]);\
+      const f16x8 ah_ = h == 0 ? fa0[0][i] : fa1[0][i], al_ = h == 0 ? fa0[1][i] : fa1[1][i];          \
+      if (term == 0) cor[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al_, bh_, cor[i], 0, 0, 0);       \
+      if (term == 1) cor[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bl_, cor[i], 0, 0, 0);       \
+      if (term == 2) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bh_, acc[i], 0, 0, 0);       \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+      if constexpr (z < kFR) {                    /* second half's A fragments */                      \
+        constexpr int pl = 1 - (z & 1), t = z >> 1;                                                    \
+        fa1[pl][t] = OpA::frag1(As_cur, pl, lane, 1, tbase + t);                                       \
+      }                                                                                                \
+      if constexpr (z >= kN0 && z < kN0 + kFR) {  /* the next tile's first half */                     \
+        constexpr int q = z - kN0, pl = 1 - (q & 1), t = q >> 1;                                       \
+        fa0[pl][t] = OpA::frag1(As_n1, pl, lane, 0, tbase + t);                                        \
+      }                                                                                                \
+      if constexpr (z * kUPS < kU) {                                                                   \
+        MAPX_W_UNIT((CUR) & 1, z * kUPS);                                                              \
+        if constexpr (kUPS == 2) MAPX_W_UNIT((CUR) & 1, (z * kUPS + 1 < kU ? z * kUPS + 1 : 0));       \
+      }                                                                                                \
+      if constexpr (z >= kFR && z < kFR + 4) {    /* B fragments of K-step kt + 3 */                   \
+        constexpr int q = z - kFR;                                                                     \
+        const int tc_ = (kt) + 3 < nk ? (kt) + 3 : nk - 1;                                             \
+        fb[((CUR) + 3) & 3][q >> 1][q & 1] =                                                           \
+            *reinterpret_cast<const u32x4*>(bbase + (int64_t)tc_ * 4096 + q * 1024);                   \
+      }                                                                                                \
+      if constexpr (z >= kC0 && z < kC0 + 4) {                                                         \
+        constexpr int q = z - kC0;                                                                     \
+        if (q < 2) *reinterpret_cast<uint4*>(As_n2 + soffA[0] + q * OpA::PLANE) =                      \
+            q == 0 ? make_uint4(cH[0][0], cH[0][1], cH[0][2], cH[0][3]) : make_uint4(cL[0][0], cL[0][1], cL[0][2], cL[0][3]);\
+        else MAPX_W_ALOAD((CUR) & 1, 0, (q >= 2 ? q - 2 : 0), (kt) + 4);                               \
+      }                                                                                                \
+      if constexpr (z >= kC1 && z < kC1 + 4) {                                                         \
+        constexpr int q = z - kC1;                                                                     \
+        if (q < 2) *reinterpret_cast<uint4*>(As_n2 + soffA[1] + q * OpA::PLANE) =                      \
+            q == 0 ? make_uint4(cH[1][0], cH[1][1], cH[1][2], cH[1][3]) : make_uint4(cL[1][0], cL[1][1], cL[1][2], cL[1][3]);\
+        else MAPX_W_ALOAD((CUR) & 1, 1, (q >= 2 ? q - 2 : 0), (kt) + 4);                               \
+      }                                                                                                \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+    }, std::make_integer_sequence<int, kNM>{});                                                        \
+    __syncthreads();                                                                                   \
+  } while (0)
+
   int kt = 0;
-  for (; kt + 3 < nk; kt += 4) {
-    MAPX_W_KSTEP(0, 0, kt);
-    MAPX_W_KSTEP(1, 1, kt + 1);
-    MAPX_W_KSTEP(0, 2, kt + 2);
-    MAPX_W_KSTEP(1, 3, kt + 3);
+  if constexpr (!DEEP) {
+    for (; kt + 3 < nk; kt += 4) {
+      MAPX_W_KSTEP(0, 0, kt);
+      MAPX_W_KSTEP(1, 1, kt + 1);
+      MAPX_W_KSTEP(0, 2, kt + 2);
+      MAPX_W_KSTEP(1, 3, kt + 3);
+    }
+    if (kt < nk) { MAPX_W_KSTEP(0, 0, kt); ++kt; }
+    if (kt < nk) { MAPX_W_KSTEP(1, 1, kt); ++kt; }
+    if (kt < nk) { MAPX_W_KSTEP(0, 2, kt); ++kt; }
+  } else {
+    for (; kt + 3 < nk; kt += 4) {
+      MAPX_WD_KSTEP(0, kt);
+      MAPX_WD_KSTEP(1, kt + 1);
+      MAPX_WD_KSTEP(2, kt + 2);
+      MAPX_WD_KSTEP(3, kt + 3);
+    }
+    if (kt < nk) { MAPX_WD_KSTEP(0, kt); ++kt; }
+    if (kt < nk) { MAPX_WD_KSTEP(1, kt); ++kt; }
+    if (kt < nk) { MAPX_WD_KSTEP(2, kt); ++kt; }
   }
-  if (kt < nk) { MAPX_W_KSTEP(0, 0, kt); ++kt; }
-  if (kt < nk) { MAPX_W_KSTEP(1, 1, kt); ++kt; }
-  if (kt < nk) { MAPX_W_KSTEP(0, 2, kt); ++kt; }
+#undef MAPX_WD_KSTEP
 #undef MAPX_W_KSTEP
 #undef MAPX_W_UNIT
 #undef MAPX_W_ALOAD
@@ -547,19 +659,28 @@ static hipError_t launch_h2w8(const GemmX3Args& g, const void* planes, hipStream
   return hipSuccess;
 }
 
-template <int WMT>
-static hipError_t launch_h2w(const GemmX3Args& g, const void* planes, hipStream_t stream) {
+template <int WMT, bool DEEP>
+static hipError_t launch_h2w_form(const GemmX3Args& g, const void* planes, hipStream_t stream) {
   constexpr int BN = WMT == 4 ? 128 : 64;
-  constexpr size_t ops = (size_t)2 * OperandA<128, 256>::LDS_ELEMS * sizeof(f16_t);
+  constexpr size_t ops = (size_t)(DEEP ? 4 : 2) * OperandA<128, 256>::LDS_ELEMS * sizeof(f16_t);
   constexpr size_t epi = ((size_t)128 * (BN + 4) + 4 * 256) * sizeof(float);
   constexpr size_t lds = ops > epi ? ops : epi;
-  static hipError_t raised = lds > 65536 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32h2w_kernel<WMT>),
+  static hipError_t raised = lds > 65536 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32h2w_kernel<WMT, DEEP>),
                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
                                          : hipSuccess;
   if (raised != hipSuccess) return raised;
-  hipLaunchKernelGGL(gemm_f32h2w_kernel<WMT>, dim3(g.tiles_m * g.tiles_n), dim3(256), lds, stream, g,
+  hipLaunchKernelGGL((gemm_f32h2w_kernel<WMT, DEEP>), dim3(g.tiles_m * g.tiles_n), dim3(256), lds, stream, g,
                      static_cast<const unsigned char*>(planes));
   return hipSuccess;
+}
+template <int WMT>
+static hipError_t launch_h2w(const GemmX3Args& g, const void* planes, hipStream_t stream) {
+  // Opt-in (read at every call: tests and A/B runs switch it): the deeper pipeline changes nothing on the step's shapes
+  // (4096 x 1000 x 1000: 33.5 vs 33.6 us, 4096 x 368 x 368: 11.9 vs 12.0; K = 4096: 115.6 -> 110.3) and doubles the
+  // operands' LDS (64 KB) — RESULTS.md section 5.
+  const char* const e = getenv("MAPX_GEMM_H2W_DEEP");
+  const bool deep = e && atoi(e) != 0;
+  return deep ? launch_h2w_form<WMT, true>(g, planes, stream) : launch_h2w_form<WMT, false>(g, planes, stream);
 }
 
 // Called by gemm_f32x3_launch (gemm_x3.hip) when the caller handed the weight operand's planes.  false: not this

@@ -173,8 +173,8 @@ def test_gemm_h2_operand_magnitudes(ops):
 
 @pytest.mark.parametrize("b_kc,M,N,K", [(1, 4096, 1000, 1024), (0, 4096, 1000, 1000), (1, 4100, 736, 368), (0, 8192, 1368, 200)])
 def test_eight_wave_weight_planes_kernel_equals_the_four_wave_one(ops, monkeypatch, b_kc, M, N, K):
-    """gemm_f32h2w8_kernel (64 x 256 tiles by eight waves, opt-in: MAPX_GEMM_H2W8=1) forms the same sums in the same
-    order as the 4-wave kernel: bit-identical C through the plain, the bias + ReLU, the ReLU-mask + column-sum and the
+    """gemm_f32h2w8_kernel (64 x 256 tiles by eight waves, opt-in: MAPX_GEMM_H2W8=1) and the 4-wave kernel with the
+    four-buffer LDS pipeline (opt-in: MAPX_GEMM_H2W_DEEP=1) form the same sums in the same order as the 4-wave kernel: bit-identical C through the plain, the bias + ReLU, the ReLU-mask + column-sum and the
     fused-backward epilogues; its partial rows (one per 64 rows) and the 4-wave kernel's (sum + zero row per 128)
     hold the same column sums grouped differently."""
     from mapx.native import EPI_BIAS_RELU, EPI_RELU_MASK_COLSUM
@@ -188,8 +188,9 @@ def test_eight_wave_weight_planes_kernel_equals_the_four_wave_one(ops, monkeypat
     c0 = 368 if N > 368 else 0
     x0, u = torch.randn(M, max(c0, 4), generator=g).to(DEV), torch.randn(M, max(c0, 4), generator=g).to(DEV)
     out = {}
-    for arm in ("0", "1"):
-        monkeypatch.setenv("MAPX_GEMM_H2W8", arm)
+    for arm in ("0", "1", "deep"):          # 4-wave kernel, 8-wave kernel, 4-wave kernel with the four-buffer pipeline
+        monkeypatch.setenv("MAPX_GEMM_H2W8", "1" if arm == "1" else "0")
+        monkeypatch.setenv("MAPX_GEMM_H2W_DEEP", "1" if arm == "deep" else "0")
         part = torch.full((ops.part_rows(M), N), 7.0, device=DEV)
         res = [ops.gemm(A, B, True, bool(b_kc), M, N, K, **kw),
                ops.gemm(A, B, True, bool(b_kc), M, N, K, epi=EPI_BIAS_RELU, bias=bias, **kw),
@@ -199,6 +200,8 @@ def test_eight_wave_weight_planes_kernel_equals_the_four_wave_one(ops, monkeypat
             C, t, dx0, p2 = ops.gemm_bwd_fused(A, B, c0, mask=y, x0=x0 if c0 else None, u=u if c0 else None, plus_v=True)
             res += [C, t if c0 else C, dx0 if c0 else C, p2]
         out[arm] = res
+    for k, (a, b) in enumerate(zip(out["0"], out["deep"])):
+        assert torch.equal(a, b), k
     for k, (a, b) in enumerate(zip(out["0"], out["1"])):
         if a.shape[0] == ops.part_rows(M) and a.shape[0] != M:          # partial rows
             assert bool((a[1::2] == 0).all()) and not bool((b[1::2] == 0).all())
