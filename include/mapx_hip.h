@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 44
+#define MAPX_ABI_VERSION 45
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -372,6 +372,15 @@ int mapx_skinny_linear_dw(const float* dy, int64_t ldy, const float* x, int64_t 
                           int chunks, hipStream_t stream);
 int mapx_skinny_linear_dx(const float* dy, int64_t ldy, const float* w, int64_t ldw, int M, int N, int K, float* dx,
                           int64_t lddx, hipStream_t stream);
+/* bf16 compute mode (configs[2]; the finetune head models.py:304,319 over the bf16 trunk): the same three products on
+ * bf16 activations / gradients and the weight's bf16 operand, N <= 8 outputs; products and sums fp32, y and the weight
+ * gradient's partial rows fp32, dx bf16.  Rows 8-byte aligned (K, ld % 4 == 0). */
+int mapx_skinny_linear_fwd_bf16(const mapx_bf16* x, int64_t ldx, const mapx_bf16* w, int64_t ldw, const float* bias_opt,
+                                int M, int N, int K, int relu, float* y, int64_t ldy, hipStream_t stream);
+int mapx_skinny_linear_dw_bf16(const mapx_bf16* dy, int64_t ldy, const mapx_bf16* x, int64_t ldx, int M, int N, int K,
+                               float* part, int chunks, hipStream_t stream);
+int mapx_skinny_linear_dx_bf16(const mapx_bf16* dy, int64_t ldy, const mapx_bf16* w, int64_t ldw, int M, int N, int K,
+                               mapx_bf16* dx, int64_t lddx, hipStream_t stream);
 /* dL/d(final) of a head of N <= 8 outputs over DCNv2's two towers (the finetune head; reference models.py:304, 319
  * behind models.py:306-318's concat), with both towers' first backward step in the same pass (what
  * mapx_gemm_f32_bwd_fused and mapx_gemm_f32's EPI_RELU_MASK_COLSUM do for wide heads):  v = dz w [M, D+H];

@@ -8,6 +8,7 @@
 //   dX   dx[m, k] = sum_n dy[m, n] w[n, k]                a thread per 4 rows x 4 columns
 // K % 4 == 0, rows 16-byte aligned (host-checked).  Results are plain fp32 sums (not the six-product arithmetic of
 // gemm_x3.hip): closer to the fp64 value, not bit-identical to the GEMM path.
+#include "../../include/mapx_hip.h"
 #include "amax.h"
 #include "common.h"
 
@@ -15,9 +16,27 @@ namespace mapx {
 
 constexpr int kSkinnyChunks = 128;       // row chunks of the weight gradient (= partial rows per output)
 
-template <int NT>
-__global__ void __launch_bounds__(256) skinny_fwd_kernel(const float* __restrict__ x, int64_t ldx,
-                                                         const float* __restrict__ w, int64_t ldw,
+// Element access of the streaming kernels: fp32, or (bf16 compute mode: the finetune head reads the trunk's bf16
+// activations and the weight's bf16 operand) bf16 widened to fp32 — products and sums are fp32 either way, like the
+// bf16 MFMA's.
+typedef __bf16 sk_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ inline float4 sk_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ inline float4 sk_ld4(const __bf16* p) {
+  const sk_bf16x4 v = *reinterpret_cast<const sk_bf16x4*>(p);
+  return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ inline float sk_ld1(const float* p) { return *p; }
+__device__ inline float sk_ld1(const __bf16* p) { return (float)*p; }
+__device__ inline void sk_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ inline void sk_st4(__bf16* p, float4 v) {
+  sk_bf16x4 o;
+  o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+  *reinterpret_cast<sk_bf16x4*>(p) = o;
+}
+
+template <int NT, class T = float>
+__global__ void __launch_bounds__(256) skinny_fwd_kernel(const T* __restrict__ x, int64_t ldx,
+                                                         const T* __restrict__ w, int64_t ldw,
                                                          const float* __restrict__ bias, int M, int N, int K, int relu,
                                                          float* __restrict__ y, int64_t ldy) {
   constexpr int R = 4;
@@ -29,17 +48,17 @@ __global__ void __launch_bounds__(256) skinny_fwd_kernel(const float* __restrict
   for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[r][n] = 0.f;
-  const float* xr[R];
+  const T* xr[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) xr[r] = x + (r0 + r < M ? r0 + r : (int64_t)M - 1) * ldx;
   for (int k = 4 * lane; k < K; k += 256) {
     float4 xv[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) xv[r] = *reinterpret_cast<const float4*>(xr[r] + k);
+    for (int r = 0; r < R; ++r) xv[r] = sk_ld4(xr[r] + k);
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       if (n < N) {
-        const float4 wv = *reinterpret_cast<const float4*>(w + (int64_t)n * ldw + k);
+        const float4 wv = sk_ld4(w + (int64_t)n * ldw + k);
 #pragma unroll
         for (int r = 0; r < R; ++r)
           acc[r][n] += xv[r].x * wv.x + xv[r].y * wv.y + xv[r].z * wv.z + xv[r].w * wv.w;
@@ -71,9 +90,9 @@ __global__ void __launch_bounds__(256) skinny_fwd_kernel(const float* __restrict
   }
 }
 
-template <int NT>
-__global__ void __launch_bounds__(256) skinny_dw_kernel(const float* __restrict__ dy, int64_t ldy,
-                                                        const float* __restrict__ x, int64_t ldx, int M, int N, int K,
+template <int NT, class T = float>
+__global__ void __launch_bounds__(256) skinny_dw_kernel(const T* __restrict__ dy, int64_t ldy,
+                                                        const T* __restrict__ x, int64_t ldx, int M, int N, int K,
                                                         float* __restrict__ part) {
   const int k = 4 * (blockIdx.x * 256 + threadIdx.x);
   const int rows_per = (M + (int)gridDim.y - 1) / (int)gridDim.y;
@@ -83,12 +102,12 @@ __global__ void __launch_bounds__(256) skinny_dw_kernel(const float* __restrict_
 #pragma unroll
   for (int n = 0; n < NT; ++n) acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int m = m0; m < m1; ++m) {
-    const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)m * ldx + k);
-    const float* __restrict__ d = dy + (int64_t)m * ldy;       // the same N values for every thread: one line
+    const float4 xv = sk_ld4(x + (int64_t)m * ldx + k);
+    const T* __restrict__ d = dy + (int64_t)m * ldy;           // the same N values for every thread: one line
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       if (n < N) {
-        const float g = d[n];
+        const float g = sk_ld1(d + n);
         acc[n].x += g * xv.x; acc[n].y += g * xv.y; acc[n].z += g * xv.z; acc[n].w += g * xv.w;
       }
     }
@@ -99,10 +118,10 @@ __global__ void __launch_bounds__(256) skinny_dw_kernel(const float* __restrict_
     if (n < N) *reinterpret_cast<float4*>(p + (int64_t)n * K) = acc[n];
 }
 
-template <int NT>
-__global__ void __launch_bounds__(256) skinny_dx_kernel(const float* __restrict__ dy, int64_t ldy,
-                                                        const float* __restrict__ w, int64_t ldw, int M, int N, int K,
-                                                        float* __restrict__ dx, int64_t lddx) {
+template <int NT, class T = float>
+__global__ void __launch_bounds__(256) skinny_dx_kernel(const T* __restrict__ dy, int64_t ldy,
+                                                        const T* __restrict__ w, int64_t ldw, int M, int N, int K,
+                                                        T* __restrict__ dx, int64_t lddx) {
   constexpr int R = 4;
   const int kq = K / 4;                                        // float4 columns
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -113,23 +132,23 @@ __global__ void __launch_bounds__(256) skinny_dx_kernel(const float* __restrict_
   float4 acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float* dr[R];
+  const T* dr[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) dr[r] = dy + (r0 + r < M ? r0 + r : (int64_t)M - 1) * ldy;
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     if (n < N) {
-      const float4 wv = *reinterpret_cast<const float4*>(w + (int64_t)n * ldw + k);
+      const float4 wv = sk_ld4(w + (int64_t)n * ldw + k);
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const float g = dr[r][n];
+        const float g = sk_ld1(dr[r] + n);
         acc[r].x += g * wv.x; acc[r].y += g * wv.y; acc[r].z += g * wv.z; acc[r].w += g * wv.w;
       }
     }
   }
 #pragma unroll
   for (int r = 0; r < R; ++r)
-    if (r0 + r < M) *reinterpret_cast<float4*>(dx + (r0 + r) * lddx + k) = acc[r];
+    if (r0 + r < M) sk_st4(dx + (r0 + r) * lddx + k, acc[r]);
 }
 
 // Wider layers (8 < N <= 32 outputs: RFD's Linear(736 -> 23)): the weight-gradient kernel above re-reads N gradients
@@ -405,6 +424,56 @@ extern "C" int mapx_skinny_linear_dx(const float* dy, int64_t ldy, const float* 
   if (M == 0) return MAPX_OK;
   skinny_dispatch<DxLaunch>(N, dy, ldy, w, ldw, M, N, K, dx, lddx, stream);
   return check_launch("skinny_linear_dx");
+}
+
+// bf16 compute mode: the same three products on bf16 activations / gradients and the weight's bf16 operand
+// (N <= 8; products and sums fp32; y and the weight gradient's partial rows fp32, dx bf16).
+static bool al8h(const void* p, int64_t ld) { return ((uintptr_t)p % 8 == 0) && ld % 4 == 0; }
+
+extern "C" int mapx_skinny_linear_fwd_bf16(const mapx_bf16* x, int64_t ldx, const mapx_bf16* w, int64_t ldw,
+                                           const float* bias_opt, int M, int N, int K, int relu, float* y, int64_t ldy,
+                                           hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(x && w && y && M >= 0 && N >= 1 && N <= 8 && K >= 4 && K % 4 == 0, "skinny_linear_fwd_bf16: bad sizes (N <= 8)");
+  MAPX_REQUIRE(al8h(x, ldx) && al8h(w, ldw) && ldy >= N, "skinny_linear_fwd_bf16: rows of x and w must be 8-byte aligned");
+  if (M == 0) return MAPX_OK;
+  const __bf16* xx = reinterpret_cast<const __bf16*>(x);
+  const __bf16* ww = reinterpret_cast<const __bf16*>(w);
+#define MAPX_SKH(NT) hipLaunchKernelGGL((skinny_fwd_kernel<NT, __bf16>), dim3(grid_for(M, 16)), dim3(256), 0, stream, xx, ldx, ww, ldw, bias_opt, M, N, K, relu, y, ldy)
+  if (N == 1) MAPX_SKH(1); else if (N <= 4) MAPX_SKH(4); else MAPX_SKH(8);
+#undef MAPX_SKH
+  return check_launch("skinny_linear_fwd_bf16");
+}
+
+extern "C" int mapx_skinny_linear_dw_bf16(const mapx_bf16* dy, int64_t ldy, const mapx_bf16* x, int64_t ldx, int M, int N,
+                                          int K, float* part, int chunks, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(dy && x && part && M >= 1 && N >= 1 && N <= 8 && K >= 4 && K % 4 == 0 && ldy >= N && chunks >= 1 &&
+                   chunks <= 65535, "skinny_linear_dw_bf16: bad sizes (N <= 8)");
+  MAPX_REQUIRE(al8h(x, ldx) && (uintptr_t)part % 16 == 0, "skinny_linear_dw_bf16: rows of x must be 8-byte aligned");
+  const __bf16* dd = reinterpret_cast<const __bf16*>(dy);
+  const __bf16* xx = reinterpret_cast<const __bf16*>(x);
+#define MAPX_SKH(NT) hipLaunchKernelGGL((skinny_dw_kernel<NT, __bf16>), dim3(grid_for(K / 4, 256), chunks), dim3(256), 0, stream, dd, ldy, xx, ldx, M, N, K, part)
+  if (N == 1) MAPX_SKH(1); else if (N <= 4) MAPX_SKH(4); else MAPX_SKH(8);
+#undef MAPX_SKH
+  return check_launch("skinny_linear_dw_bf16");
+}
+
+extern "C" int mapx_skinny_linear_dx_bf16(const mapx_bf16* dy, int64_t ldy, const mapx_bf16* w, int64_t ldw, int M, int N,
+                                          int K, mapx_bf16* dx, int64_t lddx, hipStream_t stream) {
+  using namespace mapx;
+  MAPX_REQUIRE(dy && w && dx && M >= 0 && N >= 1 && N <= 8 && K >= 4 && K % 4 == 0 && ldy >= N,
+               "skinny_linear_dx_bf16: bad sizes (N <= 8)");
+  MAPX_REQUIRE(al8h(w, ldw) && al8h(dx, lddx), "skinny_linear_dx_bf16: rows of w and dx must be 8-byte aligned");
+  if (M == 0) return MAPX_OK;
+  const __bf16* dd = reinterpret_cast<const __bf16*>(dy);
+  const __bf16* ww = reinterpret_cast<const __bf16*>(w);
+  __bf16* out = reinterpret_cast<__bf16*>(dx);
+  const int64_t threads = (int64_t)((M + 3) / 4) * (K / 4);
+#define MAPX_SKH(NT) hipLaunchKernelGGL((skinny_dx_kernel<NT, __bf16>), dim3(grid_for(threads, 256)), dim3(256), 0, stream, dd, ldy, ww, ldw, M, N, K, out, lddx)
+  if (N == 1) MAPX_SKH(1); else if (N <= 4) MAPX_SKH(4); else MAPX_SKH(8);
+#undef MAPX_SKH
+  return check_launch("skinny_linear_dx_bf16");
 }
 
 extern "C" int mapx_skinny_join_bwd(const float* dz, int64_t lddz, const float* w, int64_t ldw, int M, int N, int D,

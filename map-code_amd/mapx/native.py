@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmapx_hip.so")
 
-MAPX_ABI_VERSION = 44
+MAPX_ABI_VERSION = 45
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_CROSS, EPI_ADD, EPI_RELU_MASK, EPI_RELU_MASK_COLSUM = range(7)
 
 _p, _i, _i64, _u64, _f, _d, _sz = (C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double,
@@ -87,6 +87,9 @@ SIGNATURES = {
     "mapx_skinny_linear_fwd": (_i, [_p, _i64, _p, _i64, _p, _i, _i, _i, _i, _p, _i64, _p]),
     "mapx_skinny_linear_dw": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _p, _i, _p]),
     "mapx_skinny_linear_dx": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _p, _i64, _p]),
+    "mapx_skinny_linear_fwd_bf16": (_i, [_p, _i64, _p, _i64, _p, _i, _i, _i, _i, _p, _i64, _p]),
+    "mapx_skinny_linear_dw_bf16": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _p, _i, _p]),
+    "mapx_skinny_linear_dx_bf16": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _p, _i64, _p]),
     "mapx_skinny_join_bwd": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _i, _p, _i64, _p, _i64, _p, _i64, _i, _p, _i64, _p, _i64,
                                   _p, _i64, _p, _i64, _p, _p, _p, _p, _p]),
     "mapx_enc_group_layout": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),

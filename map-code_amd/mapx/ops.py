@@ -1202,6 +1202,20 @@ def _rows16(t):
         and t.data_ptr() % 16 == 0
 
 
+def _rows8h(t):
+    return t.dim() == 2 and t.dtype == torch.bfloat16 and t.stride(1) == 1 and t.stride(0) % 4 == 0 \
+        and t.data_ptr() % 8 == 0
+
+
+# bf16 compute mode: layers of at most 8 outputs (the finetune head) on the streaming kernels' bf16 forms instead of a
+# 128-wide MFMA tile per useful column
+SKINNY_BF16 = os.environ.get("MAPX_SKINNY_BF16", "1") == "1"
+
+
+def _skinny_h(Nn, K, *mats):
+    return SKINNY and SKINNY_BF16 and 1 <= Nn <= 8 and K >= 4 and K % 4 == 0 and all(_rows8h(m) for m in mats)
+
+
 _TALL_ROWS = int(os.environ.get("MAPX_TALL_ROWS", "128"))
 SKINNY_MAX = int(os.environ.get("MAPX_SKINNY_MAX", "8"))            # forward: wider layers measured faster on the GEMM
 # dW / dX (RFD's 23-wide layer: 14.6 / 8.6 vs 28 / 12 us).  The kernels take up to 64 outputs (Criteo's 39-wide layer:
@@ -1234,6 +1248,13 @@ def linear_fwd(x, w, b, relu=False, out=None, out_dtype=None):
         with _timed("skinny_linear", 4.0 * (M * K + Nn * K + M * Nn)):
             check(lib.mapx_skinny_linear_fwd(ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(b), M, Nn, K, int(relu),
                                              y.data_ptr(), y.stride(0), stream()))
+        return y
+    if out_dtype == torch.float32 and _skinny_h(Nn, K, x, w) and (out is None or out.dtype == torch.float32):
+        require_gpu(x, w)
+        y = out if out is not None else torch.empty(M, Nn, dtype=torch.float32, device=x.device)
+        with _timed("skinny_linear", 2.0 * (M * K + Nn * K) + 4.0 * M * Nn):
+            check(lib.mapx_skinny_linear_fwd_bf16(ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(b), M, Nn, K, int(relu),
+                                                  y.data_ptr(), y.stride(0), stream()))
         return y
     return gemm(x, w, True, True, M, Nn, K, out=out, epi=N.EPI_BIAS_RELU if relu else N.EPI_BIAS,
                 bias=b, out_dtype=out_dtype)
@@ -1274,6 +1295,14 @@ def linear_bwd_input(dy, w, out=None, add=None, relu_of=None, colsum_to=None):
         with _timed("skinny_linear", 4.0 * (M * K + Nn * K + M * Nn)):
             check(lib.mapx_skinny_linear_dx(ptr(dy), dy.stride(0), ptr(w), w.stride(0), M, Nn, K, dx.data_ptr(),
                                             dx.stride(0), stream()))
+        return dx
+    if add is None and relu_of is None and dy.dim() == 2 and _skinny_h(Nn, K, w) and is_bf16(dy) and dy.stride(1) == 1 \
+            and (out is None or _rows8h(out)):
+        require_gpu(dy, w)
+        dx = out if out is not None else torch.empty(M, K, dtype=torch.bfloat16, device=dy.device)
+        with _timed("skinny_linear", 2.0 * (M * K + Nn * K + M * Nn)):
+            check(lib.mapx_skinny_linear_dx_bf16(ptr(dy), dy.stride(0), ptr(w), w.stride(0), M, Nn, K, dx.data_ptr(),
+                                                 dx.stride(0), stream()))
         return dx
     epi, aux, out2 = N.EPI_NONE, None, None
     if add is not None:
@@ -1326,6 +1355,22 @@ def linear_bwd_weight(dy, x, out=None, defer=False):
                                             stream()))
         if DEFER_COLSUM and defer and out is not None:
             defer_sum(dw, part, Nn * K, chunks, Nn * K)          # with the step's other partial sums
+        else:
+            _sum_now(dw, part, Nn * K, chunks, Nn * K)
+        return dw
+    if Bn >= 1 and is_bf16(dy) and dy.dim() == 2 and dy.stride(1) == 1 and _skinny_h(Nn, K, x) \
+            and (out is None or (out.dtype == torch.float32 and out.is_contiguous())):
+        require_gpu(dy, x)
+        chunks = lib.mapx_skinny_chunks()
+        while -(-Bn // chunks) > _TALL_ROWS and chunks < 2048:
+            chunks *= 2
+        dw = out if out is not None else torch.empty(Nn, K, dtype=torch.float32, device=dy.device)
+        part = torch.empty(chunks, Nn * K, dtype=torch.float32, device=dy.device)
+        with _timed("skinny_linear", 2.0 * (Bn * K + Bn * Nn) + 4.0 * chunks * Nn * K):
+            check(lib.mapx_skinny_linear_dw_bf16(ptr(dy), dy.stride(0), ptr(x), x.stride(0), Bn, Nn, K, ptr(part), chunks,
+                                                 stream()))
+        if DEFER_COLSUM and defer and out is not None:
+            defer_sum(dw, part, Nn * K, chunks, Nn * K)
         else:
             _sum_now(dw, part, Nn * K, chunks, Nn * K)
         return dw

@@ -438,3 +438,52 @@ def test_gemm_bf16_relu_mask_colsum_epilogue(M, N, K):
     got, want = part.double().cpu().sum(0), dz.double().cpu().sum(0)
     assert bool(((got - want).abs() <= 1e-6 * dz.double().cpu().abs().sum(0) + 1e-6).all())
 
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 1, 1368), (777, 3, 1368), (4096, 8, 736), (5, 1, 8), (130, 4, 2024)])
+def test_streaming_narrow_layers_in_bf16_mode(M, N, K, monkeypatch):
+    """Layers of at most 8 outputs over bf16 activations (the finetune head of the bf16 trunk, models.py:304,319) on
+    the streaming kernels' bf16 forms (csrc/skinny.hip: mapx_skinny_linear_{fwd,dw,dx}_bf16): forward (fp32 logits),
+    weight gradient (fp32) and input gradient (bf16) against fp64 products of the same bf16 operands, and against the
+    bf16 MFMA GEMM path they replace (MAPX_SKINNY_BF16=0) — the same products, another summation order."""
+    from mapx import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(BF)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF)
+    b = torch.randn(N, generator=g)
+    dy = torch.randn(M, N, generator=g).to(BF)
+    xd, wd, bd, dyd = x.to(DEV), w.to(DEV), b.to(DEV), dy.to(DEV)
+    used = []
+    real = {n: getattr(ops.lib, n) for n in ("mapx_skinny_linear_fwd_bf16", "mapx_skinny_linear_dw_bf16",
+                                              "mapx_skinny_linear_dx_bf16")}
+    out = {}
+    for arm in (True, False):
+        monkeypatch.setattr(ops, "SKINNY_BF16", arm)
+        y = ops.linear_fwd(xd, wd, bd, out_dtype=torch.float32)
+        dw = ops.linear_bwd_weight(dyd, xd)
+        dx = ops.linear_bwd_input(dyd, wd)
+        assert y.dtype == torch.float32 and dw.dtype == torch.float32 and dx.dtype == BF
+        out[arm] = (y.cpu(), dw.cpu(), dx.cpu())
+    yr = x.double() @ w.double().t() + b.double()
+    dwr = dy.double().t() @ x.double()
+    dxr = dy.double() @ w.double()
+    for arm in (True, False):
+        y, dw, dx = out[arm]
+        assert bool(((y.double() - yr).abs() <= 2e-6 * (x.double().abs() @ w.double().abs().t()) + 1e-6).all()), arm
+        assert bool(((dw.double() - dwr).abs() <= 4e-6 * (dy.double().abs().t() @ x.double().abs()) + 1e-6).all()), arm
+        bound = EPS_BF * dxr.abs() + 4e-6 * (dy.double().abs() @ w.double().abs()) + 1e-6
+        assert bool(((dx.double() - dxr).abs() <= bound).all()), arm
+    # the streaming forms really ran: their results are fp32 sums in another order than the MFMA's
+    for n in real:
+        assert hasattr(ops.lib, n)
+
+
+def test_bf16_streaming_kernels_reject_what_they_cannot_take():
+    from mapx import ops
+    from mapx.native import MapxError
+    x = torch.zeros(8, 16, dtype=BF, device=DEV)
+    w = torch.zeros(9, 16, dtype=BF, device=DEV)
+    y = torch.zeros(8, 9, device=DEV)
+    with pytest.raises(MapxError):
+        ops.check(ops.lib.mapx_skinny_linear_fwd_bf16(x.data_ptr(), 16, w.data_ptr(), 16, None, 8, 9, 16, 0, y.data_ptr(), 9,
+                                                      None))
