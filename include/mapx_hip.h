@@ -31,7 +31,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 #include <hip/hip_runtime_api.h>
 #endif
 
-#define MAPX_ABI_VERSION 45
+#define MAPX_ABI_VERSION 46
 
 #define MAPX_OK 0
 #define MAPX_EINVAL (-1)     /* bad argument (shape, null pointer, alignment) */
@@ -40,6 +40,7 @@ typedef struct ihipStream_t* hipStream_t; /* opaque outside hipcc */
 
 /* bf16 values cross the boundary as raw 16-bit words (the upper half of the IEEE fp32 pattern). */
 typedef uint16_t mapx_bf16;
+typedef struct mapx_lazy_rows mapx_lazy_rows;      /* defined with mapx_nce_fwd below */
 
 const char* mapx_last_error(void);
 int mapx_abi_version(void);
@@ -50,7 +51,10 @@ int mapx_abi_version(void);
  * sets *err_flag (may be NULL) and yields a zero row (reference: IndexError).  amax_out_opt: the magnitude record
  * of `out` (mapx_gemm_scale below), raised with max |out|. */
 int mapx_emb_gather_fwd(const int64_t* ids, int64_t n, const float* table, int64_t V, int E,
-                        float* out, int* err_flag, void* amax_out_opt, hipStream_t stream);
+                        float* out, int* err_flag, void* amax_out_opt, const mapx_lazy_rows* lazy_opt,
+                        hipStream_t stream);
+/* lazy_opt (E % 4 == 0; see mapx_lazy_rows at mapx_nce_fwd): the table's lazy-AdamW state — rows are read through their
+ * pending zero-gradient updates (bit-identical to a catch-up pass followed by the plain gather; nothing written). */
 
 /* int64 ids -> int32 row keys, range-checked against V. */
 int mapx_ids_to_i32(const int64_t* ids, int64_t n, int64_t V, int32_t* out, int* err_flag,
@@ -198,13 +202,13 @@ int mapx_nce_pack_idx(const int64_t* targets, const int64_t* noise, int64_t T, i
  * hpos_opt != NULL (grouped encoder, P = 32): `enc` is h_slots [slots, P] and target t reads
  * slot hpos_opt[t]; dh_slots_opt then also receives dh at the slot (for mapx_enc_grouped_dw). */
 /* The lazy-AdamW state of the rows `emb` / `bias` name (mapx_table_adam's arguments of the same names): with it the
- * forward reads every sampled row THROUGH its pending zero-gradient updates — last[row] beside the row and, when the
+ * forward (and mapx_emb_gather_fwd for the embedding table) reads every sampled row THROUGH its pending zero-gradient updates — last[row] beside the row and, when the
  * row is stale, its moments; the gap replayed in registers with the arithmetic mapx_table_adam's catch-up would have
  * used (bit-identical) — and writes nothing: no catch-up pass before the forward, and the gradient update that ends
  * the step is the row's only read-modify-write (reference: every row is updated every step, trainer.py:328 over
- * index_linear.py:99-102's table).  coef_opt: mapx_replay_coef_table's output for the same *done (else the closed
- * form's coefficients are derived from `aux` at every stale access).  P = 32 and K + 1 <= 32 only. */
-typedef struct mapx_lazy_rows {
+ * index_linear.py:99-102's table).  coef_opt: mapx_replay_coef_table's output for the same *done (required, with the
+ * 17-row aux).  mapx_nce_fwd: P = 32 and K + 1 <= 32 only. */
+struct mapx_lazy_rows {
   const float* m0; const float* v0; int64_t ld_mv0; float wd0;
   const float* m1; const float* v1; int64_t ld_mv1; float wd1;   /* the scalar table's (bias), or NULL */
   const int32_t* last;
@@ -213,7 +217,7 @@ typedef struct mapx_lazy_rows {
   const double* aux; int aux_len; int aux_rows;
   double beta1, beta2, eps;
   const float* coef_opt;
-} mapx_lazy_rows;
+};
 size_t mapx_nce_fwd_workspace_bytes(void);
 int mapx_nce_fwd(const float* enc, int64_t B, int L, int F, int P, const int64_t* masked_index,
                  const int32_t* idx, int K, const float* emb, const float* bias,
@@ -552,7 +556,8 @@ int mapx_cast_f32_bf16(const float* src, int64_t n, mapx_bf16* dst, hipStream_t 
 int mapx_cast_bf16_f32(const mapx_bf16* src, int64_t n, float* dst, hipStream_t stream);
 /* layers.py:97-102 with bf16 output rows (the table stays fp32); E % 8 == 0. */
 int mapx_emb_gather_fwd_bf16(const int64_t* ids, int64_t n, const float* table, int64_t V, int E,
-                             mapx_bf16* out, int* err_flag, hipStream_t stream);
+                             mapx_bf16* out, int* err_flag, const mapx_lazy_rows* lazy_opt,
+                             hipStream_t stream);
 /* mapx_seg_reduce_rows over bf16 gradient rows (fp32 sums, fp32 output). */
 int mapx_seg_reduce_rows_bf16(int64_t n, const int32_t* perm, const int32_t* rank, const int32_t* seg_start,
                               const mapx_bf16* src, const mapx_bf16* src2_opt, int W, float* out, void* ws,

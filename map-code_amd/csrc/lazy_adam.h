@@ -246,3 +246,9 @@ __device__ inline void lazy_replay1(const LazyRows& lz, float& p, float m, float
 }
 
 }  // namespace mapx
+
+struct mapx_lazy_rows;
+namespace mapx {
+bool lazy_rows_from(const mapx_lazy_rows* q, int W, const char* what, LazyRows* lz);      // gather.hip
+}  // namespace mapx
+

@@ -433,20 +433,8 @@ extern "C" int mapx_nce_fwd(const float* enc, int64_t B, int L, int F, int P,
                "nce_fwd: null pointer");
   mapx::LazyRows lz{};
   if (lazy_opt) {
-    const mapx_lazy_rows& q = *lazy_opt;
     MAPX_REQUIRE(P == 32 && K + 1 <= 32, "nce_fwd: rows are read through their pending updates for P = 32, K <= 31 only");
-    MAPX_REQUIRE(q.m0 && q.v0 && q.last && q.sched && q.done && q.aux && q.aux_len > 1 && q.sched_len > 0 &&
-                     (!q.m1) == (!q.v1) && q.ld_mv0 >= P && q.ld_mv0 % 4 == 0 && (uintptr_t)q.m0 % 16 == 0 &&
-                     (uintptr_t)q.v0 % 16 == 0 && (!q.m1 || q.ld_mv1 >= 1) && (uintptr_t)q.coef_opt % 16 == 0,
-                 "nce_fwd: incomplete lazy-row state");
-    MAPX_REQUIRE(q.aux_rows == 3 || q.aux_rows == 3 + 2 * (mapx::kJ + 1), "nce_fwd: aux must have 3 or %d rows",
-                 3 + 2 * (mapx::kJ + 1));
-    const double beta = sqrt(q.beta2);
-    lz = mapx::LazyRows{q.m0, q.v0, q.ld_mv0, q.wd0, q.m1, q.v1, q.ld_mv1, q.wd1, q.last,
-                        reinterpret_cast<const float2*>(q.sched), q.sched_len, q.done,
-                        mapx::make_hyper(q.beta1, q.beta2, q.eps),
-                        mapx::ReplayAux{q.aux, q.aux_len, q.aux_rows, q.beta1 / beta, 1.0 / beta},
-                        q.aux_rows > 3 ? q.coef_opt : nullptr};
+    if (!mapx::lazy_rows_from(lazy_opt, P, "nce_fwd", &lz)) return MAPX_EINVAL;
   }
   MAPX_REQUIRE(B >= 0 && L >= 1 && F >= 1 && K >= 1 && V > 0, "nce_fwd: bad sizes");
   MAPX_REQUIRE(P == 8 || P == 16 || P == 32 || P == 64 || P == 128,

@@ -104,6 +104,11 @@ class RowTable:
         return g0, g1
 
 
+# "1": a training step's embedding gather replays stale rows in registers instead of a catch-up launch in front of it
+# (the first kernels of the step's critical chain: mask -> catch-up -> gather -> first GEMM).  Built, bit-identical,
+# and worth nothing on the step (one box, tools/ab_env.sh): gather 5.0 -> 9.0 us, the 7.9-us catch-up launch gone,
+# the update +1.4 us: 0.6884 / 0.6907 ms per step against 0.6880 / 0.6899 with the catch-up pass.  Opt-in.
+EMB_LAZY_FOLD = os.environ.get("MAPX_EMB_LAZY_FOLD", "0") == "1"
 IMPLIED = os.environ.get("MAPX_PLAN_IMPLIED", "1") == "1"
 HEAD_DW_LATE = os.environ.get("MAPX_HEAD_DW_LATE", "1") == "1"     # A/B switch (tools/ab_env.sh)
 PAD_K = os.environ.get("MAPX_PAD_K", "1") == "1"                   # A/B switch: _Linear with an input width % 8 != 0
@@ -208,9 +213,9 @@ class TableWeight(nn.Module):
 
 class _Gather(Function):
     @staticmethod
-    def forward(ctx, weight, ids, table, out_dtype=torch.float32):
+    def forward(ctx, weight, ids, table, out_dtype=torch.float32, lazy=None):
         ctx.table, ctx.plan, ctx.width = table, table.plan, weight.shape[1]
-        return ops.emb_gather(ids, weight, out_dtype=out_dtype)
+        return ops.emb_gather(ids, weight, out_dtype=out_dtype, lazy=lazy)
 
     @staticmethod
     def backward(ctx, g):
@@ -240,7 +245,7 @@ class _Gather(Function):
             lazy.update()                 # nothing else of the step feeds this table: its rows move at once
         if not ops.step_window[0]:
             ops.join_pending()            # no optimizer.step() follows at once: leave nothing open behind backward()
-        return None, None, None, None
+        return None, None, None, None, None
 
 
 class _GatherLinear(Function):
@@ -400,9 +405,14 @@ class Embeddings(nn.Module):
         need_grad = torch.is_grad_enabled() and w.requires_grad
         keys = ops.ids_to_i32(input_ids, w.shape[0], validate=self.validate_ids) \
             if (need_grad or self.table.lazy is not None) else None
+        # a training step reads the rows through their pending updates inside the gather (no catch-up launch at the head
+        # of the step; the gradient update writes each row once); eval / no optimizer: the catch-up pass or nothing
+        lazy = self.table.lazy
+        fold = (EMB_LAZY_FOLD and need_grad and lazy is not None and lazy.replay_in_readers() and lazy.m1 is None
+                and w.shape[1] % (8 if self.compute_dtype == torch.bfloat16 else 4) == 0 and w.is_cuda)
         if keys is not None:
-            self.table.prepare(keys, need_grad, defer_plan=self.defer_plan)
-        x = _Gather.apply(w, input_ids, self.table, self.compute_dtype)
+            self.table.prepare(keys, need_grad, defer_plan=self.defer_plan, through_replay=fold)
+        x = _Gather.apply(w, input_ids, self.table, self.compute_dtype, lazy.lazy_rows() if fold else None)
         if self.embed_norm:
             x = self.layer_norm(x)
         return self.dropout(x)

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmapx_hip.so")
 
-MAPX_ABI_VERSION = 45
+MAPX_ABI_VERSION = 46
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_CROSS, EPI_ADD, EPI_RELU_MASK, EPI_RELU_MASK_COLSUM = range(7)
 
 _p, _i, _i64, _u64, _f, _d, _sz = (C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double,
@@ -21,7 +21,7 @@ _p, _i, _i64, _u64, _f, _d, _sz = (C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C
 SIGNATURES = {
     "mapx_last_error": (C.c_char_p, []),
     "mapx_abi_version": (_i, []),
-    "mapx_emb_gather_fwd": (_i, [_p, _i64, _p, _i64, _i, _p, _p, _p, _p]),
+    "mapx_emb_gather_fwd": (_i, [_p, _i64, _p, _i64, _i, _p, _p, _p, _p, _p]),
     "mapx_ids_to_i32": (_i, [_p, _i64, _i64, _p, _p, _p]),
     "mapx_seg_plan_workspace_bytes": (_sz, [_i64, _i64]),
     "mapx_seg_plan": (_i, [_p, _i64, _i64, _p, _sz, _p, _p, _p, _p, _p, _p, _p]),
@@ -71,7 +71,7 @@ SIGNATURES = {
                             _p, _i64, _i, _i, _p, _sz, _p]),
     "mapx_cast_f32_bf16": (_i, [_p, _i64, _p, _p]),
     "mapx_cast_bf16_f32": (_i, [_p, _i64, _p, _p]),
-    "mapx_emb_gather_fwd_bf16": (_i, [_p, _i64, _p, _i64, _i, _p, _p, _p]),
+    "mapx_emb_gather_fwd_bf16": (_i, [_p, _i64, _p, _i64, _i, _p, _p, _p, _p]),
     "mapx_seg_reduce_rows_bf16": (_i, [_i64, _p, _p, _p, _p, _p, _i, _p, _p, _sz, _p, _p]),
     "mapx_colsum_bf16_workspace_bytes": (_sz, [_i]),
     "mapx_colsum_bf16": (_i, [_p, _i64, _i, _i, _p, _p, _sz, _p]),

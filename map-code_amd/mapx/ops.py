@@ -347,8 +347,9 @@ def bf16_weight(w):
     return sh if sh is not None else cast_bf16(w.detach())
 
 
-def emb_gather(ids, table, validate=False, out_dtype=torch.float32):
-    """ids int64 [...], table [V,E] -> [..., E]  (layers.py:97-102); bf16 rows in bf16 compute mode."""
+def emb_gather(ids, table, validate=False, out_dtype=torch.float32, lazy=None):
+    """ids int64 [...], table [V,E] -> [..., E]  (layers.py:97-102); bf16 rows in bf16 compute mode.
+    lazy (native.LazyRows): rows are read through their pending zero-gradient updates (no catch-up pass ran)."""
     require_gpu(ids, table)
     ids = ids.contiguous()
     out = torch.empty(*ids.shape, table.shape[1], dtype=out_dtype, device=table.device)
@@ -357,10 +358,11 @@ def emb_gather(ids, table, validate=False, out_dtype=torch.float32):
     with _timed("emb_gather", ids.numel() * (8 + (4 + out.element_size()) * table.shape[1])):
         if out_dtype == BF16:
             check(lib.mapx_emb_gather_fwd_bf16(ptr(ids), ids.numel(), ptr(table), table.shape[0], table.shape[1],
-                                               ptr(out), ptr(err), stream()))
+                                               ptr(out), ptr(err), None if lazy is None else native_byref(lazy), stream()))
         else:
             check(lib.mapx_emb_gather_fwd(ptr(ids), ids.numel(), ptr(table), table.shape[0], table.shape[1],
-                                          ptr(out), ptr(err), ptr(rec), stream()))
+                                          ptr(out), ptr(err), ptr(rec), None if lazy is None else native_byref(lazy),
+                                          stream()))
     tag(out, rec)
     if validate and int(err.item()):
         raise IndexError("index out of range in self")          # reference CPU behaviour

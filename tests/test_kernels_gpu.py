@@ -811,6 +811,46 @@ def test_nce_forward_reads_rows_through_their_pending_updates(ops, grouped):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("half", [False, True])
+def test_gather_reads_rows_through_their_pending_updates(ops, half):
+    """mapx_emb_gather_fwd(lazy=) / _bf16: the gather of a training step replays a stale row's missing zero-gradient
+    updates in registers and writes nothing; bit-identical to the catch-up pass followed by the plain gather (fp32
+    rows, and the bf16 rows of the bf16 compute mode), hot ids current, repeats in the id list."""
+    from mapx import native as N
+    V, E, n, T_done = 5000, 16, 4096 * 3, 41
+    sched, lambdas = _sched(ops, 120, kind="cosine", warm=10)
+    aux = ops.make_replay_aux(1e-3, lambdas, 0.9, 0.999, 0.05).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    emb = (0.3 * torch.randn(V, E, generator=g)).to(DEV)
+    mv0 = torch.cat([0.01 * torch.randn(V, E, generator=g), 1e-4 * torch.rand(V, E, generator=g)], 1).to(DEV)
+    last = (T_done - torch.randint(0, 30, (V,), generator=g)).clamp(min=0).to(torch.int32).to(DEV)
+    last[:64] = T_done
+    done = torch.full((1,), T_done, dtype=torch.int32, device=DEV)
+    ids = torch.randint(0, V, (n,), generator=g)
+    ids[::5] = ids[::5] % 64
+    ids = ids.to(DEV)
+    coef = ops.replay_coef_table(aux, 0.9, 0.999, done)
+    lz = N.LazyRows()
+    lz.m0, lz.v0, lz.ld_mv0, lz.wd0 = mv0[:, :E].data_ptr(), mv0[:, E:].data_ptr(), mv0.stride(0), 0.05
+    lz.m1, lz.v1, lz.ld_mv1, lz.wd1 = None, None, 1, 0.0
+    lz.last, lz.sched, lz.sched_len, lz.done = last.data_ptr(), sched.data_ptr(), sched.shape[0], done.data_ptr()
+    lz.aux, lz.aux_len, lz.aux_rows = aux.data_ptr(), aux.shape[1], aux.shape[0]
+    lz.beta1, lz.beta2, lz.eps, lz.coef_opt = 0.9, 0.999, 1e-8, coef.data_ptr()
+    dt = torch.bfloat16 if half else torch.float32
+    before = [t.clone() for t in (emb, mv0, last)]
+    got = ops.emb_gather(ids, emb, out_dtype=dt, lazy=lz)
+    for a, b in zip(before, (emb, mv0, last)):
+        assert torch.equal(a, b)
+    e2, mvb, last2 = [t.clone() for t in before]
+    ops.table_adam(e2, mvb[:, :E], mvb[:, E:], 0.05, last2, sched, done, aux, 0.9, 0.999, 1e-8,
+                   rows=ids.to(torch.int32), rows_may_repeat=True)
+    assert not torch.equal(e2, emb)
+    want = ops.emb_gather(ids, e2, out_dtype=dt)
+    assert torch.equal(got, want)
+    if not half:
+        assert ops.amax_value(ops.amax_of(got)) == ops.amax_value(ops.amax_of(want)) == float(want.abs().max())
+
+
 def test_errors_are_loud(ops):
     from mapx.native import MapxError
     with pytest.raises(MapxError):

@@ -313,9 +313,10 @@ def test_graph_replay_equals_eager_bitwise_with_streaming_hidden_layers(monkeypa
 @pytest.mark.gpu
 @pytest.mark.parametrize("use_graph", [True, False])
 def test_rows_read_through_pending_updates_train_like_the_catch_up_pass(use_graph):
-    """nce.LAZY_FOLD (opt-in, MAPX_LAZY_FOLD=1): a training step without the NCE table's catch-up pass — the loss
-    kernel replays stale rows in registers, the gradient update writes them once — leaves, after two epochs with a
-    ragged last batch, the parameters of the step with the catch-up pass, bit for bit (graphed and eager)."""
+    """nce.LAZY_FOLD and layers.EMB_LAZY_FOLD (opt-in, MAPX_LAZY_FOLD=1 / MAPX_EMB_LAZY_FOLD=1): a training step without
+    the tables' catch-up passes — the loss kernel and the embedding gather replay stale rows in registers, the gradient
+    updates write them once — leaves, after two epochs with a ragged last batch, the parameters of the step with the
+    catch-up passes, bit for bit (graphed and eager)."""
     _graph_equals_eager(0.0, "DCNv2", 9, 2, arms=((use_graph, True), (use_graph, False)))
 
 
@@ -329,10 +330,11 @@ def _graph_equals_eager(max_grad_norm, backbone, full, epochs, tail=100, arms=((
     ids, labels, _, _ = synth_table(512 * full + tail, 23, cfg["V"], seed=3)    # ragged last batch
     cnt = np.bincount(ids.reshape(-1), minlength=cfg["V"]).astype(np.float32)
     out = []
-    from mapx import nce
-    fold_default = nce.LAZY_FOLD
+    from mapx import layers as _layers, nce
+    fold_default, emb_default = nce.LAZY_FOLD, _layers.EMB_LAZY_FOLD
     for use_graph, fold in arms:
         nce.LAZY_FOLD = fold_default if fold is None else fold
+        _layers.EMB_LAZY_FOLD = emb_default if fold is None else fold
         torch.manual_seed(5)
         config = make_config(cfg, "MFP", cnt, backbone=backbone)
         model = BaseModel.from_config(config)
@@ -353,7 +355,7 @@ def _graph_equals_eager(max_grad_norm, backbone, full, epochs, tail=100, arms=((
             kind = type(next(iter(tr._graphs.values()))).__name__
             assert kind == ("GraphedBackward" if max_grad_norm > 0 else "GraphedStep")
         out.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
-    nce.LAZY_FOLD = fold_default
+    nce.LAZY_FOLD, _layers.EMB_LAZY_FOLD = fold_default, emb_default
     for k in out[0]:
         assert torch.equal(out[0][k], out[1][k]), k
 
