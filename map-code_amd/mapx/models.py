@@ -451,15 +451,15 @@ class DeepFM(BaseModel):
 
 class AutoInt(BaseModel):
     """Stacked multi-head self-attention over the field embeddings (reference models.py:440-488);
-    the flattened [B, F*heads*attn_size] output feeds the MFP / RFD heads or `attn_out`.
-    Built: the attention path (use_lr = False, num_dnn_layers = 0, attention dropout 0)."""
+    the flattened [B, F*heads*attn_size] output feeds the MFP / RFD heads or `attn_out`; the finetune model adds
+    the LR term (use_lr: its weight is the secondary parameter of the embedding's RowTable, as in DeepFM) and an MLP
+    tower over the flattened embeddings (num_dnn_layers > 0: `dnn` + `dnn_out`), models.py:464-471, 482-486.
+    Not built: attention dropout > 0."""
     used_params = ["embed_size", "num_attn_layers", "attn_size", "num_attn_heads", "attn_probs_dropout_rate",
                    "use_lr", "res_conn", "attn_scale", "dnn_size", "num_dnn_layers", "dnn_act", "dnn_drop"]
 
     def __init__(self, config: Config):
         super().__init__(model_name="AutoInt", config=config)
-        if not config.pretrain and (config.use_lr or config.num_dnn_layers):
-            raise NotImplementedError("AutoInt with use_lr / num_dnn_layers > 0 is not built")
         self.embed = Embeddings(config)
         self.embed.defer_plan = True
         HA = config.num_attn_heads * config.attn_size
@@ -473,36 +473,62 @@ class AutoInt(BaseModel):
             self.create_pretraining_predictor(final_dim)
         else:
             self.attn_out = HipLinear(final_dim, 1)
+            # (the reference creates these for the finetune model only: models.py:463-471)
+            self.lr_layer = LR(config) if config.use_lr else None
+            if self.lr_layer is not None:       # one row table for both [V, *] parameters read with input_ids
+                self.embed.table = RowTable("embed.embedding", self.embed.embedding.weight, self.lr_layer.embed_w.weight)
+            # The reference sizes the tower's input as final_dim (fields x heads x attn_size, models.py:466) and feeds
+            # it the flattened EMBEDDINGS (fields x embed_size, models.py:486): the option runs only when the two
+            # agree; the same shapes and the same error otherwise.
+            if config.num_dnn_layers and final_dim != config.num_fields * config.embed_size:
+                raise ValueError("AutoInt with num_dnn_layers > 0 needs embed_size == num_attn_heads * attn_size "
+                                 "(reference models.py:466, 486: the tower is sized for the attention output and fed "
+                                 "the embeddings)")
+            self.dnn = MLPBlock(input_dim=final_dim, hidden_size=config.dnn_size,
+                                num_hidden_layers=config.num_dnn_layers, hidden_dropout_rate=config.dnn_drop,
+                                hidden_act=config.dnn_act) if config.num_dnn_layers else None
+            self.dnn_out = HipLinear(config.dnn_size, 1) if config.num_dnn_layers else None
 
     def forward(self, input_ids, labels=None, masked_index=None, noise_samples=None):
-        x = self.embed(input_ids)
+        lr = None
+        if not self.config.pretrain and self.lr_layer is not None:
+            x, lr = self.embed.forward_with_linear(input_ids, self.lr_layer.embed_w.weight)
+        else:
+            x = self.embed(input_ids)
         nce_idx, early = self._sample_early(labels, masked_index, noise_samples)
         attention_out = self.self_attention(x).flatten(start_dim=1)
         self._plans_and_join(nce_idx, early)
         if self.config.pretrain:
             return self.get_outputs(attention_out, labels, masked_index, noise_samples=noise_samples, nce_idx=nce_idx)
-        return self.get_outputs(self.attn_out(attention_out), labels)
+        logits = self.attn_out(attention_out)
+        if lr is not None:
+            logits = logits + (lr.view(-1, 1) + self.lr_layer.bias)         # models.py:483-484
+        if self.dnn is not None:
+            logits = logits + self.dnn_out(self.dnn(ops.flat_rows(x)))      # models.py:485-486
+        return self.get_outputs(logits, labels)
 
 
 class xDeepFM(BaseModel):
-    """CIN + MLP (reference models.py:235-279): cat([CIN(embed), MLP(embed.flatten)]) feeds the
-    MFP / RFD heads or `fc` (+ the LR term when use_lr).  The LR weight, when present, is the
+    """CIN + MLP (reference models.py:235-279): cat([CIN(embed), MLP(embed.flatten)]) — or the CIN alone when
+    num_hidden_layers = 0 — feeds the MFP / RFD heads or `fc` (+ the LR term when use_lr).  The LR weight, when present, is the
     secondary parameter of the embedding's RowTable as in DeepFM."""
     used_params = ["embed_size", "hidden_size", "num_hidden_layers", "hidden_dropout_rate", "hidden_act",
                    "cin_layer_units", "use_lr"]
 
     def __init__(self, config: Config):
         super().__init__(model_name="xDeepFM", config=config)
-        if config.num_hidden_layers <= 0:
-            raise NotImplementedError("xDeepFM without the MLP tower (num_hidden_layers = 0) is not built")
         self.embed = Embeddings(config)
         self.embed.defer_plan = True
         units = [int(c) for c in str(config.cin_layer_units).split(",")]
         self.cin = CIN(config.num_fields, units)
-        self.dnn = MLPBlock(input_dim=config.num_fields * config.embed_size, hidden_size=config.hidden_size,
-                            num_hidden_layers=config.num_hidden_layers,
-                            hidden_dropout_rate=config.hidden_dropout_rate, hidden_act=config.hidden_act)
-        final_dim = sum(units) + config.hidden_size
+        if config.num_hidden_layers > 0:
+            self.dnn = MLPBlock(input_dim=config.num_fields * config.embed_size, hidden_size=config.hidden_size,
+                                num_hidden_layers=config.num_hidden_layers,
+                                hidden_dropout_rate=config.hidden_dropout_rate, hidden_act=config.hidden_act)
+            final_dim = sum(units) + config.hidden_size
+        else:                                   # models.py:253-255: the CIN alone feeds the heads
+            self.dnn = None
+            final_dim = sum(units)
         if config.pretrain:
             self.create_pretraining_predictor(final_dim)
         else:
@@ -519,7 +545,9 @@ class xDeepFM(BaseModel):
         else:
             x3 = self.embed(input_ids)
         nce_idx, early = self._sample_early(labels, masked_index, noise_samples)
-        final_vec = torch.cat([self.cin(x3), self.dnn(ops.flat_rows(x3))], dim=1)
+        final_vec = self.cin(x3)
+        if self.dnn is not None:
+            final_vec = torch.cat([final_vec, self.dnn(ops.flat_rows(x3))], dim=1)
         self._plans_and_join(nce_idx, early)
         if self.config.pretrain:
             return self.get_outputs(final_vec, labels, masked_index, noise_samples=noise_samples, nce_idx=nce_idx)

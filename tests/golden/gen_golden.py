@@ -41,7 +41,7 @@ def import_reference():
 
 def ref_config(arguments, cfg, mode, feat_count, data_dir, backbone="DCNv2"):
     d = dict(
-        model_name=backbone, data_dir=data_dir, input_size=cfg["V"], num_fields=cfg["F"],
+        model_name=pg.model_name_of(backbone), data_dir=data_dir, input_size=cfg["V"], num_fields=cfg["F"],
         embed_size=cfg["E"], embed_dropout_rate=0.0, embed_norm=False, layer_norm_eps=1e-12,
         hidden_size=cfg["H"], num_hidden_layers=cfg["NL"], hidden_act="relu",
         hidden_dropout_rate=0.0, num_cross_layers=cfg["NC"], pt_neg_num=cfg["K"],
@@ -62,8 +62,10 @@ def trunk_of(model, backbone, emb3):
     flat = emb3.flatten(1)
     if backbone == "DCNv2":
         return torch.cat([model.cross_net(flat), model.parallel_dnn(flat)], -1)
-    if backbone == "AutoInt":
+    if backbone.startswith("AutoInt"):
         return model.self_attention(emb3).flatten(1)
+    if backbone == "xDeepFMCin":
+        return model.cin(emb3)
     if backbone == "xDeepFM":
         return torch.cat([model.cin(emb3), model.dnn(flat)], 1)
     return model.dnn(flat)      # DNN; DeepFM's pretrain vector also appends lr + fm (not needed below)
@@ -148,9 +150,9 @@ def run_case(arguments, models, case, cfg, mode, outdir, backbone="DCNv2"):
             if backbone == "DeepFM":
                 store["mid/lr"] = model.lr_layer(ids)[0].numpy()
                 store["mid/fm"] = model.ip_layer(model.embed(ids)).numpy()
-            if backbone == "xDeepFM":
+            if backbone.startswith("xDeepFM"):
                 store["mid/cin_out"] = model.cin(model.embed(ids)).numpy()
-            if backbone == "AutoInt":
+            if backbone.startswith("AutoInt"):
                 x = model.embed(ids)
                 for li, layer in enumerate(model.self_attention):
                     x = layer(x)
@@ -188,6 +190,17 @@ def main():
     arguments, models = import_reference()
     torch.set_num_threads(1)
     manifests = {}
+    if "--only" in sys.argv:                  # one fixture variant (CTR-only ones): the other files stay as they are
+        backbone = sys.argv[sys.argv.index("--only") + 1]
+        case = "B_f25_b64"
+        path = os.path.join(HERE, "state_dict_manifest.json")
+        manifests = json.load(open(path))
+        modes = ("CTR",) if backbone in pg.CTR_ONLY else ("MFP", "RFD", "CTR")
+        for mode in modes:
+            manifests[f"{case}_{mode}_{backbone}"] = run_case(arguments, models, case, pg.CASES[case], mode, HERE, backbone)
+            print("wrote", case, mode, backbone)
+        json.dump(manifests, open(path, "w"), indent=1, sort_keys=True)
+        return
     for case, cfg in pg.CASES.items():
         for mode in ("MFP", "RFD", "CTR"):
             manifests[f"{case}_{mode}"] = run_case(arguments, models, case, cfg, mode, HERE)

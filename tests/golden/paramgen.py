@@ -72,9 +72,24 @@ AUTOINT = dict(num_attn_layers=2, attn_size=12, num_attn_heads=2, res_conn=True,
                dnn_drop=0.0)
 
 
+# AutoInt's finetune-only options (models.py:463-471, 482-486): the LR term and an MLP tower over the embeddings
+# (the reference sizes the tower's input as num_fields * heads * attn_size and feeds it the flattened EMBEDDINGS,
+# models.py:466, 486: the option only runs with embed_size == heads * attn_size — 2 x 8 = 16 here)
+AUTOINT_FULL = dict(AUTOINT, attn_size=8, use_lr=True, num_dnn_layers=2, dnn_size=40)
+CTR_ONLY = ("AutoIntFull",)                       # fixture variants that exist for the CTR mode only
+MODEL_NAME = {"AutoIntFull": "AutoInt"}          # fixture variant -> the reference's model_name
+
+
+def model_name_of(backbone):
+    return MODEL_NAME.get(backbone, backbone)
+
+
 # xDeepFM settings of the fixtures: two CIN layers of different widths; the CTR model adds the LR term
 XDEEPFM = dict(cin_layer_units="12,8", use_lr=True)
-EXTRAS = {"AutoInt": AUTOINT, "xDeepFM": XDEEPFM}
+# xDeepFM without the MLP tower (models.py:246-255: final_dim = the CIN's output alone)
+XDEEPFM_CIN = dict(XDEEPFM, num_hidden_layers=0)
+MODEL_NAME["xDeepFMCin"] = "xDeepFM"
+EXTRAS = {"AutoInt": AUTOINT, "AutoIntFull": AUTOINT_FULL, "xDeepFM": XDEEPFM, "xDeepFMCin": XDEEPFM_CIN}
 
 
 def extras_of(backbone):
@@ -96,10 +111,11 @@ def param_shapes(cfg, mode, backbone="DCNv2"):
     elif backbone == "DeepFM":
         out["lr_layer.embed_w.weight"] = ((V, 1), 0.3)
         out["lr_layer.bias"] = ((1,), 0.1)
-    elif backbone == "AutoInt":
-        HA = AUTOINT["num_attn_heads"] * AUTOINT["attn_size"]
+    elif backbone in ("AutoInt", "AutoIntFull"):
+        AI = EXTRAS[backbone]
+        HA = AI["num_attn_heads"] * AI["attn_size"]
         d_in = E
-        for i in range(AUTOINT["num_attn_layers"]):
+        for i in range(AI["num_attn_layers"]):
             for nm in ("W_q", "W_k", "W_v") + (("W_res",) if d_in != HA else ()):
                 out[f"self_attention.{i}.{nm}.weight"] = ((HA, d_in), d_in ** -0.5)
             d_in = HA
@@ -107,9 +123,23 @@ def param_shapes(cfg, mode, backbone="DCNv2"):
         if mode == "CTR":
             out["attn_out.weight"] = ((1, Dfin), Dfin ** -0.5)
             out["attn_out.bias"] = ((1,), 0.1)
+            if backbone == "AutoIntFull":
+                out["lr_layer.embed_w.weight"] = ((V, 1), 0.3)
+                out["lr_layer.bias"] = ((1,), 0.1)
+                Hd, d_in = AUTOINT_FULL["dnn_size"], Dfin          # (models.py:466: input_dim = final_dim)
+                for i in range(AUTOINT_FULL["num_dnn_layers"]):
+                    out[f"dnn.dnn.{3 * i}.weight"] = ((Hd, d_in), d_in ** -0.5)
+                    out[f"dnn.dnn.{3 * i}.bias"] = ((Hd,), 0.1)
+                    d_in = Hd
+                out["dnn_out.weight"] = ((1, Hd), Hd ** -0.5)
+                out["dnn_out.bias"] = ((1,), 0.1)
             return out
+        if backbone == "AutoIntFull":
+            raise ValueError("AutoIntFull is a finetune (CTR) fixture")
         NL = 0                                       # no MLP tower
-    elif backbone == "xDeepFM":
+    elif backbone in ("xDeepFM", "xDeepFMCin"):
+        if backbone == "xDeepFMCin":
+            NL = 0
         units = [int(c) for c in XDEEPFM["cin_layer_units"].split(",")]
         h_in = F
         for i, u in enumerate(units):                # nn.Conv1d(F * h_in, u, kernel_size=1): layers.py:701-706
@@ -129,8 +159,9 @@ def param_shapes(cfg, mode, backbone="DCNv2"):
         d_in = H
     if backbone != "AutoInt":
         cin_out = sum(int(c) for c in XDEEPFM["cin_layer_units"].split(","))
-        Dfin = {"DCNv2": D + (H if NL > 0 else 0), "DNN": H, "DeepFM": H + 1, "xDeepFM": cin_out + H}[backbone]
-    if mode == "CTR" and backbone == "xDeepFM":       # models.py:261: nn.Linear(final_dim, 1)
+        Dfin = {"DCNv2": D + (H if NL > 0 else 0), "DNN": H, "DeepFM": H + 1, "xDeepFM": cin_out + H,
+                "xDeepFMCin": cin_out}[backbone]
+    if mode == "CTR" and backbone in ("xDeepFM", "xDeepFMCin"):       # models.py:261: nn.Linear(final_dim, 1)
         out["fc.weight"] = ((1, Dfin), Dfin ** -0.5)
         out["fc.bias"] = ((1,), 0.1)
         return out

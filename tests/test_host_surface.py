@@ -69,6 +69,30 @@ def test_state_dict_layout_matches_reference(case, backbone, mode):
     assert got == gold
 
 
+@pytest.mark.parametrize("mode", ["MFP", "RFD", "CTR"])
+def test_state_dict_layout_of_xdeepfm_without_the_mlp_tower_matches_reference(mode):
+    from mapx.models import BaseModel
+    case, backbone = "B_f25_b64", "xDeepFMCin"
+    cfg = pg.CASES[case]
+    inp = pg.make_inputs(case, cfg)
+    model = BaseModel.from_config(make_config(cfg, mode, inp["feat_count"], backbone=backbone))
+    got = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in model.state_dict().items()}
+    gold = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))[f"{case}_{mode}_{backbone}"]
+    assert got == gold and not any(k.startswith("dnn.") for k in got)
+
+
+def test_state_dict_layout_of_autoint_with_lr_and_dnn_matches_reference():
+    """The finetune-only modules of AutoInt (lr_layer, dnn, dnn_out; models.py:463-471) under the reference's names."""
+    from mapx.models import BaseModel
+    case, backbone = "B_f25_b64", "AutoIntFull"
+    cfg = pg.CASES[case]
+    model = BaseModel.from_config(make_config(cfg, "CTR", None, backbone=backbone))
+    got = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in model.state_dict().items()}
+    gold = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))[f"{case}_CTR_{backbone}"]
+    assert got == gold
+    assert {"lr_layer.embed_w.weight", "lr_layer.bias", "dnn.dnn.0.weight", "dnn.dnn.3.bias", "dnn_out.weight"} <= set(got)
+
+
 def test_index_linear_buffers_and_init_match_reference():
     from mapx.models import BaseModel
     case = "B_f25_b64"

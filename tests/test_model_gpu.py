@@ -359,6 +359,33 @@ def test_other_backbones_golden(case, backbone, mode):
     """DNN / DeepFM through the same C-ABI kernels, heads and row tables vs golden vectors of the
     reference's own classes (models.py:164-233): loss, outputs and every gradient (for DeepFM
     including the LR weight rows, reduced together with the embedding rows)."""
+    _other_backbone_case(case, backbone, mode)
+
+
+def test_autoint_finetune_with_lr_term_and_dnn_tower_golden():
+    """AutoInt's finetune-only options (use_lr, num_dnn_layers > 0; models.py:463-471, 482-486) against a fixture of the
+    reference's own class: logits = attn_out(attention) + LR(ids) + dnn_out(dnn(embeddings)); the LR weight is the
+    secondary parameter of the embedding's row table, so its gradient rows come out of the same reduction.  (The
+    reference sizes the tower for the attention output and feeds it the embeddings: the fixture uses embed_size ==
+    heads x attn_size, the only setting in which the reference itself runs; any other raises here as it fails there.)"""
+    _other_backbone_case("B_f25_b64", "AutoIntFull", "CTR")
+    from util import make_config
+    from mapx.models import BaseModel
+    cfg = dict(pg.CASES["B_f25_b64"])
+    c = make_config(cfg, "CTR", None, backbone="AutoIntFull")
+    c.attn_size = 12                                    # 2 heads x 12 != embed_size 16
+    with pytest.raises(ValueError):
+        BaseModel.from_config(c)
+
+
+@pytest.mark.parametrize("mode", ["MFP", "RFD", "CTR"])
+def test_xdeepfm_without_the_mlp_tower_golden(mode):
+    """xDeepFM with num_hidden_layers = 0 (models.py:253-255: the CIN's output alone feeds the heads / `fc`) against
+    fixtures of the reference's own class, all three step kinds."""
+    _other_backbone_case("B_f25_b64", "xDeepFMCin", mode)
+
+
+def _other_backbone_case(case, backbone, mode):
     from mapx import ops
     cfg, z, inp, params = load_case(case, mode, backbone)
     model = build_model(cfg, mode, params, inp["feat_count"] if mode == "MFP" else None, backbone=backbone)
@@ -384,7 +411,7 @@ def test_other_backbones_golden(case, backbone, mode):
             from mapx.layers import fm_product_sum
             # 0.5 * sum_e((sum_f x)^2 - sum_f x^2) cancels: absolute tolerance at the scale of its two terms
             np.testing.assert_allclose(fm_product_sum(x3).detach().cpu().numpy(), z["mid/fm"], rtol=1e-5, atol=5e-6)
-        if backbone == "AutoInt":
+        if backbone.startswith("AutoInt"):
             x = model.embed(ids)
             for li, layer in enumerate(model.self_attention):
                 x = layer(x)

@@ -45,9 +45,10 @@ def make_config(cfg, mode, feat_count=None, data_dir=None, seed=42, backbone="DC
     """mapx Config for a fixture case (the 11 runtime keys of reference run.py:50-61 + flags)."""
     from mapx.arguments import Config
     extra = pg.extras_of(backbone)
-    return Config(**extra, compute_dtype=compute_dtype, model_name=backbone, data_dir=data_dir, input_size=cfg["V"], num_fields=cfg["F"],
+    nl = extra.pop("num_hidden_layers", cfg["NL"])          # (a fixture variant may override the case's tower depth)
+    return Config(**extra, compute_dtype=compute_dtype, model_name=pg.model_name_of(backbone), data_dir=data_dir, input_size=cfg["V"], num_fields=cfg["F"],
                   embed_size=cfg["E"], embed_dropout_rate=0.0, embed_norm=False, layer_norm_eps=1e-12,
-                  hidden_size=cfg["H"], num_hidden_layers=cfg["NL"], hidden_act="relu",
+                  hidden_size=cfg["H"], num_hidden_layers=nl, hidden_act="relu",
                   hidden_dropout_rate=0.0, num_cross_layers=cfg["NC"], pt_neg_num=cfg["K"],
                   proj_size=cfg["P"], pretrain=(mode != "CTR"),
                   pt_type=("RFD" if mode == "RFD" else "MFP"), RFD_replace="Unigram",
