@@ -49,7 +49,7 @@ class RowTable:
     def num_rows(self):
         return self.p0.shape[0]
 
-    def prepare(self, keys_i32, need_plan, defer_plan=False, through_replay=False):
+    def prepare(self, keys_i32, need_plan, defer_plan=False, through_replay=False, catch_up=True):
         """Called by the forward pass with this step's row ids (repeats allowed).
         * stale rows among them are brought up to date on the current stream, straight from the
           raw id list (ownership by atomicCAS in the kernel): nothing on the critical path
@@ -71,10 +71,20 @@ class RowTable:
         if self.lazy is not None and through_replay:
             self.lazy.refresh_coef()
         elif self.lazy is not None and (self.lazy.stale or torch.cuda.is_current_stream_capturing()):
-            self.lazy.catch_up_raw(keys_i32)
+            if catch_up:
+                self.lazy.catch_up_raw(keys_i32)
+            else:
+                self.pending_catch_up = keys_i32        # the caller runs it later on this stream (catch_up_pending)
         if need_plan and not defer_plan:
             self.plan.start()
         return self.plan
+
+    def catch_up_pending(self):
+        """The catch-up pass prepare(catch_up=False) left out (before the first kernel that reads the rows)."""
+        keys = getattr(self, "pending_catch_up", None)
+        if keys is not None:
+            self.pending_catch_up = None
+            self.lazy.catch_up_raw(keys)
 
     def start_plan(self, after=None):
         """`after`: a stream whose work enqueued so far the sort must not delay (PlanSlot.start_many)."""
@@ -109,6 +119,8 @@ class RowTable:
 # and worth nothing on the step (one box, tools/ab_env.sh): gather 5.0 -> 9.0 us, the 7.9-us catch-up launch gone,
 # the update +1.4 us: 0.6884 / 0.6907 ms per step against 0.6880 / 0.6899 with the catch-up pass.  Opt-in.
 EMB_LAZY_FOLD = os.environ.get("MAPX_EMB_LAZY_FOLD", "0") == "1"
+JOIN_DEEP_FIRST = int(os.environ.get("MAPX_JOIN_DEEP_FIRST", "1"))
+DX_FIRST = os.environ.get("MAPX_DX_FIRST", "0") == "1"                   # A/B switch: an MLP layer's dX product before its dW
 IMPLIED = os.environ.get("MAPX_PLAN_IMPLIED", "1") == "1"
 HEAD_DW_LATE = os.environ.get("MAPX_HEAD_DW_LATE", "1") == "1"     # A/B switch (tools/ab_env.sh)
 PAD_K = os.environ.get("MAPX_PAD_K", "1") == "1"                   # A/B switch: _Linear with an input width % 8 != 0
@@ -520,7 +532,21 @@ def join_bwd_input(dz, w, final, link):
         return torch.empty(1, 1, dtype=final.dtype, device=final.device).expand(final.shape[0], Nn)    # never read
     main = torch.cuda.current_stream() if dz.is_cuda else None
     side = ops.aux_stream("tower", dz.device) if dz.is_cuda else None
-    forked = ops.stream_wait(side, main) if dz.is_cuda else False
+    dzr = None
+    fork_ev = None
+    if JOIN_DEEP_FIRST and dz.is_cuda:
+        # (the graph runtime keeps a node's FIRST-captured successor on the node's hardware queue and sends later ones
+        # to the other queue, behind whatever that one holds — at this point of the step the segment plans' sort
+        # chain: the deep tower's product, the longer backward chain's first link, is enqueued first)
+        if JOIN_DEEP_FIRST == 2:
+            fork_ev = ops.record_event()         # the cross product forks from HERE: it does not wait for the deep one,
+                                                 # and the deep tower's chain is the deep product's first successor
+        ops.dbg_sleep("join_deep")
+        dzr = ops.linear_bwd_input(dz, ops.cols(w, D, None), relu_of=final[:, D:], colsum_to=link.relu.sb)
+    if fork_ev is not None:
+        forked = ops.stream_wait_event(side, fork_ev, main)
+    else:
+        forked = ops.stream_wait(side, main) if dz.is_cuda else False
     with (torch.cuda.stream(side) if forked else contextlib.nullcontext()):
         ops.dbg_sleep("join_cross")
         g, t, dx0, part = ops.gemm_bwd_fused(dz, ops.cols(w, 0, D), D, x0=link.x0, u=link.u, plus_v=link.plus_v)
@@ -528,8 +554,9 @@ def join_bwd_input(dz, w, final, link):
     if forked:
         dz.record_stream(side)
         ops.pending_joins.append((main, side))
-    ops.dbg_sleep("join_deep")
-    dzr = ops.linear_bwd_input(dz, ops.cols(w, D, None), relu_of=final[:, D:], colsum_to=link.relu.sb)
+    if dzr is None:
+        ops.dbg_sleep("join_deep")
+        dzr = ops.linear_bwd_input(dz, ops.cols(w, D, None), relu_of=final[:, D:], colsum_to=link.relu.sb)
     link.relu.premasked = True
     link.t, link.dx0, link.g, link.dz = t, dx0, g, dzr
     return torch.empty(1, 1, dtype=final.dtype, device=final.device).expand(final.shape[0], Nn)    # never read
@@ -573,8 +600,15 @@ class _Linear(Function):
         if ctx.relu and ctx.link_out is not None and ctx.link_out.premasked:
             # the consumer's dX GEMM has applied this layer's mask and queued its bias gradient (_ReluLink)
             dz, db = (gy if ops.row_sliceable(gy) else gy.contiguous()), None
-            dw = ops.linear_bwd_weight(dz, x, out=sw, defer=True) if ctx.needs_input_grad[1] else None
-            dw = None if sw is not None else dw
+            dw_after = None
+            if DX_FIRST and sw is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[0] and not ctx.kpad:
+                # the layer below waits for this node's dX, only the optimizer for its dW: the dX product is enqueued
+                # first, the dW product behind it on the same stream
+                dw_after = (dz, x, sw)
+                dw = None
+            else:
+                dw = ops.linear_bwd_weight(dz, x, out=sw, defer=True) if ctx.needs_input_grad[1] else None
+                dw = None if sw is not None else dw
         elif ctx.relu and (ctx.half or gy.shape[1] % 4 == 0):      # ReLU mask and bias gradient in one pass over dY
             dz, db = ops.relu_mask_colsum(gy, y, db=sb, defer=True)      # gy may be a slice of d(concat)
             if (HEAD_DW_LATE and isinstance(ctx.link_in, _JoinLink) and ops.step_window[0] and sw is not None
@@ -605,6 +639,8 @@ class _Linear(Function):
                 link.premasked = True
             else:
                 dx = ops.linear_bwd_input(dz, w)
+        if locals().get("dw_after") is not None:
+            ops.linear_bwd_weight(dw_after[0], dw_after[1], out=dw_after[2], defer=True)
         if ctx.kpad:                              # operands padded to a multiple of 8 columns in forward: cut them off
             K = w.shape[1] - ctx.kpad
             if dx is not None:

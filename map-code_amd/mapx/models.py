@@ -42,6 +42,7 @@ X0_LINK = os.environ.get("MAPX_X0_LINK", "1") == "1"       # A/B switch of layer
 # 80 us in the graph) BEHIND the cross tower's GEMMs on the tower stream instead of in front of them — in front, the
 # cross tower ended 50 us after the deep one and the encoder waited for it; the main stream joins the tower stream at
 # the cross tower's end (an event), the loss kernel alone waits for the sampled ids (`nce_idx._ready`)
+CATCHUP_AFTER_CROSS = os.environ.get("MAPX_CATCHUP_AFTER_CROSS", "0") == "1"     # A/B switch (DCNV2.forward)
 NCE_AFTER_CROSS = os.environ.get("MAPX_NCE_AFTER_CROSS", "0") == "1"
 EARLY_NCE_ALL = os.environ.get("MAPX_EARLY_NCE_ALL", "1") == "1"   # A/B switch: BaseModel._sample_early
 
@@ -294,9 +295,15 @@ class DCNV2(BaseModel):
                     # instead of alone between the towers and the loss (same branch, no new one).  (Round 2: BEHIND
                     # the cross tower's GEMMs instead, the trunk joining at the cross tower's end and only the
                     # loss kernel waiting for the sampling: 1.02 vs 0.91 ms fp32, 0.72 vs 0.66 bf16.)
-                    nce_idx = self.mfp_criterion.sample_ids(labels, noise_samples)
+                    # (CATCHUP_AFTER_CROSS: the draw stays here — the segment plans' sort waits for it — and the
+                    # catch-up of the sampled rows goes BEHIND the cross tower's products on this stream, in front of
+                    # the join: since the fp32 products became 1.3-1.9 x faster the cross tower's stream, not the deep
+                    # tower's, is the longer one in forward)
+                    nce_idx = self.mfp_criterion.sample_ids(labels, noise_samples, catch_up=not CATCHUP_AFTER_CROSS)
                 cross_output = self.cross_net(feat_embed, out=ops.alias_cols(final_buf, 0, D) if direct else None,
                                               link=join, x0_link=x0_link)
+                if early_nce and not after_cross and CATCHUP_AFTER_CROSS:
+                    self.mfp_criterion.table.catch_up_pending()
                 cross_done = None
                 if after_cross:
                     cross_done = ops.record_event()

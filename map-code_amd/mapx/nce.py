@@ -339,7 +339,7 @@ class IndexLinear(nn.Module):
     def supports_grouped_encoder(self):
         return self.proj_size == 32 and self.noise_ratio + 1 <= 32
 
-    def sample_ids(self, target, noise_samples=None):
+    def sample_ids(self, target, noise_samples=None, catch_up=True):
         """The step's sampled row ids [B*L, K+1] (target in column 0) and the lazy catch-up of the
         rows they name.  Depends on the targets only, not on the trunk: a model may call it early,
         on a stream that has slack (DCNV2 does, ahead of the cross tower), and hand the result to
@@ -356,7 +356,7 @@ class IndexLinear(nn.Module):
         lazy = self.table.lazy
         fold = (LAZY_FOLD and need_grad and lazy is not None and lazy.replay_in_readers()
                 and ops.lazy_rows_supported(self.proj_size, idx.shape[1]))
-        self.table.prepare(idx.view(-1), need_grad, defer_plan=True, through_replay=fold)
+        self.table.prepare(idx.view(-1), need_grad, defer_plan=True, through_replay=fold, catch_up=catch_up)
         idx._lazy = lazy.lazy_rows() if fold else None
         return idx
 
