@@ -233,7 +233,8 @@ class _Gather(Function):
     def backward(ctx, g):
         if ctx.plan is None:
             raise RuntimeError("embedding backward without a segment plan")
-        if getattr(ctx.table, "mark_dense_ready", False) and ops.TAIL_OVERLAP and not parallel.exchanging():
+        if (getattr(ctx.table, "mark_dense_ready", False) and ops.tail_overlap(g.dtype == torch.bfloat16)
+                and not parallel.exchanging()):
             # this node is the model's last: every dense gradient of THIS stream is enqueued (the tower stream's
             # are behind it in that stream's own order, which is where the optimizer's dense half runs) — the
             # optimizer's dense half need not wait for the table's
@@ -621,7 +622,7 @@ class _Linear(Function):
                     dz.record_stream(cur)
                     x.record_stream(cur)
                     ops.linear_bwd_weight(dz, x, out=sw, defer=True)
-                ops.add_late_task(head_dw)
+                ops.add_late_task(head_dw, dense=True)
                 dw = None
             else:
                 dw = ops.linear_bwd_weight(dz, x, out=sw, defer=True) if ctx.needs_input_grad[1] else None

@@ -247,7 +247,7 @@ class _EncNceLoss(Function):
                     t.record_stream(cur)
                 ops.enc_grouped_dw(dh_slots, final, groups, out=sw, gscale=gl)
                 ops.colsum(denc, out=sb, defer=True)
-            ops.add_late_task(encoder_grads)
+            ops.add_late_task(encoder_grads, dense=True)
             dw = db = None
         else:
             dw = ops.enc_grouped_dw(dh_slots, final, ctx.groups, out=sw, gscale=gl)

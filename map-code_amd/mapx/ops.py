@@ -124,7 +124,16 @@ unit_gradient = [None]
 # True between MapxOptimizer.backward_window(True) and (False): optimizer.step() follows this backward pass at
 # once and joins what it left open; outside the window backward() joins its side streams itself
 step_window = [False]
-TAIL_OVERLAP = os.environ.get("MAPX_TAIL_OVERLAP", "1") == "1"
+# "1": the optimizer's dense half forks from there onto the tower stream, beside the tables' half; "0": everything on
+# the main stream; "auto" (default): "1" for the fp32 trunk, "0" for the bf16 one — there the NCE table's gradient and
+# update already sit on the tower stream (early row updates follow the compute dtype) and the dense half queued up
+# behind them while the main queue idled for 72 us (profiles/r04_step_timeline_bf16.txt): 0.5454 / 0.5425 ->
+# 0.5397 / 0.5397 ms, Criteo-shaped 0.801 / 0.796 -> 0.791 / 0.790.
+TAIL_OVERLAP = os.environ.get("MAPX_TAIL_OVERLAP", "auto")
+
+
+def tail_overlap(bf16_trunk):
+    return (not bf16_trunk) if TAIL_OVERLAP == "auto" else TAIL_OVERLAP == "1"
 
 
 def add_side_task(fn):
@@ -142,13 +151,34 @@ def run_side_tasks():
 _late_tasks = []
 
 
-def add_late_task(fn):
-    _late_tasks.append(fn)
+def add_late_task(fn, dense=False):
+    """dense: the task forms gradients of DENSE parameters (a head's or the encoder's dW / db) — those run first, and an
+    event behind them (late_dense_done) lets the optimizer's dense half start without waiting for the tables' work that
+    the other late tasks put on the same stream."""
+    _late_tasks.append((fn, bool(dense)))
+
+
+LATE_DENSE_FIRST = os.environ.get("MAPX_LATE_DENSE_FIRST", "0") == "1"      # A/B switch (with MAPX_DENSE_BEFORE_JOIN)
+late_dense_done = [None, None]        # [event, stream] behind the last dense-gradient late task of this backward pass
 
 
 def run_late_tasks():
-    while _late_tasks:
-        _late_tasks.pop(0)()
+    if not _late_tasks:
+        return
+    tasks = list(_late_tasks)
+    _late_tasks.clear()
+    if not LATE_DENSE_FIRST:
+        for fn, _ in tasks:
+            fn()
+        return
+    for fn, dense in tasks:
+        if dense:
+            fn()
+    if any(not dense for _, dense in tasks) and torch.cuda.is_available():
+        late_dense_done[0], late_dense_done[1] = record_event(), torch.cuda.current_stream()
+    for fn, dense in tasks:
+        if not dense:
+            fn()
 
 
 # Main tasks: stream joins a backward node wants on the MAIN stream but not yet (the wait for a segment plan that the

@@ -16,6 +16,7 @@ import torch
 from . import ops
 
 NO_DECAY = ("bias", "LayerNorm.weight")          # trainer.py:61
+DENSE_BEFORE_JOIN = os.environ.get("MAPX_DENSE_BEFORE_JOIN", "0") == "1"     # A/B switch: MapxOptimizer.step
 PACK_MOMENTS = os.environ.get("MAPX_PACK_MOMENTS", "1") == "1"      # A/B switch: m | v of a table row in one record
 
 
@@ -279,14 +280,30 @@ class MapxOptimizer:
 
     def step(self):
         ops.run_main_tasks()            # stream joins nobody picked up
+        main = torch.cuda.current_stream() if torch.cuda.is_available() else None
+        ev, ev_stream = ops.dense_ready
+        late_ev, late_stream = ops.late_dense_done
+        ops.late_dense_done[0] = ops.late_dense_done[1] = None
+        from . import parallel
+        # The dense half first, when it runs on this stream (no fork: the bf16 trunk, ops.tail_overlap) and the side
+        # stream's dense gradients are marked by an event: it then waits for THAT event, not for the tables' gradient
+        # and row update that follow on the side stream (28 us of idle main queue in front of sum_tasks on
+        # profiles/r04_step_timeline_bf16.txt); everything else is joined behind it.
+        dense_first = (DENSE_BEFORE_JOIN and ev is None and late_ev is not None and main is not None
+                       and self.max_grad_norm <= 0 and not parallel.exchanging() and not ops._side_tasks
+                       and not ops._late_tasks)
+        if dense_first:
+            ops.stream_wait_event(main, late_ev, late_stream)
+            if self.collect_torch_grads() == 0:
+                ops.flush_deferred()
+                self._dense_update()
+            else:
+                dense_first = False        # (a torch-op gradient arrived in .grad: the plain order below)
         ops.join_pending()              # side work a backward node forked and left open
         ops.run_side_tasks()            # early table updates nobody picked up
         ops.run_late_tasks()            # optimizer-only gradients nobody picked up
         moved = self.collect_torch_grads()
-        ev, ev_stream = ops.dense_ready
         ops.dense_ready[0] = ops.dense_ready[1] = None
-        main = torch.cuda.current_stream() if torch.cuda.is_available() else None
-        from . import parallel
         # (the copies collect_torch_grads enqueued on the main stream come AFTER the dense-ready event: a side
         # stream that waits for that event alone could read the flat gradient before they land)
         if ev is not None and moved == 0 and self.max_grad_norm <= 0 and ev_stream == main \
@@ -303,6 +320,9 @@ class MapxOptimizer:
                 t.update()
             if forked:
                 ops.stream_wait(main, side)
+        elif dense_first:
+            for t in self.tables:
+                t.update()
         else:
             ops.flush_deferred()            # split-K slabs / colsum partials of this backward pass
             if self.max_grad_norm > 0:
