@@ -124,16 +124,16 @@ unit_gradient = [None]
 # True between MapxOptimizer.backward_window(True) and (False): optimizer.step() follows this backward pass at
 # once and joins what it left open; outside the window backward() joins its side streams itself
 step_window = [False]
-# "1": the optimizer's dense half forks from there onto the tower stream, beside the tables' half; "0": everything on
-# the main stream; "auto" (default): "1" for the fp32 trunk, "0" for the bf16 one — there the NCE table's gradient and
-# update already sit on the tower stream (early row updates follow the compute dtype) and the dense half queued up
-# behind them while the main queue idled for 72 us (profiles/r04_step_timeline_bf16.txt): 0.5454 / 0.5425 ->
-# 0.5397 / 0.5397 ms, Criteo-shaped 0.801 / 0.796 -> 0.791 / 0.790.
-TAIL_OVERLAP = os.environ.get("MAPX_TAIL_OVERLAP", "auto")
+# "1" (default): the optimizer's dense half forks from there onto the tower stream, beside the tables' half; "0":
+# everything on the main stream.  (With early row updates in the bf16 mode — its default until the end of round 4 — the
+# dense half queued up behind the NCE table's gradient and update on the tower stream while the main queue idled for
+# 72 us, and "0" was better there: 0.5454 / 0.5425 -> 0.5397 / 0.5397 ms; without early updates "1" wins in both modes:
+# optim.py.)  "auto" = "1".
+TAIL_OVERLAP = os.environ.get("MAPX_TAIL_OVERLAP", "1")
 
 
 def tail_overlap(bf16_trunk):
-    return (not bf16_trunk) if TAIL_OVERLAP == "auto" else TAIL_OVERLAP == "1"
+    return TAIL_OVERLAP in ("1", "auto")
 
 
 def add_side_task(fn):

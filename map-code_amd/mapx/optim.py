@@ -175,8 +175,11 @@ class MapxOptimizer:
         # tasks, the early row updates LOSE (0.8058 vs 0.7975 ms per step: the updates run in step(), beside the
         # optimizer's dense half); in the bf16 mode, whose GEMM chains are half as long, they WIN (0.5931 vs 0.6318).
         # Round 4, two sweeps: with gemm_h2.hip alone early won in fp32 too (0.7075 vs 0.7175), with the weights' planes
-        # (gemm_h2w.hip, the shipped default) it loses again (0.7315 vs 0.7120).
-        early_default = "1" if self.bf16 else "0"
+        # (gemm_h2w.hip, the shipped default) it loses again (0.7315 vs 0.7120).  End of round 4 (the deep tower's join
+        # product captured first, layers.JOIN_DEEP_FIRST): they lose in the bf16 mode as well — MFP 0.5372 / 0.5417 with
+        # them (and the dense half on the main stream) vs 0.5305 / 0.5327 without (dense half beside the tables' on the
+        # tower stream, as in fp32), RFD 0.448 / 0.441 vs 0.428 / 0.426, Criteo-shaped equal (profiles/r04_ab_tail.txt).
+        early_default = "0"
         early = (os.environ.get("MAPX_EARLY_TABLE_UPDATE", early_default) == "1" and self.max_grad_norm <= 0
                  and not parallel.exchanging())
         for t in self.tables:
