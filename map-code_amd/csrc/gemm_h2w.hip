@@ -130,11 +130,18 @@ __global__ void __launch_bounds__(256) h2_weight_planes_multi_kernel(PlaneTasks 
     const int t = (int)(blk / KS), sidx = (int)(blk % KS);
     const int n = 32 * t + r, k0 = 16 * sidx + 8 * h;
     float x[8];
+    if (tk.b_kc && n < tk.N && k0 + 8 <= tk.K && tk.ldw % 4 == 0 && ((uintptr_t)tk.W & 15) == 0) {
+      // a whole chunk of a k-contiguous row: two 16-byte loads (the wave reads 32 rows x 64 B)
+      const float4 a = *reinterpret_cast<const float4*>(tk.W + (int64_t)n * tk.ldw + k0);
+      const float4 b = *reinterpret_cast<const float4*>(tk.W + (int64_t)n * tk.ldw + k0 + 4);
+      x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = k0 + j;
-      const bool in = n < tk.N && k < tk.K;
-      x[j] = in ? (tk.b_kc ? tk.W[(int64_t)n * tk.ldw + k] : tk.W[(int64_t)k * tk.ldw + n]) : 0.f;
+      for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        const bool in = n < tk.N && k < tk.K;
+        x[j] = in ? (tk.b_kc ? tk.W[(int64_t)n * tk.ldw + k] : tk.W[(int64_t)k * tk.ldw + n]) : 0.f;
+      }
     }
     uint4 hi, lo;
     w_cut8(x, s, hi, lo);
