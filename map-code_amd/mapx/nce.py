@@ -136,6 +136,7 @@ HEAD_SIDE = os.environ.get("MAPX_HEAD_SIDE", "1") == "1"     # 0.871 vs 0.900 ms
 DEFER_PLAN_JOIN = os.environ.get("MAPX_DEFER_PLAN_JOIN", "1") == "1"    # the dense-encoder head: see _NceLoss.backward
 TOTALS_LATER = os.environ.get("MAPX_TOTALS_LATER", "1") == "1"     # loss totals formed by the head's first backward launch
 LATE_TABLE = os.environ.get("MAPX_LATE_TABLE", "1") == "1"
+TABLE_ON_PLAN = os.environ.get("MAPX_TABLE_ON_PLAN", "0") == "1"      # A/B switch: see _EncNceLoss.backward
 # "1": a training step reads the sampled table rows through their pending zero-gradient updates (no catch-up pass; the
 # gradient update is a row's one read-modify-write of the step).  Built, bit-identical, and
 # measured slower on the step it was asked for (one box, tools/ab_env.sh): the loss kernel 19.5 -> 64 us (639 k row
@@ -200,7 +201,26 @@ class _EncNceLoss(Function):
         early = lazy is not None and getattr(lazy, "early_now", False)
         # (with a gradient exchange or a clipping norm ahead the row update has to wait; the reduction need not)
         aside = HEAD_SIDE and final.is_cuda and (early or ops.HEAD_SIDE_REDUCE_ONLY)
-        if aside and joined and LATE_TABLE:
+        if TABLE_ON_PLAN and aside and joined and ctx.plan.value is not None and ops.step_window[0]:
+            # The table's gradient on the PLAN stream, right behind the sort that it alone needs: no stream waits for the
+            # plan at this point of the step (rounds 1-4 joined the plan into the main stream here — a tower <- plan join
+            # crashes hipStreamEndCapture — and the deep tower's backward chain, which continues on this stream, waited
+            # for the sort chain: 20-29 us of both queues on round 4's timelines).  The plan stream waits for this point
+            # of the main stream (dlogit, h and the loss scale are final) and is joined by optimizer.step().
+            from .layers import _side_stream
+            main, pst = torch.cuda.current_stream(), _side_stream(final.device)
+            plan = ctx.plan.value
+            if ops.stream_wait(pst, main):
+                with torch.cuda.stream(pst):
+                    ge, gb = ops.nce_table_grad(plan, dlogit, h, ctx.K, ctx.P, gscale=gl)
+                    ctx.crit.table.sparse_grad = (plan, ge, gb)
+                    if early:
+                        lazy.update()
+                for t in (ge, gb, dlogit, h, gl):
+                    t.record_stream(pst)
+                ops.pending_joins.append((main, pst))
+                early = None
+        elif aside and joined and LATE_TABLE:
             # with one product per tower the cross tower's chain starts at once on the tower stream; the table's
             # gradient reduction and row update (HBM-bound, ~70 us) go BEHIND it (ops.run_late_tasks) instead of in
             # front of it, beside the deep tower's remaining MFMA-bound GEMMs
