@@ -136,7 +136,18 @@ HEAD_SIDE = os.environ.get("MAPX_HEAD_SIDE", "1") == "1"     # 0.871 vs 0.900 ms
 DEFER_PLAN_JOIN = os.environ.get("MAPX_DEFER_PLAN_JOIN", "1") == "1"    # the dense-encoder head: see _NceLoss.backward
 TOTALS_LATER = os.environ.get("MAPX_TOTALS_LATER", "1") == "1"     # loss totals formed by the head's first backward launch
 LATE_TABLE = os.environ.get("MAPX_LATE_TABLE", "1") == "1"
-TABLE_ON_PLAN = os.environ.get("MAPX_TABLE_ON_PLAN", "0") == "1"      # A/B switch: see _EncNceLoss.backward
+# _EncNceLoss.backward: the table's gradient on the plan stream behind its sort ("1"), at the end of the cross tower's
+# chain ("0"), or ("auto") by the cross tower's width: its chain is the longer one at Criteo's 624 columns, where taking
+# the gradient off it wins (1.0155 / 1.0085 -> 0.9868 / 0.9865 ms), and has slack at Avazu's 368, where the plan
+# stream's queue is the deep tower's (0.668 -> 0.690 / 0.694 with "1").
+TABLE_ON_PLAN = os.environ.get("MAPX_TABLE_ON_PLAN", "auto")
+TABLE_ON_PLAN_MIN_D = 512
+
+
+def _table_on_plan(join):
+    if TABLE_ON_PLAN == "auto":
+        return join is not None and join.D >= TABLE_ON_PLAN_MIN_D
+    return TABLE_ON_PLAN == "1"
 # "1": a training step reads the sampled table rows through their pending zero-gradient updates (no catch-up pass; the
 # gradient update is a row's one read-modify-write of the step).  Built, bit-identical, and
 # measured slower on the step it was asked for (one box, tools/ab_env.sh): the loss kernel 19.5 -> 64 us (639 k row
@@ -201,7 +212,7 @@ class _EncNceLoss(Function):
         early = lazy is not None and getattr(lazy, "early_now", False)
         # (with a gradient exchange or a clipping norm ahead the row update has to wait; the reduction need not)
         aside = HEAD_SIDE and final.is_cuda and (early or ops.HEAD_SIDE_REDUCE_ONLY)
-        if TABLE_ON_PLAN and aside and joined and ctx.plan.value is not None and ops.step_window[0]:
+        if aside and joined and _table_on_plan(ctx.join) and ctx.plan.value is not None and ops.step_window[0]:
             # The table's gradient on the PLAN stream, right behind the sort that it alone needs: no stream waits for the
             # plan at this point of the step (rounds 1-4 joined the plan into the main stream here — a tower <- plan join
             # crashes hipStreamEndCapture — and the deep tower's backward chain, which continues on this stream, waited
