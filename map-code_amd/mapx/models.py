@@ -32,7 +32,10 @@ JOINT_PLAN = os.environ.get("MAPX_JOINT_PLAN", "auto")
 # won (0.869 / 0.873 vs 0.876 / 0.882 ms); round 3, after the backward pass changed (tools/flag_sweep.py): the tower
 # stream wins, 0.8058 vs 0.8223 ms; round 4: with the two-piece fp16 GEMMs cutting both operands main won (0.7175 vs
 # 0.7307), with the weights' planes (gemm_h2w.hip) the tower stream again (0.7120 vs 0.7175) — kept there
-LAYOUT_ON_MAIN = os.environ.get("MAPX_LAYOUT_ON_MAIN", "0") == "1"
+# "auto": on the main stream when the cross tower is at least 512 columns wide (Criteo-shaped: its stream is the longer
+# one of the forward pass, 1.0026 -> 0.9924 ms with the layout off it), on the cross tower's stream otherwise (Avazu-
+# shaped: equal either way, 0.7064 vs 0.7070)
+LAYOUT_ON_MAIN = os.environ.get("MAPX_LAYOUT_ON_MAIN", "auto")
 PLAN_AFTER_DNN = os.environ.get("MAPX_PLAN_AFTER_DNN", "1")       # 1 | tower | 0: what the joint plan goes behind
 # RFD / finetune steps: what the one table's sort goes behind: auto | main | tower | 0 (A/B switch)
 PLAN_AFTER_TRUNK = os.environ.get("MAPX_PLAN_AFTER_TRUNK", "auto")
@@ -277,7 +280,7 @@ class DCNV2(BaseModel):
             if feat_embed.dtype == torch.float32:
                 # ONE magnitude record for the concatenated output: both towers' last kernels raise it (ops.out_record)
                 ops.tag(final_buf, ops.amax_record(final_buf.device))
-            if LAYOUT_ON_MAIN and self._grouped_head(masked_index):
+            if (LAYOUT_ON_MAIN == "1" or (LAYOUT_ON_MAIN == "auto" and D >= 512)) and self._grouped_head(masked_index):
                 # the grouped encoder's slot layout (one 15-us launch) ahead of the deep tower, which by now
                 # has ~45 us of slack against the cross tower's stream (round 1 had it the other way round)
                 groups = ops.EncGroups(masked_index, self.config.num_fields)
