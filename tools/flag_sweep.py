@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 FLAGS = [("MAPX_JOIN_FUSE", "1", "0"), ("MAPX_CROSS_FUSE", "0", "1"), ("MAPX_DW_BATCH", "1", "0"),
-         ("MAPX_X0_LINK", "1", "0"), ("MAPX_LAYOUT_ON_MAIN", "0", "1"), ("MAPX_PLAN_AFTER_DNN", "1", "0"),
+         ("MAPX_X0_LINK", "1", "0"), ("MAPX_LAYOUT_ON_MAIN", "auto", "1"), ("MAPX_PLAN_AFTER_DNN", "1", "0"),
          ("MAPX_HEAD_SIDE", "1", "0"), ("MAPX_LATE_TABLE", "1", "0"), ("MAPX_TAIL_OVERLAP", "1", "0"),
          ("MAPX_NCE_EARLY", "1", "0"), ("MAPX_JOINT_PLAN", "auto", "off"), ("MAPX_RELU_LINK", "1", "0"),
          ("MAPX_EARLY_TABLE_UPDATE", "0", "1"), ("MAPX_XCD_SLICES", "1", "0"), ("MAPX_PACK_MOMENTS", "1", "0"),
@@ -17,7 +17,7 @@ FLAGS = [("MAPX_JOIN_FUSE", "1", "0"), ("MAPX_CROSS_FUSE", "0", "1"), ("MAPX_DW_
          # round 4's switches
          ("MAPX_JOIN_DEEP_FIRST", "1", "0"), ("MAPX_PLANES_AT_START", "0", "1"), ("MAPX_CATCHUP_AFTER_CROSS", "0", "1"),
          ("MAPX_DX_FIRST", "0", "1"), ("MAPX_LATE_DENSE_FIRST", "0", "1"), ("MAPX_HEAD_DW_LATE", "1", "0"),
-         ("MAPX_TOTALS_LATER", "1", "0"), ("MAPX_DEFER_COLSUM", "1", "0")]
+         ("MAPX_TOTALS_LATER", "1", "0"), ("MAPX_DEFER_COLSUM", "1", "0"), ("MAPX_TABLE_ON_PLAN", "auto", "0")]
 extra = sys.argv[1:]
 root = os.environ.get("GRAFT_REPO_ROOT", ".")
 
