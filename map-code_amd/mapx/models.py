@@ -340,7 +340,12 @@ class DCNV2(BaseModel):
                 # single-stream backbones below measured neutral (RFD / CTR) or worse (DNN + MFP): left as they were)
                 # Behind the CROSS tower's (the head is short then and the deep tower's backward would wait for the
                 # sort on its queue): finetune 0.636 -> 0.619 ms, RFD 0.768 -> 0.786 — so by the head.
-                where = PLAN_AFTER_TRUNK if PLAN_AFTER_TRUNK != "auto" else ("main" if self.config.pretrain else "tower")
+                # Round 4 (tools/mini_sweep_steps.sh, after the join's capture order changed): the finetune step with
+                # the fp32 trunk at Avazu's width now also prefers "main" (0.515 / 0.513 -> 0.493 / 0.492 ms); its
+                # Criteo-shaped (0.623 vs 0.641) and bf16 (0.345 vs 0.376) forms keep "tower".
+                narrow_f32 = self.embed.compute_dtype == torch.float32 and D < 512
+                where = PLAN_AFTER_TRUNK if PLAN_AFTER_TRUNK != "auto" else \
+                    ("main" if (self.config.pretrain or narrow_f32) else "tower")
                 self.embed.table.start_plan(after={"main": main, "tower": tower}.get(where))
             if cross_done is not None:
                 ops.stream_wait_event(main, cross_done, tower)       # (the sampled ids: waited for by the loss kernel)
